@@ -1,0 +1,169 @@
+"""ctypes binding of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+The product package (towr_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libtowr_oracle.so")
+_lib = None
+
+ROBOTS = {"monoped": 0, "biped": 1, "hyq": 2, "anymal": 3, "go1": 4}
+TERRAINS = {"flat": 0, "block": 1, "stairs": 2, "gap": 3, "slope": 4, "chimney": 5, "chimney_lr": 6}
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def build():
+    """Compile the oracle with g++ (a few seconds)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_int, C.c_int, C.c_int, _ip, _dp, _ip, C.c_double, C.c_double,
+                                 C.c_double, C.c_int, C.c_int, C.c_double]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        for f in ("orc_n_vars", "orc_n_rows", "orc_n_var_sets", "orc_n_con_sets"):
+            getattr(L, f).argtypes = [C.c_void_p]
+            getattr(L, f).restype = C.c_int
+        for f in ("orc_var_set_name", "orc_con_set_name"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_int]
+            getattr(L, f).restype = C.c_char_p
+        for f in ("orc_var_set_size", "orc_con_set_rows"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_int]
+            getattr(L, f).restype = C.c_int
+        L.orc_initial_guess.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.orc_eval.argtypes = [C.c_void_p, _dp, _dp, _ip, _ip, _dp]
+        L.orc_eval.restype = C.c_int
+        L.orc_bounds.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_time_callbacks.argtypes = [C.c_void_p, _dp, C.c_int]
+        L.orc_time_callbacks.restype = C.c_double
+        L.orc_gait.argtypes = [C.c_int, C.c_int, C.c_double, _ip, _ip, _dp, C.c_int]
+        L.orc_gait.restype = C.c_int
+        L.orc_hermite_weights.argtypes = [C.c_double, C.c_double, _dp]
+        L.orc_terrain_height.argtypes = [C.c_int, C.c_double, C.c_double]
+        L.orc_terrain_height.restype = C.c_double
+        L.orc_terrain_basis.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, _dp]
+        L.orc_terrain_dbasis.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _dp]
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def gait(n_ee, combo, t_total):
+    """Reference GaitGenerator: returns (list of per-ee phase duration arrays, contact_at_start list)."""
+    n_ph = np.zeros(n_ee, dtype=np.int32)
+    con = np.zeros(n_ee, dtype=np.int32)
+    out = np.zeros(256)
+    w = lib().orc_gait(n_ee, combo, float(t_total), _i(n_ph), _i(con), _d(out), out.size)
+    if w < 0:
+        raise RuntimeError("orc_gait failed")
+    res, o = [], 0
+    for ee in range(n_ee):
+        res.append(out[o:o + n_ph[ee]].copy())
+        o += n_ph[ee]
+    return res, [int(c) for c in con]
+
+
+class OracleProblem:
+    def __init__(self, robot, terrain, phase_durations, contact_at_start, dt_dynamic=0.1, dt_rom=0.08,
+                 duration_base_poly=0.1, polys_per_swing=2, polys_per_stance_force=3, force_limit=1000.0):
+        robot = ROBOTS[robot] if isinstance(robot, str) else robot
+        terrain = TERRAINS[terrain] if isinstance(terrain, str) else terrain
+        n_ee = len(phase_durations)
+        n_ph = np.array([len(p) for p in phase_durations], dtype=np.int32)
+        pd = np.concatenate([np.asarray(p, dtype=np.float64) for p in phase_durations])
+        con = np.array(contact_at_start, dtype=np.int32)
+        self._h = lib().orc_create(robot, terrain, n_ee, _i(n_ph), _d(pd), _i(con), dt_dynamic, dt_rom,
+                                   duration_base_poly, polys_per_swing, polys_per_stance_force, force_limit)
+        if not self._h:
+            raise RuntimeError("orc_create failed")
+        L = lib()
+        self.n_ee = n_ee
+        self.n = L.orc_n_vars(self._h)
+        self.m = L.orc_n_rows(self._h)
+        self.var_sets = [(L.orc_var_set_name(self._h, i).decode(), L.orc_var_set_size(self._h, i))
+                         for i in range(L.orc_n_var_sets(self._h))]
+        self.con_sets = [(L.orc_con_set_name(self._h, i).decode(), L.orc_con_set_rows(self._h, i))
+                         for i in range(L.orc_n_con_sets(self._h))]
+        self.nnz = L.orc_eval(self._h, _d(np.zeros(self.n)), None, None, None, None)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_destroy(self._h)
+            self._h = None
+
+    def initial_guess(self, base_lin0, base_ang0, base_lin1, base_ang1, ee_pos0):
+        x = np.zeros(self.n)
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (base_lin0, base_ang0, base_lin1, base_ang1)]
+        ee = np.ascontiguousarray(ee_pos0, dtype=np.float64).reshape(-1)
+        lib().orc_initial_guess(self._h, _d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), _d(ee), _d(x))
+        return x
+
+    def eval(self, x):
+        """Returns g, row_ptr, col_idx, vals (CSR, explicit zeros kept)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.size == self.n
+        g = np.zeros(self.m)
+        rp = np.zeros(self.m + 1, dtype=np.int32)
+        ci = np.zeros(self.nnz, dtype=np.int32)
+        va = np.zeros(self.nnz)
+        nnz = lib().orc_eval(self._h, _d(x), _d(g), _i(rp), _i(ci), _d(va))
+        assert nnz == self.nnz, "Jacobian pattern must not depend on x"
+        return g, rp, ci, va
+
+    def values(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        g = np.zeros(self.m)
+        lib().orc_eval(self._h, _d(x), _d(g), None, None, None)
+        return g
+
+    def bounds(self):
+        lo, up = np.zeros(self.m), np.zeros(self.m)
+        lib().orc_bounds(self._h, _d(lo), _d(up))
+        return lo, up
+
+    def time_callbacks(self, x, iters):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        return lib().orc_time_callbacks(self._h, _d(x), int(iters))
+
+
+def hermite_weights(t, T):
+    w = np.zeros(12)
+    lib().orc_hermite_weights(t, T, _d(w))
+    return w.reshape(3, 4)
+
+
+def terrain_height(terrain, x, y):
+    return lib().orc_terrain_height(TERRAINS[terrain], x, y)
+
+
+def terrain_basis(terrain, which, x, y):
+    o = np.zeros(3)
+    lib().orc_terrain_basis(TERRAINS[terrain], which, x, y, _d(o))
+    return o
+
+
+def terrain_dbasis(terrain, which, dim, x, y):
+    o = np.zeros(3)
+    lib().orc_terrain_dbasis(TERRAINS[terrain], which, dim, x, y, _d(o))
+    return o

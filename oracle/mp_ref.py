@@ -1,0 +1,430 @@
+"""Independent second implementation of the hot path (TEST INFRASTRUCTURE ONLY).
+
+Purpose: pin the C++ oracle (oracle/towr_oracle.cc) with something that shares no
+code with it.  This file evaluates the constraint values g(x) from the *math*
+(reference lines cited inline) in 40-digit mpmath arithmetic and
+obtains the Jacobian by high-precision central differences -- it contains no
+analytic derivative at all, so a wrong closed form in the oracle (or in the
+reference restatement) cannot hide.
+
+Run as a script to (re)generate tests/golden/mp_*.npz:
+    python -m oracle.mp_ref            # all cases, ~10 min on 8 cores
+
+Double-precision inputs that the reference computes in double (time grids,
+polynomial durations, active segment, local time) are computed here in Python
+floats (IEEE double) with the same operation order, then promoted exactly.
+
+One deliberate exception, documented in DESIGN.md: the reference's
+"derivative of the normalised terrain basis" (height_map.cc:80-91) is a
+component-wise product, not a chain rule.  The entries it feeds (force rows w.r.t.
+the stance foothold x/y) are therefore *not* true derivatives where the terrain
+has curvature (Gap); those entries are flagged in the fixture (`quirk_mask`) and
+checked by a hand known-answer test instead.
+"""
+import math
+import os
+import sys
+from multiprocessing import Pool
+
+import numpy as np
+from mpmath import mp, mpf
+
+mp.dps = 40
+
+ROBOT = {  # models/examples/*.h, models/go1/go1_model.h
+    "monoped": dict(n_ee=1, m=20.0, I=(1.2, 5.5, 6.0, 0.0, -0.2, -0.01), nom=[(0.0, 0.0, -0.58)], dev=(0.25, 0.15, 0.2)),
+    "biped": dict(n_ee=2, m=20.0, I=(1.209, 5.583, 6.056, 0.005, -0.190, -0.012),
+                  nom=[(0.0, 0.20, -0.65), (0.0, -0.20, -0.65)], dev=(0.25, 0.15, 0.15)),
+    "hyq": dict(n_ee=4, m=83.0, I=(4.26, 8.97, 9.88, -0.0063, 0.193, 0.0126),
+                nom=[(0.31, 0.29, -0.58), (0.31, -0.29, -0.58), (-0.31, 0.29, -0.58), (-0.31, -0.29, -0.58)],
+                dev=(0.25, 0.20, 0.10)),
+    "anymal": dict(n_ee=4, m=29.5, I=(0.946438, 1.94478, 2.01835, 0.000938112, -0.00595386, -0.00146328),
+                   nom=[(0.34, 0.19, -0.42), (0.34, -0.19, -0.42), (-0.34, 0.19, -0.42), (-0.34, -0.19, -0.42)],
+                   dev=(0.15, 0.1, 0.10)),
+    "go1": dict(n_ee=4, m=12.84, I=(0.0168128557, 0.063009565, 0.0716547275, -0.0002296769, -0.0002945293, -0.0000418731),
+                nom=[(0.1881, 0.04675 + 0.08, -0.3), (0.1881, -(0.04675 + 0.08), -0.3),
+                     (-0.1881, 0.04675 + 0.08, -0.3), (-0.1881, -(0.04675 + 0.08), -0.3)], dev=(0.16, 0.12, 0.06)),
+}
+G = 9.80665  # dynamic_model.cc:37
+MU = 0.5     # height_map.h:136
+
+
+# ----------------------------------------------------------------- layout
+def base_poly_durations(T, dt):  # parameters.cc:82-98
+    out, left = [], T
+    while left > 1e-10:
+        out.append(dt if left > dt else left)
+        left -= dt
+    return out
+
+
+def time_grid(T, dt):  # time_discretization_constraint.cc:37-50
+    t, g = 0.0, [0.0]
+    for _ in range(int(math.floor(T / dt))):
+        t += dt
+        g.append(t)
+    g.append(T)
+    return g
+
+
+def locate(t, durs):  # spline.cc:48-78
+    acc = 0.0
+    seg = None
+    for i, d in enumerate(durs):
+        acc += d
+        if acc >= t - 1e-10:
+            seg = i
+            break
+    assert seg is not None
+    tl = t
+    for i in range(seg):
+        tl -= durs[i]
+    return seg, tl
+
+
+class Layout:
+    """Variable layout + node tables for one problem (nlp_formulation.cc:63-181,
+    nodes_variables_all.cc:45-61, nodes_variables_phase_based.cc:38-298)."""
+
+    def __init__(self, robot, phase_durations, contact_at_start, dt_dyn=0.1, dt_rom=0.08, dur_base=0.1,
+                 polys_swing=2, polys_stance=3):
+        self.rb = ROBOT[robot]
+        self.n_ee = self.rb["n_ee"]
+        self.T = 0.0
+        for d in phase_durations[0]:
+            self.T += d
+        self.base_durs = base_poly_durations(self.T, dur_base)
+        nb = len(self.base_durs) + 1
+        self.splines = {}  # name -> dict(durs, nodes=[{(deriv,dim): idx or None}], const=[bool])
+        off = 0
+        for name in ("base-lin", "base-ang"):
+            nodes = []
+            for k in range(nb):
+                nodes.append({(dv, dm): off + 6 * k + 3 * dv + dm for dv in (0, 1) for dm in (0, 1, 2)})
+            self.splines[name] = dict(durs=self.base_durs, nodes=nodes, off=off, size=6 * nb)
+            off += 6 * nb
+        for ee in range(self.n_ee):  # ee-motion: stance phases constant
+            off = self._phase_based("ee-motion_%d" % ee, phase_durations[ee], bool(contact_at_start[ee]), polys_swing,
+                                    off, motion=True)
+        for ee in range(self.n_ee):  # ee-force: swing phases constant (zero)
+            off = self._phase_based("ee-force_%d" % ee, phase_durations[ee], not bool(contact_at_start[ee]),
+                                    polys_stance, off, motion=False)
+        self.n = off
+        self.grid_dyn = time_grid(self.T, dt_dyn)
+        self.grid_rom = time_grid(self.T, dt_rom)
+
+    def _phase_based(self, name, phases, first_const, n_change, off, motion):
+        polys = []  # (phase, is_const)
+        const = first_const
+        for ph in range(len(phases)):
+            if const:
+                polys.append((ph, True, 1))
+            else:
+                polys += [(ph, False, n_change)] * n_change
+            const = not const
+        durs = [phases[ph] / n for (ph, _, n) in polys]
+        n_nodes = len(polys) + 1
+
+        def node_const(i):
+            adj = [0] if i == 0 else ([n_nodes - 2] if i == n_nodes - 1 else [i - 1, i])
+            return any(polys[p][1] for p in adj)
+
+        nodes = [dict() for _ in range(n_nodes)]
+        consts = [node_const(i) for i in range(n_nodes)]
+        idx = off
+        i = 0
+        while i < n_nodes:
+            if not consts[i]:
+                if motion:  # px vx py vy pz  (vz fixed 0)
+                    for dm in (0, 1, 2):
+                        nodes[i][(0, dm)] = idx
+                        idx += 1
+                        if dm != 2:
+                            nodes[i][(1, dm)] = idx
+                            idx += 1
+                else:  # px vx py vy pz vz
+                    for dm in (0, 1, 2):
+                        nodes[i][(0, dm)] = idx
+                        nodes[i][(1, dm)] = idx + 1
+                        idx += 2
+                i += 1
+            else:
+                if motion:  # one position shared by both nodes, velocities zero
+                    for dm in (0, 1, 2):
+                        nodes[i][(0, dm)] = idx
+                        nodes[i + 1][(0, dm)] = idx
+                        idx += 1
+                i += 2
+        self.splines[name] = dict(durs=durs, nodes=nodes, const=consts, polys=polys, off=off, size=idx - off)
+        return idx
+
+
+# ----------------------------------------------------------------- math
+def hermite(n0, n1, T, t):
+    """pos, vel, acc of the cubic through (p0,v0)->(p1,v1) over T at t (polynomial.cc:97-104,47-61)."""
+    (p0, v0), (p1, v1) = n0, n1
+    c = -(3 * (p0 - p1) + T * (2 * v0 + v1)) / T ** 2
+    d = (2 * (p0 - p1) + T * (v0 + v1)) / T ** 3
+    return (p0 + v0 * t + c * t ** 2 + d * t ** 3, v0 + 2 * c * t + 3 * d * t ** 2, 2 * c + 6 * d * t)
+
+
+def spline_point(L, name, x, t):
+    s = L.splines[name]
+    seg, tl = locate(t, s["durs"])
+    T = mpf(s["durs"][seg])
+    tl = mpf(tl)
+    out = [[None] * 3 for _ in range(3)]
+    for dm in range(3):
+        def val(node, dv):
+            i = s["nodes"][node].get((dv, dm))
+            return x[i] if i is not None else mpf(0)
+        pva = hermite((val(seg, 0), val(seg, 1)), (val(seg + 1, 0), val(seg + 1, 1)), T, tl)
+        for d in range(3):
+            out[d][dm] = pva[d]
+    return out  # [pos, vel, acc][dim]
+
+
+def rot(e):  # euler_converter.cc:207-221 (ZYX)
+    x, y, z = e
+    sx, cx, sy, cy, sz, cz = mp.sin(x), mp.cos(x), mp.sin(y), mp.cos(y), mp.sin(z), mp.cos(z)
+    return [[cy * cz, cz * sx * sy - cx * sz, sx * sz + cx * cz * sy],
+            [cy * sz, cx * cz + sx * sy * sz, cx * sy * sz - cz * sx],
+            [-sy, cy * sx, cx * cy]]
+
+
+def omega_and_dot(e, ed, edd):  # euler_converter.cc:133-166, 58-83
+    y, z = e[1], e[2]
+    yd, zd = ed[1], ed[2]
+    sy, cy, sz, cz = mp.sin(y), mp.cos(y), mp.sin(z), mp.cos(z)
+    M = [[cy * cz, -sz, 0], [cy * sz, cz, 0], [-sy, 0, 1]]
+    Md = [[-cz * sy * yd - cy * sz * zd, -cz * zd, 0], [cy * cz * zd - sy * sz * yd, -sz * zd, 0], [-cy * yd, 0, 0]]
+    w = [sum(M[i][j] * ed[j] for j in range(3)) for i in range(3)]
+    wd = [sum(Md[i][j] * ed[j] + M[i][j] * edd[j] for j in range(3)) for i in range(3)]
+    return w, wd
+
+
+def matvec(A, v):
+    return [sum(A[i][j] * v[j] for j in range(3)) for i in range(3)]
+
+
+def cross(a, b):
+    return [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]
+
+
+def terrain_h(tid, x, y):
+    """height and slopes (height_map_examples.{h,cc}); x,y are mpf, comparisons as in the reference."""
+    z = mpf(0)
+    if tid == "flat":
+        return z, z, z
+    if tid == "block":
+        s0, ln, ht, eps = mpf(0.7), mpf(3.5), mpf(0.5), mpf(0.03)
+        slope = mpf(0.5 / 0.03)
+        h = z
+        hx = z
+        if s0 <= x <= mpf(0.7 + 0.03):
+            h = slope * (x - s0)
+            hx = slope
+        if mpf(0.7 + 0.03) <= x <= mpf(0.7 + 3.5):
+            h = ht
+        return h, hx, z
+    if tid == "stairs":
+        h = z
+        if x >= mpf(1.0):
+            h = mpf(0.2)
+        if x >= mpf(1.0 + 0.4):
+            h = mpf(0.4)
+        if x >= mpf(1.0 + 0.4 + 1.0):
+            h = z
+        return h, z, z  # quirk 5: slope not overridden
+    if tid == "gap":
+        gs, w, hh = 1.0, 0.5, 1.5
+        xc = gs + w / 2.0
+        ge = gs + w
+        a = (4 * hh) / (w * w)
+        b = -(8 * hh * xc) / (w * w)
+        c = -(hh * (w - 2 * xc) * (w + 2 * xc)) / (w * w)
+        if mpf(gs) <= x <= mpf(ge):
+            return mpf(a) * x * x + mpf(b) * x + mpf(c), 2 * mpf(a) * x + mpf(b), z
+        return z, z, z
+    if tid == "slope":
+        ss, up, dn, hc = 1.0, 1.0, 1.0, 0.7
+        xd = ss + up
+        xf = xd + dn
+        sl = hc / up
+        h, hx = z, z
+        if x >= mpf(ss):
+            h, hx = mpf(sl) * (x - mpf(ss)), mpf(sl)
+        if x >= mpf(xd):
+            h, hx = mpf(hc) - mpf(sl) * (x - mpf(xd)), -mpf(sl)
+        if x >= mpf(xf):
+            h, hx = z, z
+        return h, hx, z
+    if tid == "chimney":
+        if mpf(1.0) <= x <= mpf(1.0 + 1.5):
+            return mpf(3.0) * (y - mpf(0.5)), z, mpf(3.0)
+        return z, z, z
+    if tid == "chimney_lr":
+        h, hy = z, z
+        if mpf(0.5) <= x <= mpf(0.5 + 1.0):
+            h, hy = mpf(2) * (y - mpf(0.5)), mpf(2)
+        if mpf(0.5 + 1.0) <= x <= mpf(0.5 + 2 * 1.0):
+            h, hy = -mpf(2) * (y + mpf(0.5)), -mpf(2)
+        return h, z, hy
+    raise ValueError(tid)
+
+
+def unit(v):
+    n = mp.sqrt(sum(c * c for c in v))
+    return [c / n for c in v]
+
+
+def constraints(L, terrain, x, fn_max=1000.0):
+    """g(x) stacked in reference order: terrain-*, dynamic, rangeofmotion-*, force-*."""
+    rb = L.rb
+    g = []
+    # terrain_constraint.cc:57-70 : one row per ee-motion node id>=1
+    for ee in range(L.n_ee):
+        s = L.splines["ee-motion_%d" % ee]
+        for nid in range(1, len(s["nodes"])):
+            p = [x[s["nodes"][nid][(0, dm)]] for dm in range(3)]
+            g.append(p[2] - terrain_h(terrain, p[0], p[1])[0])
+    # dynamic_constraint.cc:59-64 + single_rigid_body_dynamics.cc:76-101
+    Ixx, Iyy, Izz, Ixy, Ixz, Iyz = [mpf(v) for v in rb["I"]]
+    Ib = [[Ixx, -Ixy, -Ixz], [-Ixy, Iyy, -Iyz], [-Ixz, -Iyz, Izz]]
+    m = mpf(rb["m"])
+    for t in L.grid_dyn:
+        c = spline_point(L, "base-lin", x, t)
+        e = spline_point(L, "base-ang", x, t)
+        R = rot(e[0])
+        w, wd = omega_and_dot(e[0], e[1], e[2])
+        Rt = [[R[j][i] for j in range(3)] for i in range(3)]
+        Iw = lambda v: matvec(R, matvec(Ib, matvec(Rt, v)))
+        tau = [mpf(0)] * 3
+        fsum = [mpf(0)] * 3
+        for ee in range(L.n_ee):
+            f = spline_point(L, "ee-force_%d" % ee, x, t)[0]
+            p = spline_point(L, "ee-motion_%d" % ee, x, t)[0]
+            tau = [a + b for a, b in zip(tau, cross(f, [c[0][i] - p[i] for i in range(3)]))]
+            fsum = [a + b for a, b in zip(fsum, f)]
+        ang = [a + b - d for a, b, d in zip(Iw(wd), cross(w, Iw(w)), tau)]
+        lin = [m * c[2][i] - fsum[i] for i in range(3)]
+        lin[2] += m * mpf(G)
+        g += ang + lin
+    # range_of_motion_constraint.cc:58-69
+    for ee in range(L.n_ee):
+        for t in L.grid_rom:
+            c = spline_point(L, "base-lin", x, t)[0]
+            e = spline_point(L, "base-ang", x, t)[0]
+            p = spline_point(L, "ee-motion_%d" % ee, x, t)[0]
+            R = rot(e)
+            d = [p[i] - c[i] for i in range(3)]
+            g += [sum(R[j][i] * d[j] for j in range(3)) for i in range(3)]
+    # force_constraint.cc:62-89
+    for ee in range(L.n_ee):
+        sf = L.splines["ee-force_%d" % ee]
+        sm = L.splines["ee-motion_%d" % ee]
+        for nid in range(len(sf["nodes"])):
+            if sf["const"][nid]:
+                continue
+            adj = 0 if nid == 0 else nid - 1  # first adjacent polynomial -> its phase
+            phase = sf["polys"][adj][0]
+            start = next(i for i, pl in enumerate(sm["polys"]) if pl[0] == phase)
+            px, py = x[sm["nodes"][start][(0, 0)]], x[sm["nodes"][start][(0, 1)]]
+            _, hx, hy = terrain_h(terrain, px, py)
+            n = unit([-hx, -hy, mpf(1)])
+            t1 = unit([mpf(1), mpf(0), hx])
+            t2 = unit([mpf(0), mpf(1), hy])
+            f = [x[sf["nodes"][nid][(0, dm)]] for dm in range(3)]
+            dot = lambda a, b: sum(u * v for u, v in zip(a, b))
+            mu = mpf(MU)
+            g.append(dot(f, n))
+            g.append(dot(f, [a - mu * b for a, b in zip(t1, n)]))
+            g.append(dot(f, [a + mu * b for a, b in zip(t1, n)]))
+            g.append(dot(f, [a - mu * b for a, b in zip(t2, n)]))
+            g.append(dot(f, [a + mu * b for a, b in zip(t2, n)]))
+    return g
+
+
+# ----------------------------------------------------------------- golden cases
+def _gait(n_ee, combo, T):
+    # input construction only: uses the oracle's gait table through ctypes
+    from oracle import binding as ob
+    pd, con = ob.gait(n_ee, combo, T)
+    return [list(map(float, p)) for p in pd], con
+
+
+def cases():
+    hop = ([[0.4, 0.2, 0.4, 0.2, 0.4, 0.2, 0.2]], [1])
+    return {
+        "hopper_flat": dict(robot="monoped", terrain="flat", phases=hop, seed=11),
+        "biped_walk_flat": dict(robot="biped", terrain="flat", phases=_gait(2, 0, 2.0), seed=12),
+        "anymal_trot_gap": dict(robot="anymal", terrain="gap", phases=_gait(4, 1, 2.0), seed=13),
+        "anymal_walk_stairs": dict(robot="anymal", terrain="stairs", phases=_gait(4, 0, 2.4), seed=14),
+        "hyq_gallop_slope": dict(robot="hyq", terrain="slope", phases=_gait(4, 4, 2.2), seed=15),
+        "go1_pace_chimney": dict(robot="go1", terrain="chimney", phases=_gait(4, 2, 1.8), seed=16),
+    }
+
+
+def make_x(L, seed):
+    """Deterministic, well-spread evaluation point: footholds are pushed along +x so that
+    several of them land on the non-flat part of every example terrain."""
+    rng = np.random.default_rng(seed)
+    x = rng.normal(size=L.n) * 0.3
+    for ee in range(L.n_ee):
+        s = L.splines["ee-motion_%d" % ee]
+        for i, nd in enumerate(s["nodes"]):
+            x[nd[(0, 0)]] = 0.4 + 2.2 * i / (len(s["nodes"]) - 1) + 0.05 * rng.normal()
+        sf = L.splines["ee-force_%d" % ee]
+        for nd in sf["nodes"]:
+            for k, i in nd.items():
+                x[i] = rng.normal() * 80.0 + (200.0 if k == (0, 2) else 0.0)
+    return x
+
+
+_CTX = {}
+
+
+def _col(j):
+    L, terrain, x = _CTX["L"], _CTX["terrain"], _CTX["x"]
+    h = mpf(10) ** (-15)
+    xp = list(x)
+    xm = list(x)
+    xp[j] += h
+    xm[j] -= h
+    gp = constraints(L, terrain, xp)
+    gm = constraints(L, terrain, xm)
+    col = [(a - b) / (2 * h) for a, b in zip(gp, gm)]
+    return j, [(i, float(v)) for i, v in enumerate(col) if abs(v) > mpf(10) ** (-25)]
+
+
+def generate(name, spec, outdir, procs=8):
+    pd, con = spec["phases"]
+    L = Layout(spec["robot"], pd, con)
+    x64 = make_x(L, spec["seed"])
+    x = [mpf(float(v)) for v in x64]
+    _CTX.update(L=L, terrain=spec["terrain"], x=x)
+    g = constraints(L, spec["terrain"], x)
+    with Pool(procs) as pool:
+        cols = pool.map(_col, range(L.n), chunksize=4)
+    rows, cidx, vals = [], [], []
+    for j, ent in cols:
+        for i, v in ent:
+            rows.append(i)
+            cidx.append(j)
+            vals.append(v)
+    np.savez_compressed(
+        os.path.join(outdir, "mp_%s.npz" % name), robot=spec["robot"], terrain=spec["terrain"],
+        n_phases=np.array([len(p) for p in pd]), phase_durations=np.concatenate([np.array(p) for p in pd]),
+        contact_at_start=np.array(con), x=x64, g=np.array([float(v) for v in g]),
+        jac_row=np.array(rows, dtype=np.int32), jac_col=np.array(cidx, dtype=np.int32), jac_val=np.array(vals))
+    print(name, "n", L.n, "m", len(g), "nnz(true)", len(vals), flush=True)
+
+
+if __name__ == "__main__":
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+    os.makedirs(out, exist_ok=True)
+    only = sys.argv[1:]
+    for name, spec in cases().items():
+        if only and name not in only:
+            continue
+        generate(name, spec, out)

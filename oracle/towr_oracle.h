@@ -1,0 +1,76 @@
+// TEST INFRASTRUCTURE ONLY -- CPU oracle for the towr NLP constraint/Jacobian path.
+//
+// A plain C++ restatement (no Eigen, no ifopt) of the reference algorithm in
+// /root/reference/towr (KaiNakamura/towr @ 2025-05-23).  Only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it; the product
+// library (towr_amd/csrc) never includes, links or calls anything in oracle/.
+//
+// PARITY UNPINNED by the reference's own tests: the reference ships no golden
+// vectors (towr/test/dynamic_model_test.cc:36-49 and dynamic_constraint_test.cc:40-43
+// are empty stubs) and cannot be compiled here (needs Eigen3 + ifopt, both absent,
+// no network).  What pins this oracle instead (tests/test_oracle_*.py):
+//   * central finite differences of oracle g(x) vs oracle Jacobian,
+//   * an independent mpmath implementation of g(x) with 40-digit numerical
+//     differentiation (oracle/mp_ref.py -> tests/golden/*.json),
+//   * hand known-answers derived from the cited reference lines.
+//
+// C interface (flat arrays, used from Python via ctypes).
+#pragma once
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_problem orc_problem;
+
+// robot: 0 Monoped, 1 Biped, 2 Hyq, 3 Anymal, 4 Go1   (towr/src/robot_model.cc:41-68)
+// terrain: 0 Flat,1 Block,2 Stairs,3 Gap,4 Slope,5 Chimney,6 ChimneyLR (height_map.h:79-86)
+// phase_durations: concatenated per-ee phase durations, n_phases[ee] entries each.
+orc_problem* orc_create(int robot, int terrain, int n_ee, const int* n_phases,
+                        const double* phase_durations, const int* in_contact_at_start,
+                        double dt_dynamic, double dt_rom, double duration_base_poly,
+                        int polys_per_swing, int polys_per_stance_force,
+                        double force_limit);
+void orc_destroy(orc_problem*);
+
+int orc_n_vars(const orc_problem*);
+int orc_n_rows(const orc_problem*);
+int orc_n_var_sets(const orc_problem*);
+int orc_n_con_sets(const orc_problem*);
+const char* orc_var_set_name(const orc_problem*, int i);
+int orc_var_set_size(const orc_problem*, int i);
+const char* orc_con_set_name(const orc_problem*, int i);
+int orc_con_set_rows(const orc_problem*, int i);
+
+// reference initial guess (nlp_formulation.cc:95-181); state arrays are 3 doubles.
+void orc_initial_guess(orc_problem*, const double* base_lin0, const double* base_ang0,
+                       const double* base_lin1, const double* base_ang1,
+                       const double* ee_pos0 /* n_ee*3 */, double* x_out);
+
+// one full callback: SetVariables(x); g = stacked GetValues(); J = stacked GetJacobian().
+// Jacobian returned as CSR over the stacked rows (columns ascending in each row, explicit
+// zeros kept) exactly as ifopt::Problem::EvalNonzerosOfJacobian would copy it out.
+// Returns nnz.  Pass NULL outputs to query sizes only.
+int orc_eval(orc_problem*, const double* x, double* g, int* row_ptr, int* col_idx, double* vals);
+void orc_bounds(orc_problem*, double* lower, double* upper);
+
+// reference-shaped timing loop for bench.py's cpu_baseline: `iters` full callbacks on
+// x (values + Jacobian), returns seconds.
+double orc_time_callbacks(orc_problem*, const double* x, int iters);
+
+// gait generator restatement (gait_generator.cc:54-105, *_gait_generator.cc).
+// Fills per-ee phase durations for combo `combo` scaled to t_total; returns the
+// number of doubles written to out (concatenated), n_phases[ee] and contact[ee].
+int orc_gait(int n_ee, int combo, double t_total, int* n_phases, int* contact_at_start,
+             double* out, int out_cap);
+
+// small probes used by known-answer tests
+void orc_hermite_weights(double t, double T, double w[12]);   // d{p,v,a}/d{p0,v0,p1,v1}
+double orc_terrain_height(int terrain, double x, double y);
+void orc_terrain_basis(int terrain, int which, double x, double y, double out[3]);
+void orc_terrain_dbasis(int terrain, int which, int dim, double x, double y, double out[3]);
+
+#ifdef __cplusplus
+}
+#endif
