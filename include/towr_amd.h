@@ -1,0 +1,150 @@
+/* towr_amd -- MI355X-native evaluation of towr's NLP constraint / Jacobian hot path.
+ *
+ * C ABI of libtowr_amd.so.  Plain pointers and sizes only; no C++/torch types.
+ * Every entry point names the reference interface it replaces (file:line under
+ * KaiNakamura/towr).  The reference has no C ABI: the path sits
+ * behind the C++ virtual interface ifopt::ConstraintSet, so the binding a maintainer adds
+ * is the small C++ adapter shown in INTEGRATION.md (towr_amd/csrc/ifopt_adapter.h).
+ *
+ * Conventions
+ *   - all functions return TWR_OK (0) or a negative error code; twr_last_error() gives
+ *     the message of the last failure on the calling thread.  No exceptions cross the ABI.
+ *   - handles are thread-compatible: distinct handles may be used from distinct threads.
+ *   - "x" is the stacked ifopt variable vector in the reference order
+ *        base-lin | base-ang | ee-motion_0.. | ee-force_0..      (nlp_formulation.cc:68-82)
+ *     "g" are the stacked constraint values and "jac" the Jacobian non-zeros in the CSR
+ *     order ifopt::Problem::EvalNonzerosOfJacobian copies out (row-major, columns
+ *     ascending, explicit structural zeros kept), for the constraint sets
+ *        terrain-ee-motion_e.. | dynamic | rangeofmotion-e.. | force-ee-force_e..
+ *     i.e. params_.constraints_ order (parameters.cc:55-60) restricted to the hot path.
+ */
+#ifndef TOWR_AMD_H_
+#define TOWR_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TWR_MAX_EE 4
+#define TWR_MAX_PHASES 32
+#define TWR_NAME_LEN 40
+
+enum { TWR_OK = 0, TWR_ERR_INVALID = -1, TWR_ERR_HIP = -2, TWR_ERR_NO_DEVICE = -3, TWR_ERR_INTERNAL = -4 };
+
+/* RobotModel::Robot (robot_model.h:70-75) */
+enum { TWR_ROBOT_MONOPED = 0, TWR_ROBOT_BIPED, TWR_ROBOT_HYQ, TWR_ROBOT_ANYMAL, TWR_ROBOT_GO1 };
+/* HeightMap::TerrainID (height_map.h:79-86) */
+enum { TWR_TERRAIN_FLAT = 0, TWR_TERRAIN_BLOCK, TWR_TERRAIN_STAIRS, TWR_TERRAIN_GAP, TWR_TERRAIN_SLOPE,
+       TWR_TERRAIN_CHIMNEY, TWR_TERRAIN_CHIMNEY_LR };
+enum { TWR_EVAL_VALUES = 1, TWR_EVAL_JACOBIAN = 2, TWR_EVAL_BOTH = 3 };
+
+/* Robot + terrain constants: the POD "model blob" that rank 0 broadcasts over RCCL.
+ * Replaces towr::RobotModel {KinematicModel, DynamicModel} + HeightMap::Ptr
+ * (robot_model.h:63-83, single_rigid_body_dynamics.h:66-77, height_map.h:71-137). */
+typedef struct twr_model {
+  int32_t n_ee;
+  int32_t terrain_id;
+  double mass;
+  double inertia[6];                    /* Ixx,Iyy,Izz,Ixy,Ixz,Iyz as given to SingleRigidBodyDynamics() */
+  double nominal_stance[TWR_MAX_EE][3]; /* KinematicModel::GetNominalStanceInBase */
+  double max_dev[3];                    /* KinematicModel::GetMaximumDeviationFromNominal */
+  double gravity;                       /* 9.80665, dynamic_model.cc:37 */
+  double friction;                      /* 0.5, height_map.h:136 */
+  double force_limit;                   /* Parameters::force_limit_in_normal_direction_, parameters.cc:48 */
+  double flat_height;                   /* FlatGround(height) */
+} twr_model;
+
+/* Contact schedule of one candidate: Parameters::ee_phase_durations_ / ee_in_contact_at_start_
+ * (parameters.h:168-171). */
+typedef struct twr_schedule {
+  int32_t n_ee;
+  int32_t n_phases[TWR_MAX_EE];
+  int32_t in_contact_at_start[TWR_MAX_EE];
+  double phase_durations[TWR_MAX_EE][TWR_MAX_PHASES];
+} twr_schedule;
+
+/* Discretisation parameters (parameters.cc:43-51). */
+typedef struct twr_params {
+  double dt_dynamic;            /* dt_constraint_dynamic_ (0.1) */
+  double dt_rom;                /* dt_constraint_range_of_motion_ (0.08) */
+  double duration_base_poly;    /* duration_base_polynomial_ (0.1) */
+  int32_t polys_per_swing;      /* ee_polynomials_per_swing_phase_ (2) */
+  int32_t polys_per_stance_force; /* force_polynomials_per_stance_phase_ (3) */
+} twr_params;
+
+typedef struct twr_sizes {
+  int32_t n_vars, n_rows, nnz;
+  int32_t n_var_sets, n_con_sets;
+  int32_t k_dynamic, k_rom;     /* TimeDiscretizationConstraint::GetNumberOfNodes */
+} twr_sizes;
+
+typedef struct twr_set_info {
+  char name[TWR_NAME_LEN];      /* ifopt component name, e.g. "rangeofmotion-2" */
+  int32_t offset;               /* first variable index / first row */
+  int32_t size;                 /* variables / rows */
+  int32_t nnz_offset, nnz;      /* constraint sets only */
+} twr_set_info;
+
+typedef struct twr_structure twr_structure; /* host: index maps + CSR pattern of one candidate */
+typedef struct twr_batch twr_batch;         /* device: tables of a batch of candidates */
+
+const char* twr_last_error(void);
+
+/* RobotModel(Robot) + HeightMap::MakeTerrain(id) + Parameters defaults (robot_model.cc:41-68,
+ * height_map.cc:37-50, parameters.cc:40-73). */
+int twr_model_preset(int robot, int terrain, twr_model* out);
+int twr_params_default(twr_params* out);
+
+/* GaitGenerator::MakeGaitGenerator(n_ee)->SetCombo(combo); GetPhaseDurations(T, ee);
+ * IsInContactAtStart(ee)  (gait_generator.cc:43-111, {monoped,biped,quadruped}_gait_generator.cc).
+ * swing_scale multiplies every table entry whose contact state has a foot in the air before the
+ * renormalisation to t_total (1.0 = reference tables); used to enumerate candidates. */
+int twr_gait_combo(int n_ee, int combo, double t_total, double swing_scale, twr_schedule* out);
+
+/* What NlpFormulation::GetVariableSets + GetConstraints + ifopt's LinkWithVariables compute once per
+ * problem (nlp_formulation.cc:63-93,200-331): variable index maps, time grids, active-polynomial
+ * tables and the x-independent CSR pattern of the stacked Jacobian. */
+int twr_structure_create(const twr_model* model, const twr_schedule* schedule, const twr_params* params,
+                         twr_structure** out);
+void twr_structure_destroy(twr_structure* s);
+int twr_structure_sizes(const twr_structure* s, twr_sizes* out);
+int twr_structure_var_set(const twr_structure* s, int i, twr_set_info* out);
+int twr_structure_con_set(const twr_structure* s, int i, twr_set_info* out);
+/* Library-owned, valid until twr_structure_destroy: CSR row_ptr[n_rows+1], col_idx[nnz]. */
+const int32_t* twr_structure_row_ptr(const twr_structure* s);
+const int32_t* twr_structure_col_idx(const twr_structure* s);
+/* ConstraintSet::GetBounds of the stacked sets (dynamic_constraint.cc:66-71,
+ * range_of_motion_constraint.cc:71-81, force_constraint.cc:91-105, terrain_constraint.cc:72-88). */
+int twr_structure_bounds(const twr_structure* s, double* lower, double* upper);
+/* Initial guess of NlpFormulation::Make{Base,Endeffector,Force}Variables (nlp_formulation.cc:95-181). */
+int twr_structure_initial_guess(const twr_structure* s, const double init_base_lin[3],
+                                const double init_base_ang[3], const double final_base_lin[3],
+                                const double final_base_ang[3], const double* init_ee_pos /* n_ee*3 */,
+                                double* x_out /* n_vars */);
+
+/* Upload the tables of a batch: problem p uses structs[struct_of_problem[p]].  device is the HIP
+ * device ordinal of this process (one process per GPU). */
+int twr_batch_create(const twr_structure* const* structs, int n_structs, const int32_t* struct_of_problem,
+                     int n_problems, int device, twr_batch** out);
+void twr_batch_destroy(twr_batch* b);
+int twr_batch_num_problems(const twr_batch* b);
+/* Ragged layout of the batch arrays, each n_problems+1 prefix sums in units of doubles:
+ * problem p owns x[x_off[p]..x_off[p+1]), g[g_off[p]..), jac[jac_off[p]..). */
+int twr_batch_layout(const twr_batch* b, int64_t* x_off, int64_t* g_off, int64_t* jac_off);
+
+/* One full NLP callback for every problem of the batch, device pointers in, device pointers out:
+ *   ifopt::Problem::EvaluateConstraints(x)        -> g     (TWR_EVAL_VALUES)
+ *   ifopt::Problem::EvalNonzerosOfJacobian(x,val) -> jac   (TWR_EVAL_JACOBIAN)
+ * i.e. Composite::SetVariables + {Terrain,Dynamic,RangeOfMotion,Force}Constraint::
+ * {GetValues, FillJacobianBlock}.  Asynchronous on `hip_stream` (hipStream_t, may be
+ * NULL for the default stream); no host synchronisation, capturable in a hipGraph. */
+int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, int flags, void* hip_stream);
+/* Convenience for single-problem / adapter use: host buffers, synchronous (H2D, eval, D2H). */
+int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_jac, int flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOWR_AMD_H_ */

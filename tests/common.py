@@ -1,0 +1,123 @@
+"""Shared helpers of the parity tests: case construction and the parity bar.
+
+Parity bar (BASELINE.json north_star: <= 1e-9 relative on constraint values and Jacobian
+non-zeros).  g is a residual and many Jacobian entries are sums with cancellation, so a pure
+relative test is ill-posed at (near-)zeros; every comparison therefore uses
+    |got - ref| <= RTOL*|ref| + FLOOR*scale
+with RTOL = 1e-9 and FLOOR = 1e-12 (1000x tighter than 1e-9) times the magnitude `scale` of
+the row the entry belongs to (max |ref| in that Jacobian row / in that constraint set for g).
+"""
+import numpy as np
+
+import towr_amd as ta
+from oracle import binding as ob
+
+RTOL = 1e-9
+FLOOR = 1e-12
+
+
+def row_scale(row_ptr, ref_vals):
+    m = len(row_ptr) - 1
+    sc = np.zeros(m)
+    absv = np.abs(ref_vals)
+    nz = row_ptr[1:] > row_ptr[:-1]
+    sc[nz] = np.maximum.reduceat(absv, row_ptr[:-1][nz])
+    return np.repeat(sc, np.diff(row_ptr))
+
+
+def set_scale(con_sets, ref_g):
+    sc = np.zeros_like(ref_g)
+    for s in con_sets:
+        a, b = s["offset"], s["offset"] + s["size"]
+        if b > a:
+            sc[a:b] = np.abs(ref_g[a:b]).max()
+    return sc
+
+
+def parity_violations(got, ref, scale):
+    err = np.abs(got - ref)
+    tol = RTOL * np.abs(ref) + FLOOR * scale
+    return np.nonzero(~(err <= tol))[0], err
+
+
+def assert_parity(S, got_g, got_j, ref_g, ref_j, what=""):
+    bad, err = parity_violations(got_g, ref_g, set_scale(S.con_sets, ref_g))
+    assert bad.size == 0, "%s: %d constraint values off, worst |err| %.3e at row %d" % (what, bad.size, err[bad].max(), bad[err[bad].argmax()])
+    bad, err = parity_violations(got_j, ref_j, row_scale(S.row_ptr, ref_j))
+    assert bad.size == 0, "%s: %d Jacobian values off, worst |err| %.3e at nz %d" % (what, bad.size, err[bad].max(), bad[err[bad].argmax()])
+
+
+class Case:
+    """One problem description realised both in the product (Structure) and in the oracle."""
+
+    def __init__(self, robot, terrain, sched, **params):
+        self.robot, self.terrain = robot, terrain
+        self.sched = sched
+        self.params = ta.params_default(**params)
+        self.model = ta.model_preset(robot, terrain)
+        self.S = ta.Structure(self.model, sched, self.params)
+        p = self.params
+        self.P = ob.OracleProblem(robot, terrain, sched.durations(), sched.contact(), dt_dynamic=p.dt_dynamic,
+                                  dt_rom=p.dt_rom, duration_base_poly=p.duration_base_poly,
+                                  polys_per_swing=p.polys_per_swing, polys_per_stance_force=p.polys_per_stance_force)
+
+    def nominal_start(self):
+        m = self.model
+        ee = [[m.nominal_stance[e][0], m.nominal_stance[e][1], 0.0] for e in range(m.n_ee)]
+        z = -m.nominal_stance[0][2]
+        return [0.0, 0.0, z], ee
+
+    def x_guess(self, goal_x=1.0):
+        lin0, ee = self.nominal_start()
+        return self.S.initial_guess(lin0, [0, 0, 0], [goal_x, 0.0, lin0[2]], [0, 0, 0], ee)
+
+    def x_perturbed(self, seed, goal_x=1.0, sigma=0.05):
+        """x0 + sigma*N(0,1)*scale (pos 0.1 m, vel 0.5 m/s, euler 0.2 rad, force 50 N)."""
+        x = self.x_guess(goal_x)
+        rng = np.random.default_rng(1234 + seed)
+        scale = np.ones(self.S.n)
+        for vs in self.S.var_sets:
+            a, b = vs["offset"], vs["offset"] + vs["size"]
+            if vs["name"] == "base-lin":
+                s = np.tile([0.1] * 3 + [0.5] * 3, vs["size"] // 6)
+            elif vs["name"] == "base-ang":
+                s = np.tile([0.2] * 3 + [0.5] * 3, vs["size"] // 6)
+            elif vs["name"].startswith("ee-motion"):
+                s = np.full(vs["size"], 0.1)
+            else:
+                s = np.full(vs["size"], 50.0)
+            scale[a:b] = s
+        return x + sigma * rng.normal(size=self.S.n) * scale
+
+    def x_wild(self, seed):
+        """Far-from-feasible point: large angles, footholds spread over the terrain features."""
+        rng = np.random.default_rng(99 + seed)
+        x = rng.normal(size=self.S.n) * 0.5
+        for vs in self.S.var_sets:
+            a, b = vs["offset"], vs["offset"] + vs["size"]
+            if vs["name"].startswith("ee-motion"):
+                x[a:b] = rng.uniform(-0.5, 3.0, size=b - a)
+            if vs["name"].startswith("ee-force"):
+                x[a:b] = rng.normal(size=b - a) * 150.0
+        return x
+
+
+def hopper_schedule():
+    return ta.schedule([[0.4, 0.2, 0.4, 0.2, 0.4, 0.2, 0.2]], [1])  # towr/test/hopper_example.cc:67-68
+
+
+def k_params(T, K):
+    """BASELINE: choose dt = T/(K-1.5) so that the reference rule floor(T/dt)+2 yields K nodes."""
+    dt = T / (K - 1.5)
+    return dict(dt_dynamic=dt, dt_rom=dt)
+
+
+def baseline_cases():
+    """The five BASELINE.json configs at sizes the oracle handles in seconds."""
+    return {
+        "C1_hopper": lambda: Case("monoped", "flat", hopper_schedule()),
+        "C2_biped_K100": lambda: Case("biped", "flat", ta.gait_combo(2, 0, 2.0), **k_params(2.0, 100)),
+        "C3_anymal_trot_K200": lambda: Case("anymal", "flat", ta.gait_combo(4, 1, 2.0), **k_params(2.0, 200)),
+        "C4_anymal_gap_K200": lambda: Case("anymal", "gap", ta.gait_combo(4, 2, 1.8, 0.9), **k_params(1.8, 200)),
+        "C4_anymal_stairs_K200": lambda: Case("anymal", "stairs", ta.gait_combo(4, 0, 2.4, 1.1), **k_params(2.4, 200)),
+    }

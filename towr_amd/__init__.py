@@ -1,0 +1,235 @@
+"""towr_amd -- MI355X-native evaluation of towr's NLP constraint/Jacobian callback.
+
+Thin ctypes layer over libtowr_amd.so (C ABI in include/towr_amd.h).  There is no CPU
+fallback: every evaluation runs the HIP kernels; importing on a box without the built
+library raises, evaluating without a GPU raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtowr_amd.so")
+
+MAX_EE, MAX_PHASES, NAME_LEN = 4, 32, 40
+ROBOTS = {"monoped": 0, "biped": 1, "hyq": 2, "anymal": 3, "go1": 4}
+TERRAINS = {"flat": 0, "block": 1, "stairs": 2, "gap": 3, "slope": 4, "chimney": 5, "chimney_lr": 6}
+EVAL_VALUES, EVAL_JACOBIAN, EVAL_BOTH = 1, 2, 3
+
+
+class Model(C.Structure):
+    _fields_ = [("n_ee", C.c_int32), ("terrain_id", C.c_int32), ("mass", C.c_double), ("inertia", C.c_double * 6),
+                ("nominal_stance", (C.c_double * 3) * MAX_EE), ("max_dev", C.c_double * 3), ("gravity", C.c_double),
+                ("friction", C.c_double), ("force_limit", C.c_double), ("flat_height", C.c_double)]
+
+
+class Schedule(C.Structure):
+    _fields_ = [("n_ee", C.c_int32), ("n_phases", C.c_int32 * MAX_EE), ("in_contact_at_start", C.c_int32 * MAX_EE),
+                ("phase_durations", (C.c_double * MAX_PHASES) * MAX_EE)]
+
+    def durations(self):
+        return [list(self.phase_durations[e][:self.n_phases[e]]) for e in range(self.n_ee)]
+
+    def contact(self):
+        return [int(self.in_contact_at_start[e]) for e in range(self.n_ee)]
+
+
+class Params(C.Structure):
+    _fields_ = [("dt_dynamic", C.c_double), ("dt_rom", C.c_double), ("duration_base_poly", C.c_double),
+                ("polys_per_swing", C.c_int32), ("polys_per_stance_force", C.c_int32)]
+
+
+class Sizes(C.Structure):
+    _fields_ = [("n_vars", C.c_int32), ("n_rows", C.c_int32), ("nnz", C.c_int32), ("n_var_sets", C.c_int32),
+                ("n_con_sets", C.c_int32), ("k_dynamic", C.c_int32), ("k_rom", C.c_int32)]
+
+
+class SetInfo(C.Structure):
+    _fields_ = [("name", C.c_char * NAME_LEN), ("offset", C.c_int32), ("size", C.c_int32),
+                ("nnz_offset", C.c_int32), ("nnz", C.c_int32)]
+
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+
+
+def build():
+    """Compile libtowr_amd.so for gfx950 with hipcc (in-tree)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libtowr_amd.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C towr_amd/csrc`")
+        L = C.CDLL(LIB_PATH)
+        L.twr_last_error.restype = C.c_char_p
+        L.twr_model_preset.argtypes = [C.c_int, C.c_int, C.POINTER(Model)]
+        L.twr_params_default.argtypes = [C.POINTER(Params)]
+        L.twr_gait_combo.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(Schedule)]
+        L.twr_structure_create.argtypes = [C.POINTER(Model), C.POINTER(Schedule), C.POINTER(Params),
+                                           C.POINTER(C.c_void_p)]
+        L.twr_structure_destroy.argtypes = [C.c_void_p]
+        L.twr_structure_destroy.restype = None
+        L.twr_structure_sizes.argtypes = [C.c_void_p, C.POINTER(Sizes)]
+        L.twr_structure_var_set.argtypes = [C.c_void_p, C.c_int, C.POINTER(SetInfo)]
+        L.twr_structure_con_set.argtypes = [C.c_void_p, C.c_int, C.POINTER(SetInfo)]
+        L.twr_structure_row_ptr.argtypes = [C.c_void_p]
+        L.twr_structure_row_ptr.restype = C.POINTER(C.c_int32)
+        L.twr_structure_col_idx.argtypes = [C.c_void_p]
+        L.twr_structure_col_idx.restype = C.POINTER(C.c_int32)
+        L.twr_structure_bounds.argtypes = [C.c_void_p, _dp, _dp]
+        L.twr_structure_initial_guess.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.twr_batch_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int,
+                                       C.POINTER(C.c_void_p)]
+        L.twr_batch_destroy.argtypes = [C.c_void_p]
+        L.twr_batch_destroy.restype = None
+        L.twr_batch_num_problems.argtypes = [C.c_void_p]
+        L.twr_batch_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.twr_batch_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.twr_batch_eval_host.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int]
+        _lib = L
+    return _lib
+
+
+class TowrError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise TowrError("towr_amd error %d: %s" % (rc, lib().twr_last_error().decode()))
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def model_preset(robot, terrain):
+    """RobotModel(robot) + HeightMap::MakeTerrain(terrain) as the POD model blob."""
+    m = Model()
+    r = ROBOTS[robot] if isinstance(robot, str) else robot
+    t = TERRAINS[terrain] if isinstance(terrain, str) else terrain
+    _check(lib().twr_model_preset(r, t, C.byref(m)))
+    return m
+
+
+def params_default(**kw):
+    p = Params()
+    _check(lib().twr_params_default(C.byref(p)))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def gait_combo(n_ee, combo, t_total, swing_scale=1.0):
+    s = Schedule()
+    _check(lib().twr_gait_combo(n_ee, combo, float(t_total), float(swing_scale), C.byref(s)))
+    return s
+
+
+def schedule(phase_durations, contact_at_start):
+    s = Schedule()
+    s.n_ee = len(phase_durations)
+    for e, pd in enumerate(phase_durations):
+        s.n_phases[e] = len(pd)
+        s.in_contact_at_start[e] = int(contact_at_start[e])
+        for i, d in enumerate(pd):
+            s.phase_durations[e][i] = float(d)
+    return s
+
+
+class Structure:
+    """x-independent part of one candidate (index maps, time tables, CSR pattern)."""
+
+    def __init__(self, model, sched, params=None):
+        params = params or params_default()
+        self._h = C.c_void_p()
+        self.model, self.schedule, self.params = model, sched, params
+        _check(lib().twr_structure_create(C.byref(model), C.byref(sched), C.byref(params), C.byref(self._h)))
+        sz = Sizes()
+        _check(lib().twr_structure_sizes(self._h, C.byref(sz)))
+        self.n, self.m, self.nnz = sz.n_vars, sz.n_rows, sz.nnz
+        self.k_dynamic, self.k_rom = sz.k_dynamic, sz.k_rom
+        self.n_ee = model.n_ee
+
+        def sets(fn, n):
+            out = []
+            for i in range(n):
+                si = SetInfo()
+                _check(fn(self._h, i, C.byref(si)))
+                out.append(dict(name=si.name.decode(), offset=si.offset, size=si.size, nnz_offset=si.nnz_offset,
+                                nnz=si.nnz))
+            return out
+
+        self.var_sets = sets(lib().twr_structure_var_set, sz.n_var_sets)
+        self.con_sets = sets(lib().twr_structure_con_set, sz.n_con_sets)
+        self.row_ptr = np.ctypeslib.as_array(lib().twr_structure_row_ptr(self._h), shape=(self.m + 1,)).copy()
+        self.col_idx = np.ctypeslib.as_array(lib().twr_structure_col_idx(self._h), shape=(self.nnz,)).copy()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().twr_structure_destroy(self._h)
+            self._h = None
+
+    @property
+    def algorithmic_bytes(self):
+        """read x once, write g once, write the Jacobian values once."""
+        return 8 * (self.n + self.m + self.nnz)
+
+    def bounds(self):
+        lo, up = np.zeros(self.m), np.zeros(self.m)
+        _check(lib().twr_structure_bounds(self._h, _d(lo), _d(up)))
+        return lo, up
+
+    def initial_guess(self, base_lin0, base_ang0, base_lin1, base_ang1, ee_pos0):
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (base_lin0, base_ang0, base_lin1, base_ang1)]
+        ee = np.ascontiguousarray(ee_pos0, dtype=np.float64).reshape(-1)
+        assert ee.size == 3 * self.n_ee
+        x = np.zeros(self.n)
+        _check(lib().twr_structure_initial_guess(self._h, _d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), _d(ee), _d(x)))
+        return x
+
+
+class Batch:
+    """Device tables of a batch of candidates; problem p uses structures[struct_of_problem[p]]."""
+
+    def __init__(self, structures, struct_of_problem=None, device=0):
+        if struct_of_problem is None:
+            struct_of_problem = list(range(len(structures)))
+        self.structures = list(structures)
+        self.struct_of_problem = np.ascontiguousarray(struct_of_problem, dtype=np.int32)
+        hs = (C.c_void_p * len(structures))(*[s._h for s in structures])
+        self._h = C.c_void_p()
+        _check(lib().twr_batch_create(hs, len(structures), self.struct_of_problem.ctypes.data_as(C.POINTER(C.c_int32)),
+                                      len(self.struct_of_problem), device, C.byref(self._h)))
+        self.device = device
+        self.n_problems = len(self.struct_of_problem)
+        xo = np.zeros(self.n_problems + 1, dtype=np.int64)
+        go, jo = xo.copy(), xo.copy()
+        p64 = C.POINTER(C.c_int64)
+        _check(lib().twr_batch_layout(self._h, xo.ctypes.data_as(p64), go.ctypes.data_as(p64), jo.ctypes.data_as(p64)))
+        self.x_off, self.g_off, self.jac_off = xo, go, jo
+        self.algorithmic_bytes = int(8 * (xo[-1] + go[-1] + jo[-1]))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().twr_batch_destroy(self._h)
+            self._h = None
+
+    def eval_device(self, d_x, d_g, d_jac, flags=EVAL_BOTH, stream=0):
+        """Asynchronous launch on raw device pointers (ints), e.g. torch tensors' data_ptr()."""
+        _check(lib().twr_batch_eval(self._h, C.c_void_p(d_x), C.c_void_p(d_g), C.c_void_p(d_jac), flags,
+                                    C.c_void_p(stream)))
+
+    def eval_host(self, x, flags=EVAL_BOTH):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.size == self.x_off[-1]
+        g = np.zeros(self.g_off[-1])
+        j = np.zeros(self.jac_off[-1])
+        _check(lib().twr_batch_eval_host(self._h, _d(x), _d(g), _d(j), flags))
+        return g, j

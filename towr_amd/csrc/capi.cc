@@ -1,0 +1,306 @@
+// C ABI of libtowr_amd.so (see include/towr_amd.h).  Host runtime: handles, error
+// reporting, device table upload, work-list construction and the launch.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "structure.h"
+
+namespace twr {
+hipError_t launch_eval(int n_ee, int n_work, const ProbRec* probs, const Work* work, const double* x, double* g,
+                       double* jac, int flags, hipStream_t stream);
+int stage_capacity_doubles();
+}  // namespace twr
+
+struct twr_structure {
+  twr::Structure s;
+};
+
+struct twr_batch {
+  int device = 0;
+  int n_problems = 0, n_ee = 0, n_work = 0;
+  std::vector<int64_t> x_off, g_off, j_off;  // n_problems+1
+  std::vector<void*> blobs;                  // device blobs, one per distinct structure
+  twr::ProbRec* d_probs = nullptr;
+  twr::Work* d_work = nullptr;
+  // lazily sized scratch for twr_batch_eval_host
+  double *d_x = nullptr, *d_g = nullptr, *d_j = nullptr;
+};
+
+namespace {
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define TWR_HIP(call)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess) throw std::runtime_error(std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+void copy_set(const twr::SetInfo& s, twr_set_info* out) {
+  std::memset(out, 0, sizeof(*out));
+  std::strncpy(out->name, s.name.c_str(), TWR_NAME_LEN - 1);
+  out->offset = s.offset;
+  out->size = s.size;
+  out->nnz_offset = s.nnz_offset;
+  out->nnz = s.nnz;
+}
+
+// Split the k range [0,K) of one constraint set into chunks whose CSR slice fits the LDS image.
+void chunk(const std::vector<int32_t>& row_ptr, int row0, int rows_per_k, int K, int cap, int prob, int kind, int ee,
+           std::vector<twr::Work>& out) {
+  int k0 = 0;
+  while (k0 < K) {
+    int k1 = k0;
+    while (k1 < K && k1 - k0 < 64 && row_ptr[row0 + rows_per_k * (k1 + 1)] - row_ptr[row0 + rows_per_k * k0] <= cap) ++k1;
+    if (k1 == k0) throw std::runtime_error("one time node exceeds the LDS staging capacity");
+    twr::Work w;
+    w.prob = prob;
+    w.kind = (int16_t)kind;
+    w.ee = (int16_t)ee;
+    w.k0 = k0;
+    w.cnt = k1 - k0;
+    out.push_back(w);
+    k0 = k1;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+const char* twr_last_error(void) { return g_err.c_str(); }
+
+int twr_model_preset(int robot, int terrain, twr_model* out) {
+  if (!out) return fail(TWR_ERR_INVALID, "null output");
+  try {
+    twr::ModelPreset(robot, terrain, out);
+    return TWR_OK;
+  } catch (const std::exception& e) {
+    return fail(TWR_ERR_INVALID, e.what());
+  }
+}
+
+int twr_params_default(twr_params* out) {
+  if (!out) return fail(TWR_ERR_INVALID, "null output");
+  out->dt_dynamic = 0.1;  // parameters.cc:43-50
+  out->dt_rom = 0.08;
+  out->duration_base_poly = 0.1;
+  out->polys_per_swing = 2;
+  out->polys_per_stance_force = 3;
+  return TWR_OK;
+}
+
+int twr_gait_combo(int n_ee, int combo, double t_total, double swing_scale, twr_schedule* out) {
+  if (!out) return fail(TWR_ERR_INVALID, "null output");
+  try {
+    if (!(t_total > 0) || !(swing_scale > 0)) throw std::runtime_error("t_total and swing_scale must be positive");
+    twr::GaitCombo(n_ee, combo, t_total, swing_scale, out);
+    return TWR_OK;
+  } catch (const std::exception& e) {
+    return fail(TWR_ERR_INVALID, e.what());
+  }
+}
+
+int twr_structure_create(const twr_model* model, const twr_schedule* schedule, const twr_params* params,
+                         twr_structure** out) {
+  if (!model || !schedule || !params || !out) return fail(TWR_ERR_INVALID, "null argument");
+  try {
+    std::unique_ptr<twr_structure> h(new twr_structure());
+    h->s.model = *model;
+    h->s.schedule = *schedule;
+    h->s.params = *params;
+    if (params->polys_per_swing < 1 || params->polys_per_stance_force < 1)
+      throw std::runtime_error("polynomials per phase must be >= 1");
+    h->s.Build();
+    *out = h.release();
+    return TWR_OK;
+  } catch (const std::exception& e) {
+    return fail(TWR_ERR_INVALID, e.what());
+  }
+}
+
+void twr_structure_destroy(twr_structure* s) { delete s; }
+
+int twr_structure_sizes(const twr_structure* s, twr_sizes* out) {
+  if (!s || !out) return fail(TWR_ERR_INVALID, "null argument");
+  out->n_vars = s->s.n_vars;
+  out->n_rows = s->s.n_rows;
+  out->nnz = s->s.nnz;
+  out->n_var_sets = (int)s->s.var_sets.size();
+  out->n_con_sets = (int)s->s.con_sets.size();
+  out->k_dynamic = (int)s->s.grid_dyn.size();
+  out->k_rom = (int)s->s.grid_rom.size();
+  return TWR_OK;
+}
+
+int twr_structure_var_set(const twr_structure* s, int i, twr_set_info* out) {
+  if (!s || !out || i < 0 || i >= (int)s->s.var_sets.size()) return fail(TWR_ERR_INVALID, "bad variable set index");
+  copy_set(s->s.var_sets[i], out);
+  return TWR_OK;
+}
+
+int twr_structure_con_set(const twr_structure* s, int i, twr_set_info* out) {
+  if (!s || !out || i < 0 || i >= (int)s->s.con_sets.size()) return fail(TWR_ERR_INVALID, "bad constraint set index");
+  copy_set(s->s.con_sets[i], out);
+  return TWR_OK;
+}
+
+const int32_t* twr_structure_row_ptr(const twr_structure* s) { return s ? s->s.row_ptr.data() : nullptr; }
+const int32_t* twr_structure_col_idx(const twr_structure* s) { return s ? s->s.col_idx.data() : nullptr; }
+
+int twr_structure_bounds(const twr_structure* s, double* lower, double* upper) {
+  if (!s || !lower || !upper) return fail(TWR_ERR_INVALID, "null argument");
+  std::memcpy(lower, s->s.lower.data(), s->s.lower.size() * sizeof(double));
+  std::memcpy(upper, s->s.upper.data(), s->s.upper.size() * sizeof(double));
+  return TWR_OK;
+}
+
+int twr_structure_initial_guess(const twr_structure* s, const double init_base_lin[3], const double init_base_ang[3],
+                                const double final_base_lin[3], const double final_base_ang[3],
+                                const double* init_ee_pos, double* x_out) {
+  if (!s || !init_base_lin || !init_base_ang || !final_base_lin || !final_base_ang || !init_ee_pos || !x_out)
+    return fail(TWR_ERR_INVALID, "null argument");
+  try {
+    s->s.InitialGuess(init_base_lin, init_base_ang, final_base_lin, final_base_ang, init_ee_pos, x_out);
+    return TWR_OK;
+  } catch (const std::exception& e) {
+    return fail(TWR_ERR_INVALID, e.what());
+  }
+}
+
+int twr_batch_create(const twr_structure* const* structs, int n_structs, const int32_t* struct_of_problem,
+                     int n_problems, int device, twr_batch** out) {
+  if (!structs || !struct_of_problem || !out || n_structs < 1 || n_problems < 1)
+    return fail(TWR_ERR_INVALID, "bad arguments");
+  std::unique_ptr<twr_batch> b(new twr_batch());
+  try {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+      return fail(TWR_ERR_NO_DEVICE, "no HIP device visible: towr_amd has no CPU fallback");
+    if (device < 0 || device >= n_dev) return fail(TWR_ERR_INVALID, "device ordinal out of range");
+    TWR_HIP(hipSetDevice(device));
+    b->device = device;
+    b->n_problems = n_problems;
+    b->n_ee = structs[0]->s.n_ee;
+    for (int i = 0; i < n_structs; ++i) {
+      if (!structs[i]) throw std::runtime_error("null structure");
+      if (structs[i]->s.n_ee != b->n_ee) throw std::runtime_error("all structures of a batch must share n_ee");
+      void* d = nullptr;
+      TWR_HIP(hipMalloc(&d, structs[i]->s.blob.size()));
+      b->blobs.push_back(d);
+      TWR_HIP(hipMemcpy(d, structs[i]->s.blob.data(), structs[i]->s.blob.size(), hipMemcpyHostToDevice));
+    }
+    b->x_off.assign(n_problems + 1, 0);
+    b->g_off.assign(n_problems + 1, 0);
+    b->j_off.assign(n_problems + 1, 0);
+    std::vector<twr::ProbRec> probs(n_problems);
+    std::vector<twr::Work> dyn, rom, node;
+    const int cap = twr::stage_capacity_doubles();
+    // chunk lists are identical for problems that share a structure: build once per structure
+    std::vector<std::vector<twr::Work>> tmpl_dyn(n_structs), tmpl_rom(n_structs);
+    for (int i = 0; i < n_structs; ++i) {
+      const twr::Structure& S = structs[i]->s;
+      int ci = S.n_ee;  // con_sets: terrain x n_ee, dynamic, rom x n_ee, force x n_ee
+      chunk(S.row_ptr, S.con_sets[ci].offset, 6, (int)S.grid_dyn.size(), cap, 0, 0, 0, tmpl_dyn[i]);
+      for (int e = 0; e < S.n_ee; ++e)
+        chunk(S.row_ptr, S.con_sets[ci + 1 + e].offset, 3, (int)S.grid_rom.size(), cap, 0, 1, e, tmpl_rom[i]);
+    }
+    for (int p = 0; p < n_problems; ++p) {
+      int si = struct_of_problem[p];
+      if (si < 0 || si >= n_structs) throw std::runtime_error("struct_of_problem out of range");
+      const twr::Structure& S = structs[si]->s;
+      b->x_off[p + 1] = b->x_off[p] + S.n_vars;
+      b->g_off[p + 1] = b->g_off[p] + S.n_rows;
+      b->j_off[p + 1] = b->j_off[p] + S.nnz;
+      probs[p].blob = reinterpret_cast<uint64_t>(b->blobs[si]);
+      probs[p].x_off = b->x_off[p];
+      probs[p].g_off = b->g_off[p];
+      probs[p].j_off = b->j_off[p];
+      for (twr::Work w : tmpl_dyn[si]) { w.prob = p; dyn.push_back(w); }
+      for (twr::Work w : tmpl_rom[si]) { w.prob = p; rom.push_back(w); }
+      twr::Work w;
+      w.prob = p; w.kind = 2; w.ee = 0; w.k0 = 0; w.cnt = 0;
+      node.push_back(w);
+    }
+    // heaviest workgroups first (dynamic), the small node blocks fill the tail
+    std::vector<twr::Work> work;
+    work.reserve(dyn.size() + rom.size() + node.size());
+    work.insert(work.end(), dyn.begin(), dyn.end());
+    work.insert(work.end(), rom.begin(), rom.end());
+    work.insert(work.end(), node.begin(), node.end());
+    b->n_work = (int)work.size();
+    TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_probs), probs.size() * sizeof(twr::ProbRec)));
+    TWR_HIP(hipMemcpy(b->d_probs, probs.data(), probs.size() * sizeof(twr::ProbRec), hipMemcpyHostToDevice));
+    TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_work), work.size() * sizeof(twr::Work)));
+    TWR_HIP(hipMemcpy(b->d_work, work.data(), work.size() * sizeof(twr::Work), hipMemcpyHostToDevice));
+    *out = b.release();
+    return TWR_OK;
+  } catch (const std::exception& e) {
+    twr_batch_destroy(b.release());
+    return fail(TWR_ERR_HIP, e.what());
+  }
+}
+
+void twr_batch_destroy(twr_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  for (void* d : b->blobs) (void)hipFree(d);
+  if (b->d_probs) (void)hipFree(b->d_probs);
+  if (b->d_work) (void)hipFree(b->d_work);
+  if (b->d_x) (void)hipFree(b->d_x);
+  if (b->d_g) (void)hipFree(b->d_g);
+  if (b->d_j) (void)hipFree(b->d_j);
+  delete b;
+}
+
+int twr_batch_num_problems(const twr_batch* b) { return b ? b->n_problems : 0; }
+
+int twr_batch_layout(const twr_batch* b, int64_t* x_off, int64_t* g_off, int64_t* jac_off) {
+  if (!b) return fail(TWR_ERR_INVALID, "null batch");
+  size_t bytes = (b->n_problems + 1) * sizeof(int64_t);
+  if (x_off) std::memcpy(x_off, b->x_off.data(), bytes);
+  if (g_off) std::memcpy(g_off, b->g_off.data(), bytes);
+  if (jac_off) std::memcpy(jac_off, b->j_off.data(), bytes);
+  return TWR_OK;
+}
+
+int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, int flags, void* hip_stream) {
+  if (!b || !d_x) return fail(TWR_ERR_INVALID, "null argument");
+  if ((flags & TWR_EVAL_BOTH) == 0) return fail(TWR_ERR_INVALID, "flags select nothing");
+  if (((flags & TWR_EVAL_VALUES) && !d_g) || ((flags & TWR_EVAL_JACOBIAN) && !d_jac))
+    return fail(TWR_ERR_INVALID, "missing output buffer");
+  hipError_t e = twr::launch_eval(b->n_ee, b->n_work, b->d_probs, b->d_work, d_x, d_g, d_jac, flags & TWR_EVAL_BOTH,
+                                  static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  return TWR_OK;
+}
+
+int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_jac, int flags) {
+  if (!b || !h_x) return fail(TWR_ERR_INVALID, "null argument");
+  try {
+    TWR_HIP(hipSetDevice(b->device));
+    const size_t nx = b->x_off.back(), ng = b->g_off.back(), nj = b->j_off.back();
+    if (!b->d_x) {
+      TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_x), nx * sizeof(double)));
+      TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_g), ng * sizeof(double)));
+      TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_j), nj * sizeof(double)));
+    }
+    TWR_HIP(hipMemcpy(b->d_x, h_x, nx * sizeof(double), hipMemcpyHostToDevice));
+    int rc = twr_batch_eval(b, b->d_x, b->d_g, b->d_j, flags, nullptr);
+    if (rc != TWR_OK) return rc;
+    TWR_HIP(hipDeviceSynchronize());
+    if ((flags & TWR_EVAL_VALUES) && h_g) TWR_HIP(hipMemcpy(h_g, b->d_g, ng * sizeof(double), hipMemcpyDeviceToHost));
+    if ((flags & TWR_EVAL_JACOBIAN) && h_jac) TWR_HIP(hipMemcpy(h_jac, b->d_j, nj * sizeof(double), hipMemcpyDeviceToHost));
+    return TWR_OK;
+  } catch (const std::exception& e) {
+    return fail(TWR_ERR_HIP, e.what());
+  }
+}
+
+}  // extern "C"

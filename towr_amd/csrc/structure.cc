@@ -1,0 +1,711 @@
+// Host-side structure builder.  Closed-form restatement of the reference's setup-time
+// logic; nothing here touches x.  Citations are file:line under /root/reference/towr/.
+#include "structure.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <stdexcept>
+
+namespace twr {
+
+namespace {
+
+// Spline::GetSegmentID + GetLocalTime (src/spline.cc:48-78): eps 1e-10, the previous segment wins
+// at junctions, local time by sequential subtraction.  Must be reproduced bit for bit because the
+// active polynomial decides which Jacobian columns exist.
+TimeNode Locate(double t_global, const std::vector<double>& durations) {
+  const double eps = 1e-10;
+  double t = 0;
+  int id = -1;
+  for (size_t i = 0; i < durations.size(); ++i) {
+    t += durations[i];
+    if (t >= t_global - eps) {
+      id = (int)i;
+      break;
+    }
+  }
+  if (id < 0) throw std::runtime_error("time grid exceeds spline duration");
+  double t_local = t_global;
+  for (int i = 0; i < id; ++i) t_local -= durations[i];
+  return {id, t_local};
+}
+
+// TimeDiscretizationConstraint ctor (src/time_discretization_constraint.cc:37-50)
+std::vector<double> TimeGrid(double T, double dt) {
+  if (!(dt > 0)) throw std::runtime_error("dt must be positive");
+  double t = 0.0;
+  std::vector<double> g = {t};
+  for (int i = 0; i < std::floor(T / dt); ++i) {
+    t += dt;
+    g.push_back(t);
+  }
+  g.push_back(T);
+  return g;
+}
+
+struct PolyPhase {
+  int phase;
+  bool constant;
+  int n_in_phase;
+};
+
+// BuildPolyInfos (src/nodes_variables_phase_based.cc:38-58)
+std::vector<PolyPhase> PhasePolys(int n_phases, bool first_constant, int n_changing) {
+  std::vector<PolyPhase> v;
+  bool c = first_constant;
+  for (int ph = 0; ph < n_phases; ++ph) {
+    if (c)
+      v.push_back({ph, true, 1});
+    else
+      for (int j = 0; j < n_changing; ++j) v.push_back({ph, false, n_changing});
+    c = !c;
+  }
+  return v;
+}
+
+// NodesVariablesEEMotion / NodesVariablesEEForce::GetPhaseBasedEEParameterization
+// (src/nodes_variables_phase_based.cc:210-298) as a direct index assignment.
+SplineLayout PhaseBasedLayout(const double* phase_durations, int n_phases, bool first_constant, int n_changing,
+                              bool is_motion, int var_offset) {
+  SplineLayout s;
+  auto polys = PhasePolys(n_phases, first_constant, n_changing);
+  for (auto& p : polys) {
+    s.durations.push_back(phase_durations[p.phase] / p.n_in_phase);  // ConvertPhaseToPolyDurations :73-84
+    s.poly_phase.push_back(p.phase);
+  }
+  s.n_nodes = (int)polys.size() + 1;
+  s.idx.assign(s.n_nodes * 6, -1);
+  s.node_constant.assign(s.n_nodes, 0);
+  for (int n = 0; n < s.n_nodes; ++n) {  // IsConstantNode :99-111
+    bool c = false;
+    if (n > 0 && polys[n - 1].constant) c = true;
+    if (n < s.n_nodes - 1 && polys[n].constant) c = true;
+    s.node_constant[n] = c;
+  }
+  int idx = var_offset;
+  auto set = [&](int node, int deriv, int dim, int v) { s.idx[(node * 2 + deriv) * 3 + dim] = v; };
+  for (int n = 0; n < s.n_nodes; ++n) {
+    if (!s.node_constant[n]) {
+      for (int d = 0; d < 3; ++d) {
+        set(n, 0, d, idx++);
+        if (is_motion) {
+          if (d != 2) set(n, 1, d, idx++);  // swing: z velocity fixed to zero
+        } else {
+          set(n, 1, d, idx++);
+        }
+      }
+    } else {
+      if (n + 1 >= s.n_nodes) throw std::runtime_error("dangling constant node");
+      if (is_motion)
+        for (int d = 0; d < 3; ++d) {  // one position shared by both nodes of the stance polynomial
+          set(n, 0, d, idx);
+          set(n + 1, 0, d, idx);
+          idx++;
+        }
+      n += 1;
+    }
+  }
+  s.var_offset = var_offset;
+  s.var_size = idx - var_offset;
+  return s;
+}
+
+EePoly MakeEePoly(const SplineLayout& s, int q) {
+  EePoly p;
+  std::memset(&p, 0, sizeof(p));
+  p.T = s.durations[q];
+  int gi[12];
+  bool shared = true;
+  for (int d = 0; d < 3; ++d)
+    if (s.at(q, 0, d) < 0 || s.at(q, 0, d) != s.at(q + 1, 0, d)) shared = false;
+  std::vector<int> uniq;
+  for (int j = 0; j < 4; ++j)
+    for (int d = 0; d < 3; ++d) {
+      int node = q + (j >= 2 ? 1 : 0), deriv = j & 1;
+      int v = s.at(node, deriv, d);
+      if (shared && j == 2) v = -1;  // folded into p0
+      gi[j * 3 + d] = v;
+      if (v >= 0) uniq.push_back(v);
+    }
+  std::sort(uniq.begin(), uniq.end());
+  uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+  if (uniq.size() > 12) throw std::runtime_error("too many slots");
+  p.nslots = (uint8_t)uniq.size();
+  p.xbase = uniq.empty() ? 0 : uniq.front();
+  for (size_t i = 0; i < uniq.size(); ++i)
+    if (uniq[i] != p.xbase + (int)i) throw std::runtime_error("polynomial variables not contiguous");
+  int dim_of_slot[12];
+  for (int c = 0; c < 12; ++c)
+    if (gi[c] >= 0) dim_of_slot[gi[c] - p.xbase] = c % 3;
+  for (int sl = 0; sl < p.nslots; ++sl) p.cnt[dim_of_slot[sl]]++;
+  for (int c = 0; c < 12; ++c) {
+    if (gi[c] < 0) {
+      p.cand[c] = 0xFFFF;
+      continue;
+    }
+    int sl = gi[c] - p.xbase, d = c % 3;
+    int ra = 0, rb = 0, rl = 0;
+    for (int s2 = 0; s2 < sl; ++s2) {
+      if (dim_of_slot[s2] != (d + 1) % 3) ra++;
+      if (dim_of_slot[s2] != (d + 2) % 3) rb++;
+      if (dim_of_slot[s2] == d) rl++;
+    }
+    p.cand[c] = (uint16_t)(sl | (ra << 4) | (rb << 8) | (rl << 12));
+  }
+  p.shared = shared ? 1 : 0;
+  return p;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ variables
+void Structure::BuildVariables() {
+  n_ee = schedule.n_ee;
+  if (n_ee < 1 || n_ee > kMaxEE || n_ee != model.n_ee) throw std::runtime_error("n_ee mismatch");
+  for (int e = 0; e < n_ee; ++e)
+    if (schedule.n_phases[e] < 1 || schedule.n_phases[e] > TWR_MAX_PHASES) throw std::runtime_error("bad phase count");
+  // Parameters::GetTotalTime (src/parameters.cc:112-126): first foot is the reference
+  T = std::accumulate(schedule.phase_durations[0], schedule.phase_durations[0] + schedule.n_phases[0], 0.0);
+  for (int e = 0; e < n_ee; ++e) {
+    double Te = std::accumulate(schedule.phase_durations[e], schedule.phase_durations[e] + schedule.n_phases[e], 0.0);
+    if (std::fabs(Te - T) >= 1e-6) throw std::runtime_error("phase durations of the feet do not sum to the same T");
+  }
+  // Parameters::GetBasePolyDurations (src/parameters.cc:82-98)
+  {
+    double dt = params.duration_base_poly, t_left = T;
+    if (!(dt > 0)) throw std::runtime_error("duration_base_poly must be positive");
+    while (t_left > 1e-10) {
+      base.durations.push_back(t_left > dt ? dt : t_left);
+      t_left -= dt;
+    }
+  }
+  // NodesVariablesAll (src/nodes_variables_all.cc:34-61): node-major, px py pz vx vy vz
+  base.n_nodes = (int)base.durations.size() + 1;
+  base.idx.resize(base.n_nodes * 6);
+  for (int n = 0; n < base.n_nodes; ++n)
+    for (int dv = 0; dv < 2; ++dv)
+      for (int d = 0; d < 3; ++d) base.idx[(n * 2 + dv) * 3 + d] = 6 * n + 3 * dv + d;
+  base.var_size = base.n_nodes * 6;
+  // variable set order: NlpFormulation::GetVariableSets (src/nlp_formulation.cc:63-93)
+  int off = 0;
+  off_base_lin = off;
+  var_sets.push_back({"base-lin", off, base.var_size, 0, 0});
+  off += base.var_size;
+  off_base_ang = off;
+  var_sets.push_back({"base-ang", off, base.var_size, 0, 0});
+  off += base.var_size;
+  for (int e = 0; e < n_ee; ++e) {  // MakeEndeffectorVariables :127-156 (stance phases constant)
+    motion.push_back(PhaseBasedLayout(schedule.phase_durations[e], schedule.n_phases[e],
+                                      schedule.in_contact_at_start[e] != 0, params.polys_per_swing, true, off));
+    var_sets.push_back({"ee-motion_" + std::to_string(e), off, motion.back().var_size, 0, 0});
+    off += motion.back().var_size;
+  }
+  for (int e = 0; e < n_ee; ++e) {  // MakeForceVariables :158-181 (swing phases constant)
+    force.push_back(PhaseBasedLayout(schedule.phase_durations[e], schedule.n_phases[e],
+                                     schedule.in_contact_at_start[e] == 0, params.polys_per_stance_force, false, off));
+    var_sets.push_back({"ee-force_" + std::to_string(e), off, force.back().var_size, 0, 0});
+    off += force.back().var_size;
+  }
+  n_vars = off;
+  mpoly.resize(n_ee);
+  fpoly.resize(n_ee);
+  for (int e = 0; e < n_ee; ++e) {
+    for (size_t q = 0; q < motion[e].durations.size(); ++q) mpoly[e].push_back(MakeEePoly(motion[e], (int)q));
+    for (size_t q = 0; q < force[e].durations.size(); ++q) fpoly[e].push_back(MakeEePoly(force[e], (int)q));
+  }
+}
+
+// ------------------------------------------------------------------ time tables
+void Structure::BuildTimeTables() {
+  grid_dyn = TimeGrid(T, params.dt_dynamic);  // DynamicConstraint ctor, dynamic_constraint.cc:37-51
+  grid_rom = TimeGrid(T, params.dt_rom);      // RangeOfMotionConstraint ctor, range_of_motion_constraint.cc:35-50
+  dyn_motion.resize(n_ee);
+  dyn_force.resize(n_ee);
+  rom_motion.resize(n_ee);
+  for (double t : grid_dyn) {
+    dyn_base.push_back(Locate(t, base.durations));
+    for (int e = 0; e < n_ee; ++e) {
+      dyn_motion[e].push_back(Locate(t, motion[e].durations));
+      dyn_force[e].push_back(Locate(t, force[e].durations));
+    }
+  }
+  for (double t : grid_rom) {
+    rom_base.push_back(Locate(t, base.durations));
+    for (int e = 0; e < n_ee; ++e) rom_motion[e].push_back(Locate(t, motion[e].durations));
+  }
+  // force / terrain node tables
+  force_nodes.resize(n_ee);
+  terrain_rows.resize(n_ee);
+  for (int e = 0; e < n_ee; ++e) {
+    const SplineLayout& f = force[e];
+    const SplineLayout& m = motion[e];
+    for (int n = 0; n < f.n_nodes; ++n) {
+      if (f.node_constant[n]) continue;  // GetIndicesOfNonConstantNodes, nodes_variables_phase_based.cc:119-129
+      int adj_poly = n == 0 ? 0 : n - 1;  // GetPhase -> GetAdjacentPolyIds(node).front(), :131-138,163-179
+      int phase = f.poly_phase[adj_poly];
+      int start = -1;                     // GetNodeIDAtStartOfPhase, :140-161
+      for (size_t q = 0; q < m.poly_phase.size(); ++q)
+        if (m.poly_phase[q] == phase) {
+          start = (int)q;
+          break;
+        }
+      if (start < 0) throw std::runtime_error("stance phase missing in ee-motion");
+      ForceNode fn;
+      fn.fidx = f.at(n, 0, 0);
+      fn.hidx = m.at(start, 0, 0);
+      if (f.at(n, 0, 1) != fn.fidx + 2 || f.at(n, 0, 2) != fn.fidx + 4 || m.at(start, 0, 1) != fn.hidx + 1)
+        throw std::runtime_error("unexpected force node layout");
+      force_nodes[e].push_back(fn);
+    }
+    for (int n = 1; n < m.n_nodes; ++n) {  // terrain_constraint.cc:49-51
+      TerrainRow tr;
+      tr.idx = m.at(n, 0, 0);
+      tr.stride = m.at(n, 0, 1) - tr.idx;
+      if (m.at(n, 0, 2) != tr.idx + 2 * tr.stride) throw std::runtime_error("unexpected motion node layout");
+      terrain_rows[e].push_back(tr);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ CSR pattern + bounds
+void Structure::BuildPattern() {
+  const double inf = 1e20;
+  std::vector<std::vector<int>> rows;
+  auto begin_set = [&](const std::string& name, int n) {
+    SetInfo s;
+    s.name = name;
+    s.offset = (int)rows.size();
+    s.size = n;
+    con_sets.push_back(s);
+  };
+  auto slots_cols = [&](const EePoly& p, int want_dim, bool equal, std::vector<int>& out) {
+    // columns of the slots whose dim ==/!= want_dim, ascending
+    int dim_of_slot[12];
+    for (int c = 0; c < 12; ++c)
+      if (p.cand[c] != 0xFFFF) dim_of_slot[p.cand[c] & 0xF] = c % 3;
+    for (int s = 0; s < p.nslots; ++s)
+      if ((dim_of_slot[s] == want_dim) == equal) out.push_back(p.xbase + s);
+  };
+  // --- terrain-ee-motion_e  (terrain_constraint.cc:90-108): [x, y, z] of node id = row+1
+  for (int e = 0; e < n_ee; ++e) {
+    begin_set("terrain-ee-motion_" + std::to_string(e), (int)terrain_rows[e].size());
+    for (size_t r = 0; r < terrain_rows[e].size(); ++r) {
+      const TerrainRow& tr = terrain_rows[e][r];
+      rows.push_back({tr.idx, tr.idx + tr.stride, tr.idx + 2 * tr.stride});
+      bool constant = motion[e].node_constant[r + 1];
+      lower.push_back(0.0);
+      upper.push_back(constant ? 0.0 : inf);  // terrain_constraint.cc:72-88
+    }
+  }
+  // --- dynamic (dynamic_constraint.cc:73-117, single_rigid_body_dynamics.cc:103-192)
+  begin_set("dynamic", (int)grid_dyn.size() * 6);
+  for (size_t k = 0; k < grid_dyn.size(); ++k) {
+    int q = dyn_base[k].poly;
+    for (int r = 0; r < 3; ++r) {  // AX, AY, AZ
+      std::vector<int> c;
+      for (int node = q; node <= q + 1; ++node)  // -sum [f]x J_pos: dims != r, pos then vel per node
+        for (int dv = 0; dv < 2; ++dv)
+          for (int d = 0; d < 3; ++d)
+            if (d != r) c.push_back(off_base_lin + 6 * node + 3 * dv + d);
+      for (int i = 0; i < 12; ++i) c.push_back(off_base_ang + 6 * q + i);  // structurally full
+      for (int e = 0; e < n_ee; ++e) slots_cols(mpoly[e][dyn_motion[e][k].poly], r, false, c);  // [f]x J_p
+      for (int e = 0; e < n_ee; ++e) slots_cols(fpoly[e][dyn_force[e][k].poly], r, false, c);   // [r]x J_f
+      rows.push_back(c);
+      lower.push_back(0.0);
+      upper.push_back(0.0);
+    }
+    for (int d = 0; d < 3; ++d) {  // LX, LY, LZ
+      std::vector<int> c;
+      for (int j = 0; j < 4; ++j) c.push_back(off_base_lin + 6 * q + 3 * j + d);  // m J_acc
+      for (int e = 0; e < n_ee; ++e) slots_cols(fpoly[e][dyn_force[e][k].poly], d, true, c);  // -J_f
+      rows.push_back(c);
+      lower.push_back(0.0);
+      upper.push_back(0.0);
+    }
+  }
+  // --- rangeofmotion-e (range_of_motion_constraint.cc:83-109)
+  for (int e = 0; e < n_ee; ++e) {
+    begin_set("rangeofmotion-" + std::to_string(e), (int)grid_rom.size() * 3);
+    for (size_t k = 0; k < grid_rom.size(); ++k) {
+      int q = rom_base[k].poly;
+      const EePoly& mp = mpoly[e][rom_motion[e][k].poly];
+      for (int r = 0; r < 3; ++r) {
+        std::vector<int> c;
+        for (int i = 0; i < 12; ++i) c.push_back(off_base_lin + 6 * q + i);  // -R^T J_c
+        for (int i = 0; i < 12; ++i)  // DerivOfRotVecMult(inverse): row 0 does not depend on roll
+          if (!(r == 0 && i % 3 == 0)) c.push_back(off_base_ang + 6 * q + i);
+        for (int s = 0; s < mp.nslots; ++s) c.push_back(mp.xbase + s);  // R^T J_p
+        rows.push_back(c);
+        lower.push_back(model.nominal_stance[e][r] - model.max_dev[r]);  // :71-81
+        upper.push_back(model.nominal_stance[e][r] + model.max_dev[r]);
+      }
+    }
+  }
+  // --- force-ee-force_e (force_constraint.cc:107-171)
+  for (int e = 0; e < n_ee; ++e) {
+    begin_set("force-ee-force_" + std::to_string(e), (int)force_nodes[e].size() * 5);
+    for (const ForceNode& fn : force_nodes[e]) {
+      for (int r = 0; r < 5; ++r) rows.push_back({fn.hidx, fn.hidx + 1, fn.fidx, fn.fidx + 2, fn.fidx + 4});
+      lower.push_back(0.0);  upper.push_back(model.force_limit);  // :91-105
+      lower.push_back(-inf); upper.push_back(0.0);
+      lower.push_back(0.0);  upper.push_back(inf);
+      lower.push_back(-inf); upper.push_back(0.0);
+      lower.push_back(0.0);  upper.push_back(inf);
+    }
+  }
+  n_rows = (int)rows.size();
+  row_ptr.assign(n_rows + 1, 0);
+  for (int r = 0; r < n_rows; ++r) {
+    if (!std::is_sorted(rows[r].begin(), rows[r].end())) throw std::runtime_error("row not sorted");
+    row_ptr[r + 1] = row_ptr[r] + (int)rows[r].size();
+    col_idx.insert(col_idx.end(), rows[r].begin(), rows[r].end());
+  }
+  nnz = row_ptr[n_rows];
+  for (auto& s : con_sets) {
+    s.nnz_offset = row_ptr[s.offset];
+    s.nnz = row_ptr[s.offset + s.size] - s.nnz_offset;
+  }
+}
+
+// ------------------------------------------------------------------ device blob
+void Structure::PackBlob() {
+  DevStruct h;
+  std::memset(&h, 0, sizeof(h));
+  std::vector<char> body;
+  auto put = [&](const void* src, size_t bytes) -> uint32_t {
+    size_t off = (sizeof(DevStruct) + body.size() + 7) / 8 * 8;
+    body.resize(off - sizeof(DevStruct) + bytes);
+    if (bytes) std::memcpy(body.data() + off - sizeof(DevStruct), src, bytes);
+    return (uint32_t)off;
+  };
+  auto put_polys = [&](const std::vector<TimeNode>& v, uint32_t& o_poly, uint32_t& o_tl) {
+    std::vector<int32_t> p;
+    std::vector<double> t;
+    for (auto& n : v) {
+      p.push_back(n.poly);
+      t.push_back(n.t_local);
+    }
+    o_tl = put(t.data(), t.size() * 8);
+    o_poly = put(p.data(), p.size() * 4);
+  };
+  h.n_ee = n_ee; h.n_vars = n_vars; h.n_rows = n_rows; h.nnz = nnz;
+  h.k_dyn = (int)grid_dyn.size(); h.k_rom = (int)grid_rom.size();
+  h.off_base_lin = off_base_lin; h.off_base_ang = off_base_ang;
+  h.n_base_polys = (int)base.durations.size();
+  h.terrain_id = model.terrain_id;
+  int ci = 0;
+  for (int e = 0; e < n_ee; ++e, ++ci) {
+    h.row_terrain[e] = con_sets[ci].offset; h.nnz_terrain[e] = con_sets[ci].nnz_offset;
+    h.n_terrain_rows[e] = con_sets[ci].size;
+  }
+  h.row_dyn = con_sets[ci].offset; h.nnz_dyn = con_sets[ci].nnz_offset; ++ci;
+  for (int e = 0; e < n_ee; ++e, ++ci) { h.row_rom[e] = con_sets[ci].offset; h.nnz_rom[e] = con_sets[ci].nnz_offset; }
+  for (int e = 0; e < n_ee; ++e, ++ci) {
+    h.row_force[e] = con_sets[ci].offset; h.nnz_force[e] = con_sets[ci].nnz_offset;
+    h.n_force_nodes[e] = (int)force_nodes[e].size();
+  }
+  h.o_base_T = put(base.durations.data(), base.durations.size() * 8);
+  for (int e = 0; e < n_ee; ++e) {
+    h.o_mpoly[e] = put(mpoly[e].data(), mpoly[e].size() * sizeof(EePoly));
+    h.o_fpoly[e] = put(fpoly[e].data(), fpoly[e].size() * sizeof(EePoly));
+  }
+  put_polys(dyn_base, h.o_dyn_base_poly, h.o_dyn_tl_base);
+  {
+    std::vector<int32_t> vo(grid_dyn.size() + 1);
+    for (size_t k = 0; k <= grid_dyn.size(); ++k) vo[k] = row_ptr[h.row_dyn + 6 * k] - h.nnz_dyn;
+    h.o_dyn_val_off = put(vo.data(), vo.size() * 4);
+  }
+  for (int e = 0; e < n_ee; ++e) {
+    put_polys(dyn_motion[e], h.o_dyn_mpoly[e], h.o_dyn_tl_m[e]);
+    put_polys(dyn_force[e], h.o_dyn_fpoly[e], h.o_dyn_tl_f[e]);
+  }
+  put_polys(rom_base, h.o_rom_base_poly, h.o_rom_tl_base);
+  for (int e = 0; e < n_ee; ++e) {
+    put_polys(rom_motion[e], h.o_rom_mpoly[e], h.o_rom_tl_m[e]);
+    std::vector<int32_t> vo(grid_rom.size() + 1);
+    for (size_t k = 0; k <= grid_rom.size(); ++k) vo[k] = row_ptr[h.row_rom[e] + 3 * k] - h.nnz_rom[e];
+    h.o_rom_val_off[e] = put(vo.data(), vo.size() * 4);
+    h.o_force_nodes[e] = put(force_nodes[e].data(), force_nodes[e].size() * sizeof(ForceNode));
+    h.o_terrain_rows[e] = put(terrain_rows[e].data(), terrain_rows[e].size() * sizeof(TerrainRow));
+  }
+  h.mass = model.mass; h.gravity = model.gravity; h.mu = model.friction; h.flat_height = model.flat_height;
+  // BuildInertiaTensor (single_rigid_body_dynamics.cc:36-44): off-diagonals are the negated products of inertia
+  const double* I = model.inertia;  // Ixx,Iyy,Izz,Ixy,Ixz,Iyz
+  h.Ib[0] = I[0]; h.Ib[1] = -I[3]; h.Ib[2] = -I[4]; h.Ib[3] = I[1]; h.Ib[4] = -I[5]; h.Ib[5] = I[2];
+  blob.resize(sizeof(DevStruct) + body.size());
+  std::memcpy(blob.data(), &h, sizeof(h));
+  if (!body.empty()) std::memcpy(blob.data() + sizeof(DevStruct), body.data(), body.size());
+  blob.resize((blob.size() + 15) / 16 * 16);
+}
+
+void Structure::Build() {
+  BuildVariables();
+  BuildTimeTables();
+  BuildPattern();
+  PackBlob();
+}
+
+// ------------------------------------------------------------------ terrain height (host, setup only)
+// HeightMap::GetHeight of the example terrains (src/height_map_examples.cc:35-197,
+// include/towr/terrain/examples/height_map_examples.h:45-166).
+double TerrainHeightHost(const twr_model& m, double x, double y) {
+  switch (m.terrain_id) {
+    case TWR_TERRAIN_FLAT: return m.flat_height;
+    case TWR_TERRAIN_BLOCK: {
+      const double start = 0.7, len = 3.5, height = 0.5, eps = 0.03, slope = height / eps;
+      double h = 0.0;
+      if (start <= x && x <= start + eps) h = slope * (x - start);
+      if (start + eps <= x && x <= start + len) h = height;
+      return h;
+    }
+    case TWR_TERRAIN_STAIRS: {
+      double h = 0.0;
+      if (x >= 1.0) h = 0.2;
+      if (x >= 1.0 + 0.4) h = 0.4;
+      if (x >= 1.0 + 0.4 + 1.0) h = 0.0;
+      return h;
+    }
+    case TWR_TERRAIN_GAP: {
+      const double gs = 1.0, w = 0.5, hh = 1.5, xc = gs + w / 2.0, ge = gs + w;
+      const double a = (4 * hh) / (w * w), b = -(8 * hh * xc) / (w * w), c = -(hh * (w - 2 * xc) * (w + 2 * xc)) / (w * w);
+      return (gs <= x && x <= ge) ? a * x * x + b * x + c : 0.0;
+    }
+    case TWR_TERRAIN_SLOPE: {
+      const double ss = 1.0, up = 1.0, dn = 1.0, hc = 0.7, xd = ss + up, xf = xd + dn, sl = hc / up;
+      double z = 0.0;
+      if (x >= ss) z = sl * (x - ss);
+      if (x >= xd) z = hc - sl * (x - xd);
+      if (x >= xf) z = 0.0;
+      return z;
+    }
+    case TWR_TERRAIN_CHIMNEY: {
+      const double xs = 1.0, len = 1.5, ys = 0.5, sl = 3.0;
+      return (xs <= x && x <= xs + len) ? sl * (y - ys) : 0.0;
+    }
+    case TWR_TERRAIN_CHIMNEY_LR: {
+      const double xs = 0.5, len = 1.0, ys = 0.5, sl = 2, xe1 = xs + len, xe2 = xs + 2 * len;
+      double z = 0.0;
+      if (xs <= x && x <= xe1) z = sl * (y - ys);
+      if (xe1 <= x && x <= xe2) z = -sl * (y + ys);
+      return z;
+    }
+  }
+  throw std::runtime_error("unknown terrain id");
+}
+
+// ------------------------------------------------------------------ initial guess
+// NlpFormulation::Make{Base,Endeffector,Force}Variables (src/nlp_formulation.cc:95-181) with
+// NodesVariables::SetByLinearInterpolation + GetValues (src/nodes_variables.cc:52-62,126-150):
+// a variable shared by two nodes ends up with the value written for the later node.
+void Structure::InitialGuess(const double* lin0, const double* ang0, const double* lin1, const double* ang1,
+                             const double* ee0, double* x) const {
+  auto interpolate = [&](const SplineLayout& s, int var_off_delta, const double* a, const double* b) {
+    double dp[3], vel[3];
+    for (int d = 0; d < 3; ++d) {
+      dp[d] = b[d] - a[d];
+      vel[d] = dp[d] / T;
+    }
+    for (int n = 0; n < s.n_nodes; ++n)
+      for (int d = 0; d < 3; ++d) {
+        int ip = s.at(n, 0, d), iv = s.at(n, 1, d);
+        if (ip >= 0) x[ip + var_off_delta] = a[d] + n / static_cast<double>(s.n_nodes - 1) * dp[d];
+        if (iv >= 0) x[iv + var_off_delta] = vel[d];
+      }
+  };
+  for (int i = 0; i < n_vars; ++i) x[i] = 0.0;
+  double fl[3] = {lin1[0], lin1[1], TerrainHeightHost(model, lin1[0], lin1[1]) - model.nominal_stance[0][2]};
+  interpolate(base, off_base_lin, lin0, fl);
+  interpolate(base, off_base_ang, ang0, ang1);
+  for (int e = 0; e < n_ee; ++e) {
+    double yaw = ang1[2];
+    // GetRotationMatrixBaseToWorld((0,0,yaw)) * nominal stance (nlp_formulation.cc:141-148)
+    double cz = std::cos(yaw), sz = std::sin(yaw), c0 = std::cos(0.0), s0 = std::sin(0.0);
+    const double* nb = model.nominal_stance[e];
+    double R[3][3] = {{c0 * cz, cz * s0 * s0 - c0 * sz, s0 * sz + c0 * cz * s0},
+                      {c0 * sz, c0 * cz + s0 * s0 * sz, c0 * s0 * sz - cz * s0},
+                      {-s0, c0 * s0, c0 * c0}};
+    double fe[3];
+    for (int i = 0; i < 3; ++i) fe[i] = lin1[i] + (R[i][0] * nb[0] + R[i][1] * nb[1] + R[i][2] * nb[2]);
+    fe[2] = TerrainHeightHost(model, fe[0], fe[1]);
+    interpolate(motion[e], 0, ee0 + 3 * e, fe);
+  }
+  for (int e = 0; e < n_ee; ++e) {
+    double f[3] = {0.0, 0.0, model.mass * model.gravity / n_ee};
+    interpolate(force[e], 0, f, f);
+  }
+}
+
+// ------------------------------------------------------------------ presets
+// RobotModel(Robot) (src/robot_model.cc:41-68) with the constants of
+// include/towr/models/examples/{monoped,biped,hyq,anymal}_model.h and models/go1/go1_model.h.
+void ModelPreset(int robot, int terrain, twr_model* m) {
+  std::memset(m, 0, sizeof(*m));
+  auto quad = [&](double xn, double yn, double zn) {
+    double s[4][3] = {{xn, yn, zn}, {xn, -yn, zn}, {-xn, yn, zn}, {-xn, -yn, zn}};  // LF RF LH RH
+    std::memcpy(m->nominal_stance, s, sizeof(s));
+  };
+  auto set = [&](int n_ee, double mass, double ixx, double iyy, double izz, double ixy, double ixz, double iyz,
+                 double dx, double dy, double dz) {
+    m->n_ee = n_ee;
+    m->mass = mass;
+    double I[6] = {ixx, iyy, izz, ixy, ixz, iyz};
+    std::memcpy(m->inertia, I, sizeof(I));
+    m->max_dev[0] = dx; m->max_dev[1] = dy; m->max_dev[2] = dz;
+  };
+  switch (robot) {
+    case TWR_ROBOT_MONOPED:
+      set(1, 20, 1.2, 5.5, 6.0, 0.0, -0.2, -0.01, 0.25, 0.15, 0.2);
+      m->nominal_stance[0][2] = -0.58;
+      break;
+    case TWR_ROBOT_BIPED:
+      set(2, 20, 1.209, 5.583, 6.056, 0.005, -0.190, -0.012, 0.25, 0.15, 0.15);
+      m->nominal_stance[0][1] = 0.20;  m->nominal_stance[0][2] = -0.65;
+      m->nominal_stance[1][1] = -0.20; m->nominal_stance[1][2] = -0.65;
+      break;
+    case TWR_ROBOT_HYQ:
+      set(4, 83, 4.26, 8.97, 9.88, -0.0063, 0.193, 0.0126, 0.25, 0.20, 0.10);
+      quad(0.31, 0.29, -0.58);
+      break;
+    case TWR_ROBOT_ANYMAL:
+      set(4, 29.5, 0.946438, 1.94478, 2.01835, 0.000938112, -0.00595386, -0.00146328, 0.15, 0.1, 0.10);
+      quad(0.34, 0.19, -0.42);
+      break;
+    case TWR_ROBOT_GO1:
+      set(4, 12.84, 0.0168128557, 0.063009565, 0.0716547275, -0.0002296769, -0.0002945293, -0.0000418731, 0.16, 0.12, 0.06);
+      quad(0.1881, 0.04675 + 0.08, -0.3);
+      break;
+    default: throw std::runtime_error("unknown robot id");
+  }
+  if (terrain < TWR_TERRAIN_FLAT || terrain > TWR_TERRAIN_CHIMNEY_LR) throw std::runtime_error("unknown terrain id");
+  m->terrain_id = terrain;
+  m->gravity = 9.80665;     // dynamic_model.cc:37
+  m->friction = 0.5;        // height_map.h:136
+  m->force_limit = 1000.0;  // parameters.cc:48
+  m->flat_height = 0.0;
+}
+
+// ------------------------------------------------------------------ gait generator
+namespace {
+struct Stride {
+  std::vector<double> times;
+  std::vector<unsigned> contacts;  // bit e set = ee e in contact
+};
+enum G { Stand = 0, Flight, Walk1, Walk2, Walk2E, Run2, Run2E, Run1, Run1E, Run3, Run3E, Hop1, Hop1E, Hop2, Hop3, Hop3E, Hop5, Hop5E };
+
+Stride DropTransition(Stride s) {  // GaitGenerator::RemoveTransition (gait_generator.cc:131-144)
+  double last = s.times.back();
+  s.times.pop_back();
+  s.times.back() += last;
+  s.contacts.pop_back();
+  return s;
+}
+// quadruped contact states, ee bits LF=1 RF=2 LH=4 RH=8 (quadruped_gait_generator.cc:39-74)
+constexpr unsigned II = 0, PI = 4, bI = 8, IP = 1, Ib = 2, Pb = 4 | 2, bP = 8 | 1, BI = 12, IB = 3, PP = 4 | 1, bb = 8 | 2,
+                   Bb = 12 | 2, BP = 12 | 1, bB = 8 | 3, PB = 4 | 3, BB = 15;
+Stride QuadStride(int g) {  // quadruped_gait_generator.cc:89-366
+  switch (g) {
+    case Stand: return {{0.3}, {BB}};
+    case Flight: return {{0.3}, {Bb}};
+    case Walk1: return {{0.3, 0.2, 0.3, 0.2, 0.3, 0.2, 0.3, 0.2}, {bB, BB, Bb, BB, PB, BB, BP, BB}};
+    case Walk2: return {{0.25, 0.13, 0.25, 0.13, 0.25, 0.13, 0.25, 0.13}, {bB, bb, Bb, Pb, PB, PP, BP, bP}};
+    case Walk2E: return DropTransition(QuadStride(Walk2));
+    case Run1: return {{0.3, 0.2, 0.3, 0.2}, {bP, BB, Pb, BB}};
+    case Run2: return {{0.4, 0.1, 0.4, 0.1}, {bP, II, Pb, II}};
+    case Run2E: return {{0.4}, {bP}};
+    case Run3: return {{0.3, 0.1, 0.3, 0.1}, {PP, II, bb, II}};
+    case Run3E: return {{0.3}, {PP}};
+    case Hop1: return {{0.3, 0.1, 0.3, 0.1}, {BI, II, IB, II}};
+    case Hop1E: return {{0.3}, {BI}};
+    case Hop2: return {{0.3, 0.4, 0.3}, {BB, II, BB}};
+    case Hop3: return {{0.2, 0.3, 0.2, 0.2, 0.2, 0.3, 0.2, 0.2}, {Bb, BI, BP, bP, bB, IB, PB, Pb}};
+    case Hop3E: return DropTransition(QuadStride(Hop3));
+    case Hop5: return {{0.1, 0.2, 0.1, 0.1, 0.2, 0.1}, {Bb, BB, IP, Bb, BB, IP}};
+  }
+  throw std::runtime_error("quadruped gait not implemented");
+}
+Stride BipedStride(int g) {  // biped_gait_generator.cc:64-226, bits L=1 R=2
+  const unsigned I = 0, P = 1, b = 2, B = 3;
+  switch (g) {
+    case Stand: return {{0.2}, {B}};
+    case Flight: return {{0.5}, {I}};
+    case Walk1: case Walk2: return {{0.3, 0.05, 0.3, 0.05}, {b, B, P, B}};
+    case Run1: case Run3: return {{0.15, 0.4, 0.15 + 0.15, 0.4, 0.15}, {b, I, P, I, b}};
+    case Hop1: return {{0.15, 0.5, 0.15}, {B, I, B}};
+    case Hop2: return {{0.15, 0.4, 0.15}, {b, I, b}};
+    case Hop3: return {{0.2, 0.2, 0.2}, {P, I, P}};
+    case Hop5: return {{0.2, 0.3, 0.2, 0.2}, {P, I, b, B}};
+  }
+  throw std::runtime_error("biped gait not implemented");
+}
+Stride MonoStride(int g) {  // monoped_gait_generator.cc:50-120
+  switch (g) {
+    case Stand: return {{0.5}, {1}};
+    case Flight: return {{0.5}, {0}};
+    case Hop1: return {{0.3, 0.3}, {1, 0}};
+    case Hop2: return {{0.2, 0.3}, {1, 0}};
+  }
+  throw std::runtime_error("monoped gait not implemented");
+}
+std::vector<int> ComboGaits(int n_ee, int combo) {
+  static const std::vector<int> quad[5] = {{Stand, Walk2, Walk2, Walk2, Walk2E, Stand},   // quadruped_gait_generator.cc:76-87
+                                           {Stand, Run2, Run2, Run2, Run2E, Stand},
+                                           {Stand, Run3, Run3, Run3, Run3E, Stand},
+                                           {Stand, Hop1, Hop1, Hop1, Hop1E, Stand},
+                                           {Stand, Hop3, Hop3, Hop3, Hop3E, Stand}};
+  static const std::vector<int> biped[5] = {{Stand, Walk1, Walk1, Walk1, Walk1, Stand},   // biped_gait_generator.cc:51-62
+                                            {Stand, Run1, Run1, Run1, Run1, Stand},
+                                            {Stand, Hop1, Hop1, Hop1, Stand},
+                                            {Stand, Hop1, Hop2, Hop2, Stand},
+                                            {Stand, Hop5, Hop5, Hop5, Stand}};
+  static const std::vector<int> mono[5] = {{Stand, Hop1, Hop1, Hop1, Hop1, Stand},        // monoped_gait_generator.cc:37-48
+                                           {Stand, Hop1, Hop1, Hop1, Stand},
+                                           {Stand, Hop1, Hop1, Hop1, Hop1, Stand},
+                                           {Stand, Hop2, Hop2, Hop2, Stand},
+                                           {Stand, Hop2, Hop2, Hop2, Hop2, Hop2, Stand}};
+  if (combo < 0 || combo > 4) throw std::runtime_error("combo must be 0..4");
+  if (n_ee == 1) return mono[combo];
+  if (n_ee == 2) return biped[combo];
+  if (n_ee == 4) return quad[combo];
+  throw std::runtime_error("no gait generator for this leg count");  // gait_generator.cc:43-52
+}
+}  // namespace
+
+void GaitCombo(int n_ee, int combo, double t_total, double swing_scale, twr_schedule* out) {
+  std::vector<double> times;
+  std::vector<unsigned> contacts;
+  for (int g : ComboGaits(n_ee, combo)) {  // SetGaits (gait_generator.cc:113-129)
+    Stride s = n_ee == 1 ? MonoStride(g) : n_ee == 2 ? BipedStride(g) : QuadStride(g);
+    times.insert(times.end(), s.times.begin(), s.times.end());
+    contacts.insert(contacts.end(), s.contacts.begin(), s.contacts.end());
+  }
+  const unsigned all = (1u << n_ee) - 1;
+  for (size_t i = 0; i < times.size(); ++i)
+    if (contacts[i] != all) times[i] *= swing_scale;  // candidate enumeration knob (1.0 = reference)
+  std::memset(out, 0, sizeof(*out));
+  out->n_ee = n_ee;
+  // GetPhaseDurations() (gait_generator.cc:76-105)
+  std::vector<std::vector<double>> foot(n_ee);
+  std::vector<double> acc(n_ee, 0.0);
+  for (size_t ph = 0; ph + 1 < contacts.size(); ++ph)
+    for (int e = 0; e < n_ee; ++e) {
+      acc[e] += times[ph];
+      bool cur = (contacts[ph] >> e) & 1, nxt = (contacts[ph + 1] >> e) & 1;
+      if (cur != nxt) {
+        foot[e].push_back(acc[e]);
+        acc[e] = 0.0;
+      }
+    }
+  for (int e = 0; e < n_ee; ++e) foot[e].push_back(acc[e] + times.back());
+  for (int e = 0; e < n_ee; ++e) {
+    if (foot[e].size() > TWR_MAX_PHASES) throw std::runtime_error("too many phases");
+    // GetNormalizedPhaseDurations + GetPhaseDurations(T, ee) (gait_generator.cc:54-74)
+    double total = std::accumulate(foot[e].begin(), foot[e].end(), 0.0);
+    out->n_phases[e] = (int)foot[e].size();
+    out->in_contact_at_start[e] = (contacts.front() >> e) & 1;  // IsInContactAtStart :107-111
+    for (size_t i = 0; i < foot[e].size(); ++i) out->phase_durations[e][i] = (foot[e][i] / total) * t_total;
+  }
+}
+
+}  // namespace twr

@@ -1,0 +1,76 @@
+// Host-side problem structure: everything about one candidate contact schedule that does
+// not depend on x.  Built once (twr_structure_create); the reference spreads the same
+// information over NlpFormulation::GetVariableSets/GetConstraints, NodesVariables*,
+// SplineHolder and the constraint constructors (see citations in structure.cc).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/towr_amd.h"
+#include "device_tables.h"
+
+namespace twr {
+
+struct SplineLayout {
+  std::vector<double> durations;                 // per polynomial
+  // x index (global, stacked) of node value (node, deriv, dim); -1 = not optimised (constant 0)
+  std::vector<int> idx;                          // [node][deriv(2)][dim(3)]
+  std::vector<char> node_constant;               // phase based sets only
+  std::vector<int> poly_phase;                   // phase of each polynomial (phase based)
+  int n_nodes = 0;
+  int var_offset = 0, var_size = 0;
+  int at(int node, int deriv, int dim) const { return idx[(node * 2 + deriv) * 3 + dim]; }
+};
+
+struct SetInfo {
+  std::string name;
+  int offset = 0, size = 0, nnz_offset = 0, nnz = 0;
+};
+
+struct TimeNode {  // result of Spline::GetLocalTime for one spline at one grid time
+  int poly;
+  double t_local;
+};
+
+struct Structure {
+  twr_model model;
+  twr_schedule schedule;
+  twr_params params;
+  int n_ee = 0;
+  double T = 0;
+
+  SplineLayout base;  // durations shared by base-lin / base-ang; idx refers to base-lin
+  int off_base_lin = 0, off_base_ang = 0;
+  std::vector<SplineLayout> motion, force;
+  std::vector<SetInfo> var_sets, con_sets;
+  int n_vars = 0, n_rows = 0, nnz = 0;
+
+  std::vector<double> grid_dyn, grid_rom;
+  std::vector<TimeNode> dyn_base, rom_base;
+  std::vector<std::vector<TimeNode>> dyn_motion, dyn_force, rom_motion;  // [ee][k]
+  std::vector<std::vector<EePoly>> mpoly, fpoly;                         // [ee][poly]
+  std::vector<std::vector<ForceNode>> force_nodes;                       // [ee]
+  std::vector<std::vector<TerrainRow>> terrain_rows;                     // [ee]
+
+  std::vector<int32_t> row_ptr, col_idx;
+  std::vector<double> lower, upper;
+
+  std::vector<char> blob;  // packed DevStruct + tables (device_tables.h)
+
+  void Build();            // throws std::runtime_error
+  void InitialGuess(const double* lin0, const double* ang0, const double* lin1, const double* ang1,
+                    const double* ee0, double* x) const;
+
+ private:
+  void BuildVariables();
+  void BuildTimeTables();
+  void BuildPattern();
+  void PackBlob();
+};
+
+// gait tables
+void GaitCombo(int n_ee, int combo, double t_total, double swing_scale, twr_schedule* out);
+void ModelPreset(int robot, int terrain, twr_model* out);
+double TerrainHeightHost(const twr_model& m, double x, double y);
+
+}  // namespace twr
