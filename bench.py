@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: full NLP callbacks (constraint values + Jacobian values) per second.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the fused HIP kernel over this rank's batch of candidates (inputs already
+resident in HBM).  Workload = BASELINE config C3: ANYmal, quadruped combo C1 (flying trot), T=2.0 s,
+flat terrain, K_dyn=K_rom=200, `--batch` problems per GPU that share the structure and differ in x
+(BASELINE.md section 4 perturbation).  Candidates shard across ranks with no data-path collective
+(weak scaling: per-GPU batch fixed); the only collective is one broadcast of the POD model blob.
+
+Prints ONE JSON line on rank 0, with the `roofline` and `cpu_baseline` objects of the contract.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def build_case(ta, model, K=200, T=2.0, combo=1):
+    sched = ta.gait_combo(model.n_ee, combo, T)
+    dt = T / (K - 1.5)  # reference rule floor(T/dt)+2 then yields K nodes
+    params = ta.params_default(dt_dynamic=dt, dt_rom=dt)
+    return sched, params, ta.Structure(model, sched, params)
+
+
+def perturbed_inputs(S, model, count, first_seed):
+    """x0 = reference initial guess (start at nominal stance, goal x=+1 m) + sigma*N(0,1)*scale."""
+    ee = [[model.nominal_stance[e][0], model.nominal_stance[e][1], 0.0] for e in range(model.n_ee)]
+    z = -model.nominal_stance[0][2]
+    x0 = S.initial_guess([0, 0, z], [0, 0, 0], [1.0, 0, z], [0, 0, 0], ee)
+    scale = np.ones(S.n)
+    for vs in S.var_sets:
+        a, b = vs["offset"], vs["offset"] + vs["size"]
+        if vs["name"] == "base-lin":
+            scale[a:b] = np.tile([0.1] * 3 + [0.5] * 3, vs["size"] // 6)
+        elif vs["name"] == "base-ang":
+            scale[a:b] = np.tile([0.2] * 3 + [0.5] * 3, vs["size"] // 6)
+        elif vs["name"].startswith("ee-motion"):
+            scale[a:b] = 0.1
+        else:
+            scale[a:b] = 50.0
+    out = np.empty((count, S.n))
+    for i in range(count):
+        rng = np.random.default_rng(1234 + first_seed + i)
+        out[i] = x0 + 0.05 * rng.normal(size=S.n) * scale
+    return out
+
+
+def cpu_baseline(sched, params, x, budget_s=12.0):
+    """The oracle ("port" of the reference's Eigen CPU path) timed on this box's host cores."""
+    from oracle import binding as ob
+
+    P = ob.OracleProblem("anymal", "flat", sched.durations(), sched.contact(), dt_dynamic=params.dt_dynamic,
+                         dt_rom=params.dt_rom, duration_base_poly=params.duration_base_poly,
+                         polys_per_swing=params.polys_per_swing, polys_per_stance_force=params.polys_per_stance_force)
+    t1 = P.time_callbacks(x, 3) / 3.0
+    iters = max(5, int(budget_s / max(t1, 1e-6)))
+    secs = P.time_callbacks(x, iters)
+    return {"value": iters / secs, "unit": "callbacks/s", "cores": 1, "kind": "port",
+            "sample": "%d callbacks of the same ANYmal K=200 problem, single-thread C++ oracle (%.1f s)" % (iters, secs)}
+
+
+def traffic_from_profile(workload):
+    """HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("workload") == workload:
+            return t.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="candidates per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import towr_amd as ta
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # --- the single collective of the design: rank 0 broadcasts the POD robot/terrain model (RCCL)
+    model = ta.Model()
+    nbytes = ctypes.sizeof(model)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+        blob = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            src = ta.model_preset("anymal", "flat")
+            blob.copy_(torch.frombuffer(bytearray(bytes(src)), dtype=torch.uint8))
+        dist.broadcast(blob, src=0)
+        ctypes.memmove(ctypes.addressof(model), bytes(blob.cpu().numpy().tobytes()), nbytes)
+    else:
+        model = ta.model_preset("anymal", "flat")
+
+    sched, params, S = build_case(ta, model)
+    B = args.batch
+    workload = "C3 ANYmal trot (combo C1), T=2.0 s, flat, K=%d, n=%d m=%d nnz=%d, %d problems/GPU distinct x" % (
+        S.k_dynamic, S.n, S.m, S.nnz, B)
+    batch = ta.Batch([S], [0] * B, device=local_rank)
+
+    # distinct x per problem: 256 seeded perturbations per rank, tiled (contents do not change the work)
+    base = perturbed_inputs(S, model, min(B, 256), first_seed=rank * 100000)
+    reps = (B + base.shape[0] - 1) // base.shape[0]
+    x_host = np.tile(base, (reps, 1))[:B].reshape(-1)
+    x = torch.from_numpy(x_host).to(dev)
+    g = torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device=dev)
+    jac = torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for a, b in ev:  # HIP events on the launch stream bracket every kernel launch
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the outputs are finite (no work skipped / no garbage)
+    assert bool(torch.isfinite(g).all()) and bool(torch.isfinite(jac).all())
+
+    if rank == 0:
+        callbacks = B * world * args.steps
+        alg_bytes = batch.algorithmic_bytes  # 8*(n+m+nnz) per problem x problems per launch
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "constraint+Jacobian evals/sec (full NLP callback), 4-EE SRBD",
+            "value": callbacks / elapsed,
+            "unit": "callbacks/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": workload, "problems_per_gpu": B, "bytes_per_callback": S.algorithmic_bytes},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile("C3"),
+                         "kernel": "twr::eval_kernel<4>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sched, params, x_host[:S.n])
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

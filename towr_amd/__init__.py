@@ -60,12 +60,31 @@ def build():
     subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7; if
+    libtowr_amd.so pulled in /opt/rocm's copy first, a later `import torch` would bring up a second
+    runtime and see no GPU.  So when torch is installed, its runtime is loaded first (without
+    importing torch) and libtowr_amd.so binds to it through the shared SONAME."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("libtowr_amd.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "or `make -C towr_amd/csrc`")
+        _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.twr_last_error.restype = C.c_char_p
         L.twr_model_preset.argtypes = [C.c_int, C.c_int, C.POINTER(Model)]
