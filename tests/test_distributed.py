@@ -1,0 +1,58 @@
+"""world_size-2 rehearsal of the multi-GPU path on CPU (gloo): model-blob broadcast, candidate
+sharding, per-rank structures.  The kernels themselves need a GPU (tests/test_gpu_parity.py)."""
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, hashlib
+sys.path.insert(0, os.environ["TWR_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+import towr_amd as ta
+from towr_amd import sweep
+from towr_amd.dist import broadcast_model, my_shard
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+model = broadcast_model(ta.model_preset("anymal", "stairs") if rank == 0 else None)
+ref = ta.model_preset("anymal", "stairs")
+assert bytes(model) == bytes(ref), "model blob differs after broadcast"
+cands = sweep.enumerate_candidates(48)
+structs = [sweep.candidate_structure(model, c) for c in cands]
+weights = [s.algorithmic_bytes for s in structs]
+a, b = my_shard(weights, rank, world)
+mine = torch.tensor([a, b, sum(weights[a:b])], dtype=torch.int64)
+allr = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+dist.all_gather(allr, mine)
+allr = [t.tolist() for t in allr]
+assert allr[0][0] == 0 and allr[-1][1] == len(cands)
+for r in range(world - 1):
+    assert allr[r][1] == allr[r + 1][0], "shards must tile the candidate list"
+assert sum(t[2] for t in allr) == sum(weights)
+assert max(t[2] for t in allr) - min(t[2] for t in allr) <= 2 * max(weights)
+# every rank derives the identical pattern for the same candidate (no rank-dependent state)
+h = hashlib.sha256(structs[7].col_idx.tobytes() + structs[7].row_ptr.tobytes()).digest()
+hs = [None] * world
+dist.all_gather_object(hs, h)
+assert all(x == hs[0] for x in hs)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok", a, b)
+'''
+
+
+def test_two_rank_gloo_broadcast_and_sharding(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, TWR_ROOT=ROOT, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout

@@ -1,0 +1,222 @@
+"""Pins the CPU oracle (oracle/towr_oracle.cc).
+
+The reference ships no golden vectors for this path (its two gtest files are empty stubs) and cannot
+be built here, so the oracle is pinned by (1) fixtures from an independent 40-digit mpmath
+implementation that differentiates g numerically (oracle/mp_ref.py -> tests/golden/mp_*.npz),
+(2) hand known-answers derived from the cited reference lines, (3) finite
+differences of the oracle's own g (what Ipopt's derivative_test would do, hopper_example.cc:86).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mp_*.npz")))
+
+
+def load_fixture(path):
+    d = np.load(path)
+    pd, o = [], 0
+    for k in d["n_phases"]:
+        pd.append(d["phase_durations"][o:o + k])
+        o += k
+    P = ob.OracleProblem(str(d["robot"]), str(d["terrain"]), pd, list(d["contact_at_start"]))
+    return d, P
+
+
+def quirk_mask(P, terrain, x, rp, ci):
+    """Force rows x stance-foothold columns on a terrain with curvature: the reference's
+    GetDerivativeOfNormalizedBasisWrt (height_map.cc:80-91) is a component-wise product, not the
+    chain rule, so these entries are not derivatives of g."""
+    mask = np.zeros(P.nnz, dtype=bool)
+    if terrain != "gap":
+        return mask
+    motion_cols = {}
+    off = 0
+    for name, size in P.var_sets:
+        if name.startswith("ee-motion_"):
+            motion_cols[int(name.split("_")[1])] = (off, off + size)
+        off += size
+    r0 = 0
+    for name, rows in P.con_sets:
+        if name.startswith("force-"):
+            a, b = motion_cols[int(name.split("_")[-1])]
+            for r in range(r0, r0 + rows):
+                for k in range(rp[r], rp[r + 1]):
+                    if a <= ci[k] < b:
+                        mask[k] = True
+        r0 += rows
+    return mask
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[3:-4] for p in GOLDEN])
+def test_oracle_matches_independent_mpmath_golden(path):
+    d, P = load_fixture(path)
+    x = d["x"]
+    assert P.n == x.size and P.m == d["g"].size
+    g, rp, ci, va = P.eval(x)
+    # constraint values: 1e-13 of the set scale (mp value rounded to double)
+    assert np.abs(g - d["g"]).max() <= 1e-13 * np.abs(d["g"]).max()
+    ref = {(int(r), int(c)): v for r, c, v in zip(d["jac_row"], d["jac_col"], d["jac_val"])}
+    rows = np.repeat(np.arange(P.m), np.diff(rp))
+    have = set(zip(rows.tolist(), ci.tolist()))
+    # every true non-zero lies inside the oracle's (x-independent) pattern
+    assert all(k in have for k in ref)
+    refv = np.array([ref.get((r, c), 0.0) for r, c in zip(rows.tolist(), ci.tolist())])
+    rowscale = np.zeros(P.m)
+    np.maximum.at(rowscale, rows, np.abs(refv))
+    tol = 1e-9 * np.abs(refv) + 1e-12 * rowscale[rows]
+    bad = np.abs(va - refv) > tol
+    qm = quirk_mask(P, str(d["terrain"]), x, rp, ci)
+    assert not (bad & ~qm).any(), "%d analytic Jacobian entries disagree with numerical differentiation" % (bad & ~qm).sum()
+    if str(d["terrain"]) == "gap":
+        assert (bad & qm).any(), "fixture should exercise the terrain-basis quirk (footholds inside the gap)"
+
+
+def test_terrain_basis_derivative_quirk_known_answer():
+    """height_map.cc:80-91,141-148 evaluated by hand at a point inside the Gap parabola."""
+    x, y = 1.1, 0.3
+    w, h, gs = 0.5, 1.5, 1.0
+    xc = gs + w / 2
+    a, b = 4 * h / (w * w), -(8 * h * xc) / (w * w)
+    hx, hxx = 2 * a * x + b, 2 * a
+    for which, v, dv in ((0, np.array([-hx, 0.0, 1.0]), np.array([-hxx, 0.0, 0.0])),
+                         (1, np.array([1.0, 0.0, hx]), np.array([0.0, 0.0, hxx]))):
+        nrm = np.linalg.norm(v)
+        unit = np.array([1.0, 0.0, 0.0])
+        outer = (1 / (nrm * nrm)) * (nrm * unit - v[0] * (v / nrm))
+        expect = outer * dv  # component-wise, exactly as the reference
+        got = ob.terrain_dbasis("gap", which, 0, x, y)
+        assert np.allclose(got, expect, rtol=1e-14, atol=0)
+        # ... and it is NOT the derivative of the normalised vector (documented quirk)
+        eps = 1e-6
+
+        def nb(xx):
+            hx2 = 2 * a * xx + b
+            vv = np.array([-hx2, 0.0, 1.0]) if which == 0 else np.array([1.0, 0.0, hx2])
+            return vv / np.linalg.norm(vv)
+
+        true = (nb(x + eps) - nb(x - eps)) / (2 * eps)
+        assert np.abs(true - expect).max() > 1e-3
+    assert np.array_equal(ob.terrain_dbasis("gap", 2, 0, x, y), np.zeros(3))
+    assert np.array_equal(ob.terrain_dbasis("gap", 0, 1, x, y), np.zeros(3))
+
+
+def test_hermite_weights_known_answers():
+    """polynomial.cc:140-234 at the segment ends."""
+    T = 0.37
+    w0, wT = ob.hermite_weights(0.0, T), ob.hermite_weights(T, T)
+    assert np.allclose(w0[0], [1, 0, 0, 0], atol=1e-15) and np.allclose(wT[0], [0, 0, 1, 0], atol=1e-14)
+    assert abs(w0[1][1] - 1) < 1e-15 and abs(wT[1][3] - 1) < 1e-13
+    assert np.allclose(w0[2], [-6 / T**2, -4 / T, 6 / T**2, -2 / T], rtol=1e-14)
+    # partition of unity of the position weights on p0,p1 and exactness on cubics
+    t = 0.123
+    w = ob.hermite_weights(t, T)
+    assert abs(w[0][0] + w[0][2] - 1) < 1e-15
+    c = np.array([0.3, -1.2, 0.7, 2.1])  # p(t) = c0 + c1 t + c2 t^2 + c3 t^3
+    p = lambda s: c @ [1, s, s * s, s**3]
+    v = lambda s: c @ [0, 1, 2 * s, 3 * s * s]
+    acc = lambda s: c @ [0, 0, 2, 6 * s]
+    nodes = np.array([p(0), v(0), p(T), v(T)])
+    assert abs(w[0] @ nodes - p(t)) < 1e-14 and abs(w[1] @ nodes - v(t)) < 1e-13 and abs(w[2] @ nodes - acc(t)) < 1e-11
+
+
+def test_terrain_known_answers():
+    """height_map_examples.{h,cc}: heights, inclusive range tests, Stairs has zero slope."""
+    assert ob.terrain_height("flat", 3.0, -2.0) == 0.0
+    assert ob.terrain_height("stairs", 0.99, 0) == 0.0 and ob.terrain_height("stairs", 1.0, 0) == 0.2
+    assert ob.terrain_height("stairs", 1.4, 0) == 0.4 and ob.terrain_height("stairs", 2.4, 0) == 0.0
+    assert np.array_equal(ob.terrain_basis("stairs", 0, 1.2, 0.0), [0, 0, 1])
+    assert ob.terrain_height("gap", 1.0, 0) == pytest.approx(0.0, abs=1e-12)
+    assert ob.terrain_height("gap", 1.25, 0) == pytest.approx(-1.5, abs=1e-12)
+    assert ob.terrain_height("gap", 1.5000001, 0) == 0.0
+    assert ob.terrain_height("block", 0.7 + 0.03, 0) == 0.5 and ob.terrain_height("block", 0.715, 0) == pytest.approx(0.25)
+    assert ob.terrain_height("slope", 1.5, 0) == pytest.approx(0.35) and ob.terrain_height("slope", 2.5, 0) == pytest.approx(0.35)
+    assert ob.terrain_height("chimney", 1.2, 0.7) == pytest.approx(0.6) and ob.terrain_height("chimney", 0.9, 0.7) == 0.0
+    assert ob.terrain_height("chimney_lr", 1.0, 0.2) == pytest.approx(-0.6) and ob.terrain_height("chimney_lr", 2.0, 0.2) == pytest.approx(-1.4)
+    n = ob.terrain_basis("slope", 0, 1.5, 0.0)
+    assert np.allclose(n, np.array([-0.7, 0, 1]) / np.hypot(0.7, 1), rtol=1e-15)
+
+
+def _anymal_static():
+    pd, con = [[1.0]] * 4, [1] * 4          # one stance phase per foot: the robot just stands
+    P = ob.OracleProblem("anymal", "flat", pd, con)
+    ee = [[0.34, 0.19, 0], [0.34, -0.19, 0], [-0.34, 0.19, 0], [-0.34, -0.19, 0]]
+    x = P.initial_guess([0, 0, 0.42], [0, 0, 0], [0, 0, 0.42], [0, 0, 0], ee)  # goal == start: standing still
+    return P, x
+
+
+def test_static_stance_known_answers():
+    """standing still on flat ground with m g/4 per leg."""
+    P, x = _anymal_static()
+    g, rp, ci, va = P.eval(x)
+    sets, r0 = {}, 0
+    for name, rows in P.con_sets:
+        sets[name] = (r0, r0 + rows)
+        r0 += rows
+    a, b = sets["dynamic"]
+    assert np.abs(g[a:b]).max() < 1e-12          # force balance + zero net torque by symmetry
+    nominal = {0: [0.34, 0.19, -0.42], 1: [0.34, -0.19, -0.42], 2: [-0.34, 0.19, -0.42], 3: [-0.34, -0.19, -0.42]}
+    lo, up = P.bounds()
+    for e in range(4):
+        a, b = sets["rangeofmotion-%d" % e]
+        assert np.allclose(g[a:b].reshape(-1, 3), nominal[e], atol=1e-14)   # R = I: g = p - c
+        assert np.allclose((lo[a:b] + up[a:b]).reshape(-1, 3) / 2, nominal[e], atol=1e-15)
+        a, b = sets["terrain-ee-motion_%d" % e]
+        assert np.array_equal(g[a:b], np.zeros(b - a))                       # p.z - 0
+        for r in range(a, b):
+            assert np.array_equal(va[rp[r]:rp[r + 1]], [-0.0, -0.0, 1.0])    # (-h_x, -h_y, 1)
+        a, b = sets["force-ee-force_%d" % e]
+        fz = 29.5 * 9.80665 / 4
+        assert np.allclose(g[a:b].reshape(-1, 5), [fz, -0.5 * fz, 0.5 * fz, -0.5 * fz, 0.5 * fz], rtol=1e-15)
+        blk = va[rp[a]:rp[a + 5]].reshape(5, 5)   # cols: foothold x,y | f x,y,z
+        assert np.array_equal(blk[:, :2], np.zeros((5, 2)))
+        assert np.array_equal(blk[:, 2:], [[0, 0, 1], [1, 0, -0.5], [1, 0, 0.5], [0, 1, -0.5], [0, 1, 0.5]])
+    assert np.array_equal(lo[sets["dynamic"][0]:sets["dynamic"][1]], np.zeros(sets["dynamic"][1] - sets["dynamic"][0]))
+
+
+def test_time_grid_and_sizes_follow_the_reference_rules():
+    """time_discretization_constraint.cc:37-50: K = floor(T/dt)+2 with a (near-)duplicate last node;
+    sizes of the BASELINE configs as derived in SURVEY App. B."""
+    P = ob.OracleProblem("monoped", "flat", [[0.4, 0.2, 0.4, 0.2, 0.4, 0.2, 0.2]], [1])
+    assert (P.n, P.m, P.nnz) == (339, 273, 4672)
+    assert dict(P.con_sets) == {"terrain-ee-motion_0": 10, "dynamic": 22 * 6, "rangeofmotion-0": 27 * 3,
+                                "force-ee-force_0": 50}
+    pd, con = ob.gait(4, 1, 2.0)
+    assert [len(p) for p in pd] == [7, 9, 9, 7] and con == [1, 1, 1, 1]
+    Q = ob.OracleProblem("anymal", "flat", pd, con, dt_dynamic=2.0 / 198.5, dt_rom=2.0 / 198.5)
+    assert (Q.n, Q.m, Q.nnz) == (640, 3866, 102896)
+    assert [s for _, s in Q.var_sets] == [126, 126, 27, 35, 35, 27, 60, 72, 72, 60]
+    pd, con = ob.gait(2, 0, 2.0)
+    Bp = ob.OracleProblem("biped", "flat", pd, con, dt_dynamic=2.0 / 98.5, dt_rom=2.0 / 98.5)
+    assert (Bp.n, Bp.m, Bp.nnz) == (466, 1346, 29676)
+
+
+@pytest.mark.parametrize("robot,terrain,n_ee,combo,T", [("monoped", "flat", 1, 0, 2.0), ("biped", "block", 2, 1, 1.6),
+                                                        ("anymal", "gap", 4, 3, 1.4), ("hyq", "chimney_lr", 4, 4, 1.5)])
+def test_oracle_jacobian_vs_finite_differences(robot, terrain, n_ee, combo, T):
+    pd, con = ob.gait(n_ee, combo, T)
+    P = ob.OracleProblem(robot, terrain, pd, con)
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=P.n) * 0.3
+    g, rp, ci, va = P.eval(x)
+    J = np.zeros((P.m, P.n))
+    rows = np.repeat(np.arange(P.m), np.diff(rp))
+    J[rows, ci] = va
+    h = 1e-6
+    Jfd = np.empty_like(J)
+    for j in range(P.n):
+        e = np.zeros(P.n)
+        e[j] = h
+        Jfd[:, j] = (P.values(x + e) - P.values(x - e)) / (2 * h)
+    mask = np.zeros_like(J, dtype=bool)
+    mask[rows, ci] = True
+    assert np.abs(Jfd[~mask]).max() == 0.0          # nothing outside the pattern
+    qm = np.zeros_like(J, dtype=bool)
+    qk = quirk_mask(P, terrain, x, rp, ci)
+    qm[rows[qk], ci[qk]] = True
+    err = np.abs(J - Jfd) / np.maximum(1.0, np.abs(Jfd))
+    assert err[~qm].max() < 2e-5

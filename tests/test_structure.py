@@ -1,0 +1,177 @@
+"""Host logic of the product library vs the oracle: variable layout, CSR pattern, bounds, initial
+guess, gait generator; and the C ABI surface (symbols, error behaviour).  No GPU needed."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import towr_amd as ta
+from oracle import binding as ob
+from tests.common import Case, hopper_schedule, k_params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CONFIGS = [
+    ("monoped", "flat", None, 2.0, {}),
+    ("monoped", "block", 3, 1.7, {}),
+    ("biped", "flat", 0, 2.0, k_params(2.0, 100)),
+    ("anymal", "flat", 1, 2.0, k_params(2.0, 200)),
+    ("anymal", "gap", 0, 2.0, {}),
+    ("anymal", "stairs", 2, 2.4, {}),
+    ("biped", "stairs", 1, 1.8, {}),
+    ("biped", "slope", 3, 2.4, {}),
+    ("hyq", "chimney_lr", 4, 2.3, dict(polys_per_swing=3, polys_per_stance_force=2, duration_base_poly=0.15)),
+    ("go1", "stairs", 0, 2.3, dict(polys_per_swing=1, polys_per_stance_force=1, duration_base_poly=0.07,
+                                   dt_dynamic=0.033, dt_rom=0.05)),
+    ("go1", "chimney", 3, 2.6, dict(dt_dynamic=0.25, dt_rom=0.3)),
+]
+
+
+def make(robot, terrain, combo, T, kw):
+    n_ee = ta.model_preset(robot, terrain).n_ee
+    sched = hopper_schedule() if combo is None else ta.gait_combo(n_ee, combo, T)
+    return Case(robot, terrain, sched, **kw)
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=["%s-%s-c%s" % (c[0], c[1], c[2]) for c in CONFIGS])
+def test_structure_matches_oracle(cfg):
+    case = make(*cfg)
+    S, P = case.S, case.P
+    assert (S.n, S.m, S.nnz) == (P.n, P.m, P.nnz)
+    assert [(s["name"], s["size"]) for s in S.var_sets] == P.var_sets
+    assert [(s["name"], s["size"]) for s in S.con_sets] == P.con_sets
+    x = np.random.default_rng(0).normal(size=P.n)
+    _, rp, ci, _ = P.eval(x)
+    assert np.array_equal(rp, S.row_ptr) and np.array_equal(ci, S.col_idx)
+    # the pattern must not depend on x (Ipopt fixes the structure once)
+    _, rp2, ci2, _ = P.eval(np.zeros(P.n))
+    assert np.array_equal(rp, rp2) and np.array_equal(ci, ci2)
+    lo, up = S.bounds()
+    lo2, up2 = P.bounds()
+    assert np.array_equal(lo, lo2) and np.array_equal(up, up2)
+    # set offsets are consistent with the CSR arrays
+    for s in S.con_sets:
+        assert s["nnz_offset"] == S.row_ptr[s["offset"]]
+        assert s["nnz"] == S.row_ptr[s["offset"] + s["size"]] - S.row_ptr[s["offset"]]
+    ee0 = np.array([[0.1 * i, 0.05 * i, 0.0] for i in range(S.n_ee)])
+    args = ([0.1, 0.2, 0.5], [0.01, 0.02, 0.3], [1.3, 0.1, 0.5], [0.0, 0.0, 0.7], ee0)
+    assert np.array_equal(S.initial_guess(*args), P.initial_guess(*args))
+
+
+@pytest.mark.parametrize("n_ee", [1, 2, 4])
+@pytest.mark.parametrize("combo", range(5))
+def test_gait_generator_matches_oracle_tables(n_ee, combo):
+    for T in (1.3, 2.0, 3.1):
+        s = ta.gait_combo(n_ee, combo, T)
+        pd, con = ob.gait(n_ee, combo, T)
+        assert s.contact() == con
+        for e in range(n_ee):
+            assert np.array_equal(np.array(s.durations()[e]), pd[e])
+            assert abs(sum(s.durations()[e]) - T) < 1e-12
+
+
+def test_gait_known_answer_flying_trot():
+    """quadruped_gait_generator.cc:80-81,113-126,223-255 by hand: Stand(0.3) + 3x Run2 + Run2E + Stand."""
+    s = ta.gait_combo(4, 1, 3.0)  # table total = 0.3 + 3*1.0 + 0.4 + 0.3 = 4.0
+    k = 3.0 / 4.0
+    lf = [0.3 + 0.4, 0.1 + 0.4 + 0.1, 0.4, 0.6, 0.4, 0.6, 0.4 + 0.3]
+    rf = [0.3, 0.4 + 0.1, 0.4, 0.6, 0.4, 0.6, 0.4, 0.1 + 0.4, 0.3]
+    assert np.allclose(s.durations()[0], np.array(lf) * k, rtol=1e-14)
+    assert np.allclose(s.durations()[1], np.array(rf) * k, rtol=1e-14)
+    assert np.allclose(s.durations()[2], s.durations()[1], rtol=0) and np.allclose(s.durations()[3], s.durations()[0], rtol=0)
+    # swing_scale only stretches phases with a foot in the air, then renormalises to T
+    s2 = ta.gait_combo(4, 1, 3.0, 0.8)
+    assert abs(sum(s2.durations()[0]) - 3.0) < 1e-12 and s2.durations()[0][1] < s.durations()[0][1]
+
+
+def test_robot_presets_match_reference_constants():
+    m = ta.model_preset("anymal", "gap")  # anymal_model.h:44-67
+    assert (m.n_ee, m.mass, m.gravity, m.friction, m.force_limit) == (4, 29.5, 9.80665, 0.5, 1000.0)
+    assert list(m.inertia) == [0.946438, 1.94478, 2.01835, 0.000938112, -0.00595386, -0.00146328]
+    assert [list(m.nominal_stance[e]) for e in range(4)] == [[0.34, 0.19, -0.42], [0.34, -0.19, -0.42],
+                                                             [-0.34, 0.19, -0.42], [-0.34, -0.19, -0.42]]
+    assert list(m.max_dev) == [0.15, 0.1, 0.10]
+    g = ta.model_preset("go1", "flat")  # go1_model.h:19-52
+    assert g.mass == 12.84 and g.nominal_stance[0][1] == 0.04675 + 0.08
+    p = ta.params_default()  # parameters.cc:43-50
+    assert (p.dt_dynamic, p.dt_rom, p.duration_base_poly, p.polys_per_swing, p.polys_per_stance_force) == (0.1, 0.08, 0.1, 2, 3)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "towr_amd.h")).read()
+    names = set(re.findall(r"\b(twr_[a-z_0-9]+)\s*\(", hdr))
+    assert len(names) >= 18
+    lib = C.CDLL(ta.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_struct_layouts_match_the_header():
+    """ctypes mirrors must have the sizes the C compiler gives the header's structs."""
+    import subprocess
+    import tempfile
+
+    src = '#include "towr_amd.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu",sizeof(twr_model),sizeof(twr_schedule),sizeof(twr_params),sizeof(twr_sizes),sizeof(twr_set_info));}'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")])
+        sizes = list(map(int, subprocess.check_output([os.path.join(d, "t")]).split()))
+    assert sizes == [C.sizeof(ta.Model), C.sizeof(ta.Schedule), C.sizeof(ta.Params), C.sizeof(ta.Sizes), C.sizeof(ta.SetInfo)]
+
+
+def test_error_behaviour():
+    L = ta.lib()
+    m = ta.Model()
+    assert L.twr_model_preset(99, 0, C.byref(m)) == -1 and b"robot" in L.twr_last_error()
+    assert L.twr_model_preset(0, 42, C.byref(m)) == -1 and b"terrain" in L.twr_last_error()
+    s = ta.Schedule()
+    assert L.twr_gait_combo(3, 0, 2.0, 1.0, C.byref(s)) == -1   # no 3-legged gait generator (gait_generator.cc:43-52)
+    assert L.twr_gait_combo(4, 7, 2.0, 1.0, C.byref(s)) == -1
+    assert L.twr_gait_combo(4, 1, -1.0, 1.0, C.byref(s)) == -1
+    # feet whose phase durations do not sum to the same T (assert in parameters.cc:120-123)
+    bad = ta.schedule([[0.5, 0.5], [0.5, 0.6]], [1, 1])
+    with pytest.raises(ta.TowrError, match="same T"):
+        ta.Structure(ta.model_preset("biped", "flat"), bad)
+    with pytest.raises(ta.TowrError, match="n_ee"):
+        ta.Structure(ta.model_preset("anymal", "flat"), bad)
+    with pytest.raises(ta.TowrError):
+        ta.Structure(ta.model_preset("biped", "flat"), ta.gait_combo(2, 0, 2.0), ta.params_default(dt_dynamic=0.0))
+    h = C.c_void_p()
+    assert L.twr_structure_create(None, None, None, C.byref(h)) == -1
+    assert L.twr_batch_eval(None, None, None, None, 3, None) == -1
+
+
+def test_no_cpu_fallback_without_a_gpu():
+    """On a box without a GPU the product path must fail loudly, not fall back to anything."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    S = ta.Structure(ta.model_preset("monoped", "flat"), hopper_schedule())
+    with pytest.raises(ta.TowrError, match="no HIP device|TWR|hip"):
+        ta.Batch([S], [0])
+
+
+def test_sweep_enumeration_and_sharding():
+    from towr_amd import sweep
+
+    c = sweep.enumerate_candidates(1024)
+    assert len(c) == 1024 and c[0] == (0, 1.2, 0.80) and c[26][1] == pytest.approx(1.4) and c[208][0] == 1
+    with pytest.raises(ValueError):
+        sweep.enumerate_candidates(2000)
+    m = ta.model_preset("anymal", "stairs")
+    sizes = [sweep.candidate_structure(m, x).algorithmic_bytes for x in c[:64:4]]
+    assert len(set(sizes)) > 1          # ragged
+    S = sweep.candidate_structure(m, c[40])
+    assert S.k_dynamic == 200 and S.k_rom == 200
+    rng = np.random.default_rng(3)
+    for world in (1, 2, 3, 4, 8):
+        w = rng.integers(800_000, 900_000, size=1024)
+        b = sweep.shard_bounds(w, world)
+        assert b[0] == 0 and b[-1] == 1024 and all(b[i] <= b[i + 1] for i in range(world))
+        loads = [w[b[r]:b[r + 1]].sum() for r in range(world)]
+        assert max(loads) - min(loads) <= 2 * w.max()
+    assert sweep.shard_bounds([5, 1, 1, 1, 1, 1], 2) == [0, 1, 6]
+    assert sweep.shard_bounds([1, 1], 4)[-1] == 2

@@ -1,0 +1,48 @@
+"""Candidate contact-sequence sweeps (BASELINE configs C4/C5) and their sharding over ranks.
+
+The reference has no sweep code (fpowr solves one hard-coded gait per goal,
+fpowr/src/footstep_plan_server.cc:191-200); the candidates are enumerated deterministically from the
+reference's GaitGenerator tables as SURVEY.md section 8(d) prescribes:
+lexicographic over combo C0..C4 x T_i = 1.2 + 0.2 i (i = 0..7) x swing scale s_j = 0.80 + 0.016 j
+(j = 0..25), truncated to the first B.  Every candidate has its own structure (ragged n/m/nnz).
+"""
+import numpy as np
+
+from . import Structure, gait_combo, params_default
+
+
+def enumerate_candidates(count, n_ee=4):
+    """[(combo, T, swing_scale)] in the canonical order; 1040 candidates exist."""
+    out = []
+    for combo in range(5):
+        for i in range(8):
+            for j in range(26):
+                out.append((combo, 1.2 + 0.2 * i, 0.80 + 0.016 * j))
+    if count > len(out):
+        raise ValueError("only %d candidates are defined" % len(out))
+    return out[:count]
+
+
+def candidate_structure(model, cand, k_nodes=200):
+    combo, T, scale = cand
+    sched = gait_combo(model.n_ee, combo, T, scale)
+    dt = T / (k_nodes - 1.5)  # the reference rule floor(T/dt)+2 then gives k_nodes time nodes
+    return Structure(model, sched, params_default(dt_dynamic=dt, dt_rom=dt))
+
+
+def shard_bounds(weights, world):
+    """Contiguous shards balanced by the prefix sum of `weights` (bytes per candidate):
+    rank r owns [bounds[r], bounds[r+1]).  Every candidate lands in exactly one shard."""
+    w = np.asarray(weights, dtype=np.float64)
+    csum = np.concatenate([[0.0], np.cumsum(w)])
+    total = csum[-1]
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r / world
+        i = int(np.searchsorted(csum, target, side="left"))
+        # pick the boundary whose prefix sum is closest to the target
+        if i > 0 and abs(csum[i - 1] - target) <= abs(csum[min(i, len(w))] - target):
+            i -= 1
+        bounds.append(min(max(i, bounds[-1]), len(w)))
+    bounds.append(len(w))
+    return bounds
