@@ -14,7 +14,6 @@ flat terrain, K_dyn=K_rom=200, `--batch` problems per GPU that share the structu
 Prints ONE JSON line on rank 0, with the `roofline` and `cpu_baseline` objects of the contract.
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -110,16 +109,11 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     # --- the single collective of the design: rank 0 broadcasts the POD robot/terrain model (RCCL)
-    model = ta.Model()
-    nbytes = ctypes.sizeof(model)
     if world > 1:
+        from towr_amd.dist import broadcast_model
+
         dist.init_process_group("nccl", device_id=dev)
-        blob = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            src = ta.model_preset("anymal", "flat")
-            blob.copy_(torch.frombuffer(bytearray(bytes(src)), dtype=torch.uint8))
-        dist.broadcast(blob, src=0)
-        ctypes.memmove(ctypes.addressof(model), bytes(blob.cpu().numpy().tobytes()), nbytes)
+        model = broadcast_model(ta.model_preset("anymal", "flat") if rank == 0 else None, src=0, device=dev)
     else:
         model = ta.model_preset("anymal", "flat")
 

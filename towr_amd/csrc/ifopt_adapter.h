@@ -1,0 +1,142 @@
+// ifopt adapter: presents the device path as ordinary ifopt::ConstraintSet objects so that CPU
+// Ipopt keeps driving the outer solve and NlpFormulation is unchanged apart from which classes
+// it instantiates (INTEGRATION.md shows the three-line change in nlp_formulation.cc).
+//
+// COMPILE-GATED: needs <ifopt/constraint_set.h> and Eigen, which this build image does not have
+// (SURVEY.md section 0); the core library and its tests do not depend on this header.  It is the only
+// C++/Eigen-typed code on top of the C ABI of include/towr_amd.h.
+//
+// Replaces (same component names, same row order, same Jacobian pattern incl. explicit zeros):
+//   towr::TerrainConstraint        "terrain-ee-motion_<ee>"   towr/src/terrain_constraint.cc:36-108
+//   towr::DynamicConstraint        "dynamic"                  towr/src/dynamic_constraint.cc:37-137
+//   towr::RangeOfMotionConstraint  "rangeofmotion-<ee>"       towr/src/range_of_motion_constraint.cc:35-109
+//   towr::ForceConstraint          "force-ee-force_<ee>"      towr/src/force_constraint.cc:37-171
+#pragma once
+#if __has_include(<ifopt/constraint_set.h>)
+#include <ifopt/constraint_set.h>
+
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "towr_amd.h"
+
+namespace towr_amd {
+
+// One problem on one GPU.  All adapter sets of a problem share it; x is uploaded and the fused kernel
+// runs once per new x (ifopt calls GetValues / FillJacobianBlock once per set and per variable set).
+class DeviceProblem {
+ public:
+  DeviceProblem(const twr_model& model, const twr_schedule& schedule, const twr_params& params, int device = 0) {
+    Check(twr_structure_create(&model, &schedule, &params, &structure_));
+    const twr_structure* list[1] = {structure_};
+    const int32_t map[1] = {0};
+    Check(twr_batch_create(list, 1, map, 1, device, &batch_));
+    Check(twr_structure_sizes(structure_, &sizes_));
+    x_.assign(sizes_.n_vars, 0.0);
+    g_.assign(sizes_.n_rows, 0.0);
+    jac_.assign(sizes_.nnz, 0.0);
+    lower_.resize(sizes_.n_rows);
+    upper_.resize(sizes_.n_rows);
+    Check(twr_structure_bounds(structure_, lower_.data(), upper_.data()));
+  }
+  ~DeviceProblem() {
+    twr_batch_destroy(batch_);
+    twr_structure_destroy(structure_);
+  }
+  DeviceProblem(const DeviceProblem&) = delete;
+  DeviceProblem& operator=(const DeviceProblem&) = delete;
+
+  // Composite::GetValues() of the variable composite, stacked in ifopt order.
+  void Update(const Eigen::VectorXd& x) {
+    if (x.size() != sizes_.n_vars) throw std::runtime_error("towr_amd: variable count mismatch");
+    if (valid_ && std::memcmp(x.data(), x_.data(), sizeof(double) * x_.size()) == 0) return;
+    std::memcpy(x_.data(), x.data(), sizeof(double) * x_.size());
+    Check(twr_batch_eval_host(batch_, x_.data(), g_.data(), jac_.data(), TWR_EVAL_BOTH));
+    valid_ = true;
+  }
+  const twr_structure* structure() const { return structure_; }
+  const twr_sizes& sizes() const { return sizes_; }
+  const std::vector<double>& g() const { return g_; }
+  const std::vector<double>& jac() const { return jac_; }
+  const std::vector<double>& lower() const { return lower_; }
+  const std::vector<double>& upper() const { return upper_; }
+
+ private:
+  static void Check(int rc) {
+    if (rc != TWR_OK) throw std::runtime_error(std::string("towr_amd: ") + twr_last_error());
+  }
+  twr_structure* structure_ = nullptr;
+  twr_batch* batch_ = nullptr;
+  twr_sizes sizes_{};
+  std::vector<double> x_, g_, jac_, lower_, upper_;
+  bool valid_ = false;
+};
+
+class DeviceConstraintSet : public ifopt::ConstraintSet {
+ public:
+  DeviceConstraintSet(std::shared_ptr<DeviceProblem> problem, int set_index)
+      : ifopt::ConstraintSet(kSpecifyLater, SetName(*problem, set_index)), problem_(std::move(problem)) {
+    if (twr_structure_con_set(problem_->structure(), set_index, &info_) != TWR_OK)
+      throw std::runtime_error(twr_last_error());
+    SetRows(info_.size);
+    int n_sets = problem_->sizes().n_var_sets;
+    for (int i = 0; i < n_sets; ++i) {
+      twr_set_info v;
+      twr_structure_var_set(problem_->structure(), i, &v);
+      var_sets_.push_back(v);
+    }
+  }
+
+  VectorXd GetValues() const override {
+    problem_->Update(GetVariables()->GetValues());
+    return Eigen::Map<const VectorXd>(problem_->g().data() + info_.offset, info_.size);
+  }
+
+  VecBound GetBounds() const override {
+    VecBound b(info_.size);
+    for (int i = 0; i < info_.size; ++i)
+      b[i] = ifopt::Bounds(problem_->lower()[info_.offset + i], problem_->upper()[info_.offset + i]);
+    return b;
+  }
+
+  void FillJacobianBlock(std::string var_set, Jacobian& jac) const override {
+    problem_->Update(GetVariables()->GetValues());
+    const twr_set_info* vs = nullptr;
+    for (const auto& v : var_sets_)
+      if (var_set == v.name) vs = &v;
+    if (!vs) return;  // e.g. "ee-schedule<i>": fixed timings, no columns
+    const int32_t* row_ptr = twr_structure_row_ptr(problem_->structure());
+    const int32_t* col_idx = twr_structure_col_idx(problem_->structure());
+    const double* val = problem_->jac().data();
+    for (int r = 0; r < info_.size; ++r)
+      for (int k = row_ptr[info_.offset + r]; k < row_ptr[info_.offset + r + 1]; ++k) {
+        int c = col_idx[k] - vs->offset;
+        if (c >= 0 && c < vs->size) jac.coeffRef(r, c) = val[k];  // explicit zeros kept, like the reference
+      }
+  }
+
+ private:
+  static std::string SetName(const DeviceProblem& p, int i) {
+    twr_set_info s;
+    if (twr_structure_con_set(p.structure(), i, &s) != TWR_OK) throw std::runtime_error(twr_last_error());
+    return s.name;
+  }
+  std::shared_ptr<DeviceProblem> problem_;
+  twr_set_info info_{};
+  std::vector<twr_set_info> var_sets_;
+};
+
+// All hot-path sets of one problem, in the reference's relative order.
+inline std::vector<ifopt::ConstraintSet::Ptr> MakeDeviceConstraints(const twr_model& model, const twr_schedule& schedule,
+                                                                    const twr_params& params, int device = 0) {
+  auto problem = std::make_shared<DeviceProblem>(model, schedule, params, device);
+  std::vector<ifopt::ConstraintSet::Ptr> sets;
+  for (int i = 0; i < problem->sizes().n_con_sets; ++i) sets.push_back(std::make_shared<DeviceConstraintSet>(problem, i));
+  return sets;
+}
+
+}  // namespace towr_amd
+#endif  // __has_include(<ifopt/constraint_set.h>)
