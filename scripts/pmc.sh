@@ -1,0 +1,26 @@
+#!/bin/bash
+# PMC passes for the fused kernel (each counter group in its own rocprofv3 run; --pmc only with kernel-trace)
+export TMPDIR=/tmp
+OUT=gpurun_out/pmc_${1:-run}
+mkdir -p $OUT
+run() { # name counters...
+  name=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/$name.log 2>&1
+  f=$(find $OUT/$name -name "*counter_collection.csv" | head -1)
+  python3 - "$f" <<'PY'
+import csv,sys,collections
+f=sys.argv[1]
+acc=collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    if 'eval_kernel' in r['Kernel_Name']:
+        acc[r['Counter_Name']].append(float(r['Counter_Value']))
+for k,v in acc.items():
+    print("%-28s mean/launch %.6g  (n=%d)"%(k,sum(v)/len(v),len(v)))
+PY
+}
+run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
+run sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM
+run tcc1 FETCH_SIZE
+run tcc2 WRITE_SIZE
+run tcc3 TCC_HIT_sum TCC_MISS_sum
+run grbm GRBM_GUI_ACTIVE

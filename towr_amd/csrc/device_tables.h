@@ -22,7 +22,7 @@ constexpr int kMaxEE = 4;
 // kernel folds w_p1 into w_p0 and the p1 candidates are marked absent.
 // (reference: nodes_variables_phase_based.cc:210-298, node_spline.cc:84-112)
 struct EePoly {
-  double T;
+  double iT;       // 1 / duration
   int32_t xbase;
   uint8_t nslots;
   uint8_t cnt[3];  // slots per dim
@@ -53,7 +53,7 @@ struct DevStruct {
   int32_t row_rom[kMaxEE], nnz_rom[kMaxEE];
   int32_t row_force[kMaxEE], nnz_force[kMaxEE], n_force_nodes[kMaxEE];
   // byte offsets of the tables inside the blob (from the blob start)
-  uint32_t o_base_T;                                   // double[n_base_polys]
+  uint32_t o_base_iT;                                  // double[n_base_polys], 1/duration
   uint32_t o_mpoly[kMaxEE], o_fpoly[kMaxEE];           // EePoly[]
   uint32_t o_dyn_tl_base, o_dyn_base_poly, o_dyn_val_off;  // double[K], int32[K], int32[K+1]
   uint32_t o_dyn_mpoly[kMaxEE], o_dyn_tl_m[kMaxEE];    // int32[K], double[K]

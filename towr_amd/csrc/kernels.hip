@@ -30,17 +30,18 @@ TWR_DEV const T* tbl(const char* blob, uint32_t off) {
 }
 
 // ---------------------------------------------------------------- cubic Hermite weights
-// d{pos,vel,acc}/d{p0,v0,p1,v1} of CubicHermitePolynomial (src/polynomial.cc:140-234).
-TWR_DEV void hermite_pos(double t, double T, double w[4]) {
-  const double iT = 1.0 / T, iT2 = iT * iT, iT3 = iT2 * iT;
+// d{pos,vel,acc}/d{p0,v0,p1,v1} of CubicHermitePolynomial (src/polynomial.cc:140-234); iT = 1/T comes
+// from the tables (one IEEE division on the host instead of one per lane and spline).
+TWR_DEV void hermite_pos(double t, double iT, double w[4]) {
+  const double iT2 = iT * iT, iT3 = iT2 * iT;
   const double t2 = t * t, t3 = t2 * t;
   w[0] = 2.0 * t3 * iT3 - 3.0 * t2 * iT2 + 1.0;
   w[1] = t - 2.0 * t2 * iT + t3 * iT2;
   w[2] = 3.0 * t2 * iT2 - 2.0 * t3 * iT3;
   w[3] = t3 * iT2 - t2 * iT;
 }
-TWR_DEV void hermite_all(double t, double T, double wp[4], double wv[4], double wa[4]) {
-  const double iT = 1.0 / T, iT2 = iT * iT, iT3 = iT2 * iT;
+TWR_DEV void hermite_all(double t, double iT, double wp[4], double wv[4], double wa[4]) {
+  const double iT2 = iT * iT, iT3 = iT2 * iT;
   const double t2 = t * t, t3 = t2 * t;
   wp[0] = 2.0 * t3 * iT3 - 3.0 * t2 * iT2 + 1.0;
   wp[1] = t - 2.0 * t2 * iT + t3 * iT2;
@@ -58,7 +59,7 @@ TWR_DEV void hermite_all(double t, double T, double wp[4], double wv[4], double 
 
 // ---------------------------------------------------------------- ee polynomial record
 struct PolyR {
-  double T;
+  double iT;
   int xbase;
   uint32_t meta;   // nslots | cnt[0]<<8 | cnt[1]<<16 | cnt[2]<<24
   uint32_t c[6];   // 12 candidate descriptors (16 bit each)
@@ -67,11 +68,13 @@ struct PolyR {
   TWR_DEV int cnt(int d) const { return (meta >> (8 * (d + 1))) & 0xFF; }
   TWR_DEV uint32_t cand(int i) const { return (c[i >> 1] >> (16 * (i & 1))) & 0xFFFFu; }
 };
+TWR_DEV int meta_nslots(uint32_t meta) { return meta & 0xFF; }
+TWR_DEV int meta_cnt(uint32_t meta, int d) { return (meta >> (8 * (d + 1))) & 0xFF; }
 TWR_DEV PolyR load_poly(const EePoly* p) {
   const uint4* q = reinterpret_cast<const uint4*>(p);
   const uint4 a = q[0], b = q[1], d = q[2];
   PolyR r;
-  r.T = __hiloint2double((int)a.y, (int)a.x);
+  r.iT = __hiloint2double((int)a.y, (int)a.x);
   r.xbase = (int)a.z;
   r.meta = a.w;
   r.c[0] = b.x; r.c[1] = b.y; r.c[2] = b.z; r.c[3] = b.w;
@@ -83,16 +86,23 @@ TWR_DEV PolyR load_poly(const EePoly* p) {
 // (Spline::GetPoint, src/spline.cc:80-93, in Hermite basis form).  A stance ee-motion
 // polynomial keeps one shared position variable for both nodes: w_p1 is folded into w_p0.
 TWR_DEV void ee_weights_and_point(const PolyR& P, double tl, const double* __restrict__ xp, double w[4], double out[3]) {
-  hermite_pos(tl, P.T, w);
+  hermite_pos(tl, P.iT, w);
   if (P.shared) w[0] += w[2];
+  // all 12 loads are issued unconditionally (absent candidates read slot 0 and get weight 0): one
+  // memory round trip instead of twelve dependent, branch-guarded ones
+  double v[12];
+#pragma unroll
+  for (int c = 0; c < 12; ++c) {
+    const int sl = P.cand(c) & 0xF;
+    v[c] = xp[P.xbase + (sl != 0xF ? sl : 0)];
+  }
   out[0] = out[1] = out[2] = 0.0;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      const uint32_t cd = P.cand(j * 3 + d);
-      const int sl = cd & 0xF;
-      if (sl != 0xF) out[d] += w[j] * xp[P.xbase + sl];
+      const bool valid = (P.cand(j * 3 + d) & 0xF) != 0xF;
+      out[d] = fma(valid ? w[j] : 0.0, v[j * 3 + d], out[d]);
     }
 }
 
@@ -159,12 +169,13 @@ TWR_DEV void symmul(const double I[6], const double v[3], double o[3]) {  // I =
 //   A_d = d g_ang/d e_d, B_d = d g_ang/d edot_d, C_d = d g_ang/d eddot_d  (3-vectors).
 template <int NEE>
 TWR_DEV void dyn_item(const DevStruct* __restrict__ S, const char* __restrict__ blob, const double* __restrict__ xp,
-                      double* __restrict__ gp, double* __restrict__ stage, int soff, int k, bool want_g, bool want_j) {
+                      double* __restrict__ gp, double* __restrict__ stage, int soff, int trash, int k, bool want_g,
+                      bool want_j) {
   const double tb = tbl<double>(blob, S->o_dyn_tl_base)[k];
   const int q = tbl<int32_t>(blob, S->o_dyn_base_poly)[k];
-  const double Tb = tbl<double>(blob, S->o_base_T)[q];
+  const double iTb = tbl<double>(blob, S->o_base_iT)[q];
   double wP[4], wV[4], wA[4];
-  hermite_all(tb, Tb, wP, wV, wA);
+  hermite_all(tb, iTb, wP, wV, wA);
   const double* xl = xp + S->off_base_lin + 6 * q;  // [p0 v0 p1 v1] x 3, NodesVariablesAll order
   const double* xa = xp + S->off_base_ang + 6 * q;
   double c[3], cdd[3], e[3], ed[3], edd[3];
@@ -179,9 +190,11 @@ TWR_DEV void dyn_item(const DevStruct* __restrict__ S, const char* __restrict__ 
     edd[d] = wA[0] * a0 + wA[1] * a1 + wA[2] * a2 + wA[3] * a3;
   }
 
-  // --- end-effector splines
-  PolyR MP[NEE], FP[NEE];
-  double wm[NEE][4], wf[NEE][4], f[NEE][3], rv[NEE][3];
+  // --- pass A over the end-effectors: spline points, force / torque sums, slot counts.
+  // Only f_i, r_i = c - p_i and the two count words per ee stay live; the polynomial records and
+  // weights are re-read (L1 hits) in pass B, which keeps the lane under 256 VGPRs.
+  double f[NEE][3], rv[NEE][3];
+  uint32_t mmeta[NEE], fmeta[NEE];
   double F[3] = {0.0, 0.0, 0.0}, tau[3] = {0.0, 0.0, 0.0};
 #pragma unroll
   for (int ee = 0; ee < NEE; ++ee) {
@@ -189,11 +202,13 @@ TWR_DEV void dyn_item(const DevStruct* __restrict__ S, const char* __restrict__ 
     const int fq = tbl<int32_t>(blob, S->o_dyn_fpoly[ee])[k];
     const double tm = tbl<double>(blob, S->o_dyn_tl_m[ee])[k];
     const double tf = tbl<double>(blob, S->o_dyn_tl_f[ee])[k];
-    MP[ee] = load_poly(tbl<EePoly>(blob, S->o_mpoly[ee]) + mq);
-    FP[ee] = load_poly(tbl<EePoly>(blob, S->o_fpoly[ee]) + fq);
-    double p[3];
-    ee_weights_and_point(MP[ee], tm, xp, wm[ee], p);
-    ee_weights_and_point(FP[ee], tf, xp, wf[ee], f[ee]);
+    const PolyR MP = load_poly(tbl<EePoly>(blob, S->o_mpoly[ee]) + mq);
+    const PolyR FP = load_poly(tbl<EePoly>(blob, S->o_fpoly[ee]) + fq);
+    double wm[4], wf[4], p[3];
+    ee_weights_and_point(MP, tm, xp, wm, p);
+    ee_weights_and_point(FP, tf, xp, wf, f[ee]);
+    mmeta[ee] = MP.meta;
+    fmeta[ee] = FP.meta;
     double t3[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) rv[ee][d] = c[d] - p[d];
@@ -254,9 +269,9 @@ TWR_DEV void dyn_item(const DevStruct* __restrict__ S, const char* __restrict__ 
   for (int ee = 0; ee < NEE; ++ee)
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      nma[r] += MP[ee].nslots() - MP[ee].cnt(r);
-      nfa[r] += FP[ee].nslots() - FP[ee].cnt(r);
-      nfl[r] += FP[ee].cnt(r);
+      nma[r] += meta_nslots(mmeta[ee]) - meta_cnt(mmeta[ee], r);
+      nfa[r] += meta_nslots(fmeta[ee]) - meta_cnt(fmeta[ee], r);
+      nfl[r] += meta_cnt(fmeta[ee], r);
     }
   int rs[3], rl[3];
   rs[0] = soff;
@@ -377,27 +392,36 @@ TWR_DEV void dyn_item(const DevStruct* __restrict__ S, const char* __restrict__ 
           stage[rs[r] + 8 + 3 * j + d] = A[d][r] * wP[j] + B[d][r] * wV[j] + C[d][r] * wA[j];
   }
 
-  // --- ee-motion blocks [f]x J_p (:181-192) and ee-force blocks {[r]x J_f ; -J_f} (:167-179)
+  // --- pass B: ee-motion blocks [f]x J_p (:181-192) and ee-force blocks {[r]x J_f ; -J_f} (:167-179).
+  // Candidates that are not variables write to the lane's trash slot instead of branching.
   int ms[3] = {rs[0] + 20, rs[1] + 20, rs[2] + 20};
   int fs[3] = {ms[0] + nma[0], ms[1] + nma[1], ms[2] + nma[2]};
   int ls[3] = {rl[0] + 4, rl[1] + 4, rl[2] + 4};
 #pragma unroll
   for (int ee = 0; ee < NEE; ++ee) {
+    const int mq = tbl<int32_t>(blob, S->o_dyn_mpoly[ee])[k];
+    const int fq = tbl<int32_t>(blob, S->o_dyn_fpoly[ee])[k];
+    const double tm = tbl<double>(blob, S->o_dyn_tl_m[ee])[k];
+    const double tf = tbl<double>(blob, S->o_dyn_tl_f[ee])[k];
+    const PolyR MP = load_poly(tbl<EePoly>(blob, S->o_mpoly[ee]) + mq);
+    const PolyR FP = load_poly(tbl<EePoly>(blob, S->o_fpoly[ee]) + fq);
+    double wm[4], wf[4];
+    hermite_pos(tm, MP.iT, wm);
+    if (MP.shared) wm[0] += wm[2];
+    hermite_pos(tf, FP.iT, wf);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-#define TWR_EE_TILE(D, R1, R2)                                                         \
-  {                                                                                    \
-    const uint32_t cm = MP[ee].cand(j * 3 + D);                                        \
-    if ((cm & 0xF) != 0xF) {                                                           \
-      stage[ms[R1] + ((cm >> 4) & 0xF)] = crs<R1, D>(f[ee]) * wm[ee][j];               \
-      stage[ms[R2] + ((cm >> 8) & 0xF)] = crs<R2, D>(f[ee]) * wm[ee][j];               \
-    }                                                                                  \
-    const uint32_t cf = FP[ee].cand(j * 3 + D);                                        \
-    if ((cf & 0xF) != 0xF) {                                                           \
-      stage[fs[R1] + ((cf >> 4) & 0xF)] = crs<R1, D>(rv[ee]) * wf[ee][j];              \
-      stage[fs[R2] + ((cf >> 8) & 0xF)] = crs<R2, D>(rv[ee]) * wf[ee][j];              \
-      stage[ls[D] + ((cf >> 12) & 0xF)] = -wf[ee][j];                                  \
-    }                                                                                  \
+#define TWR_EE_TILE(D, R1, R2)                                                             \
+  {                                                                                        \
+    const uint32_t cm = MP.cand(j * 3 + D);                                                \
+    const bool vm = (cm & 0xF) != 0xF;                                                     \
+    stage[vm ? ms[R1] + (int)((cm >> 4) & 0xF) : trash] = crs<R1, D>(f[ee]) * wm[j];       \
+    stage[vm ? ms[R2] + (int)((cm >> 8) & 0xF) : trash] = crs<R2, D>(f[ee]) * wm[j];       \
+    const uint32_t cf = FP.cand(j * 3 + D);                                                \
+    const bool vf = (cf & 0xF) != 0xF;                                                     \
+    stage[vf ? fs[R1] + (int)((cf >> 4) & 0xF) : trash] = crs<R1, D>(rv[ee]) * wf[j];      \
+    stage[vf ? fs[R2] + (int)((cf >> 8) & 0xF) : trash] = crs<R2, D>(rv[ee]) * wf[j];      \
+    stage[vf ? ls[D] + (int)((cf >> 12) & 0xF) : trash] = -wf[j];                          \
   }
       TWR_EE_TILE(0, 1, 2)
       TWR_EE_TILE(1, 2, 0)
@@ -406,9 +430,9 @@ TWR_DEV void dyn_item(const DevStruct* __restrict__ S, const char* __restrict__ 
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      ms[r] += MP[ee].nslots() - MP[ee].cnt(r);
-      fs[r] += FP[ee].nslots() - FP[ee].cnt(r);
-      ls[r] += FP[ee].cnt(r);
+      ms[r] += meta_nslots(mmeta[ee]) - meta_cnt(mmeta[ee], r);
+      fs[r] += meta_nslots(fmeta[ee]) - meta_cnt(fmeta[ee], r);
+      ls[r] += meta_cnt(fmeta[ee], r);
     }
   }
 }
@@ -417,13 +441,13 @@ TWR_DEV void dyn_item(const DevStruct* __restrict__ S, const char* __restrict__ 
 // RangeOfMotionConstraint::{UpdateConstraintAtInstance, UpdateJacobianAtInstance}
 // (range_of_motion_constraint.cc:58-109) for one (time node, ee).
 TWR_DEV void rom_item(const DevStruct* __restrict__ S, const char* __restrict__ blob, const double* __restrict__ xp,
-                      double* __restrict__ gp, double* __restrict__ stage, int soff, int k, int ee, bool want_g,
-                      bool want_j) {
+                      double* __restrict__ gp, double* __restrict__ stage, int soff, int trash, int k, int ee,
+                      bool want_g, bool want_j) {
   const double tb = tbl<double>(blob, S->o_rom_tl_base)[k];
   const int q = tbl<int32_t>(blob, S->o_rom_base_poly)[k];
-  const double Tb = tbl<double>(blob, S->o_base_T)[q];
+  const double iTb = tbl<double>(blob, S->o_base_iT)[q];
   double wP[4];
-  hermite_pos(tb, Tb, wP);
+  hermite_pos(tb, iTb, wP);
   const double* xl = xp + S->off_base_lin + 6 * q;
   const double* xa = xp + S->off_base_ang + 6 * q;
   double c[3], e[3];
@@ -472,7 +496,8 @@ TWR_DEV void rom_item(const DevStruct* __restrict__ S, const char* __restrict__ 
 #pragma unroll
       for (int d = 0; d < 3; ++d) {  // R^T J_p
         const uint32_t cd = MP.cand(j * 3 + d);
-        if ((cd & 0xF) != 0xF) stage[rs[r] + mo[r] + (cd & 0xF)] = ro.R[d][r] * wm[j];
+        const bool valid = (cd & 0xF) != 0xF;
+        stage[valid ? rs[r] + mo[r] + (int)(cd & 0xF) : trash] = ro.R[d][r] * wm[j];
       }
     }
   }
@@ -615,13 +640,14 @@ TWR_DEV void copy_out(double* __restrict__ dst, const double* __restrict__ stage
   if ((total & 1) && lane == 0 && total - 1 >= par) al[total - 1] = stage[total - 1];
 }
 
-constexpr int kStageDoubles = 5000;  // ~39 KiB LDS image per workgroup: four workgroups share a CU's 160 KiB
+constexpr int kStageDoubles = 4936;  // ~39 KiB LDS image per workgroup: four workgroups share a CU's 160 KiB
 
 template <int NEE>
 __global__ __launch_bounds__(64) void eval_kernel(const ProbRec* __restrict__ probs, const Work* __restrict__ work,
                                                   const double* __restrict__ x, double* __restrict__ g,
                                                   double* __restrict__ jac, int flags) {
-  __shared__ __attribute__((aligned(16))) double stage[kStageDoubles + 2];
+  __shared__ __attribute__((aligned(16))) double stage[kStageDoubles + 2 + 64];  // image + parity slack + trash slots
+  const int trash = kStageDoubles + 2 + (int)threadIdx.x;
   const Work w = work[blockIdx.x];
   const ProbRec pr = probs[w.prob];
   const char* blob = reinterpret_cast<const char*>(pr.blob);
@@ -639,7 +665,7 @@ __global__ __launch_bounds__(64) void eval_kernel(const ProbRec* __restrict__ pr
     const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
     if (lane < w.cnt) {
       const int k = w.k0 + lane;
-      dyn_item<NEE>(S, blob, xp, gp, stage, par + vo[k] - base, k, want_g, want_j);
+      dyn_item<NEE>(S, blob, xp, gp, stage, par + vo[k] - base, trash, k, want_g, want_j);
     }
     if (want_j) {
       __syncthreads();
@@ -653,7 +679,7 @@ __global__ __launch_bounds__(64) void eval_kernel(const ProbRec* __restrict__ pr
     const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
     if (lane < w.cnt) {
       const int k = w.k0 + lane;
-      rom_item(S, blob, xp, gp, stage, par + vo[k] - base, k, ee, want_g, want_j);
+      rom_item(S, blob, xp, gp, stage, par + vo[k] - base, trash, k, ee, want_g, want_j);
     }
     if (want_j) {
       __syncthreads();

@@ -115,7 +115,7 @@ SplineLayout PhaseBasedLayout(const double* phase_durations, int n_phases, bool 
 EePoly MakeEePoly(const SplineLayout& s, int q) {
   EePoly p;
   std::memset(&p, 0, sizeof(p));
-  p.T = s.durations[q];
+  p.iT = 1.0 / s.durations[q];
   int gi[12];
   bool shared = true;
   for (int d = 0; d < 3; ++d)
@@ -406,7 +406,11 @@ void Structure::PackBlob() {
     h.row_force[e] = con_sets[ci].offset; h.nnz_force[e] = con_sets[ci].nnz_offset;
     h.n_force_nodes[e] = (int)force_nodes[e].size();
   }
-  h.o_base_T = put(base.durations.data(), base.durations.size() * 8);
+  {
+    std::vector<double> inv;
+    for (double d : base.durations) inv.push_back(1.0 / d);
+    h.o_base_iT = put(inv.data(), inv.size() * 8);
+  }
   for (int e = 0; e < n_ee; ++e) {
     h.o_mpoly[e] = put(mpoly[e].data(), mpoly[e].size() * sizeof(EePoly));
     h.o_fpoly[e] = put(fpoly[e].data(), fpoly[e].size() * sizeof(EePoly));
