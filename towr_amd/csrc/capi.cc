@@ -11,9 +11,11 @@
 #include "structure.h"
 
 namespace twr {
-hipError_t launch_eval(int n_ee, int n_work, const ProbRec* probs, const Work* work, const double* x, double* g,
-                       double* jac, int flags, hipStream_t stream);
-int stage_capacity_doubles();
+hipError_t launch_eval(int n_ee, const Work* dyn, int n_dyn, const Work* rom, int n_rom, const Work* node, int n_node,
+                       const double* x, double* g, double* jac, int flags, hipStream_t stream);
+int dyn_stage_capacity();
+int rom_stage_capacity();
+int dyn_nodes_per_block();
 }  // namespace twr
 
 struct twr_structure {
@@ -22,11 +24,11 @@ struct twr_structure {
 
 struct twr_batch {
   int device = 0;
-  int n_problems = 0, n_ee = 0, n_work = 0;
+  int n_problems = 0, n_ee = 0;
+  int n_dyn = 0, n_rom = 0, n_node = 0;
   std::vector<int64_t> x_off, g_off, j_off;  // n_problems+1
   std::vector<void*> blobs;                  // device blobs, one per distinct structure
-  twr::ProbRec* d_probs = nullptr;
-  twr::Work* d_work = nullptr;
+  twr::Work* d_work = nullptr;  // [dyn | rom | node] work items
   // lazily sized scratch for twr_batch_eval_host
   double *d_x = nullptr, *d_g = nullptr, *d_j = nullptr;
 };
@@ -52,18 +54,19 @@ void copy_set(const twr::SetInfo& s, twr_set_info* out) {
   out->nnz = s.nnz;
 }
 
-// Split the k range [0,K) of one constraint set into chunks whose CSR slice fits the LDS image.
-void chunk(const std::vector<int32_t>& row_ptr, int row0, int rows_per_k, int K, int cap, int prob, int kind, int ee,
+// Split the k range [0,K) of one constraint set into chunks of at most max_cnt time nodes whose CSR
+// slice fits the LDS image of the kernel.
+void chunk(const std::vector<int32_t>& row_ptr, int row0, int rows_per_k, int K, int cap, int max_cnt, int ee,
            std::vector<twr::Work>& out) {
   int k0 = 0;
   while (k0 < K) {
     int k1 = k0;
-    while (k1 < K && k1 - k0 < 64 && row_ptr[row0 + rows_per_k * (k1 + 1)] - row_ptr[row0 + rows_per_k * k0] <= cap) ++k1;
+    while (k1 < K && k1 - k0 < max_cnt && row_ptr[row0 + rows_per_k * (k1 + 1)] - row_ptr[row0 + rows_per_k * k0] <= cap)
+      ++k1;
     if (k1 == k0) throw std::runtime_error("one time node exceeds the LDS staging capacity");
     twr::Work w;
-    w.prob = prob;
-    w.kind = (int16_t)kind;
-    w.ee = (int16_t)ee;
+    std::memset(&w, 0, sizeof(w));
+    w.ee = ee;
     w.k0 = k0;
     w.cnt = k1 - k0;
     out.push_back(w);
@@ -199,17 +202,17 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     b->x_off.assign(n_problems + 1, 0);
     b->g_off.assign(n_problems + 1, 0);
     b->j_off.assign(n_problems + 1, 0);
-    std::vector<twr::ProbRec> probs(n_problems);
     std::vector<twr::Work> dyn, rom, node;
-    const int cap = twr::stage_capacity_doubles();
     // chunk lists are identical for problems that share a structure: build once per structure
     std::vector<std::vector<twr::Work>> tmpl_dyn(n_structs), tmpl_rom(n_structs);
     for (int i = 0; i < n_structs; ++i) {
       const twr::Structure& S = structs[i]->s;
       int ci = S.n_ee;  // con_sets: terrain x n_ee, dynamic, rom x n_ee, force x n_ee
-      chunk(S.row_ptr, S.con_sets[ci].offset, 6, (int)S.grid_dyn.size(), cap, 0, 0, 0, tmpl_dyn[i]);
+      chunk(S.row_ptr, S.con_sets[ci].offset, 6, (int)S.grid_dyn.size(), twr::dyn_stage_capacity(),
+            twr::dyn_nodes_per_block(), 0, tmpl_dyn[i]);
       for (int e = 0; e < S.n_ee; ++e)
-        chunk(S.row_ptr, S.con_sets[ci + 1 + e].offset, 3, (int)S.grid_rom.size(), cap, 0, 1, e, tmpl_rom[i]);
+        chunk(S.row_ptr, S.con_sets[ci + 1 + e].offset, 3, (int)S.grid_rom.size(), twr::rom_stage_capacity(), 64, e,
+              tmpl_rom[i]);
     }
     for (int p = 0; p < n_problems; ++p) {
       int si = struct_of_problem[p];
@@ -218,25 +221,27 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
       b->x_off[p + 1] = b->x_off[p] + S.n_vars;
       b->g_off[p + 1] = b->g_off[p] + S.n_rows;
       b->j_off[p + 1] = b->j_off[p] + S.nnz;
-      probs[p].blob = reinterpret_cast<uint64_t>(b->blobs[si]);
-      probs[p].x_off = b->x_off[p];
-      probs[p].g_off = b->g_off[p];
-      probs[p].j_off = b->j_off[p];
-      for (twr::Work w : tmpl_dyn[si]) { w.prob = p; dyn.push_back(w); }
-      for (twr::Work w : tmpl_rom[si]) { w.prob = p; rom.push_back(w); }
+      auto bind = [&](twr::Work w) {
+        w.blob = reinterpret_cast<uint64_t>(b->blobs[si]);
+        w.x_off = b->x_off[p];
+        w.g_off = b->g_off[p];
+        w.j_off = b->j_off[p];
+        return w;
+      };
+      for (const twr::Work& w : tmpl_dyn[si]) dyn.push_back(bind(w));
+      for (const twr::Work& w : tmpl_rom[si]) rom.push_back(bind(w));
       twr::Work w;
-      w.prob = p; w.kind = 2; w.ee = 0; w.k0 = 0; w.cnt = 0;
-      node.push_back(w);
+      std::memset(&w, 0, sizeof(w));
+      node.push_back(bind(w));
     }
-    // heaviest workgroups first (dynamic), the small node blocks fill the tail
+    b->n_dyn = (int)dyn.size();
+    b->n_rom = (int)rom.size();
+    b->n_node = (int)node.size();
     std::vector<twr::Work> work;
     work.reserve(dyn.size() + rom.size() + node.size());
     work.insert(work.end(), dyn.begin(), dyn.end());
     work.insert(work.end(), rom.begin(), rom.end());
     work.insert(work.end(), node.begin(), node.end());
-    b->n_work = (int)work.size();
-    TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_probs), probs.size() * sizeof(twr::ProbRec)));
-    TWR_HIP(hipMemcpy(b->d_probs, probs.data(), probs.size() * sizeof(twr::ProbRec), hipMemcpyHostToDevice));
     TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_work), work.size() * sizeof(twr::Work)));
     TWR_HIP(hipMemcpy(b->d_work, work.data(), work.size() * sizeof(twr::Work), hipMemcpyHostToDevice));
     *out = b.release();
@@ -251,7 +256,6 @@ void twr_batch_destroy(twr_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   for (void* d : b->blobs) (void)hipFree(d);
-  if (b->d_probs) (void)hipFree(b->d_probs);
   if (b->d_work) (void)hipFree(b->d_work);
   if (b->d_x) (void)hipFree(b->d_x);
   if (b->d_g) (void)hipFree(b->d_g);
@@ -275,7 +279,8 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
   if ((flags & TWR_EVAL_BOTH) == 0) return fail(TWR_ERR_INVALID, "flags select nothing");
   if (((flags & TWR_EVAL_VALUES) && !d_g) || ((flags & TWR_EVAL_JACOBIAN) && !d_jac))
     return fail(TWR_ERR_INVALID, "missing output buffer");
-  hipError_t e = twr::launch_eval(b->n_ee, b->n_work, b->d_probs, b->d_work, d_x, d_g, d_jac, flags & TWR_EVAL_BOTH,
+  hipError_t e = twr::launch_eval(b->n_ee, b->d_work, b->n_dyn, b->d_work + b->n_dyn, b->n_rom,
+                                  b->d_work + b->n_dyn + b->n_rom, b->n_node, d_x, d_g, d_jac, flags & TWR_EVAL_BOTH,
                                   static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   return TWR_OK;

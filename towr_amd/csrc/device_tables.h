@@ -69,19 +69,15 @@ struct DevStruct {
                  // single_rigid_body_dynamics.cc:40-42
 };
 
-// One workgroup's job.  kind: 0 dynamic chunk, 1 range-of-motion chunk (one ee), 2 node block
-// (all force + terrain sets of the problem).
+// One workgroup's job: a contiguous run of time nodes of one constraint set of one problem
+// (dynamic: cnt <= 16, rangeofmotion-<ee>: cnt <= 64) or the node block of a problem.
 struct Work {
-  int32_t prob;
-  int16_t kind;
-  int16_t ee;
-  int32_t k0;
-  int32_t cnt;
-};
-
-struct ProbRec {
   uint64_t blob;    // device address of the problem's DevStruct blob
-  int64_t x_off, g_off, j_off;
+  int64_t x_off, g_off, j_off;  // offsets of the problem inside the batch arrays (doubles)
+  int32_t k0, cnt;
+  int32_t ee;
+  int32_t pad;
 };
+static_assert(sizeof(Work) == 48, "Work layout");
 
 }  // namespace twr

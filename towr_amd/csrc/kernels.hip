@@ -1,11 +1,11 @@
 // HIP kernels (gfx950 / CDNA4) for towr's NLP constraint + Jacobian callback.
 //
-// One fused launch evaluates every constraint set of every problem of the batch.
+// Three launches per callback batch (dynamic, range of motion, force/terrain nodes), one stream.
 // A workgroup is one wavefront (64 lanes) and owns one *contiguous* slice of one
 // problem's CSR value array:
-//   kind 0  dynamic           : lanes = consecutive time nodes k       (6 rows each)
-//   kind 1  rangeofmotion-ee  : lanes = consecutive time nodes k       (3 rows each)
-//   kind 2  force-* / terrain-* sets of the problem: lanes = spline nodes
+//   dyn_kernel   dynamic           : 16 consecutive time nodes k, FOUR lanes per node (6 rows each)
+//   rom_kernel   rangeofmotion-ee  : lanes = consecutive time nodes k               (3 rows each)
+//   node_kernel  force-* / terrain-* sets of the problem: lanes = spline nodes
 // Every lane computes its rows in registers (FP64, no MFMA: the work is 3x3 algebra),
 // scatters the values into an LDS image of the slice at the CSR position they have in
 // global memory, and the wave then streams the image out with 16-byte coalesced stores.
@@ -126,11 +126,7 @@ struct Rot {
   double R[3][3], Rx[3][3], Ry[3][3], Rz[3][3];
   double sx, cx, sy, cy, sz, cz;
 };
-TWR_DEV void rotation(const double e[3], Rot& o) {
-  double sx, cx, sy, cy, sz, cz;
-  sincos(e[0], &sx, &cx);
-  sincos(e[1], &sy, &cy);
-  sincos(e[2], &sz, &cz);
+TWR_DEV void rotation_from_sincos(double sx, double cx, double sy, double cy, double sz, double cz, Rot& o) {
   o.sx = sx; o.cx = cx; o.sy = sy; o.cy = cy; o.sz = sz; o.cz = cz;
   o.R[0][0] = cy * cz; o.R[0][1] = cz * sx * sy - cx * sz; o.R[0][2] = sx * sz + cx * cz * sy;
   o.R[1][0] = cy * sz; o.R[1][1] = cx * cz + sx * sy * sz; o.R[1][2] = cx * sy * sz - cz * sx;
@@ -144,6 +140,13 @@ TWR_DEV void rotation(const double e[3], Rot& o) {
   o.Rz[0][0] = -cy * sz; o.Rz[0][1] = -sx * sy * sz - cx * cz; o.Rz[0][2] = cz * sx - cx * sy * sz;
   o.Rz[1][0] = cy * cz;  o.Rz[1][1] = cz * sx * sy - cx * sz;  o.Rz[1][2] = cx * cz * sy + sx * sz;
   o.Rz[2][0] = 0.0;      o.Rz[2][1] = 0.0;                     o.Rz[2][2] = 0.0;
+}
+TWR_DEV void rotation(const double e[3], Rot& o) {
+  double sx, cx, sy, cy, sz, cz;
+  sincos(e[0], &sx, &cx);
+  sincos(e[1], &sy, &cy);
+  sincos(e[2], &sz, &cz);
+  rotation_from_sincos(sx, cx, sy, cy, sz, cz, o);
 }
 TWR_DEV void matvec(const double A[3][3], const double v[3], double o[3]) {
 #pragma unroll
@@ -159,21 +162,55 @@ TWR_DEV void symmul(const double I[6], const double v[3], double o[3]) {  // I =
   o[2] = I[2] * v[0] + I[4] * v[1] + I[5] * v[2];
 }
 
-// ---------------------------------------------------------------- dynamic (SRBD) item
+// ---------------------------------------------------------------- quad helpers
+// The dynamic kernel maps FOUR lanes to one time node (a "quad" = lanes 4i..4i+3); they exchange
+// scalars with DPP quad permutes (no LDS, no memory).
+template <int CTRL>
+TWR_DEV double quad_perm(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+TWR_DEV uint32_t quad_perm_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+TWR_DEV double quad_sum(double v) {
+  v += quad_perm<0xB1>(v);  // lane ^ 1
+  v += quad_perm<0x4E>(v);  // lane ^ 2
+  return v;
+}
+TWR_DEV double sel3(int i, double a, double b, double c) { return i == 0 ? a : (i == 1 ? b : c); }
+
+// ---------------------------------------------------------------- dynamic (SRBD) quad
 // DynamicConstraint::{UpdateModel, UpdateConstraintAtInstance, UpdateJacobianAtInstance}
 // (dynamic_constraint.cc:59-137) with SingleRigidBodyDynamics::{GetDynamicViolation,
 // GetJacobianWrt{BaseLin,BaseAng,Force,EEPos}} (single_rigid_body_dynamics.cc:76-192) and the
-// EulerConverter derivatives (euler_converter.cc:85-131,168-198,223-304) for one time node.
+// EulerConverter derivatives (euler_converter.cc:85-131,168-198,223-304) for one time node,
+// computed by the four lanes of a quad:
+//   role = lane & 3 evaluates end-effector `role` (splines, [f]x J_p and {[r]x J_f ; -J_f} blocks),
+//   role 0..2 additionally produce Euler dimension `role` of the base-ang block, role 3 the
+//   base-lin block and the six constraint values.
 // The base-ang block is evaluated in factored form: with u = (p0,v0,p1,v1) of Euler dim d,
 //   d g_ang / d u_j = A_d wP[j] + B_d wV[j] + C_d wA[j],
 //   A_d = d g_ang/d e_d, B_d = d g_ang/d edot_d, C_d = d g_ang/d eddot_d  (3-vectors).
 template <int NEE>
-TWR_DEV void dyn_item(const DevStruct* __restrict__ S, const char* __restrict__ blob, const double* __restrict__ xp,
-                      double* __restrict__ gp, double* __restrict__ stage, int soff, int trash, int k, bool want_g,
-                      bool want_j) {
+TWR_DEV void dyn_quad(const DevStruct* __restrict__ S, const char* __restrict__ blob, const double* __restrict__ xp,
+                      double* __restrict__ gp, double* __restrict__ stage, int soff, int trash, int k, int role,
+                      bool want_g, bool want_j) {
   const double tb = tbl<double>(blob, S->o_dyn_tl_base)[k];
   const int q = tbl<int32_t>(blob, S->o_dyn_base_poly)[k];
   const double iTb = tbl<double>(blob, S->o_base_iT)[q];
+  // --- this lane's end-effector: active polynomials, weights, spline points
+  const bool has_ee = role < NEE;
+  const int ee = has_ee ? role : 0;
+  const int mq = tbl<int32_t>(blob, S->o_dyn_mpoly[ee])[k];
+  const int fq = tbl<int32_t>(blob, S->o_dyn_fpoly[ee])[k];
+  const double tm = tbl<double>(blob, S->o_dyn_tl_m[ee])[k];
+  const double tf = tbl<double>(blob, S->o_dyn_tl_f[ee])[k];
+  const PolyR MP = load_poly(tbl<EePoly>(blob, S->o_mpoly[ee]) + mq);
+  const PolyR FP = load_poly(tbl<EePoly>(blob, S->o_fpoly[ee]) + fq);
+
   double wP[4], wV[4], wA[4];
   hermite_all(tb, iTb, wP, wV, wA);
   const double* xl = xp + S->off_base_lin + 6 * q;  // [p0 v0 p1 v1] x 3, NodesVariablesAll order
@@ -189,40 +226,37 @@ TWR_DEV void dyn_item(const DevStruct* __restrict__ S, const char* __restrict__ 
     ed[d] = wV[0] * a0 + wV[1] * a1 + wV[2] * a2 + wV[3] * a3;
     edd[d] = wA[0] * a0 + wA[1] * a1 + wA[2] * a2 + wA[3] * a3;
   }
-
-  // --- pass A over the end-effectors: spline points, force / torque sums, slot counts.
-  // Only f_i, r_i = c - p_i and the two count words per ee stay live; the polynomial records and
-  // weights are re-read (L1 hits) in pass B, which keeps the lane under 256 VGPRs.
-  double f[NEE][3], rv[NEE][3];
-  uint32_t mmeta[NEE], fmeta[NEE];
-  double F[3] = {0.0, 0.0, 0.0}, tau[3] = {0.0, 0.0, 0.0};
+  double wm[4], wf[4], p[3], f[3], rv[3];
+  ee_weights_and_point(MP, tm, xp, wm, p);
+  ee_weights_and_point(FP, tf, xp, wf, f);
 #pragma unroll
-  for (int ee = 0; ee < NEE; ++ee) {
-    const int mq = tbl<int32_t>(blob, S->o_dyn_mpoly[ee])[k];
-    const int fq = tbl<int32_t>(blob, S->o_dyn_fpoly[ee])[k];
-    const double tm = tbl<double>(blob, S->o_dyn_tl_m[ee])[k];
-    const double tf = tbl<double>(blob, S->o_dyn_tl_f[ee])[k];
-    const PolyR MP = load_poly(tbl<EePoly>(blob, S->o_mpoly[ee]) + mq);
-    const PolyR FP = load_poly(tbl<EePoly>(blob, S->o_fpoly[ee]) + fq);
-    double wm[4], wf[4], p[3];
-    ee_weights_and_point(MP, tm, xp, wm, p);
-    ee_weights_and_point(FP, tf, xp, wf, f[ee]);
-    mmeta[ee] = MP.meta;
-    fmeta[ee] = FP.meta;
-    double t3[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) rv[ee][d] = c[d] - p[d];
-    cross3(f[ee], rv[ee], t3);  // f x (c - p), single_rigid_body_dynamics.cc:84-88
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      tau[d] += t3[d];
-      F[d] += f[ee][d];
-    }
+  for (int d = 0; d < 3; ++d) {
+    rv[d] = c[d] - p[d];
+    if (!has_ee) f[d] = 0.0;
   }
+  // force and torque sums over the end-effectors (single_rigid_body_dynamics.cc:81-88)
+  double t3[3], F[3], tau[3];
+  cross3(f, rv, t3);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    F[d] = quad_sum(f[d]);
+    tau[d] = quad_sum(t3[d]);
+  }
+  // slot counts of every end-effector of the quad (row layout below)
+  const uint32_t my_mm = has_ee ? MP.meta : 0u, my_fm = has_ee ? FP.meta : 0u;
+  uint32_t mmeta[4], fmeta[4];
+  mmeta[0] = quad_perm_u32<0x00>(my_mm); fmeta[0] = quad_perm_u32<0x00>(my_fm);
+  mmeta[1] = quad_perm_u32<0x55>(my_mm); fmeta[1] = quad_perm_u32<0x55>(my_fm);
+  mmeta[2] = quad_perm_u32<0xAA>(my_mm); fmeta[2] = quad_perm_u32<0xAA>(my_fm);
+  mmeta[3] = quad_perm_u32<0xFF>(my_mm); fmeta[3] = quad_perm_u32<0xFF>(my_fm);
 
-  // --- angular quantities (euler_converter.cc:58-83,133-166)
+  // --- rotation: lanes 0..2 of the quad evaluate one sincos each and broadcast it
+  double my_s, my_c;
+  sincos(sel3(role, e[0], e[1], e[2]), &my_s, &my_c);
   Rot ro;
-  rotation(e, ro);
+  rotation_from_sincos(quad_perm<0x00>(my_s), quad_perm<0x00>(my_c), quad_perm<0x55>(my_s), quad_perm<0x55>(my_c),
+                       quad_perm<0xAA>(my_s), quad_perm<0xAA>(my_c), ro);
+  // --- angular quantities (euler_converter.cc:58-83,133-166)
   const double sy = ro.sy, cy = ro.cy, sz = ro.sz, cz = ro.cz;
   const double xd = ed[0], yd = ed[1], zd = ed[2];
   const double Mx[3] = {cy * cz, cy * sz, -sy}, My[3] = {-sz, cz, 0.0};
@@ -251,27 +285,18 @@ TWR_DEV void dyn_item(const DevStruct* __restrict__ S, const char* __restrict__ 
   Iw(om, Iw_w);
   const double m = S->mass;
 
-  if (want_g) {  // GetDynamicViolation, single_rigid_body_dynamics.cc:76-101
-    double wxIw[3];
-    cross3(om, Iw_w, wxIw);
-    double* go = gp + S->row_dyn + 6 * k;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) go[i] = Iw_wd[i] + wxIw[i] - tau[i];
-    go[3] = m * cdd[0] - F[0];
-    go[4] = m * cdd[1] - F[1];
-    go[5] = m * cdd[2] - F[2] + m * S->gravity;
-  }
-  if (!want_j) return;
-
   // --- row layout of this time node inside the CSR slice
-  int nma[3] = {0, 0, 0}, nfa[3] = {0, 0, 0}, nfl[3] = {0, 0, 0};
+  int nma[3] = {0, 0, 0}, nfa[3] = {0, 0, 0}, nfl[3] = {0, 0, 0};   // totals over the end-effectors
+  int pma[3] = {0, 0, 0}, pfa[3] = {0, 0, 0}, pfl[3] = {0, 0, 0};   // prefix for this lane's end-effector
 #pragma unroll
-  for (int ee = 0; ee < NEE; ++ee)
+  for (int e2 = 0; e2 < NEE; ++e2)
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      nma[r] += meta_nslots(mmeta[ee]) - meta_cnt(mmeta[ee], r);
-      nfa[r] += meta_nslots(fmeta[ee]) - meta_cnt(fmeta[ee], r);
-      nfl[r] += meta_cnt(fmeta[ee], r);
+      const int a = meta_nslots(mmeta[e2]) - meta_cnt(mmeta[e2], r);
+      const int b = meta_nslots(fmeta[e2]) - meta_cnt(fmeta[e2], r);
+      const int l = meta_cnt(fmeta[e2], r);
+      nma[r] += a; nfa[r] += b; nfl[r] += l;
+      if (e2 < role) { pma[r] += a; pfa[r] += b; pfl[r] += l; }
     }
   int rs[3], rl[3];
   rs[0] = soff;
@@ -281,159 +306,127 @@ TWR_DEV void dyn_item(const DevStruct* __restrict__ S, const char* __restrict__ 
   rl[1] = rl[0] + 4 + nfl[0];
   rl[2] = rl[1] + 4 + nfl[1];
 
-  // --- base-lin block: ang rows -sum_i [f_i]x J_pos, lin rows m J_acc (:103-121)
+  if (role == 3) {
+    if (want_g) {  // GetDynamicViolation, single_rigid_body_dynamics.cc:76-101
+      double wxIw[3];
+      cross3(om, Iw_w, wxIw);
+      double* go = gp + S->row_dyn + 6 * k;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    stage[rs[0] + 2 * j + 0] = -crs<0, 1>(F) * wP[j];
-    stage[rs[0] + 2 * j + 1] = -crs<0, 2>(F) * wP[j];
-    stage[rs[1] + 2 * j + 0] = -crs<1, 0>(F) * wP[j];
-    stage[rs[1] + 2 * j + 1] = -crs<1, 2>(F) * wP[j];
-    stage[rs[2] + 2 * j + 0] = -crs<2, 0>(F) * wP[j];
-    stage[rs[2] + 2 * j + 1] = -crs<2, 1>(F) * wP[j];
+      for (int i = 0; i < 3; ++i) go[i] = Iw_wd[i] + wxIw[i] - tau[i];
+      go[3] = m * cdd[0] - F[0];
+      go[4] = m * cdd[1] - F[1];
+      go[5] = m * cdd[2] - F[2] + m * S->gravity;
+    }
+    if (want_j) {  // base-lin block: ang rows -sum_i [f_i]x J_pos, lin rows m J_acc (:103-121)
 #pragma unroll
-    for (int d = 0; d < 3; ++d) stage[rl[d] + j] = m * wA[j];
-  }
-
-  // --- base-ang block (:123-165), factored
-  {
+      for (int j = 0; j < 4; ++j) {
+        stage[rs[0] + 2 * j + 0] = -crs<0, 1>(F) * wP[j];
+        stage[rs[0] + 2 * j + 1] = -crs<0, 2>(F) * wP[j];
+        stage[rs[1] + 2 * j + 0] = -crs<1, 0>(F) * wP[j];
+        stage[rs[1] + 2 * j + 1] = -crs<1, 2>(F) * wP[j];
+        stage[rs[2] + 2 * j + 0] = -crs<2, 0>(F) * wP[j];
+        stage[rs[2] + 2 * j + 1] = -crs<2, 1>(F) * wP[j];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) stage[rl[d] + j] = m * wA[j];
+      }
+    }
+  } else if (want_j) {
+    // --- base-ang block (:123-165), Euler dimension d = role, factored
     double RtWd[3], RtW[3], aWd[3], aW[3];
     matTvec(ro.R, omd, RtWd);
     matTvec(ro.R, om, RtW);
     symmul(Ib, RtWd, aWd);  // I_b R^T omega_dot  (v11)
     symmul(Ib, RtW, aW);    // I_b R^T omega      (v21)
+    double Rd[3][3];        // dR/d e_d (euler_converter.cc:241-268)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Rd[i][j] = sel3(role, ro.Rx[i][j], ro.Ry[i][j], ro.Rz[i][j]);
     // d(I_w v)/d e_d = R_d I_b R^T v + R I_b R_d^T v   (jac11+jac12 / jac21+jac22)
-    auto dIw = [&](const double Rd[3][3], const double v[3], const double av[3], double o[3]) {
-      double t1[3], t2[3], t3[3], t4[3];
+    auto dIw = [&](const double v[3], const double av[3], double o[3]) {
+      double t1[3], t2[3], t3b[3], t4[3];
       matvec(Rd, av, t1);
       matTvec(Rd, v, t2);
-      symmul(Ib, t2, t3);
-      matvec(ro.R, t3, t4);
+      symmul(Ib, t2, t3b);
+      matvec(ro.R, t3b, t4);
 #pragma unroll
       for (int i = 0; i < 3; ++i) o[i] = t1[i] + t4[i];
     };
-    // columns of M and the partials of omega, omega_dot (euler_converter.cc:168-198,270-304)
-    const double Mz[3] = {0.0, 0.0, 1.0};
+    // column d of M and the partials of omega, omega_dot (euler_converter.cc:168-198,270-304)
     const double dMx_dy[3] = {-sy * cz, -sy * sz, -cy};
     const double dMx_dz[3] = {-cy * sz, cy * cz, 0.0};
     const double dMy_dz[3] = {-cz, -sz, 0.0};
     const double dMdx_dy[3] = {-cz * cy * yd + sy * sz * zd, -sy * cz * zd - cy * sz * yd, sy * yd};
     const double dMdx_dz[3] = {sz * sy * yd - cy * cz * zd, -cy * sz * zd - sy * cz * yd, 0.0};
     const double dMdy_dz[3] = {sz * zd, -cz * zd, 0.0};
-    double A[3][3], B[3][3], C[3][3];  // [euler dim][row]
-    Iw(Mx, C[0]);
-    Iw(My, C[1]);
-    Iw(Mz, C[2]);
-    // B_d = I_w d(omega_dot)/d(edot_d) + M_d x (I_w omega) + omega x (I_w M_d)
-    {
-      double dwd[3][3];
+    double Md[3], dwd_ed[3], dw[3], dwd[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        dwd[0][i] = Mdx[i];
-        dwd[1][i] = Mdy[i] + xd * dMx_dy[i];
-        dwd[2][i] = xd * dMx_dz[i] + yd * dMy_dz[i];
-      }
-      const double Mc[3][3] = {{Mx[0], Mx[1], Mx[2]}, {My[0], My[1], My[2]}, {Mz[0], Mz[1], Mz[2]}};
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        double t1[3], t2[3], t3[3];
-        Iw(dwd[d], t1);
-        cross3(Mc[d], Iw_w, t2);
-        cross3(om, C[d], t3);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) B[d][i] = t1[i] + t2[i] + t3[i];
-      }
+    for (int i = 0; i < 3; ++i) {
+      Md[i] = sel3(role, Mx[i], My[i], i == 2 ? 1.0 : 0.0);
+      // d omega_dot / d edot_d
+      dwd_ed[i] = sel3(role, Mdx[i], Mdy[i] + xd * dMx_dy[i], xd * dMx_dz[i] + yd * dMy_dz[i]);
+      // d omega / d e_d , d omega_dot / d e_d   (roll: none)
+      dw[i] = sel3(role, 0.0, xd * dMx_dy[i], xd * dMx_dz[i] + yd * dMy_dz[i]);
+      dwd[i] = sel3(role, 0.0, xd * dMdx_dy[i] + edd[0] * dMx_dy[i],
+                    xd * dMdx_dz[i] + yd * dMdy_dz[i] + edd[0] * dMx_dz[i] + edd[1] * dMy_dz[i]);
     }
-    // A_d = dI_w(omega_dot) + I_w d(omega_dot) + d(omega) x I_w omega + omega x (dI_w(omega) + I_w d(omega))
-    {
-      double dw[3][3], dwd[3][3];
+    double A[3], B[3], C[3];
+    Iw(Md, C);
+    {  // B_d = I_w d(omega_dot)/d(edot_d) + M_d x (I_w omega) + omega x (I_w M_d)
+      double t1[3], t2[3], t3b[3];
+      Iw(dwd_ed, t1);
+      cross3(Md, Iw_w, t2);
+      cross3(om, C, t3b);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        dw[0][i] = 0.0;
-        dwd[0][i] = 0.0;
-        dw[1][i] = xd * dMx_dy[i];
-        dwd[1][i] = xd * dMdx_dy[i] + edd[0] * dMx_dy[i];
-        dw[2][i] = xd * dMx_dz[i] + yd * dMy_dz[i];
-        dwd[2][i] = xd * dMdx_dz[i] + yd * dMdy_dz[i] + edd[0] * dMx_dz[i] + edd[1] * dMy_dz[i];
-      }
-      {  // roll: omega, omega_dot do not depend on it
-        double t1[3], t2[3], t3[3];
-        dIw(ro.Rx, omd, aWd, t1);
-        dIw(ro.Rx, om, aW, t2);
-        cross3(om, t2, t3);
+      for (int i = 0; i < 3; ++i) B[i] = t1[i] + t2[i] + t3b[i];
+    }
+    {  // A_d = dI_w(omega_dot) + I_w d(omega_dot) + d(omega) x I_w omega + omega x (dI_w(omega) + I_w d(omega))
+      double t1[3], t2[3], t3b[3], t4[3], t5[3], t6[3], t7[3];
+      dIw(omd, aWd, t1);
+      Iw(dwd, t2);
+      cross3(dw, Iw_w, t3b);
+      dIw(om, aW, t4);
+      Iw(dw, t5);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) A[0][i] = t1[i] + t3[i];
-      }
+      for (int i = 0; i < 3; ++i) t6[i] = t4[i] + t5[i];
+      cross3(om, t6, t7);
 #pragma unroll
-      for (int d = 1; d < 3; ++d) {
-        double t1[3], t2[3], t3[3], t4[3], t5[3], t6[3], t7[3];
-        if (d == 1) {
-          dIw(ro.Ry, omd, aWd, t1);
-          dIw(ro.Ry, om, aW, t4);
-        } else {
-          dIw(ro.Rz, omd, aWd, t1);
-          dIw(ro.Rz, om, aW, t4);
-        }
-        Iw(dwd[d], t2);
-        cross3(dw[d], Iw_w, t3);
-        Iw(dw[d], t5);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) t6[i] = t4[i] + t5[i];
-        cross3(om, t6, t7);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) A[d][i] = t1[i] + t2[i] + t3[i] + t7[i];
-      }
+      for (int i = 0; i < 3; ++i) A[i] = t1[i] + t2[i] + t3b[i] + t7[i];
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-          stage[rs[r] + 8 + 3 * j + d] = A[d][r] * wP[j] + B[d][r] * wV[j] + C[d][r] * wA[j];
+      for (int j = 0; j < 4; ++j) stage[rs[r] + 8 + 3 * j + role] = A[r] * wP[j] + B[r] * wV[j] + C[r] * wA[j];
   }
+  if (!want_j) return;
 
-  // --- pass B: ee-motion blocks [f]x J_p (:181-192) and ee-force blocks {[r]x J_f ; -J_f} (:167-179).
-  // Candidates that are not variables write to the lane's trash slot instead of branching.
-  int ms[3] = {rs[0] + 20, rs[1] + 20, rs[2] + 20};
-  int fs[3] = {ms[0] + nma[0], ms[1] + nma[1], ms[2] + nma[2]};
-  int ls[3] = {rl[0] + 4, rl[1] + 4, rl[2] + 4};
+  // --- ee-motion block [f]x J_p (:181-192) and ee-force block {[r]x J_f ; -J_f} (:167-179) of this
+  // lane's end-effector.  Candidates that are not variables write to the lane's trash slot.
+  int ms[3], fs[3], ls[3];
 #pragma unroll
-  for (int ee = 0; ee < NEE; ++ee) {
-    const int mq = tbl<int32_t>(blob, S->o_dyn_mpoly[ee])[k];
-    const int fq = tbl<int32_t>(blob, S->o_dyn_fpoly[ee])[k];
-    const double tm = tbl<double>(blob, S->o_dyn_tl_m[ee])[k];
-    const double tf = tbl<double>(blob, S->o_dyn_tl_f[ee])[k];
-    const PolyR MP = load_poly(tbl<EePoly>(blob, S->o_mpoly[ee]) + mq);
-    const PolyR FP = load_poly(tbl<EePoly>(blob, S->o_fpoly[ee]) + fq);
-    double wm[4], wf[4];
-    hermite_pos(tm, MP.iT, wm);
-    if (MP.shared) wm[0] += wm[2];
-    hermite_pos(tf, FP.iT, wf);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#define TWR_EE_TILE(D, R1, R2)                                                             \
-  {                                                                                        \
-    const uint32_t cm = MP.cand(j * 3 + D);                                                \
-    const bool vm = (cm & 0xF) != 0xF;                                                     \
-    stage[vm ? ms[R1] + (int)((cm >> 4) & 0xF) : trash] = crs<R1, D>(f[ee]) * wm[j];       \
-    stage[vm ? ms[R2] + (int)((cm >> 8) & 0xF) : trash] = crs<R2, D>(f[ee]) * wm[j];       \
-    const uint32_t cf = FP.cand(j * 3 + D);                                                \
-    const bool vf = (cf & 0xF) != 0xF;                                                     \
-    stage[vf ? fs[R1] + (int)((cf >> 4) & 0xF) : trash] = crs<R1, D>(rv[ee]) * wf[j];      \
-    stage[vf ? fs[R2] + (int)((cf >> 8) & 0xF) : trash] = crs<R2, D>(rv[ee]) * wf[j];      \
-    stage[vf ? ls[D] + (int)((cf >> 12) & 0xF) : trash] = -wf[j];                          \
+  for (int r = 0; r < 3; ++r) {
+    ms[r] = rs[r] + 20 + pma[r];
+    fs[r] = rs[r] + 20 + nma[r] + pfa[r];
+    ls[r] = rl[r] + 4 + pfl[r];
   }
-      TWR_EE_TILE(0, 1, 2)
-      TWR_EE_TILE(1, 2, 0)
-      TWR_EE_TILE(2, 0, 1)
-#undef TWR_EE_TILE
-    }
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      ms[r] += meta_nslots(mmeta[ee]) - meta_cnt(mmeta[ee], r);
-      fs[r] += meta_nslots(fmeta[ee]) - meta_cnt(fmeta[ee], r);
-      ls[r] += meta_cnt(fmeta[ee], r);
-    }
+  for (int j = 0; j < 4; ++j) {
+#define TWR_EE_TILE(D, R1, R2)                                                              \
+  {                                                                                         \
+    const uint32_t cm = MP.cand(j * 3 + D);                                                 \
+    const bool vm = has_ee && (cm & 0xF) != 0xF;                                            \
+    stage[vm ? ms[R1] + (int)((cm >> 4) & 0xF) : trash] = crs<R1, D>(f) * wm[j];            \
+    stage[vm ? ms[R2] + (int)((cm >> 8) & 0xF) : trash] = crs<R2, D>(f) * wm[j];            \
+    const uint32_t cf = FP.cand(j * 3 + D);                                                 \
+    const bool vf = has_ee && (cf & 0xF) != 0xF;                                            \
+    stage[vf ? fs[R1] + (int)((cf >> 4) & 0xF) : trash] = crs<R1, D>(rv) * wf[j];           \
+    stage[vf ? fs[R2] + (int)((cf >> 8) & 0xF) : trash] = crs<R2, D>(rv) * wf[j];           \
+    stage[vf ? ls[D] + (int)((cf >> 12) & 0xF) : trash] = -wf[j];                           \
+  }
+    TWR_EE_TILE(0, 1, 2)
+    TWR_EE_TILE(1, 2, 0)
+    TWR_EE_TILE(2, 0, 1)
+#undef TWR_EE_TILE
   }
 }
 
@@ -640,113 +633,154 @@ TWR_DEV void copy_out(double* __restrict__ dst, const double* __restrict__ stage
   if ((total & 1) && lane == 0 && total - 1 >= par) al[total - 1] = stage[total - 1];
 }
 
-constexpr int kStageDoubles = 4936;  // ~39 KiB LDS image per workgroup: four workgroups share a CU's 160 KiB
+// LDS image sizes (doubles).  dynamic: 16 time nodes per wave (~170 values each at 4 ee) -> 22.5 KiB,
+// seven workgroups per CU; range of motion / nodes: 64 lanes x ~84 values -> 39 KiB, four per CU.
+constexpr int kDynStage = 2816;
+constexpr int kRomStage = 4936;
+constexpr int kNodeStage = 64 * 25;
 
+struct Ctx {
+  const char* blob;
+  const DevStruct* S;
+  const double* xp;
+  double* gp;
+  double* jp;
+};
+TWR_DEV Ctx make_ctx(const Work& w, const double* x, double* g, double* jac) {
+  Ctx c;
+  c.blob = reinterpret_cast<const char*>(w.blob);
+  c.S = reinterpret_cast<const DevStruct*>(c.blob);
+  c.xp = x + w.x_off;
+  c.gp = g + w.g_off;
+  c.jp = jac + w.j_off;
+  return c;
+}
+
+// kind 0: rows 6k..6k+5 of "dynamic" for w.cnt <= 16 consecutive time nodes, four lanes per node
 template <int NEE>
-__global__ __launch_bounds__(64) void eval_kernel(const ProbRec* __restrict__ probs, const Work* __restrict__ work,
-                                                  const double* __restrict__ x, double* __restrict__ g,
-                                                  double* __restrict__ jac, int flags) {
-  __shared__ __attribute__((aligned(16))) double stage[kStageDoubles + 2 + 64];  // image + parity slack + trash slots
-  const int trash = kStageDoubles + 2 + (int)threadIdx.x;
+__global__ __launch_bounds__(64, 2) void dyn_kernel(const Work* __restrict__ work, const double* __restrict__ x,
+                                                    double* __restrict__ g, double* __restrict__ jac, int flags) {
+  __shared__ __attribute__((aligned(16))) double stage[kDynStage + 2 + 64];  // image + parity slack + trash slots
   const Work w = work[blockIdx.x];
-  const ProbRec pr = probs[w.prob];
-  const char* blob = reinterpret_cast<const char*>(pr.blob);
-  const DevStruct* S = reinterpret_cast<const DevStruct*>(blob);
-  const double* xp = x + pr.x_off;
-  double* gp = g + pr.g_off;
-  double* jp = jac + pr.j_off;
+  const Ctx c = make_ctx(w, x, g, jac);
   const bool want_g = flags & 1, want_j = flags & 2;
   const int lane = threadIdx.x;
+  const int trash = kDynStage + 2 + lane;
+  const int32_t* vo = tbl<int32_t>(c.blob, c.S->o_dyn_val_off);
+  const int base = vo[w.k0], end = vo[w.k0 + w.cnt];
+  double* dst = c.jp + c.S->nnz_dyn + base;
+  const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+  // every lane of the wave runs the quad code (DPP needs its neighbours); nodes past the chunk are
+  // clamped to the last one and write to the trash slot / skip their g store
+  const int kk = lane >> 2, role = lane & 3;
+  const bool live = kk < w.cnt;
+  const int k = w.k0 + (live ? kk : w.cnt - 1);
+  dyn_quad<NEE>(c.S, c.blob, c.xp, c.gp, stage, par + vo[k] - base, trash, k, role, want_g && live, want_j && live);
+  if (want_j) {
+    __syncthreads();
+    copy_out(dst, stage, end - base, par, lane);
+  }
+}
 
-  if (w.kind == 0) {
-    const int32_t* vo = tbl<int32_t>(blob, S->o_dyn_val_off);
-    const int base = vo[w.k0], end = vo[w.k0 + w.cnt];
-    double* dst = jp + S->nnz_dyn + base;
-    const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-    if (lane < w.cnt) {
-      const int k = w.k0 + lane;
-      dyn_item<NEE>(S, blob, xp, gp, stage, par + vo[k] - base, trash, k, want_g, want_j);
-    }
-    if (want_j) {
-      __syncthreads();
-      copy_out(dst, stage, end - base, par, lane);
-    }
-  } else if (w.kind == 1) {
-    const int ee = w.ee;
-    const int32_t* vo = tbl<int32_t>(blob, S->o_rom_val_off[ee]);
-    const int base = vo[w.k0], end = vo[w.k0 + w.cnt];
-    double* dst = jp + S->nnz_rom[ee] + base;
-    const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-    if (lane < w.cnt) {
-      const int k = w.k0 + lane;
-      rom_item(S, blob, xp, gp, stage, par + vo[k] - base, trash, k, ee, want_g, want_j);
-    }
-    if (want_j) {
-      __syncthreads();
-      copy_out(dst, stage, end - base, par, lane);
-    }
-  } else {
-    // terrain-ee-motion_e (terrain_constraint.cc:57-108) then force-ee-force_e, 64 nodes at a time
-    for (int ee = 0; ee < S->n_ee; ++ee) {
-      const TerrainRow* rows = tbl<TerrainRow>(blob, S->o_terrain_rows[ee]);
-      const int nr = S->n_terrain_rows[ee];
-      for (int r0 = 0; r0 < nr; r0 += 64) {
-        const int cnt = min(64, nr - r0);
-        double* dst = jp + S->nnz_terrain[ee] + 3 * r0;
-        const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-        if (lane < cnt) {
-          const TerrainRow tr = rows[r0 + lane];
-          const double px = xp[tr.idx], py = xp[tr.idx + tr.stride], pz = xp[tr.idx + 2 * tr.stride];
-          const Terr t = terrain_eval(S->terrain_id, S->flat_height, px, py);
-          if (want_g) gp[S->row_terrain[ee] + r0 + lane] = pz - t.h;
-          if (want_j) {
-            stage[par + 3 * lane + 0] = -t.hx;
-            stage[par + 3 * lane + 1] = -t.hy;
-            stage[par + 3 * lane + 2] = 1.0;
-          }
-        }
+// kind 1: rows 3k..3k+2 of "rangeofmotion-<ee>" for w.cnt <= 64 consecutive time nodes
+__global__ __launch_bounds__(64, 2) void rom_kernel(const Work* __restrict__ work, const double* __restrict__ x,
+                                                    double* __restrict__ g, double* __restrict__ jac, int flags) {
+  __shared__ __attribute__((aligned(16))) double stage[kRomStage + 2 + 64];
+  const Work w = work[blockIdx.x];
+  const Ctx c = make_ctx(w, x, g, jac);
+  const bool want_g = flags & 1, want_j = flags & 2;
+  const int lane = threadIdx.x;
+  const int trash = kRomStage + 2 + lane;
+  const int ee = w.ee;
+  const int32_t* vo = tbl<int32_t>(c.blob, c.S->o_rom_val_off[ee]);
+  const int base = vo[w.k0], end = vo[w.k0 + w.cnt];
+  double* dst = c.jp + c.S->nnz_rom[ee] + base;
+  const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+  if (lane < w.cnt) {
+    const int k = w.k0 + lane;
+    rom_item(c.S, c.blob, c.xp, c.gp, stage, par + vo[k] - base, trash, k, ee, want_g, want_j);
+  }
+  if (want_j) {
+    __syncthreads();
+    copy_out(dst, stage, end - base, par, lane);
+  }
+}
+
+// kind 2: all terrain-ee-motion_e (terrain_constraint.cc:57-108) and force-ee-force_e sets of one
+// problem, 64 spline nodes at a time
+__global__ __launch_bounds__(64) void node_kernel(const Work* __restrict__ work, const double* __restrict__ x,
+                                                  double* __restrict__ g, double* __restrict__ jac, int flags) {
+  __shared__ __attribute__((aligned(16))) double stage[kNodeStage + 2];
+  const Work w = work[blockIdx.x];
+  const Ctx c = make_ctx(w, x, g, jac);
+  const DevStruct* S = c.S;
+  const bool want_g = flags & 1, want_j = flags & 2;
+  const int lane = threadIdx.x;
+  for (int ee = 0; ee < S->n_ee; ++ee) {
+    const TerrainRow* rows = tbl<TerrainRow>(c.blob, S->o_terrain_rows[ee]);
+    const int nr = S->n_terrain_rows[ee];
+    for (int r0 = 0; r0 < nr; r0 += 64) {
+      const int cnt = min(64, nr - r0);
+      double* dst = c.jp + S->nnz_terrain[ee] + 3 * r0;
+      const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+      if (lane < cnt) {
+        const TerrainRow tr = rows[r0 + lane];
+        const double px = c.xp[tr.idx], py = c.xp[tr.idx + tr.stride], pz = c.xp[tr.idx + 2 * tr.stride];
+        const Terr t = terrain_eval(S->terrain_id, S->flat_height, px, py);
+        if (want_g) c.gp[S->row_terrain[ee] + r0 + lane] = pz - t.h;
         if (want_j) {
-          __syncthreads();
-          copy_out(dst, stage, 3 * cnt, par, lane);
-          __syncthreads();
+          stage[par + 3 * lane + 0] = -t.hx;
+          stage[par + 3 * lane + 1] = -t.hy;
+          stage[par + 3 * lane + 2] = 1.0;
         }
       }
+      if (want_j) {
+        __syncthreads();
+        copy_out(dst, stage, 3 * cnt, par, lane);
+        __syncthreads();
+      }
     }
-    for (int ee = 0; ee < S->n_ee; ++ee) {
-      const ForceNode* nodes = tbl<ForceNode>(blob, S->o_force_nodes[ee]);
-      const int nn = S->n_force_nodes[ee];
-      for (int i0 = 0; i0 < nn; i0 += 64) {
-        const int cnt = min(64, nn - i0);
-        double* dst = jp + S->nnz_force[ee] + 25 * i0;
-        const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-        if (lane < cnt)
-          force_item(S, nodes[i0 + lane], xp, gp + S->row_force[ee] + 5 * (i0 + lane), stage + par + 25 * lane, want_g,
-                     want_j);
-        if (want_j) {
-          __syncthreads();
-          copy_out(dst, stage, 25 * cnt, par, lane);
-          __syncthreads();
-        }
+  }
+  for (int ee = 0; ee < S->n_ee; ++ee) {
+    const ForceNode* nodes = tbl<ForceNode>(c.blob, S->o_force_nodes[ee]);
+    const int nn = S->n_force_nodes[ee];
+    for (int i0 = 0; i0 < nn; i0 += 64) {
+      const int cnt = min(64, nn - i0);
+      double* dst = c.jp + S->nnz_force[ee] + 25 * i0;
+      const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+      if (lane < cnt)
+        force_item(S, nodes[i0 + lane], c.xp, c.gp + S->row_force[ee] + 5 * (i0 + lane), stage + par + 25 * lane,
+                   want_g, want_j);
+      if (want_j) {
+        __syncthreads();
+        copy_out(dst, stage, 25 * cnt, par, lane);
+        __syncthreads();
       }
     }
   }
 }
 
-// host-side launcher (called from capi.cc)
-hipError_t launch_eval(int n_ee, int n_work, const ProbRec* probs, const Work* work, const double* x, double* g,
-                       double* jac, int flags, hipStream_t stream) {
-  if (n_work <= 0) return hipSuccess;
-  dim3 grid(n_work), block(64);
-  switch (n_ee) {
-    case 1: hipLaunchKernelGGL(eval_kernel<1>, grid, block, 0, stream, probs, work, x, g, jac, flags); break;
-    case 2: hipLaunchKernelGGL(eval_kernel<2>, grid, block, 0, stream, probs, work, x, g, jac, flags); break;
-    case 3: hipLaunchKernelGGL(eval_kernel<3>, grid, block, 0, stream, probs, work, x, g, jac, flags); break;
-    case 4: hipLaunchKernelGGL(eval_kernel<4>, grid, block, 0, stream, probs, work, x, g, jac, flags); break;
-    default: return hipErrorInvalidValue;
+// host-side launcher (called from capi.cc): three launches on one stream
+hipError_t launch_eval(int n_ee, const Work* dyn, int n_dyn, const Work* rom, int n_rom, const Work* node, int n_node,
+                       const double* x, double* g, double* jac, int flags, hipStream_t stream) {
+  dim3 block(64);
+  if (n_dyn > 0) {
+    dim3 grid(n_dyn);
+    switch (n_ee) {
+      case 1: hipLaunchKernelGGL(dyn_kernel<1>, grid, block, 0, stream, dyn, x, g, jac, flags); break;
+      case 2: hipLaunchKernelGGL(dyn_kernel<2>, grid, block, 0, stream, dyn, x, g, jac, flags); break;
+      case 3: hipLaunchKernelGGL(dyn_kernel<3>, grid, block, 0, stream, dyn, x, g, jac, flags); break;
+      case 4: hipLaunchKernelGGL(dyn_kernel<4>, grid, block, 0, stream, dyn, x, g, jac, flags); break;
+      default: return hipErrorInvalidValue;
+    }
   }
+  if (n_rom > 0) hipLaunchKernelGGL(rom_kernel, dim3(n_rom), block, 0, stream, rom, x, g, jac, flags);
+  if (n_node > 0) hipLaunchKernelGGL(node_kernel, dim3(n_node), block, 0, stream, node, x, g, jac, flags);
   return hipGetLastError();
 }
 
-int stage_capacity_doubles() { return kStageDoubles; }
+int dyn_stage_capacity() { return kDynStage; }
+int rom_stage_capacity() { return kRomStage; }
+int dyn_nodes_per_block() { return 16; }
 
 }  // namespace twr
