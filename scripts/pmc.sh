@@ -12,10 +12,12 @@ import csv,sys,collections
 f=sys.argv[1]
 acc=collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if 'eval_kernel' in r['Kernel_Name']:
-        acc[r['Counter_Name']].append(float(r['Counter_Value']))
-for k,v in acc.items():
-    print("%-28s mean/launch %.6g  (n=%d)"%(k,sum(v)/len(v),len(v)))
+    kn=r['Kernel_Name']
+    if 'twr::' in kn:
+        short=kn.split('twr::')[1].split('(')[0]
+        acc[(short,r['Counter_Name'])].append(float(r['Counter_Value']))
+for k,v in sorted(acc.items()):
+    print("%-14s %-26s mean/launch %.6g"%(k[0],k[1],sum(v)/len(v)))
 PY
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS

@@ -6,13 +6,15 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "structure.h"
 
 namespace twr {
-hipError_t launch_eval(int n_ee, const Work* dyn, int n_dyn, const Work* rom, int n_rom, const Work* node, int n_node,
-                       const double* x, double* g, double* jac, int flags, hipStream_t stream);
+hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
+                       const NodeWork* node, int n_node, const double* x, double* g, double* jac, int flags,
+                       hipStream_t stream);
 int dyn_stage_capacity();
 int rom_stage_capacity();
 int dyn_nodes_per_block();
@@ -25,10 +27,12 @@ struct twr_structure {
 struct twr_batch {
   int device = 0;
   int n_problems = 0, n_ee = 0;
-  int n_dyn = 0, n_rom = 0, n_node = 0;
+  int n_dyn = 0, n_rom = 0, n_node = 0, n_cu = 0;
   std::vector<int64_t> x_off, g_off, j_off;  // n_problems+1
   std::vector<void*> blobs;                  // device blobs, one per distinct structure
-  twr::Work* d_work = nullptr;  // [dyn | rom | node] work items
+  twr::DynWork* d_dyn = nullptr;
+  twr::RomWork* d_rom = nullptr;
+  twr::NodeWork* d_node = nullptr;
   // lazily sized scratch for twr_batch_eval_host
   double *d_x = nullptr, *d_g = nullptr, *d_j = nullptr;
 };
@@ -54,24 +58,21 @@ void copy_set(const twr::SetInfo& s, twr_set_info* out) {
   out->nnz = s.nnz;
 }
 
-// Split the k range [0,K) of one constraint set into chunks of at most max_cnt time nodes whose CSR
-// slice fits the LDS image of the kernel.
-void chunk(const std::vector<int32_t>& row_ptr, int row0, int rows_per_k, int K, int cap, int max_cnt, int ee,
-           std::vector<twr::Work>& out) {
+// Split the k range [0,K) of one constraint set into runs of at most max_cnt time nodes whose CSR
+// slice fits the LDS image of the kernel.  Returns (k0, cnt) pairs.
+std::vector<std::pair<int, int>> chunk(const std::vector<int32_t>& row_ptr, int row0, int rows_per_k, int K, int cap,
+                                       int max_cnt) {
+  std::vector<std::pair<int, int>> out;
   int k0 = 0;
   while (k0 < K) {
     int k1 = k0;
     while (k1 < K && k1 - k0 < max_cnt && row_ptr[row0 + rows_per_k * (k1 + 1)] - row_ptr[row0 + rows_per_k * k0] <= cap)
       ++k1;
     if (k1 == k0) throw std::runtime_error("one time node exceeds the LDS staging capacity");
-    twr::Work w;
-    std::memset(&w, 0, sizeof(w));
-    w.ee = ee;
-    w.k0 = k0;
-    w.cnt = k1 - k0;
-    out.push_back(w);
+    out.push_back({k0, k1 - k0});
     k0 = k1;
   }
+  return out;
 }
 }  // namespace
 
@@ -202,17 +203,23 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     b->x_off.assign(n_problems + 1, 0);
     b->g_off.assign(n_problems + 1, 0);
     b->j_off.assign(n_problems + 1, 0);
-    std::vector<twr::Work> dyn, rom, node;
-    // chunk lists are identical for problems that share a structure: build once per structure
-    std::vector<std::vector<twr::Work>> tmpl_dyn(n_structs), tmpl_rom(n_structs);
+    hipDeviceProp_t prop;
+    TWR_HIP(hipGetDeviceProperties(&prop, device));
+    b->n_cu = prop.multiProcessorCount;
+    std::vector<twr::DynWork> dyn;
+    std::vector<twr::RomWork> rom;
+    std::vector<twr::NodeWork> node;
+    // run lists are identical for problems that share a structure: build once per structure
+    std::vector<std::vector<std::pair<int, int>>> runs_dyn(n_structs);
+    std::vector<std::vector<std::vector<std::pair<int, int>>>> runs_rom(n_structs);
     for (int i = 0; i < n_structs; ++i) {
       const twr::Structure& S = structs[i]->s;
       int ci = S.n_ee;  // con_sets: terrain x n_ee, dynamic, rom x n_ee, force x n_ee
-      chunk(S.row_ptr, S.con_sets[ci].offset, 6, (int)S.grid_dyn.size(), twr::dyn_stage_capacity(),
-            twr::dyn_nodes_per_block(), 0, tmpl_dyn[i]);
+      runs_dyn[i] = chunk(S.row_ptr, S.con_sets[ci].offset, 6, (int)S.grid_dyn.size(), twr::dyn_stage_capacity(),
+                          twr::dyn_nodes_per_block());
       for (int e = 0; e < S.n_ee; ++e)
-        chunk(S.row_ptr, S.con_sets[ci + 1 + e].offset, 3, (int)S.grid_rom.size(), twr::rom_stage_capacity(), 64, e,
-              tmpl_rom[i]);
+        runs_rom[i].push_back(chunk(S.row_ptr, S.con_sets[ci + 1 + e].offset, 3, (int)S.grid_rom.size(),
+                                    twr::rom_stage_capacity(), 64));
     }
     for (int p = 0; p < n_problems; ++p) {
       int si = struct_of_problem[p];
@@ -221,29 +228,57 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
       b->x_off[p + 1] = b->x_off[p] + S.n_vars;
       b->g_off[p + 1] = b->g_off[p] + S.n_rows;
       b->j_off[p + 1] = b->j_off[p] + S.nnz;
-      auto bind = [&](twr::Work w) {
-        w.blob = reinterpret_cast<uint64_t>(b->blobs[si]);
+      const uint64_t blob = reinterpret_cast<uint64_t>(b->blobs[si]);
+      const int ci = S.n_ee;
+      const twr::SetInfo& ds = S.con_sets[ci];
+      for (auto& r : runs_dyn[si]) {
+        twr::DynWork w;
+        std::memset(&w, 0, sizeof(w));
+        w.shared = blob + S.off_dyn_shared + sizeof(twr::DynShared) * (size_t)r.first;
+        w.lanes = blob + S.off_dyn_lanes + sizeof(twr::DynLane) * (size_t)r.first * S.n_ee;
+        w.hdr = blob;
         w.x_off = b->x_off[p];
-        w.g_off = b->g_off[p];
-        w.j_off = b->j_off[p];
-        return w;
-      };
-      for (const twr::Work& w : tmpl_dyn[si]) dyn.push_back(bind(w));
-      for (const twr::Work& w : tmpl_rom[si]) rom.push_back(bind(w));
-      twr::Work w;
-      std::memset(&w, 0, sizeof(w));
-      node.push_back(bind(w));
+        w.g_off = b->g_off[p] + ds.offset + 6 * r.first;
+        w.j_off = b->j_off[p] + S.row_ptr[ds.offset + 6 * r.first];
+        w.off_lin = S.off_base_lin;
+        w.off_ang = S.off_base_ang;
+        w.cnt = r.second;
+        w.nvals = S.row_ptr[ds.offset + 6 * (r.first + r.second)] - S.row_ptr[ds.offset + 6 * r.first];
+        dyn.push_back(w);
+      }
+      for (int e = 0; e < S.n_ee; ++e) {
+        const twr::SetInfo& rs = S.con_sets[ci + 1 + e];
+        for (auto& r : runs_rom[si][e]) {
+          twr::RomWork w;
+          std::memset(&w, 0, sizeof(w));
+          w.recs = blob + S.off_rom_recs[e] + sizeof(twr::RomRec) * (size_t)r.first;
+          w.x_off = b->x_off[p];
+          w.g_off = b->g_off[p] + rs.offset + 3 * r.first;
+          w.j_off = b->j_off[p] + S.row_ptr[rs.offset + 3 * r.first];
+          w.off_lin = S.off_base_lin;
+          w.off_ang = S.off_base_ang;
+          w.cnt = r.second;
+          w.nvals = S.row_ptr[rs.offset + 3 * (r.first + r.second)] - S.row_ptr[rs.offset + 3 * r.first];
+          rom.push_back(w);
+        }
+      }
+      twr::NodeWork nw;
+      nw.blob = blob;
+      nw.x_off = b->x_off[p];
+      nw.g_off = b->g_off[p];
+      nw.j_off = b->j_off[p];
+      node.push_back(nw);
     }
     b->n_dyn = (int)dyn.size();
     b->n_rom = (int)rom.size();
     b->n_node = (int)node.size();
-    std::vector<twr::Work> work;
-    work.reserve(dyn.size() + rom.size() + node.size());
-    work.insert(work.end(), dyn.begin(), dyn.end());
-    work.insert(work.end(), rom.begin(), rom.end());
-    work.insert(work.end(), node.begin(), node.end());
-    TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_work), work.size() * sizeof(twr::Work)));
-    TWR_HIP(hipMemcpy(b->d_work, work.data(), work.size() * sizeof(twr::Work), hipMemcpyHostToDevice));
+    auto upload = [&](const void* src, size_t bytes, void** dst) {
+      TWR_HIP(hipMalloc(dst, bytes));
+      TWR_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    };
+    upload(dyn.data(), dyn.size() * sizeof(twr::DynWork), reinterpret_cast<void**>(&b->d_dyn));
+    upload(rom.data(), rom.size() * sizeof(twr::RomWork), reinterpret_cast<void**>(&b->d_rom));
+    upload(node.data(), node.size() * sizeof(twr::NodeWork), reinterpret_cast<void**>(&b->d_node));
     *out = b.release();
     return TWR_OK;
   } catch (const std::exception& e) {
@@ -256,7 +291,9 @@ void twr_batch_destroy(twr_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   for (void* d : b->blobs) (void)hipFree(d);
-  if (b->d_work) (void)hipFree(b->d_work);
+  if (b->d_dyn) (void)hipFree(b->d_dyn);
+  if (b->d_rom) (void)hipFree(b->d_rom);
+  if (b->d_node) (void)hipFree(b->d_node);
   if (b->d_x) (void)hipFree(b->d_x);
   if (b->d_g) (void)hipFree(b->d_g);
   if (b->d_j) (void)hipFree(b->d_j);
@@ -279,9 +316,8 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
   if ((flags & TWR_EVAL_BOTH) == 0) return fail(TWR_ERR_INVALID, "flags select nothing");
   if (((flags & TWR_EVAL_VALUES) && !d_g) || ((flags & TWR_EVAL_JACOBIAN) && !d_jac))
     return fail(TWR_ERR_INVALID, "missing output buffer");
-  hipError_t e = twr::launch_eval(b->n_ee, b->d_work, b->n_dyn, b->d_work + b->n_dyn, b->n_rom,
-                                  b->d_work + b->n_dyn + b->n_rom, b->n_node, d_x, d_g, d_jac, flags & TWR_EVAL_BOTH,
-                                  static_cast<hipStream_t>(hip_stream));
+  hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->d_rom, b->n_rom, b->d_node, b->n_node, d_x,
+                                  d_g, d_jac, flags & TWR_EVAL_BOTH, static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   return TWR_OK;
 }

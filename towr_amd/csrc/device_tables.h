@@ -1,8 +1,10 @@
-// Layout of the per-structure device blob shared by the host packer (structure.cc)
-// and the HIP kernels (kernels.hip).  All tables are x-independent: they are what the
-// reference recomputes on every call (active polynomial, local time, node->variable
-// maps) hoisted to setup time.  One blob per distinct contact schedule; every problem
-// of a batch that shares the schedule shares the blob (it stays L2 resident).
+// Device-side tables shared by the host packer (structure.cc / capi.cc) and the HIP kernels
+// (kernels.hip).  Everything here is x-independent: it is what the reference recomputes on every
+// call (active polynomial, local time, node->variable maps, CSR positions) hoisted to setup time and
+// flattened into one fixed-size record per lane, so that a lane needs exactly two dependent memory
+// round trips (its record, then its slice of x) before it can compute.
+// One blob per distinct contact schedule; every problem of a batch that shares the schedule shares
+// the blob (it stays L2 resident).
 #pragma once
 #include <stdint.h>
 
@@ -10,27 +12,55 @@ namespace twr {
 
 constexpr int kMaxEE = 4;
 
-// One cubic-Hermite polynomial of an ee-motion / ee-force spline.
-// The optimisation variables that touch it are the contiguous range x[xbase, xbase+nslots)
-// ("slots", ascending column order).  cand[j*3+d] describes node value (j,d), j in
-// {p0,v0,p1,v1}, d in {x,y,z}:
+// Candidate descriptors of one cubic-Hermite polynomial of an ee-motion / ee-force spline.
+// The optimisation variables that touch the polynomial are the contiguous range
+// x[xbase, xbase+nslots) ("slots", ascending column order).  Candidate c = j*3+d is node value
+// (j,d), j in {p0,v0,p1,v1}, d in {x,y,z}; its 16-bit descriptor holds
 //   bits 0-3   slot of the variable holding it, 0xF = not a variable (constant 0)
 //   bits 4-7   rank of that slot among slots with dim != (d+1)%3   (dynamic ang row (d+1)%3)
 //   bits 8-11  rank of that slot among slots with dim != (d+2)%3   (dynamic ang row (d+2)%3)
 //   bits 12-15 rank of that slot among slots with dim == d         (dynamic lin row d)
-// `shared` = 1 for a stance ee-motion polynomial: p0 and p1 are the same variable, the
-// kernel folds w_p1 into w_p0 and the p1 candidates are marked absent.
+// meta = nslots | cnt[0]<<4 | cnt[1]<<8 | cnt[2]<<12 | shared<<16 (cnt = slots per dim).
+// `shared` marks a stance ee-motion polynomial: p0 and p1 are the same variable, the kernel folds
+// w_p1 into w_p0 and the p1 candidates are marked absent.
 // (reference: nodes_variables_phase_based.cc:210-298, node_spline.cc:84-112)
-struct EePoly {
-  double iT;       // 1 / duration
+struct PolyDesc {
+  double iT;  // 1 / duration
   int32_t xbase;
-  uint8_t nslots;
-  uint8_t cnt[3];  // slots per dim
+  uint32_t meta;
   uint16_t cand[12];
-  uint8_t shared;
-  uint8_t pad[7];
 };
-static_assert(sizeof(EePoly) == 48, "EePoly layout");
+
+// rangeofmotion-<ee>, one record per time node (64 B)
+struct RomRec {
+  double tb, iTb;     // base spline: local time in the active polynomial, 1/duration
+  double tm, iTm;     // ee-motion spline
+  int32_t q6;         // 6 * (active base polynomial): offset of its first node in base-lin / base-ang
+  int32_t xbase;      // first x index of the active ee-motion polynomial's variables
+  int32_t voff;       // CSR offset of row 3k relative to the set's first value
+  uint32_t meta;      // as PolyDesc::meta
+  uint32_t slots[2];  // 12 x 4 bit: slot of candidate c, 0xF = absent
+  uint32_t pad[2];
+};
+static_assert(sizeof(RomRec) == 64, "RomRec layout");
+
+// dynamic, per time node, shared by the four lanes of the quad (32 B)
+struct DynShared {
+  double tb, iTb;
+  int32_t q6;
+  int32_t voff;  // CSR offset of row 6k relative to the set's first value
+  uint32_t pad[2];
+};
+static_assert(sizeof(DynShared) == 32, "DynShared layout");
+
+// dynamic, per (time node, ee) (96 B)
+struct DynLane {
+  double tm, iTm, tf, iTf;
+  int32_t xbase_m, xbase_f;
+  uint32_t meta_m, meta_f;
+  uint16_t cand_m[12], cand_f[12];
+};
+static_assert(sizeof(DynLane) == 96, "DynLane layout");
 
 struct ForceNode {   // one non-constant ee-force node (force_constraint.cc:50-60)
   int32_t fidx;      // x index of the node's force px (py = +2, pz = +4)
@@ -41,43 +71,44 @@ struct TerrainRow {  // one ee-motion node id >= 1 (terrain_constraint.cc:44-55)
   int32_t stride;    // py = idx+stride, pz = idx+2*stride (1 stance node, 2 swing node)
 };
 
+// Blob header: model constants + what the node kernel needs.
 struct DevStruct {
-  int32_t n_ee, n_vars, n_rows, nnz;
-  int32_t k_dyn, k_rom;
-  int32_t off_base_lin, off_base_ang;  // x offsets of the two base variable sets
-  int32_t n_base_polys;
-  int32_t terrain_id;
-  // constraint-set offsets inside one problem's g / jac arrays
+  int32_t n_ee, terrain_id;
   int32_t row_terrain[kMaxEE], nnz_terrain[kMaxEE], n_terrain_rows[kMaxEE];
-  int32_t row_dyn, nnz_dyn;
-  int32_t row_rom[kMaxEE], nnz_rom[kMaxEE];
   int32_t row_force[kMaxEE], nnz_force[kMaxEE], n_force_nodes[kMaxEE];
-  // byte offsets of the tables inside the blob (from the blob start)
-  uint32_t o_base_iT;                                  // double[n_base_polys], 1/duration
-  uint32_t o_mpoly[kMaxEE], o_fpoly[kMaxEE];           // EePoly[]
-  uint32_t o_dyn_tl_base, o_dyn_base_poly, o_dyn_val_off;  // double[K], int32[K], int32[K+1]
-  uint32_t o_dyn_mpoly[kMaxEE], o_dyn_tl_m[kMaxEE];    // int32[K], double[K]
-  uint32_t o_dyn_fpoly[kMaxEE], o_dyn_tl_f[kMaxEE];
-  uint32_t o_rom_tl_base, o_rom_base_poly;             // double[K], int32[K]
-  uint32_t o_rom_mpoly[kMaxEE], o_rom_tl_m[kMaxEE], o_rom_val_off[kMaxEE];  // int32[K], double[K], int32[K+1]
-  uint32_t o_force_nodes[kMaxEE];                      // ForceNode[]
-  uint32_t o_terrain_rows[kMaxEE];                     // TerrainRow[]
-  uint32_t pad_;
-  // model constants
+  uint32_t o_force_nodes[kMaxEE];   // byte offsets inside the blob: ForceNode[]
+  uint32_t o_terrain_rows[kMaxEE];  // TerrainRow[]
   double mass, gravity, mu, flat_height;
   double Ib[6];  // body inertia tensor entries (0,0),(0,1),(0,2),(1,1),(1,2),(2,2) incl. the sign of
                  // single_rigid_body_dynamics.cc:40-42
 };
 
-// One workgroup's job: a contiguous run of time nodes of one constraint set of one problem
-// (dynamic: cnt <= 16, rangeofmotion-<ee>: cnt <= 64) or the node block of a problem.
-struct Work {
-  uint64_t blob;    // device address of the problem's DevStruct blob
-  int64_t x_off, g_off, j_off;  // offsets of the problem inside the batch arrays (doubles)
-  int32_t k0, cnt;
-  int32_t ee;
-  int32_t pad;
+// Work items: one contiguous run of time nodes of one constraint set of one problem.  All
+// pointers / offsets are absolute so that a workgroup needs no header lookup.
+struct DynWork {          // cnt <= 16 time nodes of "dynamic"
+  uint64_t shared;        // DynShared[k0..]
+  uint64_t lanes;         // DynLane[k0 * n_ee ..]
+  uint64_t hdr;           // DevStruct (mass, gravity, inertia)
+  int64_t x_off;          // problem's x
+  int64_t g_off;          // first constraint value of the run (row 6*k0 of the set)
+  int64_t j_off;          // first Jacobian value of the run
+  int32_t off_lin, off_ang;  // x offsets of base-lin / base-ang inside the problem
+  int32_t cnt, nvals;     // time nodes, Jacobian values of the run
 };
-static_assert(sizeof(Work) == 48, "Work layout");
+static_assert(sizeof(DynWork) == 64, "DynWork layout");
+
+struct RomWork {          // cnt <= 64 time nodes of "rangeofmotion-<ee>"
+  uint64_t recs;          // RomRec[k0..] of that ee
+  int64_t x_off, g_off, j_off;
+  int32_t off_lin, off_ang;
+  int32_t cnt, nvals;
+};
+static_assert(sizeof(RomWork) == 48, "RomWork layout");
+
+struct NodeWork {         // all terrain-* and force-* sets of one problem
+  uint64_t blob;
+  int64_t x_off, g_off, j_off;
+};
+static_assert(sizeof(NodeWork) == 32, "NodeWork layout");
 
 }  // namespace twr

@@ -1,8 +1,8 @@
 // HIP kernels (gfx950 / CDNA4) for towr's NLP constraint + Jacobian callback.
 //
 // Three launches per callback batch (dynamic, range of motion, force/terrain nodes), one stream.
-// A workgroup is one wavefront (64 lanes) and owns one *contiguous* slice of one
-// problem's CSR value array:
+// A workgroup is one wavefront (64 lanes); it walks a strided list of work items, each one a
+// *contiguous* slice of one problem's CSR value array:
 //   dyn_kernel   dynamic           : 16 consecutive time nodes k, FOUR lanes per node (6 rows each)
 //   rom_kernel   rangeofmotion-ee  : lanes = consecutive time nodes k               (3 rows each)
 //   node_kernel  force-* / terrain-* sets of the problem: lanes = spline nodes
@@ -10,13 +10,17 @@
 // scatters the values into an LDS image of the slice at the CSR position they have in
 // global memory, and the wave then streams the image out with 16-byte coalesced stores.
 // x-independent index work (active polynomial, local time, node->column maps, CSR
-// offsets) comes from the per-structure tables of device_tables.h.
+// offsets) comes from the per-lane records of device_tables.h.  The dyn/rom kernels are
+// software pipelined over their work list: while slice i is computed and stored, the record of
+// slice i+2 and the x values of slice i+1 are already in flight, so the only exposed memory
+// latency per slice is the LDS round trip.
 //
 // Math follows the reference line by line in meaning (citations per function); the
 // arithmetic is re-associated (Hermite basis form, factored base-ang tile) and agrees
 // with the reference formulas to rounding, tests/ pin that at <= 1e-9.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "device_tables.h"
 
@@ -57,53 +61,39 @@ TWR_DEV void hermite_all(double t, double iT, double wp[4], double wv[4], double
   wa[3] = 6.0 * t * iT2 - 2.0 * iT;
 }
 
-// ---------------------------------------------------------------- ee polynomial record
-struct PolyR {
-  double iT;
-  int xbase;
-  uint32_t meta;   // nslots | cnt[0]<<8 | cnt[1]<<16 | cnt[2]<<24
-  uint32_t c[6];   // 12 candidate descriptors (16 bit each)
-  uint32_t shared;
-  TWR_DEV int nslots() const { return meta & 0xFF; }
-  TWR_DEV int cnt(int d) const { return (meta >> (8 * (d + 1))) & 0xFF; }
-  TWR_DEV uint32_t cand(int i) const { return (c[i >> 1] >> (16 * (i & 1))) & 0xFFFFu; }
-};
-TWR_DEV int meta_nslots(uint32_t meta) { return meta & 0xFF; }
-TWR_DEV int meta_cnt(uint32_t meta, int d) { return (meta >> (8 * (d + 1))) & 0xFF; }
-TWR_DEV PolyR load_poly(const EePoly* p) {
-  const uint4* q = reinterpret_cast<const uint4*>(p);
-  const uint4 a = q[0], b = q[1], d = q[2];
-  PolyR r;
-  r.iT = __hiloint2double((int)a.y, (int)a.x);
-  r.xbase = (int)a.z;
-  r.meta = a.w;
-  r.c[0] = b.x; r.c[1] = b.y; r.c[2] = b.z; r.c[3] = b.w;
-  r.c[4] = d.x; r.c[5] = d.y;
-  r.shared = d.z & 0xFF;
-  return r;
-}
-// Position of an ee spline at the lane's time: sum over the node values that are variables
-// (Spline::GetPoint, src/spline.cc:80-93, in Hermite basis form).  A stance ee-motion
-// polynomial keeps one shared position variable for both nodes: w_p1 is folded into w_p0.
-TWR_DEV void ee_weights_and_point(const PolyR& P, double tl, const double* __restrict__ xp, double w[4], double out[3]) {
-  hermite_pos(tl, P.iT, w);
-  if (P.shared) w[0] += w[2];
-  // all 12 loads are issued unconditionally (absent candidates read slot 0 and get weight 0): one
-  // memory round trip instead of twelve dependent, branch-guarded ones
-  double v[12];
+// ---------------------------------------------------------------- candidate descriptors
+TWR_DEV int meta_nslots(uint32_t meta) { return meta & 0xF; }
+TWR_DEV int meta_cnt(uint32_t meta, int d) { return (meta >> (4 * (d + 1))) & 0xF; }
+TWR_DEV bool meta_shared(uint32_t meta) { return (meta >> 16) & 1; }
+// all 12 candidate loads are issued unconditionally (absent candidates read slot 0 and later get
+// weight 0): one memory round trip, no branches (Spline::GetPoint needs at most these 12 values)
+TWR_DEV void gather12(const double* __restrict__ xp, int xbase, uint64_t slots, double v[12]) {
 #pragma unroll
   for (int c = 0; c < 12; ++c) {
-    const int sl = P.cand(c) & 0xF;
-    v[c] = xp[P.xbase + (sl != 0xF ? sl : 0)];
+    const int sl = (int)((slots >> (4 * c)) & 0xF);
+    v[c] = xp[xbase + (sl != 0xF ? sl : 0)];
   }
+}
+// Position of an ee spline from its gathered node values (Spline::GetPoint, src/spline.cc:80-93, in
+// Hermite basis form).  A stance ee-motion polynomial keeps one shared position variable for both
+// nodes: w_p1 is folded into w_p0.
+TWR_DEV void ee_point(uint64_t slots, bool shared, double tl, double iT, const double v[12], double w[4], double out[3]) {
+  hermite_pos(tl, iT, w);
+  if (shared) w[0] += w[2];
   out[0] = out[1] = out[2] = 0.0;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      const bool valid = (P.cand(j * 3 + d) & 0xF) != 0xF;
+      const bool valid = ((slots >> (4 * (j * 3 + d))) & 0xF) != 0xF;
       out[d] = fma(valid ? w[j] : 0.0, v[j * 3 + d], out[d]);
     }
+}
+TWR_DEV uint64_t slots_of(const uint16_t cand[12]) {
+  uint64_t s = 0;
+#pragma unroll
+  for (int c = 0; c < 12; ++c) s |= (uint64_t)(cand[c] & 0xF) << (4 * c);
+  return s;
 }
 
 // entry (r,d), r != d, of the cross-product matrix [v]x (single_rigid_body_dynamics.cc:46-57)
@@ -194,41 +184,52 @@ TWR_DEV double sel3(int i, double a, double b, double c) { return i == 0 ? a : (
 // The base-ang block is evaluated in factored form: with u = (p0,v0,p1,v1) of Euler dim d,
 //   d g_ang / d u_j = A_d wP[j] + B_d wV[j] + C_d wA[j],
 //   A_d = d g_ang/d e_d, B_d = d g_ang/d edot_d, C_d = d g_ang/d eddot_d  (3-vectors).
+struct DynX {  // the lane's slice of x: base-lin / base-ang nodes of the active polynomial, ee candidates
+  double bl[12], ba[12], m[12], f[12];
+};
 template <int NEE>
-TWR_DEV void dyn_quad(const DevStruct* __restrict__ S, const char* __restrict__ blob, const double* __restrict__ xp,
-                      double* __restrict__ gp, double* __restrict__ stage, int soff, int trash, int k, int role,
-                      bool want_g, bool want_j) {
-  const double tb = tbl<double>(blob, S->o_dyn_tl_base)[k];
-  const int q = tbl<int32_t>(blob, S->o_dyn_base_poly)[k];
-  const double iTb = tbl<double>(blob, S->o_base_iT)[q];
-  // --- this lane's end-effector: active polynomials, weights, spline points
-  const bool has_ee = role < NEE;
-  const int ee = has_ee ? role : 0;
-  const int mq = tbl<int32_t>(blob, S->o_dyn_mpoly[ee])[k];
-  const int fq = tbl<int32_t>(blob, S->o_dyn_fpoly[ee])[k];
-  const double tm = tbl<double>(blob, S->o_dyn_tl_m[ee])[k];
-  const double tf = tbl<double>(blob, S->o_dyn_tl_f[ee])[k];
-  const PolyR MP = load_poly(tbl<EePoly>(blob, S->o_mpoly[ee]) + mq);
-  const PolyR FP = load_poly(tbl<EePoly>(blob, S->o_fpoly[ee]) + fq);
+TWR_DEV void dyn_load_rec(const DynWork& w, int lane, DynShared& sh, DynLane& ln) {
+  const int kk = min(lane >> 2, w.cnt - 1), role = min(lane & 3, NEE - 1);
+  sh = reinterpret_cast<const DynShared*>(w.shared)[kk];
+  ln = reinterpret_cast<const DynLane*>(w.lanes)[kk * NEE + role];
+}
+TWR_DEV void dyn_load_x(const DynWork& w, const DynShared& sh, const DynLane& ln, const double* __restrict__ x, DynX& X) {
+  const double* xp = x + w.x_off;
+  const double* xl = xp + w.off_lin + sh.q6;  // [p0 v0 p1 v1] x 3, NodesVariablesAll order
+  const double* xa = xp + w.off_ang + sh.q6;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    X.bl[i] = xl[i];
+    X.ba[i] = xa[i];
+  }
+  gather12(xp, ln.xbase_m, slots_of(ln.cand_m), X.m);
+  gather12(xp, ln.xbase_f, slots_of(ln.cand_f), X.f);
+}
 
+template <int NEE>
+TWR_DEV void dyn_quad(const DynWork& w, const DynShared& sh, const DynLane& ln, const DynX& X, double* __restrict__ g,
+                      double* __restrict__ stage, int par, int vbase, int trash, int lane, bool want_g, bool want_j) {
+  const int kk = lane >> 2, role = lane & 3;
+  const bool live = kk < w.cnt;
+  const bool has_ee = role < NEE;
+  const int soff = par + sh.voff - vbase;
   double wP[4], wV[4], wA[4];
-  hermite_all(tb, iTb, wP, wV, wA);
-  const double* xl = xp + S->off_base_lin + 6 * q;  // [p0 v0 p1 v1] x 3, NodesVariablesAll order
-  const double* xa = xp + S->off_base_ang + 6 * q;
+  hermite_all(sh.tb, sh.iTb, wP, wV, wA);
   double c[3], cdd[3], e[3], ed[3], edd[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    const double l0 = xl[d], l1 = xl[3 + d], l2 = xl[6 + d], l3 = xl[9 + d];
-    const double a0 = xa[d], a1 = xa[3 + d], a2 = xa[6 + d], a3 = xa[9 + d];
+    const double l0 = X.bl[d], l1 = X.bl[3 + d], l2 = X.bl[6 + d], l3 = X.bl[9 + d];
+    const double a0 = X.ba[d], a1 = X.ba[3 + d], a2 = X.ba[6 + d], a3 = X.ba[9 + d];
     c[d] = wP[0] * l0 + wP[1] * l1 + wP[2] * l2 + wP[3] * l3;
     cdd[d] = wA[0] * l0 + wA[1] * l1 + wA[2] * l2 + wA[3] * l3;
     e[d] = wP[0] * a0 + wP[1] * a1 + wP[2] * a2 + wP[3] * a3;
     ed[d] = wV[0] * a0 + wV[1] * a1 + wV[2] * a2 + wV[3] * a3;
     edd[d] = wA[0] * a0 + wA[1] * a1 + wA[2] * a2 + wA[3] * a3;
   }
+  // --- this lane's end-effector: weights and spline points
   double wm[4], wf[4], p[3], f[3], rv[3];
-  ee_weights_and_point(MP, tm, xp, wm, p);
-  ee_weights_and_point(FP, tf, xp, wf, f);
+  ee_point(slots_of(ln.cand_m), meta_shared(ln.meta_m), ln.tm, ln.iTm, X.m, wm, p);
+  ee_point(slots_of(ln.cand_f), false, ln.tf, ln.iTf, X.f, wf, f);
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     rv[d] = c[d] - p[d];
@@ -242,50 +243,13 @@ TWR_DEV void dyn_quad(const DevStruct* __restrict__ S, const char* __restrict__ 
     F[d] = quad_sum(f[d]);
     tau[d] = quad_sum(t3[d]);
   }
-  // slot counts of every end-effector of the quad (row layout below)
-  const uint32_t my_mm = has_ee ? MP.meta : 0u, my_fm = has_ee ? FP.meta : 0u;
+  // slot counts of every end-effector of the quad -> row layout of this time node in the CSR slice
+  const uint32_t my_mm = has_ee ? ln.meta_m : 0u, my_fm = has_ee ? ln.meta_f : 0u;
   uint32_t mmeta[4], fmeta[4];
   mmeta[0] = quad_perm_u32<0x00>(my_mm); fmeta[0] = quad_perm_u32<0x00>(my_fm);
   mmeta[1] = quad_perm_u32<0x55>(my_mm); fmeta[1] = quad_perm_u32<0x55>(my_fm);
   mmeta[2] = quad_perm_u32<0xAA>(my_mm); fmeta[2] = quad_perm_u32<0xAA>(my_fm);
   mmeta[3] = quad_perm_u32<0xFF>(my_mm); fmeta[3] = quad_perm_u32<0xFF>(my_fm);
-
-  // --- rotation: lanes 0..2 of the quad evaluate one sincos each and broadcast it
-  double my_s, my_c;
-  sincos(sel3(role, e[0], e[1], e[2]), &my_s, &my_c);
-  Rot ro;
-  rotation_from_sincos(quad_perm<0x00>(my_s), quad_perm<0x00>(my_c), quad_perm<0x55>(my_s), quad_perm<0x55>(my_c),
-                       quad_perm<0xAA>(my_s), quad_perm<0xAA>(my_c), ro);
-  // --- angular quantities (euler_converter.cc:58-83,133-166)
-  const double sy = ro.sy, cy = ro.cy, sz = ro.sz, cz = ro.cz;
-  const double xd = ed[0], yd = ed[1], zd = ed[2];
-  const double Mx[3] = {cy * cz, cy * sz, -sy}, My[3] = {-sz, cz, 0.0};
-  const double Mdx[3] = {-cz * sy * yd - cy * sz * zd, cy * cz * zd - sy * sz * yd, -cy * yd};
-  const double Mdy[3] = {-cz * zd, -sz * zd, 0.0};
-  double om[3], omd[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    om[i] = Mx[i] * xd + My[i] * yd;
-    omd[i] = Mdx[i] * xd + Mdy[i] * yd + Mx[i] * edd[0] + My[i] * edd[1];
-  }
-  om[2] += zd;
-  omd[2] += edd[2];
-  double Ib[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) Ib[i] = S->Ib[i];
-  // I_w v = R I_b R^T v  (single_rigid_body_dynamics.cc:91)
-  auto Iw = [&](const double v[3], double o[3]) {
-    double a[3], b[3];
-    matTvec(ro.R, v, a);
-    symmul(Ib, a, b);
-    matvec(ro.R, b, o);
-  };
-  double Iw_wd[3], Iw_w[3];
-  Iw(omd, Iw_wd);
-  Iw(om, Iw_w);
-  const double m = S->mass;
-
-  // --- row layout of this time node inside the CSR slice
   int nma[3] = {0, 0, 0}, nfa[3] = {0, 0, 0}, nfl[3] = {0, 0, 0};   // totals over the end-effectors
   int pma[3] = {0, 0, 0}, pfa[3] = {0, 0, 0}, pfl[3] = {0, 0, 0};   // prefix for this lane's end-effector
 #pragma unroll
@@ -306,11 +270,84 @@ TWR_DEV void dyn_quad(const DevStruct* __restrict__ S, const char* __restrict__ 
   rl[1] = rl[0] + 4 + nfl[0];
   rl[2] = rl[1] + 4 + nfl[1];
 
+  // --- rotation: lanes 0..2 of the quad evaluate one sincos each and broadcast it
+  double my_s, my_c;
+  sincos(sel3(role, e[0], e[1], e[2]), &my_s, &my_c);
+  const double sx = quad_perm<0x00>(my_s), cx = quad_perm<0x00>(my_c);
+  const double sy = quad_perm<0x55>(my_s), cy = quad_perm<0x55>(my_c);
+  const double sz = quad_perm<0xAA>(my_s), cz = quad_perm<0xAA>(my_c);
+  if (!live) return;  // (all DPP exchanges are done)
+
+  // --- ee-motion block [f]x J_p (:181-192) and ee-force block {[r]x J_f ; -J_f} (:167-179) of this
+  // lane's end-effector, written first so that their inputs die before the base-ang algebra.
+  // Candidates that are not variables write to the lane's trash slot.
+  if (want_j) {
+    int ms[3], fs[3], ls[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      ms[r] = rs[r] + 20 + pma[r];
+      fs[r] = rs[r] + 20 + nma[r] + pfa[r];
+      ls[r] = rl[r] + 4 + pfl[r];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#define TWR_EE_TILE(D, R1, R2)                                                              \
+  {                                                                                         \
+    const uint32_t cm = ln.cand_m[j * 3 + D];                                               \
+    const bool vm = has_ee && (cm & 0xF) != 0xF;                                            \
+    stage[vm ? ms[R1] + (int)((cm >> 4) & 0xF) : trash] = crs<R1, D>(f) * wm[j];            \
+    stage[vm ? ms[R2] + (int)((cm >> 8) & 0xF) : trash] = crs<R2, D>(f) * wm[j];            \
+    const uint32_t cf = ln.cand_f[j * 3 + D];                                               \
+    const bool vf = has_ee && (cf & 0xF) != 0xF;                                            \
+    stage[vf ? fs[R1] + (int)((cf >> 4) & 0xF) : trash] = crs<R1, D>(rv) * wf[j];           \
+    stage[vf ? fs[R2] + (int)((cf >> 8) & 0xF) : trash] = crs<R2, D>(rv) * wf[j];           \
+    stage[vf ? ls[D] + (int)((cf >> 12) & 0xF) : trash] = -wf[j];                           \
+  }
+      TWR_EE_TILE(0, 1, 2)
+      TWR_EE_TILE(1, 2, 0)
+      TWR_EE_TILE(2, 0, 1)
+#undef TWR_EE_TILE
+    }
+  }
+
+  // --- angular quantities (euler_converter.cc:58-83,133-166,207-221)
+  double R[3][3];
+  R[0][0] = cy * cz; R[0][1] = cz * sx * sy - cx * sz; R[0][2] = sx * sz + cx * cz * sy;
+  R[1][0] = cy * sz; R[1][1] = cx * cz + sx * sy * sz; R[1][2] = cx * sy * sz - cz * sx;
+  R[2][0] = -sy;     R[2][1] = cy * sx;                R[2][2] = cx * cy;
+  const double xd = ed[0], yd = ed[1], zd = ed[2];
+  const double Mx[3] = {cy * cz, cy * sz, -sy}, My[3] = {-sz, cz, 0.0};
+  const double Mdx[3] = {-cz * sy * yd - cy * sz * zd, cy * cz * zd - sy * sz * yd, -cy * yd};
+  const double Mdy[3] = {-cz * zd, -sz * zd, 0.0};
+  double om[3], omd[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    om[i] = Mx[i] * xd + My[i] * yd;
+    omd[i] = Mdx[i] * xd + Mdy[i] * yd + Mx[i] * edd[0] + My[i] * edd[1];
+  }
+  om[2] += zd;
+  omd[2] += edd[2];
+  const DevStruct* S = reinterpret_cast<const DevStruct*>(w.hdr);
+  double Ib[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) Ib[i] = S->Ib[i];
+  // I_w v = R I_b R^T v  (single_rigid_body_dynamics.cc:91)
+  auto Iw = [&](const double v[3], double o[3]) {
+    double a[3], b[3];
+    matTvec(R, v, a);
+    symmul(Ib, a, b);
+    matvec(R, b, o);
+  };
+  double Iw_wd[3], Iw_w[3];
+  Iw(omd, Iw_wd);
+  Iw(om, Iw_w);
+  const double m = S->mass;
+
   if (role == 3) {
     if (want_g) {  // GetDynamicViolation, single_rigid_body_dynamics.cc:76-101
       double wxIw[3];
       cross3(om, Iw_w, wxIw);
-      double* go = gp + S->row_dyn + 6 * k;
+      double* go = g + w.g_off + 6 * kk;
 #pragma unroll
       for (int i = 0; i < 3; ++i) go[i] = Iw_wd[i] + wxIw[i] - tau[i];
       go[3] = m * cdd[0] - F[0];
@@ -333,22 +370,27 @@ TWR_DEV void dyn_quad(const DevStruct* __restrict__ S, const char* __restrict__ 
   } else if (want_j) {
     // --- base-ang block (:123-165), Euler dimension d = role, factored
     double RtWd[3], RtW[3], aWd[3], aW[3];
-    matTvec(ro.R, omd, RtWd);
-    matTvec(ro.R, om, RtW);
+    matTvec(R, omd, RtWd);
+    matTvec(R, om, RtW);
     symmul(Ib, RtWd, aWd);  // I_b R^T omega_dot  (v11)
     symmul(Ib, RtW, aW);    // I_b R^T omega      (v21)
-    double Rd[3][3];        // dR/d e_d (euler_converter.cc:241-268)
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) Rd[i][j] = sel3(role, ro.Rx[i][j], ro.Ry[i][j], ro.Rz[i][j]);
+    double Rd[3][3];        // dR/d e_d, d = role (cell-wise derivatives of euler_converter.cc:241-268)
+    Rd[0][0] = sel3(role, 0.0, -cz * sy, -cy * sz);
+    Rd[0][1] = sel3(role, cx * cz * sy + sx * sz, cy * cz * sx, -sx * sy * sz - cx * cz);
+    Rd[0][2] = sel3(role, cx * sz - cz * sx * sy, cx * cy * cz, cz * sx - cx * sy * sz);
+    Rd[1][0] = sel3(role, 0.0, -sy * sz, cy * cz);
+    Rd[1][1] = sel3(role, cx * sy * sz - cz * sx, cy * sx * sz, cz * sx * sy - cx * sz);
+    Rd[1][2] = sel3(role, -sx * sy * sz - cx * cz, cx * cy * sz, cx * cz * sy + sx * sz);
+    Rd[2][0] = sel3(role, 0.0, -cy, 0.0);
+    Rd[2][1] = sel3(role, cx * cy, -sx * sy, 0.0);
+    Rd[2][2] = sel3(role, -cy * sx, -cx * sy, 0.0);
     // d(I_w v)/d e_d = R_d I_b R^T v + R I_b R_d^T v   (jac11+jac12 / jac21+jac22)
     auto dIw = [&](const double v[3], const double av[3], double o[3]) {
       double t1[3], t2[3], t3b[3], t4[3];
       matvec(Rd, av, t1);
       matTvec(Rd, v, t2);
       symmul(Ib, t2, t3b);
-      matvec(ro.R, t3b, t4);
+      matvec(R, t3b, t4);
 #pragma unroll
       for (int i = 0; i < 3; ++i) o[i] = t1[i] + t4[i];
     };
@@ -398,62 +440,43 @@ TWR_DEV void dyn_quad(const DevStruct* __restrict__ S, const char* __restrict__ 
 #pragma unroll
       for (int j = 0; j < 4; ++j) stage[rs[r] + 8 + 3 * j + role] = A[r] * wP[j] + B[r] * wV[j] + C[r] * wA[j];
   }
-  if (!want_j) return;
-
-  // --- ee-motion block [f]x J_p (:181-192) and ee-force block {[r]x J_f ; -J_f} (:167-179) of this
-  // lane's end-effector.  Candidates that are not variables write to the lane's trash slot.
-  int ms[3], fs[3], ls[3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    ms[r] = rs[r] + 20 + pma[r];
-    fs[r] = rs[r] + 20 + nma[r] + pfa[r];
-    ls[r] = rl[r] + 4 + pfl[r];
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-#define TWR_EE_TILE(D, R1, R2)                                                              \
-  {                                                                                         \
-    const uint32_t cm = MP.cand(j * 3 + D);                                                 \
-    const bool vm = has_ee && (cm & 0xF) != 0xF;                                            \
-    stage[vm ? ms[R1] + (int)((cm >> 4) & 0xF) : trash] = crs<R1, D>(f) * wm[j];            \
-    stage[vm ? ms[R2] + (int)((cm >> 8) & 0xF) : trash] = crs<R2, D>(f) * wm[j];            \
-    const uint32_t cf = FP.cand(j * 3 + D);                                                 \
-    const bool vf = has_ee && (cf & 0xF) != 0xF;                                            \
-    stage[vf ? fs[R1] + (int)((cf >> 4) & 0xF) : trash] = crs<R1, D>(rv) * wf[j];           \
-    stage[vf ? fs[R2] + (int)((cf >> 8) & 0xF) : trash] = crs<R2, D>(rv) * wf[j];           \
-    stage[vf ? ls[D] + (int)((cf >> 12) & 0xF) : trash] = -wf[j];                           \
-  }
-    TWR_EE_TILE(0, 1, 2)
-    TWR_EE_TILE(1, 2, 0)
-    TWR_EE_TILE(2, 0, 1)
-#undef TWR_EE_TILE
-  }
 }
 
 // ---------------------------------------------------------------- range-of-motion item
 // RangeOfMotionConstraint::{UpdateConstraintAtInstance, UpdateJacobianAtInstance}
 // (range_of_motion_constraint.cc:58-109) for one (time node, ee).
-TWR_DEV void rom_item(const DevStruct* __restrict__ S, const char* __restrict__ blob, const double* __restrict__ xp,
-                      double* __restrict__ gp, double* __restrict__ stage, int soff, int trash, int k, int ee,
-                      bool want_g, bool want_j) {
-  const double tb = tbl<double>(blob, S->o_rom_tl_base)[k];
-  const int q = tbl<int32_t>(blob, S->o_rom_base_poly)[k];
-  const double iTb = tbl<double>(blob, S->o_base_iT)[q];
+struct RomX {
+  double bl[12], ba[12], m[12];
+};
+TWR_DEV uint64_t rom_slots(const RomRec& r) { return ((uint64_t)r.slots[1] << 32) | r.slots[0]; }
+TWR_DEV RomRec rom_load_rec(const RomWork& w, int lane) {
+  return reinterpret_cast<const RomRec*>(w.recs)[min(lane, w.cnt - 1)];
+}
+TWR_DEV void rom_load_x(const RomWork& w, const RomRec& r, const double* __restrict__ x, RomX& X) {
+  const double* xp = x + w.x_off;
+  const double* xl = xp + w.off_lin + r.q6;
+  const double* xa = xp + w.off_ang + r.q6;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    X.bl[i] = xl[i];
+    X.ba[i] = xa[i];
+  }
+  gather12(xp, r.xbase, rom_slots(r), X.m);
+}
+TWR_DEV void rom_item(const RomWork& w, const RomRec& r, const RomX& X, double* __restrict__ g, double* __restrict__ stage,
+                      int par, int vbase, int trash, int lane, bool want_g, bool want_j) {
+  const int soff = par + r.voff - vbase;
   double wP[4];
-  hermite_pos(tb, iTb, wP);
-  const double* xl = xp + S->off_base_lin + 6 * q;
-  const double* xa = xp + S->off_base_ang + 6 * q;
+  hermite_pos(r.tb, r.iTb, wP);
   double c[3], e[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    c[d] = wP[0] * xl[d] + wP[1] * xl[3 + d] + wP[2] * xl[6 + d] + wP[3] * xl[9 + d];
-    e[d] = wP[0] * xa[d] + wP[1] * xa[3 + d] + wP[2] * xa[6 + d] + wP[3] * xa[9 + d];
+    c[d] = wP[0] * X.bl[d] + wP[1] * X.bl[3 + d] + wP[2] * X.bl[6 + d] + wP[3] * X.bl[9 + d];
+    e[d] = wP[0] * X.ba[d] + wP[1] * X.ba[3 + d] + wP[2] * X.ba[6 + d] + wP[3] * X.ba[9 + d];
   }
-  const int mq = tbl<int32_t>(blob, S->o_rom_mpoly[ee])[k];
-  const double tm = tbl<double>(blob, S->o_rom_tl_m[ee])[k];
-  const PolyR MP = load_poly(tbl<EePoly>(blob, S->o_mpoly[ee]) + mq);
+  const uint64_t slots = rom_slots(r);
   double wm[4], p[3], v[3];
-  ee_weights_and_point(MP, tm, xp, wm, p);
+  ee_point(slots, meta_shared(r.meta), r.tm, r.iTm, X.m, wm, p);
 #pragma unroll
   for (int d = 0; d < 3; ++d) v[d] = p[d] - c[d];
   Rot ro;
@@ -461,7 +484,7 @@ TWR_DEV void rom_item(const DevStruct* __restrict__ S, const char* __restrict__ 
   if (want_g) {
     double gv[3];
     matTvec(ro.R, v, gv);  // b_R_w (p - c)
-    double* go = gp + S->row_rom[ee] + 3 * k;
+    double* go = g + w.g_off + 3 * lane;
     go[0] = gv[0]; go[1] = gv[1]; go[2] = gv[2];
   }
   if (!want_j) return;
@@ -469,28 +492,27 @@ TWR_DEV void rom_item(const DevStruct* __restrict__ S, const char* __restrict__ 
   matTvec(ro.Rx, v, ux);
   matTvec(ro.Ry, v, uy);
   matTvec(ro.Rz, v, uz);
-  const int nm = MP.nslots();
+  const int nm = meta_nslots(r.meta);
   const int rs[3] = {soff, soff + 20 + nm, soff + 44 + 2 * nm};
   const int mo[3] = {20, 24, 24};
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
+  for (int row = 0; row < 3; ++row) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
-      for (int d = 0; d < 3; ++d) stage[rs[r] + 3 * j + d] = -ro.R[d][r] * wP[j];  // -R^T J_c
-      if (r == 0) {  // row 0 of R^T v does not depend on roll
+      for (int d = 0; d < 3; ++d) stage[rs[row] + 3 * j + d] = -ro.R[d][row] * wP[j];  // -R^T J_c
+      if (row == 0) {  // row 0 of R^T v does not depend on roll
         stage[rs[0] + 12 + 2 * j + 0] = wP[j] * uy[0];
         stage[rs[0] + 12 + 2 * j + 1] = wP[j] * uz[0];
       } else {
-        stage[rs[r] + 12 + 3 * j + 0] = wP[j] * ux[r];
-        stage[rs[r] + 12 + 3 * j + 1] = wP[j] * uy[r];
-        stage[rs[r] + 12 + 3 * j + 2] = wP[j] * uz[r];
+        stage[rs[row] + 12 + 3 * j + 0] = wP[j] * ux[row];
+        stage[rs[row] + 12 + 3 * j + 1] = wP[j] * uy[row];
+        stage[rs[row] + 12 + 3 * j + 2] = wP[j] * uz[row];
       }
 #pragma unroll
       for (int d = 0; d < 3; ++d) {  // R^T J_p
-        const uint32_t cd = MP.cand(j * 3 + d);
-        const bool valid = (cd & 0xF) != 0xF;
-        stage[valid ? rs[r] + mo[r] + (int)(cd & 0xF) : trash] = ro.R[d][r] * wm[j];
+        const int sl = (int)((slots >> (4 * (j * 3 + d))) & 0xF);
+        stage[sl != 0xF ? rs[row] + mo[row] + sl : trash] = ro.R[d][row] * wm[j];
       }
     }
   }
@@ -634,100 +656,123 @@ TWR_DEV void copy_out(double* __restrict__ dst, const double* __restrict__ stage
 }
 
 // LDS image sizes (doubles).  dynamic: 16 time nodes per wave (~170 values each at 4 ee) -> 22.5 KiB,
-// seven workgroups per CU; range of motion / nodes: 64 lanes x ~84 values -> 39 KiB, four per CU.
+// seven workgroups per CU; range of motion: 64 lanes x ~84 values -> 39 KiB, four per CU.
 constexpr int kDynStage = 2816;
 constexpr int kRomStage = 4936;
 constexpr int kNodeStage = 64 * 25;
 
-struct Ctx {
-  const char* blob;
-  const DevStruct* S;
-  const double* xp;
-  double* gp;
-  double* jp;
-};
-TWR_DEV Ctx make_ctx(const Work& w, const double* x, double* g, double* jac) {
-  Ctx c;
-  c.blob = reinterpret_cast<const char*>(w.blob);
-  c.S = reinterpret_cast<const DevStruct*>(c.blob);
-  c.xp = x + w.x_off;
-  c.gp = g + w.g_off;
-  c.jp = jac + w.j_off;
-  return c;
-}
-
-// kind 0: rows 6k..6k+5 of "dynamic" for w.cnt <= 16 consecutive time nodes, four lanes per node
+// dynamic: persistent, software pipelined over the strided work list (see the file header).
 template <int NEE>
-__global__ __launch_bounds__(64, 2) void dyn_kernel(const Work* __restrict__ work, const double* __restrict__ x,
-                                                    double* __restrict__ g, double* __restrict__ jac, int flags) {
+__global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ work, int n_work,
+                                                    const double* __restrict__ x, double* __restrict__ g,
+                                                    double* __restrict__ jac, int flags) {
   __shared__ __attribute__((aligned(16))) double stage[kDynStage + 2 + 64];  // image + parity slack + trash slots
-  const Work w = work[blockIdx.x];
-  const Ctx c = make_ctx(w, x, g, jac);
   const bool want_g = flags & 1, want_j = flags & 2;
   const int lane = threadIdx.x;
   const int trash = kDynStage + 2 + lane;
-  const int32_t* vo = tbl<int32_t>(c.blob, c.S->o_dyn_val_off);
-  const int base = vo[w.k0], end = vo[w.k0 + w.cnt];
-  double* dst = c.jp + c.S->nnz_dyn + base;
-  const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-  // every lane of the wave runs the quad code (DPP needs its neighbours); nodes past the chunk are
-  // clamped to the last one and write to the trash slot / skip their g store
-  const int kk = lane >> 2, role = lane & 3;
-  const bool live = kk < w.cnt;
-  const int k = w.k0 + (live ? kk : w.cnt - 1);
-  dyn_quad<NEE>(c.S, c.blob, c.xp, c.gp, stage, par + vo[k] - base, trash, k, role, want_g && live, want_j && live);
-  if (want_j) {
-    __syncthreads();
-    copy_out(dst, stage, end - base, par, lane);
+  const int stride = gridDim.x;
+  int i = blockIdx.x;
+  if (i >= n_work) return;
+  DynWork w0 = work[i], w1 = w0, w2 = w0;
+  DynShared sh0, sh1;
+  DynLane ln0, ln1;
+  dyn_load_rec<NEE>(w0, lane, sh0, ln0);
+  sh1 = sh0;
+  ln1 = ln0;
+  if (i + stride < n_work) {
+    w1 = work[i + stride];
+    dyn_load_rec<NEE>(w1, lane, sh1, ln1);
+  }
+  for (; i < n_work; i += stride) {
+    const bool has2 = i + 2 * stride < n_work;
+    if (has2) w2 = work[i + 2 * stride];
+    // --- slice i: its x values (the record was prefetched two slices ago), then the math into LDS
+    double* dst = jac + w0.j_off;
+    const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+    const int vbase = __builtin_amdgcn_readfirstlane(sh0.voff);  // lane 0 holds the first node of the run
+    {
+      DynX X0;
+      dyn_load_x(w0, sh0, ln0, x, X0);
+      dyn_quad<NEE>(w0, sh0, ln0, X0, g, stage, par, vbase, trash, lane, want_g, want_j);
+    }
+    // --- prefetch the record of slice i+2
+    DynShared sh2 = sh1;
+    DynLane ln2 = ln1;
+    if (has2) dyn_load_rec<NEE>(w2, lane, sh2, ln2);
+    // --- slice i: LDS image -> HBM
+    if (want_j) {
+      __syncthreads();
+      copy_out(dst, stage, w0.nvals, par, lane);
+      __syncthreads();
+    }
+    w0 = w1; sh0 = sh1; ln0 = ln1;
+    w1 = w2; sh1 = sh2; ln1 = ln2;
   }
 }
 
-// kind 1: rows 3k..3k+2 of "rangeofmotion-<ee>" for w.cnt <= 64 consecutive time nodes
-__global__ __launch_bounds__(64, 2) void rom_kernel(const Work* __restrict__ work, const double* __restrict__ x,
-                                                    double* __restrict__ g, double* __restrict__ jac, int flags) {
+__global__ __launch_bounds__(64, 2) void rom_kernel(const RomWork* __restrict__ work, int n_work,
+                                                    const double* __restrict__ x, double* __restrict__ g,
+                                                    double* __restrict__ jac, int flags) {
   __shared__ __attribute__((aligned(16))) double stage[kRomStage + 2 + 64];
-  const Work w = work[blockIdx.x];
-  const Ctx c = make_ctx(w, x, g, jac);
   const bool want_g = flags & 1, want_j = flags & 2;
   const int lane = threadIdx.x;
   const int trash = kRomStage + 2 + lane;
-  const int ee = w.ee;
-  const int32_t* vo = tbl<int32_t>(c.blob, c.S->o_rom_val_off[ee]);
-  const int base = vo[w.k0], end = vo[w.k0 + w.cnt];
-  double* dst = c.jp + c.S->nnz_rom[ee] + base;
-  const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-  if (lane < w.cnt) {
-    const int k = w.k0 + lane;
-    rom_item(c.S, c.blob, c.xp, c.gp, stage, par + vo[k] - base, trash, k, ee, want_g, want_j);
+  const int stride = gridDim.x;
+  int i = blockIdx.x;
+  if (i >= n_work) return;
+  RomWork w0 = work[i], w1 = w0, w2 = w0;
+  RomRec r0 = rom_load_rec(w0, lane), r1 = r0;
+  RomX X0;
+  if (i + stride < n_work) {
+    w1 = work[i + stride];
+    r1 = rom_load_rec(w1, lane);
   }
-  if (want_j) {
-    __syncthreads();
-    copy_out(dst, stage, end - base, par, lane);
+  rom_load_x(w0, r0, x, X0);
+  for (; i < n_work; i += stride) {
+    const bool has1 = i + stride < n_work, has2 = i + 2 * stride < n_work;
+    if (has2) w2 = work[i + 2 * stride];
+    double* dst = jac + w0.j_off;
+    const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+    const int vbase = __builtin_amdgcn_readfirstlane(r0.voff);
+    if (lane < w0.cnt) rom_item(w0, r0, X0, g, stage, par, vbase, trash, lane, want_g, want_j);
+    RomRec r2 = r1;
+    if (has1) rom_load_x(w1, r1, x, X0);
+    if (has2) r2 = rom_load_rec(w2, lane);
+    if (want_j) {
+      __syncthreads();
+      copy_out(dst, stage, w0.nvals, par, lane);
+      __syncthreads();
+    }
+    w0 = w1; r0 = r1;
+    w1 = w2; r1 = r2;
   }
 }
 
-// kind 2: all terrain-ee-motion_e (terrain_constraint.cc:57-108) and force-ee-force_e sets of one
+// all terrain-ee-motion_e (terrain_constraint.cc:57-108) and force-ee-force_e sets of one
 // problem, 64 spline nodes at a time
-__global__ __launch_bounds__(64) void node_kernel(const Work* __restrict__ work, const double* __restrict__ x,
+__global__ __launch_bounds__(64) void node_kernel(const NodeWork* __restrict__ work, const double* __restrict__ x,
                                                   double* __restrict__ g, double* __restrict__ jac, int flags) {
   __shared__ __attribute__((aligned(16))) double stage[kNodeStage + 2];
-  const Work w = work[blockIdx.x];
-  const Ctx c = make_ctx(w, x, g, jac);
-  const DevStruct* S = c.S;
+  const NodeWork w = work[blockIdx.x];
+  const char* blob = reinterpret_cast<const char*>(w.blob);
+  const DevStruct* S = reinterpret_cast<const DevStruct*>(blob);
+  const double* xp = x + w.x_off;
+  double* gp = g + w.g_off;
+  double* jp = jac + w.j_off;
   const bool want_g = flags & 1, want_j = flags & 2;
   const int lane = threadIdx.x;
   for (int ee = 0; ee < S->n_ee; ++ee) {
-    const TerrainRow* rows = tbl<TerrainRow>(c.blob, S->o_terrain_rows[ee]);
+    const TerrainRow* rows = tbl<TerrainRow>(blob, S->o_terrain_rows[ee]);
     const int nr = S->n_terrain_rows[ee];
     for (int r0 = 0; r0 < nr; r0 += 64) {
       const int cnt = min(64, nr - r0);
-      double* dst = c.jp + S->nnz_terrain[ee] + 3 * r0;
+      double* dst = jp + S->nnz_terrain[ee] + 3 * r0;
       const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
       if (lane < cnt) {
         const TerrainRow tr = rows[r0 + lane];
-        const double px = c.xp[tr.idx], py = c.xp[tr.idx + tr.stride], pz = c.xp[tr.idx + 2 * tr.stride];
+        const double px = xp[tr.idx], py = xp[tr.idx + tr.stride], pz = xp[tr.idx + 2 * tr.stride];
         const Terr t = terrain_eval(S->terrain_id, S->flat_height, px, py);
-        if (want_g) c.gp[S->row_terrain[ee] + r0 + lane] = pz - t.h;
+        if (want_g) gp[S->row_terrain[ee] + r0 + lane] = pz - t.h;
         if (want_j) {
           stage[par + 3 * lane + 0] = -t.hx;
           stage[par + 3 * lane + 1] = -t.hy;
@@ -742,15 +787,15 @@ __global__ __launch_bounds__(64) void node_kernel(const Work* __restrict__ work,
     }
   }
   for (int ee = 0; ee < S->n_ee; ++ee) {
-    const ForceNode* nodes = tbl<ForceNode>(c.blob, S->o_force_nodes[ee]);
+    const ForceNode* nodes = tbl<ForceNode>(blob, S->o_force_nodes[ee]);
     const int nn = S->n_force_nodes[ee];
     for (int i0 = 0; i0 < nn; i0 += 64) {
       const int cnt = min(64, nn - i0);
-      double* dst = c.jp + S->nnz_force[ee] + 25 * i0;
+      double* dst = jp + S->nnz_force[ee] + 25 * i0;
       const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
       if (lane < cnt)
-        force_item(S, nodes[i0 + lane], c.xp, c.gp + S->row_force[ee] + 5 * (i0 + lane), stage + par + 25 * lane,
-                   want_g, want_j);
+        force_item(S, nodes[i0 + lane], xp, gp + S->row_force[ee] + 5 * (i0 + lane), stage + par + 25 * lane, want_g,
+                   want_j);
       if (want_j) {
         __syncthreads();
         copy_out(dst, stage, 25 * cnt, par, lane);
@@ -760,21 +805,44 @@ __global__ __launch_bounds__(64) void node_kernel(const Work* __restrict__ work,
   }
 }
 
-// host-side launcher (called from capi.cc): three launches on one stream
-hipError_t launch_eval(int n_ee, const Work* dyn, int n_dyn, const Work* rom, int n_rom, const Work* node, int n_node,
-                       const double* x, double* g, double* jac, int flags, hipStream_t stream) {
+// host-side launcher (called from capi.cc): three launches on one stream.  The dyn/rom grids are
+// persistent: exactly as many workgroups as are resident at once (occupancy query, LDS bound).
+template <typename K>
+static int resident_blocks(K kernel, int n_cu) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  if (const char* e = getenv("TWR_BLOCKS_PER_CU")) {  // tuning knob for experiments
+    int v = atoi(e);
+    if (v > 0) per_cu = v;
+  }
+  return per_cu * n_cu;
+}
+hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
+                       const NodeWork* node, int n_node, const double* x, double* g, double* jac, int flags,
+                       hipStream_t stream) {
+  static int res_dyn[5] = {0, 0, 0, 0, 0}, res_rom = 0;
   dim3 block(64);
+  if (n_ee < 1 || n_ee > 4) return hipErrorInvalidValue;
+  if (!res_rom) {
+    res_dyn[1] = resident_blocks(dyn_kernel<1>, n_cu);
+    res_dyn[2] = resident_blocks(dyn_kernel<2>, n_cu);
+    res_dyn[3] = resident_blocks(dyn_kernel<3>, n_cu);
+    res_dyn[4] = resident_blocks(dyn_kernel<4>, n_cu);
+    res_rom = resident_blocks(rom_kernel, n_cu);
+  }
   if (n_dyn > 0) {
-    dim3 grid(n_dyn);
+    dim3 grid(n_dyn < res_dyn[n_ee] ? n_dyn : res_dyn[n_ee]);
     switch (n_ee) {
-      case 1: hipLaunchKernelGGL(dyn_kernel<1>, grid, block, 0, stream, dyn, x, g, jac, flags); break;
-      case 2: hipLaunchKernelGGL(dyn_kernel<2>, grid, block, 0, stream, dyn, x, g, jac, flags); break;
-      case 3: hipLaunchKernelGGL(dyn_kernel<3>, grid, block, 0, stream, dyn, x, g, jac, flags); break;
-      case 4: hipLaunchKernelGGL(dyn_kernel<4>, grid, block, 0, stream, dyn, x, g, jac, flags); break;
-      default: return hipErrorInvalidValue;
+      case 1: hipLaunchKernelGGL(dyn_kernel<1>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags); break;
+      case 2: hipLaunchKernelGGL(dyn_kernel<2>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags); break;
+      case 3: hipLaunchKernelGGL(dyn_kernel<3>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags); break;
+      case 4: hipLaunchKernelGGL(dyn_kernel<4>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags); break;
     }
   }
-  if (n_rom > 0) hipLaunchKernelGGL(rom_kernel, dim3(n_rom), block, 0, stream, rom, x, g, jac, flags);
+  if (n_rom > 0) {
+    dim3 grid(n_rom < res_rom ? n_rom : res_rom);
+    hipLaunchKernelGGL(rom_kernel, grid, block, 0, stream, rom, n_rom, x, g, jac, flags);
+  }
   if (n_node > 0) hipLaunchKernelGGL(node_kernel, dim3(n_node), block, 0, stream, node, x, g, jac, flags);
   return hipGetLastError();
 }

@@ -112,8 +112,8 @@ SplineLayout PhaseBasedLayout(const double* phase_durations, int n_phases, bool 
   return s;
 }
 
-EePoly MakeEePoly(const SplineLayout& s, int q) {
-  EePoly p;
+PolyDesc MakeEePoly(const SplineLayout& s, int q) {
+  PolyDesc p;
   std::memset(&p, 0, sizeof(p));
   p.iT = 1.0 / s.durations[q];
   int gi[12];
@@ -132,14 +132,14 @@ EePoly MakeEePoly(const SplineLayout& s, int q) {
   std::sort(uniq.begin(), uniq.end());
   uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
   if (uniq.size() > 12) throw std::runtime_error("too many slots");
-  p.nslots = (uint8_t)uniq.size();
+  const int nslots = (int)uniq.size();
   p.xbase = uniq.empty() ? 0 : uniq.front();
   for (size_t i = 0; i < uniq.size(); ++i)
     if (uniq[i] != p.xbase + (int)i) throw std::runtime_error("polynomial variables not contiguous");
-  int dim_of_slot[12];
+  int dim_of_slot[12], cnt[3] = {0, 0, 0};
   for (int c = 0; c < 12; ++c)
     if (gi[c] >= 0) dim_of_slot[gi[c] - p.xbase] = c % 3;
-  for (int sl = 0; sl < p.nslots; ++sl) p.cnt[dim_of_slot[sl]]++;
+  for (int sl = 0; sl < nslots; ++sl) cnt[dim_of_slot[sl]]++;
   for (int c = 0; c < 12; ++c) {
     if (gi[c] < 0) {
       p.cand[c] = 0xFFFF;
@@ -154,7 +154,7 @@ EePoly MakeEePoly(const SplineLayout& s, int q) {
     }
     p.cand[c] = (uint16_t)(sl | (ra << 4) | (rb << 8) | (rl << 12));
   }
-  p.shared = shared ? 1 : 0;
+  p.meta = (uint32_t)(nslots | (cnt[0] << 4) | (cnt[1] << 8) | (cnt[2] << 12) | ((shared ? 1 : 0) << 16));
   return p;
 }
 
@@ -280,12 +280,13 @@ void Structure::BuildPattern() {
     s.size = n;
     con_sets.push_back(s);
   };
-  auto slots_cols = [&](const EePoly& p, int want_dim, bool equal, std::vector<int>& out) {
+  auto slots_cols = [&](const PolyDesc& p, int want_dim, bool equal, std::vector<int>& out) {
     // columns of the slots whose dim ==/!= want_dim, ascending
     int dim_of_slot[12];
     for (int c = 0; c < 12; ++c)
       if (p.cand[c] != 0xFFFF) dim_of_slot[p.cand[c] & 0xF] = c % 3;
-    for (int s = 0; s < p.nslots; ++s)
+    const int nslots = p.meta & 0xF;
+    for (int s = 0; s < nslots; ++s)
       if ((dim_of_slot[s] == want_dim) == equal) out.push_back(p.xbase + s);
   };
   // --- terrain-ee-motion_e  (terrain_constraint.cc:90-108): [x, y, z] of node id = row+1
@@ -330,13 +331,13 @@ void Structure::BuildPattern() {
     begin_set("rangeofmotion-" + std::to_string(e), (int)grid_rom.size() * 3);
     for (size_t k = 0; k < grid_rom.size(); ++k) {
       int q = rom_base[k].poly;
-      const EePoly& mp = mpoly[e][rom_motion[e][k].poly];
+      const PolyDesc& mp = mpoly[e][rom_motion[e][k].poly];
       for (int r = 0; r < 3; ++r) {
         std::vector<int> c;
         for (int i = 0; i < 12; ++i) c.push_back(off_base_lin + 6 * q + i);  // -R^T J_c
         for (int i = 0; i < 12; ++i)  // DerivOfRotVecMult(inverse): row 0 does not depend on roll
           if (!(r == 0 && i % 3 == 0)) c.push_back(off_base_ang + 6 * q + i);
-        for (int s = 0; s < mp.nslots; ++s) c.push_back(mp.xbase + s);  // R^T J_p
+        for (int s = 0; s < (int)(mp.meta & 0xF); ++s) c.push_back(mp.xbase + s);  // R^T J_p
         rows.push_back(c);
         lower.push_back(model.nominal_stance[e][r] - model.max_dev[r]);  // :71-81
         upper.push_back(model.nominal_stance[e][r] + model.max_dev[r]);
@@ -375,62 +376,73 @@ void Structure::PackBlob() {
   std::memset(&h, 0, sizeof(h));
   std::vector<char> body;
   auto put = [&](const void* src, size_t bytes) -> uint32_t {
-    size_t off = (sizeof(DevStruct) + body.size() + 7) / 8 * 8;
+    size_t off = (sizeof(DevStruct) + body.size() + 15) / 16 * 16;
     body.resize(off - sizeof(DevStruct) + bytes);
     if (bytes) std::memcpy(body.data() + off - sizeof(DevStruct), src, bytes);
     return (uint32_t)off;
   };
-  auto put_polys = [&](const std::vector<TimeNode>& v, uint32_t& o_poly, uint32_t& o_tl) {
-    std::vector<int32_t> p;
-    std::vector<double> t;
-    for (auto& n : v) {
-      p.push_back(n.poly);
-      t.push_back(n.t_local);
-    }
-    o_tl = put(t.data(), t.size() * 8);
-    o_poly = put(p.data(), p.size() * 4);
-  };
-  h.n_ee = n_ee; h.n_vars = n_vars; h.n_rows = n_rows; h.nnz = nnz;
-  h.k_dyn = (int)grid_dyn.size(); h.k_rom = (int)grid_rom.size();
-  h.off_base_lin = off_base_lin; h.off_base_ang = off_base_ang;
-  h.n_base_polys = (int)base.durations.size();
+  h.n_ee = n_ee;
   h.terrain_id = model.terrain_id;
   int ci = 0;
   for (int e = 0; e < n_ee; ++e, ++ci) {
     h.row_terrain[e] = con_sets[ci].offset; h.nnz_terrain[e] = con_sets[ci].nnz_offset;
     h.n_terrain_rows[e] = con_sets[ci].size;
   }
-  h.row_dyn = con_sets[ci].offset; h.nnz_dyn = con_sets[ci].nnz_offset; ++ci;
-  for (int e = 0; e < n_ee; ++e, ++ci) { h.row_rom[e] = con_sets[ci].offset; h.nnz_rom[e] = con_sets[ci].nnz_offset; }
+  const int row_dyn = con_sets[ci].offset, nnz_dyn = con_sets[ci].nnz_offset;
+  ++ci;
+  int row_rom[kMaxEE], nnz_rom[kMaxEE];
+  for (int e = 0; e < n_ee; ++e, ++ci) { row_rom[e] = con_sets[ci].offset; nnz_rom[e] = con_sets[ci].nnz_offset; }
   for (int e = 0; e < n_ee; ++e, ++ci) {
     h.row_force[e] = con_sets[ci].offset; h.nnz_force[e] = con_sets[ci].nnz_offset;
     h.n_force_nodes[e] = (int)force_nodes[e].size();
   }
+  // --- per-lane records of the dynamic kernel
   {
-    std::vector<double> inv;
-    for (double d : base.durations) inv.push_back(1.0 / d);
-    h.o_base_iT = put(inv.data(), inv.size() * 8);
+    std::vector<DynShared> sh(grid_dyn.size());
+    std::vector<DynLane> ln(grid_dyn.size() * n_ee);
+    for (size_t k = 0; k < grid_dyn.size(); ++k) {
+      std::memset(&sh[k], 0, sizeof(DynShared));
+      sh[k].tb = dyn_base[k].t_local;
+      sh[k].iTb = 1.0 / base.durations[dyn_base[k].poly];
+      sh[k].q6 = 6 * dyn_base[k].poly;
+      sh[k].voff = row_ptr[row_dyn + 6 * k] - nnz_dyn;
+      for (int e = 0; e < n_ee; ++e) {
+        DynLane& L = ln[k * n_ee + e];
+        std::memset(&L, 0, sizeof(L));
+        const PolyDesc& mp = mpoly[e][dyn_motion[e][k].poly];
+        const PolyDesc& fp = fpoly[e][dyn_force[e][k].poly];
+        L.tm = dyn_motion[e][k].t_local; L.iTm = mp.iT;
+        L.tf = dyn_force[e][k].t_local;  L.iTf = fp.iT;
+        L.xbase_m = mp.xbase; L.xbase_f = fp.xbase;
+        L.meta_m = mp.meta;   L.meta_f = fp.meta;
+        std::memcpy(L.cand_m, mp.cand, sizeof(L.cand_m));
+        std::memcpy(L.cand_f, fp.cand, sizeof(L.cand_f));
+      }
+    }
+    off_dyn_shared = put(sh.data(), sh.size() * sizeof(DynShared));
+    off_dyn_lanes = put(ln.data(), ln.size() * sizeof(DynLane));
   }
+  // --- per-lane records of the range-of-motion kernel
   for (int e = 0; e < n_ee; ++e) {
-    h.o_mpoly[e] = put(mpoly[e].data(), mpoly[e].size() * sizeof(EePoly));
-    h.o_fpoly[e] = put(fpoly[e].data(), fpoly[e].size() * sizeof(EePoly));
-  }
-  put_polys(dyn_base, h.o_dyn_base_poly, h.o_dyn_tl_base);
-  {
-    std::vector<int32_t> vo(grid_dyn.size() + 1);
-    for (size_t k = 0; k <= grid_dyn.size(); ++k) vo[k] = row_ptr[h.row_dyn + 6 * k] - h.nnz_dyn;
-    h.o_dyn_val_off = put(vo.data(), vo.size() * 4);
-  }
-  for (int e = 0; e < n_ee; ++e) {
-    put_polys(dyn_motion[e], h.o_dyn_mpoly[e], h.o_dyn_tl_m[e]);
-    put_polys(dyn_force[e], h.o_dyn_fpoly[e], h.o_dyn_tl_f[e]);
-  }
-  put_polys(rom_base, h.o_rom_base_poly, h.o_rom_tl_base);
-  for (int e = 0; e < n_ee; ++e) {
-    put_polys(rom_motion[e], h.o_rom_mpoly[e], h.o_rom_tl_m[e]);
-    std::vector<int32_t> vo(grid_rom.size() + 1);
-    for (size_t k = 0; k <= grid_rom.size(); ++k) vo[k] = row_ptr[h.row_rom[e] + 3 * k] - h.nnz_rom[e];
-    h.o_rom_val_off[e] = put(vo.data(), vo.size() * 4);
+    std::vector<RomRec> rc(grid_rom.size());
+    for (size_t k = 0; k < grid_rom.size(); ++k) {
+      RomRec& R = rc[k];
+      std::memset(&R, 0, sizeof(R));
+      const PolyDesc& mp = mpoly[e][rom_motion[e][k].poly];
+      R.tb = rom_base[k].t_local;
+      R.iTb = 1.0 / base.durations[rom_base[k].poly];
+      R.tm = rom_motion[e][k].t_local;
+      R.iTm = mp.iT;
+      R.q6 = 6 * rom_base[k].poly;
+      R.xbase = mp.xbase;
+      R.voff = row_ptr[row_rom[e] + 3 * k] - nnz_rom[e];
+      R.meta = mp.meta;
+      uint64_t slots = 0;
+      for (int c = 0; c < 12; ++c) slots |= (uint64_t)(mp.cand[c] & 0xF) << (4 * c);
+      R.slots[0] = (uint32_t)slots;
+      R.slots[1] = (uint32_t)(slots >> 32);
+    }
+    off_rom_recs[e] = put(rc.data(), rc.size() * sizeof(RomRec));
     h.o_force_nodes[e] = put(force_nodes[e].data(), force_nodes[e].size() * sizeof(ForceNode));
     h.o_terrain_rows[e] = put(terrain_rows[e].data(), terrain_rows[e].size() * sizeof(TerrainRow));
   }

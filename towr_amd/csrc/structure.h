@@ -48,7 +48,7 @@ struct Structure {
   std::vector<double> grid_dyn, grid_rom;
   std::vector<TimeNode> dyn_base, rom_base;
   std::vector<std::vector<TimeNode>> dyn_motion, dyn_force, rom_motion;  // [ee][k]
-  std::vector<std::vector<EePoly>> mpoly, fpoly;                         // [ee][poly]
+  std::vector<std::vector<PolyDesc>> mpoly, fpoly;                       // [ee][poly]
   std::vector<std::vector<ForceNode>> force_nodes;                       // [ee]
   std::vector<std::vector<TerrainRow>> terrain_rows;                     // [ee]
 
@@ -56,6 +56,9 @@ struct Structure {
   std::vector<double> lower, upper;
 
   std::vector<char> blob;  // packed DevStruct + tables (device_tables.h)
+  // byte offsets of the per-lane record arrays inside the blob
+  uint32_t off_dyn_shared = 0, off_dyn_lanes = 0;
+  uint32_t off_rom_recs[kMaxEE] = {0, 0, 0, 0};
 
   void Build();            // throws std::runtime_error
   void InitialGuess(const double* lin0, const double* ang0, const double* lin1, const double* ang1,
