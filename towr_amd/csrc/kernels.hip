@@ -32,6 +32,17 @@ template <typename T>
 TWR_DEV const T* tbl(const char* blob, uint32_t off) {
   return reinterpret_cast<const T*>(blob + off);
 }
+// Device addresses stored as integers in the work items: tell the compiler they are global memory
+// (a plain reinterpret_cast yields a generic pointer -> flat_load, which also ties up lgkmcnt).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TWR_GLOBAL __attribute__((address_space(1)))
+#else
+#define TWR_GLOBAL
+#endif
+template <typename T>
+TWR_DEV const TWR_GLOBAL T* gptr(uint64_t addr) {
+  return reinterpret_cast<const TWR_GLOBAL T*>(addr);
+}
 
 // ---------------------------------------------------------------- cubic Hermite weights
 // d{pos,vel,acc}/d{p0,v0,p1,v1} of CubicHermitePolynomial (src/polynomial.cc:140-234); iT = 1/T comes
@@ -110,6 +121,38 @@ TWR_DEV void cross3(const double a[3], const double b[3], double o[3]) {
   o[2] = a[0] * b[1] - a[1] * b[0];
 }
 
+// sin and cos of one Euler angle.  Cody-Waite reduction by pi/2 in three FMA steps and the fdlibm
+// minimax kernels (k_sin.c / k_cos.c coefficients), ~35 FP64 instructions for both results and
+// accurate to about 1 ulp for |x| < 1e5; anything larger (or non-finite) takes the ocml path.
+// The reference calls libm sin/cos (euler_converter.cc:133-221); the difference is rounding level.
+TWR_DEV void sincos_fast(double x, double* __restrict__ s, double* __restrict__ c) {
+  if (!(fabs(x) < 1.0e5)) {
+    sincos(x, s, c);
+    return;
+  }
+  const double n = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-n, 1.5707963267948966e+00, x);
+  r = fma(-n, 6.1232339957367574e-17, r);
+  r = fma(-n, 8.4784276603688985e-32, r);
+  const double z = r * r;
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  const double sr = fma(z * r, ps, r);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
+  const int q = (int)n & 3;
+  const double ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
+  *s = (q & 2) ? -ss : ss;
+  *c = ((q + 1) & 2) ? -cc : cc;
+}
+
 // ZYX Euler rotation and its partial derivatives w.r.t. roll/pitch/yaw
 // (euler_converter.cc:207-221 and the cell-wise derivatives of :241-268).
 struct Rot {
@@ -133,9 +176,9 @@ TWR_DEV void rotation_from_sincos(double sx, double cx, double sy, double cy, do
 }
 TWR_DEV void rotation(const double e[3], Rot& o) {
   double sx, cx, sy, cy, sz, cz;
-  sincos(e[0], &sx, &cx);
-  sincos(e[1], &sy, &cy);
-  sincos(e[2], &sz, &cz);
+  sincos_fast(e[0], &sx, &cx);
+  sincos_fast(e[1], &sy, &cy);
+  sincos_fast(e[2], &sz, &cz);
   rotation_from_sincos(sx, cx, sy, cy, sz, cz, o);
 }
 TWR_DEV void matvec(const double A[3][3], const double v[3], double o[3]) {
@@ -190,8 +233,8 @@ struct DynX {  // the lane's slice of x: base-lin / base-ang nodes of the active
 template <int NEE>
 TWR_DEV void dyn_load_rec(const DynWork& w, int lane, DynShared& sh, DynLane& ln) {
   const int kk = min(lane >> 2, w.cnt - 1), role = min(lane & 3, NEE - 1);
-  sh = reinterpret_cast<const DynShared*>(w.shared)[kk];
-  ln = reinterpret_cast<const DynLane*>(w.lanes)[kk * NEE + role];
+  sh = gptr<DynShared>(w.shared)[kk];
+  ln = gptr<DynLane>(w.lanes)[kk * NEE + role];
 }
 TWR_DEV void dyn_load_x(const DynWork& w, const DynShared& sh, const DynLane& ln, const double* __restrict__ x, DynX& X) {
   const double* xp = x + w.x_off;
@@ -272,7 +315,7 @@ TWR_DEV void dyn_quad(const DynWork& w, const DynShared& sh, const DynLane& ln, 
 
   // --- rotation: lanes 0..2 of the quad evaluate one sincos each and broadcast it
   double my_s, my_c;
-  sincos(sel3(role, e[0], e[1], e[2]), &my_s, &my_c);
+  sincos_fast(sel3(role, e[0], e[1], e[2]), &my_s, &my_c);
   const double sx = quad_perm<0x00>(my_s), cx = quad_perm<0x00>(my_c);
   const double sy = quad_perm<0x55>(my_s), cy = quad_perm<0x55>(my_c);
   const double sz = quad_perm<0xAA>(my_s), cz = quad_perm<0xAA>(my_c);
@@ -327,7 +370,7 @@ TWR_DEV void dyn_quad(const DynWork& w, const DynShared& sh, const DynLane& ln, 
   }
   om[2] += zd;
   omd[2] += edd[2];
-  const DevStruct* S = reinterpret_cast<const DevStruct*>(w.hdr);
+  const TWR_GLOBAL DevStruct* S = gptr<DevStruct>(w.hdr);
   double Ib[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) Ib[i] = S->Ib[i];
@@ -450,7 +493,7 @@ struct RomX {
 };
 TWR_DEV uint64_t rom_slots(const RomRec& r) { return ((uint64_t)r.slots[1] << 32) | r.slots[0]; }
 TWR_DEV RomRec rom_load_rec(const RomWork& w, int lane) {
-  return reinterpret_cast<const RomRec*>(w.recs)[min(lane, w.cnt - 1)];
+  return gptr<RomRec>(w.recs)[min(lane, w.cnt - 1)];
 }
 TWR_DEV void rom_load_x(const RomWork& w, const RomRec& r, const double* __restrict__ x, RomX& X) {
   const double* xp = x + w.x_off;
@@ -654,14 +697,48 @@ TWR_DEV void copy_out(double* __restrict__ dst, const double* __restrict__ stage
   }
   if ((total & 1) && lane == 0 && total - 1 >= par) al[total - 1] = stage[total - 1];
 }
+// Same, with a compile-time number of store instructions: iterations past the end re-store the
+// last pair (idempotent).  A fixed count lets the compiler keep the stores in flight behind a
+// counted s_waitcnt vmcnt(N) when the persistent loop next touches its prefetched loads (on gfx9
+// loads and stores retire through one in-order counter; an unknown store count would force
+// vmcnt(0), i.e. a full store drain per slice).
+template <int NIT>
+TWR_DEV void copy_out_fixed(double* __restrict__ dst, const double* __restrict__ stage, int n, int par, int lane) {
+  double* al = dst - par;  // 16-byte aligned
+  const int total = n + par;
+  const int npairs = total >> 1;  // pairs [par, npairs) are complete; a slice has >= 20 values
+  constexpr int kBatch = 8;       // LDS reads in flight before the first store needs its data
+#pragma unroll
+  for (int it0 = 0; it0 < NIT; it0 += kBatch) {
+    double2 v[kBatch];
+    int t[kBatch];
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b)
+      if (it0 + b < NIT) {
+        t[b] = min(par + lane + 64 * (it0 + b), npairs - 1);
+        v[b] = *reinterpret_cast<const double2*>(stage + 2 * t[b]);
+      }
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b)
+      if (it0 + b < NIT) *reinterpret_cast<double2*>(al + 2 * t[b]) = v[b];
+  }
+  if (par && lane == 0 && n > 0) al[1] = stage[1];
+  if ((total & 1) && lane == 0 && total - 1 > par) al[total - 1] = stage[total - 1];
+}
 
 // LDS image sizes (doubles).  dynamic: 16 time nodes per wave (~170 values each at 4 ee) -> 22.5 KiB,
 // seven workgroups per CU; range of motion: 64 lanes x ~84 values -> 39 KiB, four per CU.
-constexpr int kDynStage = 2816;
+constexpr int kDynStage = 2750;
 constexpr int kRomStage = 4936;
 constexpr int kNodeStage = 64 * 25;
 
-// dynamic: persistent, software pipelined over the strided work list (see the file header).
+// dynamic / range of motion: persistent workgroups, software pipelined over the strided work list.
+// Loop body for slice i (its values are already in the LDS image):
+//   A  issue the x loads of slice i+1 (record prefetched earlier) and the record loads of slice i+2
+//   B  stream the image of slice i to HBM (fixed number of store instructions)
+//   C  wait for A's loads only -- s_waitcnt vmcnt(#stores) keeps B's stores in flight -- and compute
+//      slice i+1 into the image
+// so neither load latency nor store drain is exposed between slices.
 template <int NEE>
 __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ work, int n_work,
                                                     const double* __restrict__ x, double* __restrict__ g,
@@ -676,6 +753,7 @@ __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ 
   DynWork w0 = work[i], w1 = w0, w2 = w0;
   DynShared sh0, sh1;
   DynLane ln0, ln1;
+  DynX X;
   dyn_load_rec<NEE>(w0, lane, sh0, ln0);
   sh1 = sh0;
   ln1 = ln0;
@@ -683,30 +761,27 @@ __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ 
     w1 = work[i + stride];
     dyn_load_rec<NEE>(w1, lane, sh1, ln1);
   }
-  for (; i < n_work; i += stride) {
-    const bool has2 = i + 2 * stride < n_work;
+  dyn_load_x(w0, sh0, ln0, x, X);
+  double* dst = jac + w0.j_off;
+  int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+  dyn_quad<NEE>(w0, sh0, ln0, X, g, stage, par, __builtin_amdgcn_readfirstlane(sh0.voff), trash, lane, want_g, want_j);
+  for (;;) {
+    const bool has1 = i + stride < n_work, has2 = i + 2 * stride < n_work;
     if (has2) w2 = work[i + 2 * stride];
-    // --- slice i: its x values (the record was prefetched two slices ago), then the math into LDS
-    double* dst = jac + w0.j_off;
-    const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-    const int vbase = __builtin_amdgcn_readfirstlane(sh0.voff);  // lane 0 holds the first node of the run
-    {
-      DynX X0;
-      dyn_load_x(w0, sh0, ln0, x, X0);
-      dyn_quad<NEE>(w0, sh0, ln0, X0, g, stage, par, vbase, trash, lane, want_g, want_j);
-    }
-    // --- prefetch the record of slice i+2
     DynShared sh2 = sh1;
     DynLane ln2 = ln1;
-    if (has2) dyn_load_rec<NEE>(w2, lane, sh2, ln2);
-    // --- slice i: LDS image -> HBM
-    if (want_j) {
-      __syncthreads();
-      copy_out(dst, stage, w0.nvals, par, lane);
-      __syncthreads();
-    }
-    w0 = w1; sh0 = sh1; ln0 = ln1;
-    w1 = w2; sh1 = sh2; ln1 = ln2;
+    if (has2) dyn_load_rec<NEE>(w2, lane, sh2, ln2);  // A (the x loads of slice i+1 would not fit the
+                                                      //    256-register budget of two waves per SIMD)
+    if (want_j)                                       // B (one wave per workgroup: its LDS accesses
+      copy_out_fixed<(kDynStage + 2 + 127) / 128>(dst, stage, w0.nvals, par, lane);  // are ordered, no barrier)
+    if (!has1) break;
+    dst = jac + w1.j_off;                             // C
+    par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+    dyn_load_x(w1, sh1, ln1, x, X);
+    dyn_quad<NEE>(w1, sh1, ln1, X, g, stage, par, __builtin_amdgcn_readfirstlane(sh1.voff), trash, lane, want_g, want_j);
+    w0 = w1; w1 = w2;
+    sh1 = sh2; ln1 = ln2;
+    i += stride;
   }
 }
 
@@ -722,29 +797,32 @@ __global__ __launch_bounds__(64, 2) void rom_kernel(const RomWork* __restrict__ 
   if (i >= n_work) return;
   RomWork w0 = work[i], w1 = w0, w2 = w0;
   RomRec r0 = rom_load_rec(w0, lane), r1 = r0;
-  RomX X0;
+  RomX X;
   if (i + stride < n_work) {
     w1 = work[i + stride];
     r1 = rom_load_rec(w1, lane);
   }
-  rom_load_x(w0, r0, x, X0);
-  for (; i < n_work; i += stride) {
+  rom_load_x(w0, r0, x, X);
+  double* dst = jac + w0.j_off;
+  int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+  if (lane < w0.cnt)
+    rom_item(w0, r0, X, g, stage, par, __builtin_amdgcn_readfirstlane(r0.voff), trash, lane, want_g, want_j);
+  for (;;) {
     const bool has1 = i + stride < n_work, has2 = i + 2 * stride < n_work;
     if (has2) w2 = work[i + 2 * stride];
-    double* dst = jac + w0.j_off;
-    const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-    const int vbase = __builtin_amdgcn_readfirstlane(r0.voff);
-    if (lane < w0.cnt) rom_item(w0, r0, X0, g, stage, par, vbase, trash, lane, want_g, want_j);
     RomRec r2 = r1;
-    if (has1) rom_load_x(w1, r1, x, X0);
-    if (has2) r2 = rom_load_rec(w2, lane);
-    if (want_j) {
-      __syncthreads();
-      copy_out(dst, stage, w0.nvals, par, lane);
-      __syncthreads();
-    }
-    w0 = w1; r0 = r1;
-    w1 = w2; r1 = r2;
+    if (has2) r2 = rom_load_rec(w2, lane);            // A (records first: the wait for x retires them too)
+    if (has1) rom_load_x(w1, r1, x, X);
+    if (want_j)                                       // B (one wave per workgroup: its LDS accesses
+      copy_out_fixed<(kRomStage + 2 + 127) / 128>(dst, stage, w0.nvals, par, lane);  // are ordered, no barrier)
+    if (!has1) break;
+    dst = jac + w1.j_off;                             // C
+    par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+    const int vbase = __builtin_amdgcn_readfirstlane(r1.voff);
+    if (lane < w1.cnt) rom_item(w1, r1, X, g, stage, par, vbase, trash, lane, want_g, want_j);
+    w0 = w1; w1 = w2;
+    r1 = r2;
+    i += stride;
   }
 }
 
