@@ -71,13 +71,15 @@ struct TerrainRow {  // one ee-motion node id >= 1 (terrain_constraint.cc:44-55)
   int32_t stride;    // py = idx+stride, pz = idx+2*stride (1 stance node, 2 swing node)
 };
 
-// Blob header: model constants + what the node kernel needs.
+// Blob header: model constants + what the node kernel needs.  The terrain-ee-motion_e sets are
+// adjacent in g / jac, and so are the force-ee-force_e sets, so each family is one flat node list.
 struct DevStruct {
   int32_t n_ee, terrain_id;
-  int32_t row_terrain[kMaxEE], nnz_terrain[kMaxEE], n_terrain_rows[kMaxEE];
-  int32_t row_force[kMaxEE], nnz_force[kMaxEE], n_force_nodes[kMaxEE];
-  uint32_t o_force_nodes[kMaxEE];   // byte offsets inside the blob: ForceNode[]
-  uint32_t o_terrain_rows[kMaxEE];  // TerrainRow[]
+  int32_t row_terrain, nnz_terrain, n_terrain_rows;  // first row / first value / rows over all ee
+  int32_t row_force, nnz_force, n_force_nodes;
+  uint32_t o_force_nodes;   // byte offsets inside the blob: ForceNode[n_force_nodes]
+  uint32_t o_terrain_rows;  // TerrainRow[n_terrain_rows]
+  uint32_t pad_[2];
   double mass, gravity, mu, flat_height;
   double Ib[6];  // body inertia tensor entries (0,0),(0,1),(0,2),(1,1),(1,2),(2,2) incl. the sign of
                  // single_rigid_body_dynamics.cc:40-42

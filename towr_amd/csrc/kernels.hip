@@ -733,12 +733,13 @@ constexpr int kRomStage = 4936;
 constexpr int kNodeStage = 64 * 25;
 
 // dynamic / range of motion: persistent workgroups, software pipelined over the strided work list.
-// Loop body for slice i (its values are already in the LDS image):
-//   A  issue the x loads of slice i+1 (record prefetched earlier) and the record loads of slice i+2
-//   B  stream the image of slice i to HBM (fixed number of store instructions)
-//   C  wait for A's loads only -- s_waitcnt vmcnt(#stores) keeps B's stores in flight -- and compute
-//      slice i+1 into the image
-// so neither load latency nor store drain is exposed between slices.
+// Loop body for slice i (its record -- and for rom its x values -- were prefetched):
+//   C  compute slice i into the LDS image          (the ONLY call site of the math: every slice of a
+//      batch goes through the same instruction sequence, so equal x give bit-identical results
+//      wherever they sit in the batch)
+//   A  issue the record loads of slice i+2 and (rom) the x loads of slice i+1
+//   B  stream the image of slice i to HBM with a fixed number of store instructions
+// One wave per workgroup: its LDS accesses are ordered, no barriers.
 template <int NEE>
 __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ work, int n_work,
                                                     const double* __restrict__ x, double* __restrict__ g,
@@ -753,7 +754,6 @@ __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ 
   DynWork w0 = work[i], w1 = w0, w2 = w0;
   DynShared sh0, sh1;
   DynLane ln0, ln1;
-  DynX X;
   dyn_load_rec<NEE>(w0, lane, sh0, ln0);
   sh1 = sh0;
   ln1 = ln0;
@@ -761,27 +761,23 @@ __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ 
     w1 = work[i + stride];
     dyn_load_rec<NEE>(w1, lane, sh1, ln1);
   }
-  dyn_load_x(w0, sh0, ln0, x, X);
-  double* dst = jac + w0.j_off;
-  int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-  dyn_quad<NEE>(w0, sh0, ln0, X, g, stage, par, __builtin_amdgcn_readfirstlane(sh0.voff), trash, lane, want_g, want_j);
-  for (;;) {
-    const bool has1 = i + stride < n_work, has2 = i + 2 * stride < n_work;
+  for (; i < n_work; i += stride) {
+    const bool has2 = i + 2 * stride < n_work;
     if (has2) w2 = work[i + 2 * stride];
+    double* dst = jac + w0.j_off;
+    const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+    {                                                   // C (the x loads of the next slice would not fit
+      DynX X;                                           //    the 256-register budget of two waves per SIMD)
+      dyn_load_x(w0, sh0, ln0, x, X);
+      dyn_quad<NEE>(w0, sh0, ln0, X, g, stage, par, __builtin_amdgcn_readfirstlane(sh0.voff), trash, lane, want_g, want_j);
+    }
     DynShared sh2 = sh1;
     DynLane ln2 = ln1;
-    if (has2) dyn_load_rec<NEE>(w2, lane, sh2, ln2);  // A (the x loads of slice i+1 would not fit the
-                                                      //    256-register budget of two waves per SIMD)
-    if (want_j)                                       // B (one wave per workgroup: its LDS accesses
-      copy_out_fixed<(kDynStage + 2 + 127) / 128>(dst, stage, w0.nvals, par, lane);  // are ordered, no barrier)
-    if (!has1) break;
-    dst = jac + w1.j_off;                             // C
-    par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-    dyn_load_x(w1, sh1, ln1, x, X);
-    dyn_quad<NEE>(w1, sh1, ln1, X, g, stage, par, __builtin_amdgcn_readfirstlane(sh1.voff), trash, lane, want_g, want_j);
-    w0 = w1; w1 = w2;
-    sh1 = sh2; ln1 = ln2;
-    i += stride;
+    if (has2) dyn_load_rec<NEE>(w2, lane, sh2, ln2);    // A
+    if (want_j)                                         // B
+      copy_out_fixed<(kDynStage + 2 + 127) / 128>(dst, stage, w0.nvals, par, lane);
+    w0 = w1; sh0 = sh1; ln0 = ln1;
+    w1 = w2; sh1 = sh2; ln1 = ln2;
   }
 }
 
@@ -803,26 +799,20 @@ __global__ __launch_bounds__(64, 2) void rom_kernel(const RomWork* __restrict__ 
     r1 = rom_load_rec(w1, lane);
   }
   rom_load_x(w0, r0, x, X);
-  double* dst = jac + w0.j_off;
-  int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-  if (lane < w0.cnt)
-    rom_item(w0, r0, X, g, stage, par, __builtin_amdgcn_readfirstlane(r0.voff), trash, lane, want_g, want_j);
-  for (;;) {
+  for (; i < n_work; i += stride) {
     const bool has1 = i + stride < n_work, has2 = i + 2 * stride < n_work;
     if (has2) w2 = work[i + 2 * stride];
+    double* dst = jac + w0.j_off;
+    const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+    const int vbase = __builtin_amdgcn_readfirstlane(r0.voff);
+    if (lane < w0.cnt) rom_item(w0, r0, X, g, stage, par, vbase, trash, lane, want_g, want_j);   // C
     RomRec r2 = r1;
-    if (has2) r2 = rom_load_rec(w2, lane);            // A (records first: the wait for x retires them too)
+    if (has2) r2 = rom_load_rec(w2, lane);              // A (records first: the wait for x retires them too)
     if (has1) rom_load_x(w1, r1, x, X);
-    if (want_j)                                       // B (one wave per workgroup: its LDS accesses
-      copy_out_fixed<(kRomStage + 2 + 127) / 128>(dst, stage, w0.nvals, par, lane);  // are ordered, no barrier)
-    if (!has1) break;
-    dst = jac + w1.j_off;                             // C
-    par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-    const int vbase = __builtin_amdgcn_readfirstlane(r1.voff);
-    if (lane < w1.cnt) rom_item(w1, r1, X, g, stage, par, vbase, trash, lane, want_g, want_j);
-    w0 = w1; w1 = w2;
-    r1 = r2;
-    i += stride;
+    if (want_j)                                         // B
+      copy_out_fixed<(kRomStage + 2 + 127) / 128>(dst, stage, w0.nvals, par, lane);
+    w0 = w1; r0 = r1;
+    w1 = w2; r1 = r2;
   }
 }
 
@@ -839,77 +829,61 @@ __global__ __launch_bounds__(64) void node_kernel(const NodeWork* __restrict__ w
   double* jp = jac + w.j_off;
   const bool want_g = flags & 1, want_j = flags & 2;
   const int lane = threadIdx.x;
-  for (int ee = 0; ee < S->n_ee; ++ee) {
-    const TerrainRow* rows = tbl<TerrainRow>(blob, S->o_terrain_rows[ee]);
-    const int nr = S->n_terrain_rows[ee];
+  {
+    const TerrainRow* rows = tbl<TerrainRow>(blob, S->o_terrain_rows);
+    const int nr = S->n_terrain_rows;
     for (int r0 = 0; r0 < nr; r0 += 64) {
       const int cnt = min(64, nr - r0);
-      double* dst = jp + S->nnz_terrain[ee] + 3 * r0;
+      double* dst = jp + S->nnz_terrain + 3 * r0;
       const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
       if (lane < cnt) {
         const TerrainRow tr = rows[r0 + lane];
         const double px = xp[tr.idx], py = xp[tr.idx + tr.stride], pz = xp[tr.idx + 2 * tr.stride];
         const Terr t = terrain_eval(S->terrain_id, S->flat_height, px, py);
-        if (want_g) gp[S->row_terrain[ee] + r0 + lane] = pz - t.h;
+        if (want_g) gp[S->row_terrain + r0 + lane] = pz - t.h;
         if (want_j) {
           stage[par + 3 * lane + 0] = -t.hx;
           stage[par + 3 * lane + 1] = -t.hy;
           stage[par + 3 * lane + 2] = 1.0;
         }
       }
-      if (want_j) {
-        __syncthreads();
-        copy_out(dst, stage, 3 * cnt, par, lane);
-        __syncthreads();
-      }
+      if (want_j) copy_out(dst, stage, 3 * cnt, par, lane);  // single wave: LDS accesses are ordered
     }
   }
-  for (int ee = 0; ee < S->n_ee; ++ee) {
-    const ForceNode* nodes = tbl<ForceNode>(blob, S->o_force_nodes[ee]);
-    const int nn = S->n_force_nodes[ee];
+  {
+    const ForceNode* nodes = tbl<ForceNode>(blob, S->o_force_nodes);
+    const int nn = S->n_force_nodes;
     for (int i0 = 0; i0 < nn; i0 += 64) {
       const int cnt = min(64, nn - i0);
-      double* dst = jp + S->nnz_force[ee] + 25 * i0;
+      double* dst = jp + S->nnz_force + 25 * i0;
       const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
       if (lane < cnt)
-        force_item(S, nodes[i0 + lane], xp, gp + S->row_force[ee] + 5 * (i0 + lane), stage + par + 25 * lane, want_g,
-                   want_j);
-      if (want_j) {
-        __syncthreads();
-        copy_out(dst, stage, 25 * cnt, par, lane);
-        __syncthreads();
-      }
+        force_item(S, nodes[i0 + lane], xp, gp + S->row_force + 5 * (i0 + lane), stage + par + 25 * lane, want_g, want_j);
+      if (want_j) copy_out(dst, stage, 25 * cnt, par, lane);
     }
   }
 }
 
 // host-side launcher (called from capi.cc): three launches on one stream.  The dyn/rom grids are
-// persistent: exactly as many workgroups as are resident at once (occupancy query, LDS bound).
-template <typename K>
-static int resident_blocks(K kernel, int n_cu) {
-  int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-  if (const char* e = getenv("TWR_BLOCKS_PER_CU")) {  // tuning knob for experiments
-    int v = atoi(e);
-    if (v > 0) per_cu = v;
-  }
-  return per_cu * n_cu;
+// persistent: as many workgroups as are resident at once.  Residency is LDS bound; the occupancy API
+// over-reports it for the dynamic kernel (measured: 7 x 22.5 KB resident, an 8th starts a second
+// round), so the per-CU counts are fixed here and can be overridden for experiments.
+// (Running dyn and rom concurrently on two streams was measured and is slower than back to back.)
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  if (!e) return dflt;
+  int v = atoi(e);
+  return v > 0 ? v : dflt;
 }
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
                        const NodeWork* node, int n_node, const double* x, double* g, double* jac, int flags,
                        hipStream_t stream) {
-  static int res_dyn[5] = {0, 0, 0, 0, 0}, res_rom = 0;
+  static const int dyn_bpc = env_int("TWR_DYN_BPC", 7), rom_bpc = env_int("TWR_ROM_BPC", 4);
   dim3 block(64);
   if (n_ee < 1 || n_ee > 4) return hipErrorInvalidValue;
-  if (!res_rom) {
-    res_dyn[1] = resident_blocks(dyn_kernel<1>, n_cu);
-    res_dyn[2] = resident_blocks(dyn_kernel<2>, n_cu);
-    res_dyn[3] = resident_blocks(dyn_kernel<3>, n_cu);
-    res_dyn[4] = resident_blocks(dyn_kernel<4>, n_cu);
-    res_rom = resident_blocks(rom_kernel, n_cu);
-  }
   if (n_dyn > 0) {
-    dim3 grid(n_dyn < res_dyn[n_ee] ? n_dyn : res_dyn[n_ee]);
+    const int res = dyn_bpc * n_cu;
+    dim3 grid(n_dyn < res ? n_dyn : res);
     switch (n_ee) {
       case 1: hipLaunchKernelGGL(dyn_kernel<1>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags); break;
       case 2: hipLaunchKernelGGL(dyn_kernel<2>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags); break;
@@ -918,7 +892,8 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
     }
   }
   if (n_rom > 0) {
-    dim3 grid(n_rom < res_rom ? n_rom : res_rom);
+    const int res = rom_bpc * n_cu;
+    dim3 grid(n_rom < res ? n_rom : res);
     hipLaunchKernelGGL(rom_kernel, grid, block, 0, stream, rom, n_rom, x, g, jac, flags);
   }
   if (n_node > 0) hipLaunchKernelGGL(node_kernel, dim3(n_node), block, 0, stream, node, x, g, jac, flags);

@@ -384,18 +384,28 @@ void Structure::PackBlob() {
   h.n_ee = n_ee;
   h.terrain_id = model.terrain_id;
   int ci = 0;
+  std::vector<TerrainRow> all_rows;
+  std::vector<ForceNode> all_nodes;
+  h.row_terrain = con_sets[0].offset;
+  h.nnz_terrain = con_sets[0].nnz_offset;
   for (int e = 0; e < n_ee; ++e, ++ci) {
-    h.row_terrain[e] = con_sets[ci].offset; h.nnz_terrain[e] = con_sets[ci].nnz_offset;
-    h.n_terrain_rows[e] = con_sets[ci].size;
+    if (con_sets[ci].offset != h.row_terrain + (int)all_rows.size()) throw std::runtime_error("terrain sets not adjacent");
+    all_rows.insert(all_rows.end(), terrain_rows[e].begin(), terrain_rows[e].end());
   }
+  h.n_terrain_rows = (int)all_rows.size();
   const int row_dyn = con_sets[ci].offset, nnz_dyn = con_sets[ci].nnz_offset;
   ++ci;
   int row_rom[kMaxEE], nnz_rom[kMaxEE];
   for (int e = 0; e < n_ee; ++e, ++ci) { row_rom[e] = con_sets[ci].offset; nnz_rom[e] = con_sets[ci].nnz_offset; }
+  h.row_force = con_sets[ci].offset;
+  h.nnz_force = con_sets[ci].nnz_offset;
   for (int e = 0; e < n_ee; ++e, ++ci) {
-    h.row_force[e] = con_sets[ci].offset; h.nnz_force[e] = con_sets[ci].nnz_offset;
-    h.n_force_nodes[e] = (int)force_nodes[e].size();
+    if (con_sets[ci].offset != h.row_force + 5 * (int)all_nodes.size()) throw std::runtime_error("force sets not adjacent");
+    all_nodes.insert(all_nodes.end(), force_nodes[e].begin(), force_nodes[e].end());
   }
+  h.n_force_nodes = (int)all_nodes.size();
+  h.o_force_nodes = put(all_nodes.data(), all_nodes.size() * sizeof(ForceNode));
+  h.o_terrain_rows = put(all_rows.data(), all_rows.size() * sizeof(TerrainRow));
   // --- per-lane records of the dynamic kernel
   {
     std::vector<DynShared> sh(grid_dyn.size());
@@ -443,8 +453,6 @@ void Structure::PackBlob() {
       R.slots[1] = (uint32_t)(slots >> 32);
     }
     off_rom_recs[e] = put(rc.data(), rc.size() * sizeof(RomRec));
-    h.o_force_nodes[e] = put(force_nodes[e].data(), force_nodes[e].size() * sizeof(ForceNode));
-    h.o_terrain_rows[e] = put(terrain_rows[e].data(), terrain_rows[e].size() * sizeof(TerrainRow));
   }
   h.mass = model.mass; h.gravity = model.gravity; h.mu = model.friction; h.flat_height = model.flat_height;
   // BuildInertiaTensor (single_rigid_body_dynamics.cc:36-44): off-diagonals are the negated products of inertia
