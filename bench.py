@@ -71,14 +71,15 @@ def cpu_baseline(sched, params, x, budget_s=12.0):
             "sample": "%d callbacks of the same ANYmal K=200 problem, single-thread C++ oracle (%.1f s)" % (iters, secs)}
 
 
-def traffic_from_profile(workload):
-    """HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/traffic.json), or None."""
+def traffic_from_profile(workload, kernel):
+    """HBM bytes per launch of `kernel` from a committed rocprofv3 --pmc pass (profiles/traffic.json:
+    WRITE_SIZE + 2*FETCH_SIZE in KiB, the gfx950 correction of MI355X_MICROARCH.md), or None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
         if t.get("workload") == workload:
-            return t.get("hbm_bytes_per_launch")
+            return t.get("hbm_bytes_per_launch", {}).get(kernel)
     except (OSError, ValueError):
         pass
     return None
@@ -137,20 +138,20 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events on the launch stream bracket each of the three kernels of every timed step
+    batch.profile_begin(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for a, b in ev:  # HIP events on the launch stream bracket every kernel launch
-        a.record()
+    for _ in range(args.steps):
         step()
-        b.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kern_ms, n_prof = batch.profile_end()
+    assert n_prof == args.steps
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -162,8 +163,13 @@ def main():
 
     if rank == 0:
         callbacks = B * world * args.steps
-        alg_bytes = batch.algorithmic_bytes  # 8*(n+m+nnz) per problem x problems per launch
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        alg_bytes = batch.algorithmic_bytes  # 8*(n+m+nnz) per problem x problems per step
+        kbytes = batch.kernel_bytes()
+        dom = max(kern_ms, key=kern_ms.get)  # dominant kernel by measured time
+        achieved = kbytes[dom] / (kern_ms[dom] * 1e-3) / 1e9
+        path_ms = sum(kern_ms.values())
+        path_achieved = alg_bytes / (path_ms * 1e-3) / 1e9
+        names = {"dynamic": "twr::dyn_kernel<4>", "rangeofmotion": "twr::rom_kernel", "nodes": "twr::node_kernel"}
         out = {
             "metric": "constraint+Jacobian evals/sec (full NLP callback), 4-EE SRBD",
             "value": callbacks / elapsed,
@@ -179,9 +185,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "problems_per_gpu": B, "bytes_per_callback": S.algorithmic_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile("C3"),
-                         "kernel": "twr::eval_kernel<4>", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile("C3", names[dom]),
+                         "kernel": names[dom], "kernel_ms": kern_ms[dom],
+                         "algorithmic_bytes_per_launch": kbytes[dom],
+                         # the whole callback = the three kernels back to back (SURVEY 8d figure 8*(n+m+nnz))
+                         "path": {"achieved": path_achieved, "frac": path_achieved / HBM_PEAK_GBS,
+                                  "kernel_ms": {names[k]: v for k, v in kern_ms.items()},
+                                  "algorithmic_bytes_per_step": alg_bytes}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sched, params, x_host[:S.n])

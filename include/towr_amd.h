@@ -141,6 +141,11 @@ int twr_batch_layout(const twr_batch* b, int64_t* x_off, int64_t* g_off, int64_t
  * {GetValues, FillJacobianBlock}.  Asynchronous on `hip_stream` (hipStream_t, may be
  * NULL for the default stream); no host synchronisation, capturable in a hipGraph. */
 int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, int flags, void* hip_stream);
+/* Measurement aid (bench.py): after _begin, the next max_evals calls of twr_batch_eval also record
+ * HIP events on their launch stream around each of the three kernels (dynamic, range of motion,
+ * force/terrain nodes); _end waits for the last one and returns the average duration of each. */
+int twr_batch_profile_begin(twr_batch* b, int max_evals);
+int twr_batch_profile_end(twr_batch* b, double avg_ms[3], int* n_evals);
 /* Convenience for single-problem / adapter use: host buffers, synchronous (H2D, eval, D2H). */
 int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_jac, int flags);
 

@@ -111,6 +111,8 @@ def lib():
         L.twr_batch_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.twr_batch_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.twr_batch_eval_host.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int]
+        L.twr_batch_profile_begin.argtypes = [C.c_void_p, C.c_int]
+        L.twr_batch_profile_end.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -244,6 +246,32 @@ class Batch:
         """Asynchronous launch on raw device pointers (ints), e.g. torch tensors' data_ptr()."""
         _check(lib().twr_batch_eval(self._h, C.c_void_p(d_x), C.c_void_p(d_g), C.c_void_p(d_jac), flags,
                                     C.c_void_p(stream)))
+
+    def profile_begin(self, max_evals):
+        """Record HIP events around each kernel of the next `max_evals` eval_device calls."""
+        _check(lib().twr_batch_profile_begin(self._h, int(max_evals)))
+
+    def profile_end(self):
+        """Average duration [ms] of the dynamic / range-of-motion / node kernels, and the eval count."""
+        ms = np.zeros(3)
+        n = C.c_int(0)
+        _check(lib().twr_batch_profile_end(self._h, _d(ms), C.byref(n)))
+        return dict(dynamic=float(ms[0]), rangeofmotion=float(ms[1]), nodes=float(ms[2])), n.value
+
+    def kernel_bytes(self):
+        """Algorithmic bytes per launch of each kernel: it reads x once and writes its own rows of g
+        and its own Jacobian values once (SURVEY 8d applied per kernel; x is counted for each kernel,
+        so the three figures sum to algorithmic_bytes + 2*8*n per problem)."""
+        out = dict(dynamic=0, rangeofmotion=0, nodes=0)
+        for si in self.struct_of_problem:
+            S = self.structures[si]
+            for cs in S.con_sets:
+                k = "dynamic" if cs["name"] == "dynamic" else ("rangeofmotion" if cs["name"].startswith("rangeofmotion")
+                                                               else "nodes")
+                out[k] += 8 * (cs["size"] + cs["nnz"])
+            for k in out:
+                out[k] += 8 * S.n
+        return out
 
     def eval_host(self, x, flags=EVAL_BOTH):
         x = np.ascontiguousarray(x, dtype=np.float64)

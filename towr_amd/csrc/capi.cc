@@ -14,7 +14,7 @@
 namespace twr {
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
                        const NodeWork* node, int n_node, const double* x, double* g, double* jac, int flags,
-                       hipStream_t stream);
+                       hipStream_t stream, hipEvent_t* ev);
 int dyn_stage_capacity();
 int rom_stage_capacity();
 int dyn_nodes_per_block();
@@ -35,6 +35,9 @@ struct twr_batch {
   twr::NodeWork* d_node = nullptr;
   // lazily sized scratch for twr_batch_eval_host
   double *d_x = nullptr, *d_g = nullptr, *d_j = nullptr;
+  // optional per-kernel timing (twr_batch_profile_begin/end): 4 events per recorded eval
+  std::vector<hipEvent_t> prof_events;
+  int prof_capacity = 0, prof_count = 0;
 };
 
 namespace {
@@ -294,6 +297,7 @@ void twr_batch_destroy(twr_batch* b) {
   if (b->d_dyn) (void)hipFree(b->d_dyn);
   if (b->d_rom) (void)hipFree(b->d_rom);
   if (b->d_node) (void)hipFree(b->d_node);
+  for (hipEvent_t e : b->prof_events) (void)hipEventDestroy(e);
   if (b->d_x) (void)hipFree(b->d_x);
   if (b->d_g) (void)hipFree(b->d_g);
   if (b->d_j) (void)hipFree(b->d_j);
@@ -316,10 +320,50 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
   if ((flags & TWR_EVAL_BOTH) == 0) return fail(TWR_ERR_INVALID, "flags select nothing");
   if (((flags & TWR_EVAL_VALUES) && !d_g) || ((flags & TWR_EVAL_JACOBIAN) && !d_jac))
     return fail(TWR_ERR_INVALID, "missing output buffer");
+  hipEvent_t* ev = nullptr;
+  if (b->prof_count < b->prof_capacity) ev = b->prof_events.data() + 4 * b->prof_count++;
   hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->d_rom, b->n_rom, b->d_node, b->n_node, d_x,
-                                  d_g, d_jac, flags & TWR_EVAL_BOTH, static_cast<hipStream_t>(hip_stream));
+                                  d_g, d_jac, flags & TWR_EVAL_BOTH, static_cast<hipStream_t>(hip_stream), ev);
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   return TWR_OK;
+}
+
+int twr_batch_profile_begin(twr_batch* b, int max_evals) {
+  if (!b || max_evals < 1) return fail(TWR_ERR_INVALID, "bad arguments");
+  try {
+    TWR_HIP(hipSetDevice(b->device));
+    for (hipEvent_t e : b->prof_events) (void)hipEventDestroy(e);
+    b->prof_events.assign(4 * (size_t)max_evals, nullptr);
+    for (auto& e : b->prof_events) TWR_HIP(hipEventCreate(&e));
+    b->prof_capacity = max_evals;
+    b->prof_count = 0;
+    return TWR_OK;
+  } catch (const std::exception& e) {
+    return fail(TWR_ERR_HIP, e.what());
+  }
+}
+
+int twr_batch_profile_end(twr_batch* b, double avg_ms[3], int* n_evals) {
+  if (!b || !avg_ms) return fail(TWR_ERR_INVALID, "null argument");
+  try {
+    const int n = b->prof_count;
+    avg_ms[0] = avg_ms[1] = avg_ms[2] = 0.0;
+    if (n > 0) {
+      TWR_HIP(hipEventSynchronize(b->prof_events[4 * (size_t)n - 1]));
+      for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+          float ms = 0.f;
+          TWR_HIP(hipEventElapsedTime(&ms, b->prof_events[4 * (size_t)i + k], b->prof_events[4 * (size_t)i + k + 1]));
+          avg_ms[k] += ms / n;
+        }
+    }
+    if (n_evals) *n_evals = n;
+    b->prof_capacity = 0;
+    b->prof_count = 0;
+    return TWR_OK;
+  } catch (const std::exception& e) {
+    return fail(TWR_ERR_HIP, e.what());
+  }
 }
 
 int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_jac, int flags) {

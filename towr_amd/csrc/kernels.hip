@@ -877,10 +877,11 @@ static int env_int(const char* name, int dflt) {
 }
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
                        const NodeWork* node, int n_node, const double* x, double* g, double* jac, int flags,
-                       hipStream_t stream) {
+                       hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */) {
   static const int dyn_bpc = env_int("TWR_DYN_BPC", 7), rom_bpc = env_int("TWR_ROM_BPC", 4);
   dim3 block(64);
   if (n_ee < 1 || n_ee > 4) return hipErrorInvalidValue;
+  if (ev) (void)hipEventRecord(ev[0], stream);
   if (n_dyn > 0) {
     const int res = dyn_bpc * n_cu;
     dim3 grid(n_dyn < res ? n_dyn : res);
@@ -891,12 +892,15 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
       case 4: hipLaunchKernelGGL(dyn_kernel<4>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags); break;
     }
   }
+  if (ev) (void)hipEventRecord(ev[1], stream);
   if (n_rom > 0) {
     const int res = rom_bpc * n_cu;
     dim3 grid(n_rom < res ? n_rom : res);
     hipLaunchKernelGGL(rom_kernel, grid, block, 0, stream, rom, n_rom, x, g, jac, flags);
   }
+  if (ev) (void)hipEventRecord(ev[2], stream);
   if (n_node > 0) hipLaunchKernelGGL(node_kernel, dim3(n_node), block, 0, stream, node, x, g, jac, flags);
+  if (ev) (void)hipEventRecord(ev[3], stream);
   return hipGetLastError();
 }
 
