@@ -250,12 +250,15 @@ TWR_DEV void dyn_load_x(const DynWork& w, const DynShared& sh, const DynLane& ln
 }
 
 template <int NEE>
-TWR_DEV void dyn_quad(const DynWork& w, const DynShared& sh, const DynLane& ln, const DynX& X, double* __restrict__ g,
+TWR_DEV void dyn_quad(const DynWork& w, const DynShared& sh, const DynLane& ln, const DynX& X, double* __restrict__ gst,
                       double* __restrict__ stage, int par, int vbase, int trash, int lane, bool want_g, bool want_j) {
   const int kk = lane >> 2, role = lane & 3;
   const bool live = kk < w.cnt;
   const bool has_ee = role < NEE;
   const int soff = par + sh.voff - vbase;
+#ifdef TWR_EXP_NOMATH
+  { double acc = 0; for (int i2 = 0; i2 < 12; ++i2) acc += X.bl[i2] + X.ba[i2] + X.m[i2] + X.f[i2]; if (live && want_j) stage[soff + role] = acc; return; }
+#endif
   double wP[4], wV[4], wA[4];
   hermite_all(sh.tb, sh.iTb, wP, wV, wA);
   double c[3], cdd[3], e[3], ed[3], edd[3];
@@ -390,7 +393,7 @@ TWR_DEV void dyn_quad(const DynWork& w, const DynShared& sh, const DynLane& ln, 
     if (want_g) {  // GetDynamicViolation, single_rigid_body_dynamics.cc:76-101
       double wxIw[3];
       cross3(om, Iw_w, wxIw);
-      double* go = g + w.g_off + 6 * kk;
+      double* go = gst + 6 * kk;  // staged in LDS, written out coalesced with the Jacobian slice
 #pragma unroll
       for (int i = 0; i < 3; ++i) go[i] = Iw_wd[i] + wxIw[i] - tau[i];
       go[3] = m * cdd[0] - F[0];
@@ -506,9 +509,12 @@ TWR_DEV void rom_load_x(const RomWork& w, const RomRec& r, const double* __restr
   }
   gather12(xp, r.xbase, rom_slots(r), X.m);
 }
-TWR_DEV void rom_item(const RomWork& w, const RomRec& r, const RomX& X, double* __restrict__ g, double* __restrict__ stage,
+TWR_DEV void rom_item(const RomWork& w, const RomRec& r, const RomX& X, double* __restrict__ gst, double* __restrict__ stage,
                       int par, int vbase, int trash, int lane, bool want_g, bool want_j) {
   const int soff = par + r.voff - vbase;
+#ifdef TWR_EXP_NOMATH
+  { double acc = 0; for (int i2 = 0; i2 < 12; ++i2) acc += X.bl[i2] + X.ba[i2] + X.m[i2]; if (want_j) stage[soff] = acc; return; }
+#endif
   double wP[4];
   hermite_pos(r.tb, r.iTb, wP);
   double c[3], e[3];
@@ -527,7 +533,7 @@ TWR_DEV void rom_item(const RomWork& w, const RomRec& r, const RomX& X, double* 
   if (want_g) {
     double gv[3];
     matTvec(ro.R, v, gv);  // b_R_w (p - c)
-    double* go = g + w.g_off + 3 * lane;
+    double* go = gst + 3 * lane;  // staged in LDS, written out coalesced with the Jacobian slice
     go[0] = gv[0]; go[1] = gv[1]; go[2] = gv[2];
   }
   if (!want_j) return;
@@ -728,8 +734,8 @@ TWR_DEV void copy_out_fixed(double* __restrict__ dst, const double* __restrict__
 
 // LDS image sizes (doubles).  dynamic: 16 time nodes per wave (~170 values each at 4 ee) -> 22.5 KiB,
 // seven workgroups per CU; range of motion: 64 lanes x ~84 values -> 39 KiB, four per CU.
-constexpr int kDynStage = 2750;
-constexpr int kRomStage = 4936;
+constexpr int kDynStage = 2654;   // + 2 + 64 + 96 doubles = 22528 B
+constexpr int kRomStage = 4856;   // + 2 + 64 + 192 doubles = 40912 B
 constexpr int kNodeStage = 64 * 25;
 
 // dynamic / range of motion: persistent workgroups, software pipelined over the strided work list.
@@ -744,10 +750,12 @@ template <int NEE>
 __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ work, int n_work,
                                                     const double* __restrict__ x, double* __restrict__ g,
                                                     double* __restrict__ jac, int flags) {
-  __shared__ __attribute__((aligned(16))) double stage[kDynStage + 2 + 64];  // image + parity slack + trash slots
+  // Jacobian image + parity slack + trash slots + constraint values of the slice
+  __shared__ __attribute__((aligned(16))) double stage[kDynStage + 2 + 64 + 96];
   const bool want_g = flags & 1, want_j = flags & 2;
   const int lane = threadIdx.x;
   const int trash = kDynStage + 2 + lane;
+  double* gst = stage + kDynStage + 2 + 64;
   const int stride = gridDim.x;
   int i = blockIdx.x;
   if (i >= n_work) return;
@@ -769,13 +777,18 @@ __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ 
     {                                                   // C (the x loads of the next slice would not fit
       DynX X;                                           //    the 256-register budget of two waves per SIMD)
       dyn_load_x(w0, sh0, ln0, x, X);
-      dyn_quad<NEE>(w0, sh0, ln0, X, g, stage, par, __builtin_amdgcn_readfirstlane(sh0.voff), trash, lane, want_g, want_j);
+      dyn_quad<NEE>(w0, sh0, ln0, X, gst, stage, par, __builtin_amdgcn_readfirstlane(sh0.voff), trash, lane, want_g, want_j);
     }
     DynShared sh2 = sh1;
     DynLane ln2 = ln1;
     if (has2) dyn_load_rec<NEE>(w2, lane, sh2, ln2);    // A
     if (want_j)                                         // B
       copy_out_fixed<(kDynStage + 2 + 127) / 128>(dst, stage, w0.nvals, par, lane);
+    if (want_g) {                                       //   6 constraint values per time node, contiguous in g
+      double* go = g + w0.g_off;
+      if (lane < 6 * w0.cnt) go[lane] = gst[lane];
+      if (lane + 64 < 6 * w0.cnt) go[lane + 64] = gst[lane + 64];
+    }
     w0 = w1; sh0 = sh1; ln0 = ln1;
     w1 = w2; sh1 = sh2; ln1 = ln2;
   }
@@ -784,10 +797,11 @@ __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ 
 __global__ __launch_bounds__(64, 2) void rom_kernel(const RomWork* __restrict__ work, int n_work,
                                                     const double* __restrict__ x, double* __restrict__ g,
                                                     double* __restrict__ jac, int flags) {
-  __shared__ __attribute__((aligned(16))) double stage[kRomStage + 2 + 64];
+  __shared__ __attribute__((aligned(16))) double stage[kRomStage + 2 + 64 + 192];
   const bool want_g = flags & 1, want_j = flags & 2;
   const int lane = threadIdx.x;
   const int trash = kRomStage + 2 + lane;
+  double* gst = stage + kRomStage + 2 + 64;
   const int stride = gridDim.x;
   int i = blockIdx.x;
   if (i >= n_work) return;
@@ -805,12 +819,18 @@ __global__ __launch_bounds__(64, 2) void rom_kernel(const RomWork* __restrict__ 
     double* dst = jac + w0.j_off;
     const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
     const int vbase = __builtin_amdgcn_readfirstlane(r0.voff);
-    if (lane < w0.cnt) rom_item(w0, r0, X, g, stage, par, vbase, trash, lane, want_g, want_j);   // C
+    if (lane < w0.cnt) rom_item(w0, r0, X, gst, stage, par, vbase, trash, lane, want_g, want_j);   // C
     RomRec r2 = r1;
     if (has2) r2 = rom_load_rec(w2, lane);              // A (records first: the wait for x retires them too)
     if (has1) rom_load_x(w1, r1, x, X);
     if (want_j)                                         // B
       copy_out_fixed<(kRomStage + 2 + 127) / 128>(dst, stage, w0.nvals, par, lane);
+    if (want_g) {                                       //   3 constraint values per time node, contiguous in g
+      double* go = g + w0.g_off;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        if (lane + 64 * t < 3 * w0.cnt) go[lane + 64 * t] = gst[lane + 64 * t];
+    }
     w0 = w1; r0 = r1;
     w1 = w2; r1 = r2;
   }
