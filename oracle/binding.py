@@ -108,7 +108,7 @@ class OracleProblem:
         self.nnz = L.orc_eval(self._h, _d(np.zeros(self.n)), None, None, None, None)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # (module globals are gone at interpreter exit)
             lib().orc_destroy(self._h)
             self._h = None
 

@@ -193,7 +193,7 @@ class Structure:
         self.col_idx = np.ctypeslib.as_array(lib().twr_structure_col_idx(self._h), shape=(self.nnz,)).copy()
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # (module globals are gone at interpreter exit)
             lib().twr_structure_destroy(self._h)
             self._h = None
 
@@ -238,7 +238,7 @@ class Batch:
         self.algorithmic_bytes = int(8 * (xo[-1] + go[-1] + jo[-1]))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib().twr_batch_destroy(self._h)
             self._h = None
 

@@ -153,33 +153,20 @@ TWR_DEV void sincos_fast(double x, double* __restrict__ s, double* __restrict__ 
   *c = ((q + 1) & 2) ? -cc : cc;
 }
 
-// ZYX Euler rotation and its partial derivatives w.r.t. roll/pitch/yaw
-// (euler_converter.cc:207-221 and the cell-wise derivatives of :241-268).
+// ZYX Euler rotation base->world (euler_converter.cc:207-221).
 struct Rot {
-  double R[3][3], Rx[3][3], Ry[3][3], Rz[3][3];
+  double R[3][3];
   double sx, cx, sy, cy, sz, cz;
 };
-TWR_DEV void rotation_from_sincos(double sx, double cx, double sy, double cy, double sz, double cz, Rot& o) {
-  o.sx = sx; o.cx = cx; o.sy = sy; o.cy = cy; o.sz = sz; o.cz = cz;
-  o.R[0][0] = cy * cz; o.R[0][1] = cz * sx * sy - cx * sz; o.R[0][2] = sx * sz + cx * cz * sy;
-  o.R[1][0] = cy * sz; o.R[1][1] = cx * cz + sx * sy * sz; o.R[1][2] = cx * sy * sz - cz * sx;
-  o.R[2][0] = -sy;     o.R[2][1] = cy * sx;                o.R[2][2] = cx * cy;
-  o.Rx[0][0] = 0.0; o.Rx[0][1] = cx * cz * sy + sx * sz;  o.Rx[0][2] = cx * sz - cz * sx * sy;
-  o.Rx[1][0] = 0.0; o.Rx[1][1] = cx * sy * sz - cz * sx;  o.Rx[1][2] = -sx * sy * sz - cx * cz;
-  o.Rx[2][0] = 0.0; o.Rx[2][1] = cx * cy;                 o.Rx[2][2] = -cy * sx;
-  o.Ry[0][0] = -cz * sy; o.Ry[0][1] = cy * cz * sx; o.Ry[0][2] = cx * cy * cz;
-  o.Ry[1][0] = -sy * sz; o.Ry[1][1] = cy * sx * sz; o.Ry[1][2] = cx * cy * sz;
-  o.Ry[2][0] = -cy;      o.Ry[2][1] = -sx * sy;     o.Ry[2][2] = -cx * sy;
-  o.Rz[0][0] = -cy * sz; o.Rz[0][1] = -sx * sy * sz - cx * cz; o.Rz[0][2] = cz * sx - cx * sy * sz;
-  o.Rz[1][0] = cy * cz;  o.Rz[1][1] = cz * sx * sy - cx * sz;  o.Rz[1][2] = cx * cz * sy + sx * sz;
-  o.Rz[2][0] = 0.0;      o.Rz[2][1] = 0.0;                     o.Rz[2][2] = 0.0;
-}
 TWR_DEV void rotation(const double e[3], Rot& o) {
   double sx, cx, sy, cy, sz, cz;
   sincos_fast(e[0], &sx, &cx);
   sincos_fast(e[1], &sy, &cy);
   sincos_fast(e[2], &sz, &cz);
-  rotation_from_sincos(sx, cx, sy, cy, sz, cz, o);
+  o.sx = sx; o.cx = cx; o.sy = sy; o.cy = cy; o.sz = sz; o.cz = cz;
+  o.R[0][0] = cy * cz; o.R[0][1] = cz * sx * sy - cx * sz; o.R[0][2] = sx * sz + cx * cz * sy;
+  o.R[1][0] = cy * sz; o.R[1][1] = cx * cz + sx * sy * sz; o.R[1][2] = cx * sy * sz - cz * sx;
+  o.R[2][0] = -sy;     o.R[2][1] = cy * sx;                o.R[2][2] = cx * cy;
 }
 TWR_DEV void matvec(const double A[3][3], const double v[3], double o[3]) {
 #pragma unroll
@@ -249,19 +236,25 @@ TWR_DEV void dyn_load_x(const DynWork& w, const DynShared& sh, const DynLane& ln
   gather12(xp, ln.xbase_f, slots_of(ln.cand_f), X.f);
 }
 
+// Front half of the quad: consumes the x values (so their registers die before the previous slice
+// is copied out), everything that needs a DPP exchange, and the row layout.
+struct DynFront {
+  double wP[4], wV[4], wA[4];
+  double cdd[3], ed[3], edd[3];
+  double wm[4], wf[4], f[3], rv[3], F[3], tau[3];
+  double sx, cx, sy, cy, sz, cz;
+  int rs[3], rl[3], ms[3], fs[3], ls[3];
+};
 template <int NEE>
-TWR_DEV void dyn_quad(const DynWork& w, const DynShared& sh, const DynLane& ln, const DynX& X, double* __restrict__ gst,
-                      double* __restrict__ stage, int par, int vbase, int trash, int lane, bool want_g, bool want_j) {
-  const int kk = lane >> 2, role = lane & 3;
-  const bool live = kk < w.cnt;
+TWR_DEV void dyn_front(const DynWork& w, const DynShared& sh, const DynLane& ln, const DynX& X, int par, int vbase,
+                       int lane, DynFront& S) {
+  const int role = lane & 3;
   const bool has_ee = role < NEE;
   const int soff = par + sh.voff - vbase;
-#ifdef TWR_EXP_NOMATH
-  { double acc = 0; for (int i2 = 0; i2 < 12; ++i2) acc += X.bl[i2] + X.ba[i2] + X.m[i2] + X.f[i2]; if (live && want_j) stage[soff + role] = acc; return; }
-#endif
-  double wP[4], wV[4], wA[4];
+  double (&wP)[4] = S.wP, (&wV)[4] = S.wV, (&wA)[4] = S.wA;
   hermite_all(sh.tb, sh.iTb, wP, wV, wA);
-  double c[3], cdd[3], e[3], ed[3], edd[3];
+  double c[3], e[3];
+  double (&cdd)[3] = S.cdd, (&ed)[3] = S.ed, (&edd)[3] = S.edd;
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const double l0 = X.bl[d], l1 = X.bl[3 + d], l2 = X.bl[6 + d], l3 = X.bl[9 + d];
@@ -273,7 +266,8 @@ TWR_DEV void dyn_quad(const DynWork& w, const DynShared& sh, const DynLane& ln, 
     edd[d] = wA[0] * a0 + wA[1] * a1 + wA[2] * a2 + wA[3] * a3;
   }
   // --- this lane's end-effector: weights and spline points
-  double wm[4], wf[4], p[3], f[3], rv[3];
+  double p[3];
+  double (&wm)[4] = S.wm, (&wf)[4] = S.wf, (&f)[3] = S.f, (&rv)[3] = S.rv;
   ee_point(slots_of(ln.cand_m), meta_shared(ln.meta_m), ln.tm, ln.iTm, X.m, wm, p);
   ee_point(slots_of(ln.cand_f), false, ln.tf, ln.iTf, X.f, wf, f);
 #pragma unroll
@@ -282,12 +276,12 @@ TWR_DEV void dyn_quad(const DynWork& w, const DynShared& sh, const DynLane& ln, 
     if (!has_ee) f[d] = 0.0;
   }
   // force and torque sums over the end-effectors (single_rigid_body_dynamics.cc:81-88)
-  double t3[3], F[3], tau[3];
+  double t3[3];
   cross3(f, rv, t3);
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    F[d] = quad_sum(f[d]);
-    tau[d] = quad_sum(t3[d]);
+    S.F[d] = quad_sum(f[d]);
+    S.tau[d] = quad_sum(t3[d]);
   }
   // slot counts of every end-effector of the quad -> row layout of this time node in the CSR slice
   const uint32_t my_mm = has_ee ? ln.meta_m : 0u, my_fm = has_ee ? ln.meta_f : 0u;
@@ -308,33 +302,45 @@ TWR_DEV void dyn_quad(const DynWork& w, const DynShared& sh, const DynLane& ln, 
       nma[r] += a; nfa[r] += b; nfl[r] += l;
       if (e2 < role) { pma[r] += a; pfa[r] += b; pfl[r] += l; }
     }
-  int rs[3], rl[3];
+  int (&rs)[3] = S.rs, (&rl)[3] = S.rl;
   rs[0] = soff;
   rs[1] = rs[0] + 20 + nma[0] + nfa[0];
   rs[2] = rs[1] + 20 + nma[1] + nfa[1];
   rl[0] = rs[2] + 20 + nma[2] + nfa[2];
   rl[1] = rl[0] + 4 + nfl[0];
   rl[2] = rl[1] + 4 + nfl[1];
-
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    S.ms[r] = rs[r] + 20 + pma[r];
+    S.fs[r] = rs[r] + 20 + nma[r] + pfa[r];
+    S.ls[r] = rl[r] + 4 + pfl[r];
+  }
   // --- rotation: lanes 0..2 of the quad evaluate one sincos each and broadcast it
   double my_s, my_c;
   sincos_fast(sel3(role, e[0], e[1], e[2]), &my_s, &my_c);
-  const double sx = quad_perm<0x00>(my_s), cx = quad_perm<0x00>(my_c);
-  const double sy = quad_perm<0x55>(my_s), cy = quad_perm<0x55>(my_c);
-  const double sz = quad_perm<0xAA>(my_s), cz = quad_perm<0xAA>(my_c);
-  if (!live) return;  // (all DPP exchanges are done)
+  S.sx = quad_perm<0x00>(my_s); S.cx = quad_perm<0x00>(my_c);
+  S.sy = quad_perm<0x55>(my_s); S.cy = quad_perm<0x55>(my_c);
+  S.sz = quad_perm<0xAA>(my_s); S.cz = quad_perm<0xAA>(my_c);
+}
+
+// Back half: the Jacobian blocks and the constraint values, written into the LDS image.
+template <int NEE>
+TWR_DEV void dyn_back(const DynWork& w, const DynLane& ln, const DynFront& S, double* __restrict__ gst,
+                      double* __restrict__ stage, int trash, int lane, bool want_g, bool want_j) {
+  const int kk = lane >> 2, role = lane & 3;
+  if (kk >= w.cnt) return;
+  const bool has_ee = role < NEE;
+  const double (&wP)[4] = S.wP, (&wV)[4] = S.wV, (&wA)[4] = S.wA;
+  const double (&cdd)[3] = S.cdd, (&ed)[3] = S.ed, (&edd)[3] = S.edd;
+  const double (&wm)[4] = S.wm, (&wf)[4] = S.wf, (&f)[3] = S.f, (&rv)[3] = S.rv, (&F)[3] = S.F, (&tau)[3] = S.tau;
+  const double sx = S.sx, cx = S.cx, sy = S.sy, cy = S.cy, sz = S.sz, cz = S.cz;
+  const int (&rs)[3] = S.rs, (&rl)[3] = S.rl;
 
   // --- ee-motion block [f]x J_p (:181-192) and ee-force block {[r]x J_f ; -J_f} (:167-179) of this
   // lane's end-effector, written first so that their inputs die before the base-ang algebra.
   // Candidates that are not variables write to the lane's trash slot.
   if (want_j) {
-    int ms[3], fs[3], ls[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      ms[r] = rs[r] + 20 + pma[r];
-      fs[r] = rs[r] + 20 + nma[r] + pfa[r];
-      ls[r] = rl[r] + 4 + pfl[r];
-    }
+    const int (&ms)[3] = S.ms, (&fs)[3] = S.fs, (&ls)[3] = S.ls;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #define TWR_EE_TILE(D, R1, R2)                                                              \
@@ -373,21 +379,31 @@ TWR_DEV void dyn_quad(const DynWork& w, const DynShared& sh, const DynLane& ln, 
   }
   om[2] += zd;
   omd[2] += edd[2];
-  const TWR_GLOBAL DevStruct* S = gptr<DevStruct>(w.hdr);
-  double Ib[6];
+  const TWR_GLOBAL DevStruct* H = gptr<DevStruct>(w.hdr);
+  // I_w = R I_b R^T (single_rigid_body_dynamics.cc:91), symmetric: (00,01,02,11,12,22)
+  double Iw6[6];
+  {
+    double Ib[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) Ib[i] = S->Ib[i];
-  // I_w v = R I_b R^T v  (single_rigid_body_dynamics.cc:91)
-  auto Iw = [&](const double v[3], double o[3]) {
-    double a[3], b[3];
-    matTvec(R, v, a);
-    symmul(Ib, a, b);
-    matvec(R, b, o);
-  };
+    for (int i = 0; i < 6; ++i) Ib[i] = H->Ib[i];
+    double T[3][3];  // R I_b
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      T[i][0] = R[i][0] * Ib[0] + R[i][1] * Ib[1] + R[i][2] * Ib[2];
+      T[i][1] = R[i][0] * Ib[1] + R[i][1] * Ib[3] + R[i][2] * Ib[4];
+      T[i][2] = R[i][0] * Ib[2] + R[i][1] * Ib[4] + R[i][2] * Ib[5];
+    }
+    Iw6[0] = T[0][0] * R[0][0] + T[0][1] * R[0][1] + T[0][2] * R[0][2];
+    Iw6[1] = T[0][0] * R[1][0] + T[0][1] * R[1][1] + T[0][2] * R[1][2];
+    Iw6[2] = T[0][0] * R[2][0] + T[0][1] * R[2][1] + T[0][2] * R[2][2];
+    Iw6[3] = T[1][0] * R[1][0] + T[1][1] * R[1][1] + T[1][2] * R[1][2];
+    Iw6[4] = T[1][0] * R[2][0] + T[1][1] * R[2][1] + T[1][2] * R[2][2];
+    Iw6[5] = T[2][0] * R[2][0] + T[2][1] * R[2][1] + T[2][2] * R[2][2];
+  }
   double Iw_wd[3], Iw_w[3];
-  Iw(omd, Iw_wd);
-  Iw(om, Iw_w);
-  const double m = S->mass;
+  symmul(Iw6, omd, Iw_wd);
+  symmul(Iw6, om, Iw_w);
+  const double m = H->mass;
 
   if (role == 3) {
     if (want_g) {  // GetDynamicViolation, single_rigid_body_dynamics.cc:76-101
@@ -398,7 +414,7 @@ TWR_DEV void dyn_quad(const DynWork& w, const DynShared& sh, const DynLane& ln, 
       for (int i = 0; i < 3; ++i) go[i] = Iw_wd[i] + wxIw[i] - tau[i];
       go[3] = m * cdd[0] - F[0];
       go[4] = m * cdd[1] - F[1];
-      go[5] = m * cdd[2] - F[2] + m * S->gravity;
+      go[5] = m * cdd[2] - F[2] + m * H->gravity;
     }
     if (want_j) {  // base-lin block: ang rows -sum_i [f_i]x J_pos, lin rows m J_acc (:103-121)
 #pragma unroll
@@ -414,33 +430,11 @@ TWR_DEV void dyn_quad(const DynWork& w, const DynShared& sh, const DynLane& ln, 
       }
     }
   } else if (want_j) {
-    // --- base-ang block (:123-165), Euler dimension d = role, factored
-    double RtWd[3], RtW[3], aWd[3], aW[3];
-    matTvec(R, omd, RtWd);
-    matTvec(R, om, RtW);
-    symmul(Ib, RtWd, aWd);  // I_b R^T omega_dot  (v11)
-    symmul(Ib, RtW, aW);    // I_b R^T omega      (v21)
-    double Rd[3][3];        // dR/d e_d, d = role (cell-wise derivatives of euler_converter.cc:241-268)
-    Rd[0][0] = sel3(role, 0.0, -cz * sy, -cy * sz);
-    Rd[0][1] = sel3(role, cx * cz * sy + sx * sz, cy * cz * sx, -sx * sy * sz - cx * cz);
-    Rd[0][2] = sel3(role, cx * sz - cz * sx * sy, cx * cy * cz, cz * sx - cx * sy * sz);
-    Rd[1][0] = sel3(role, 0.0, -sy * sz, cy * cz);
-    Rd[1][1] = sel3(role, cx * sy * sz - cz * sx, cy * sx * sz, cz * sx * sy - cx * sz);
-    Rd[1][2] = sel3(role, -sx * sy * sz - cx * cz, cx * cy * sz, cx * cz * sy + sx * sz);
-    Rd[2][0] = sel3(role, 0.0, -cy, 0.0);
-    Rd[2][1] = sel3(role, cx * cy, -sx * sy, 0.0);
-    Rd[2][2] = sel3(role, -cy * sx, -cx * sy, 0.0);
-    // d(I_w v)/d e_d = R_d I_b R^T v + R I_b R_d^T v   (jac11+jac12 / jac21+jac22)
-    auto dIw = [&](const double v[3], const double av[3], double o[3]) {
-      double t1[3], t2[3], t3b[3], t4[3];
-      matvec(Rd, av, t1);
-      matTvec(Rd, v, t2);
-      symmul(Ib, t2, t3b);
-      matvec(R, t3b, t4);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) o[i] = t1[i] + t4[i];
-    };
-    // column d of M and the partials of omega, omega_dot (euler_converter.cc:168-198,270-304)
+    // --- base-ang block (:123-165), Euler dimension d = role, factored.
+    // The columns of M are the rotation axes of the ZYX sequence, so dR/d e_d = [M_d]x R
+    // (the cell-wise derivatives of euler_converter.cc:241-268 in closed form) and
+    //   d(I_w v)/d e_d = R_d I_b R^T v + R I_b R_d^T v = M_d x (I_w v) + I_w (v x M_d)
+    // (jac11+jac12 resp. jac21+jac22 of the reference) without ever forming R_d.
     const double dMx_dy[3] = {-sy * cz, -sy * sz, -cy};
     const double dMx_dz[3] = {-cy * sz, cy * cz, 0.0};
     const double dMy_dz[3] = {-cz, -sz, 0.0};
@@ -450,19 +444,27 @@ TWR_DEV void dyn_quad(const DynWork& w, const DynShared& sh, const DynLane& ln, 
     double Md[3], dwd_ed[3], dw[3], dwd[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      Md[i] = sel3(role, Mx[i], My[i], i == 2 ? 1.0 : 0.0);
+      Md[i] = sel3(role, Mx[i], My[i], i == 2 ? 1.0 : 0.0);  // column d of M (euler_converter.cc:133-148)
       // d omega_dot / d edot_d
       dwd_ed[i] = sel3(role, Mdx[i], Mdy[i] + xd * dMx_dy[i], xd * dMx_dz[i] + yd * dMy_dz[i]);
-      // d omega / d e_d , d omega_dot / d e_d   (roll: none)
+      // d omega / d e_d , d omega_dot / d e_d   (roll: none)   (euler_converter.cc:168-198,270-304)
       dw[i] = sel3(role, 0.0, xd * dMx_dy[i], xd * dMx_dz[i] + yd * dMy_dz[i]);
       dwd[i] = sel3(role, 0.0, xd * dMdx_dy[i] + edd[0] * dMx_dy[i],
                     xd * dMdx_dz[i] + yd * dMdy_dz[i] + edd[0] * dMx_dz[i] + edd[1] * dMy_dz[i]);
     }
+    auto dIw = [&](const double v[3], const double Iwv[3], double o[3]) {
+      double t1[3], t2[3], t3b[3];
+      cross3(Md, Iwv, t1);
+      cross3(v, Md, t2);
+      symmul(Iw6, t2, t3b);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) o[i] = t1[i] + t3b[i];
+    };
     double A[3], B[3], C[3];
-    Iw(Md, C);
+    symmul(Iw6, Md, C);
     {  // B_d = I_w d(omega_dot)/d(edot_d) + M_d x (I_w omega) + omega x (I_w M_d)
       double t1[3], t2[3], t3b[3];
-      Iw(dwd_ed, t1);
+      symmul(Iw6, dwd_ed, t1);
       cross3(Md, Iw_w, t2);
       cross3(om, C, t3b);
 #pragma unroll
@@ -470,11 +472,11 @@ TWR_DEV void dyn_quad(const DynWork& w, const DynShared& sh, const DynLane& ln, 
     }
     {  // A_d = dI_w(omega_dot) + I_w d(omega_dot) + d(omega) x I_w omega + omega x (dI_w(omega) + I_w d(omega))
       double t1[3], t2[3], t3b[3], t4[3], t5[3], t6[3], t7[3];
-      dIw(omd, aWd, t1);
-      Iw(dwd, t2);
+      dIw(omd, Iw_wd, t1);
+      symmul(Iw6, dwd, t2);
       cross3(dw, Iw_w, t3b);
-      dIw(om, aW, t4);
-      Iw(dw, t5);
+      dIw(om, Iw_w, t4);
+      symmul(Iw6, dw, t5);
 #pragma unroll
       for (int i = 0; i < 3; ++i) t6[i] = t4[i] + t5[i];
       cross3(om, t6, t7);
@@ -537,10 +539,19 @@ TWR_DEV void rom_item(const RomWork& w, const RomRec& r, const RomX& X, double* 
     go[0] = gv[0]; go[1] = gv[1]; go[2] = gv[2];
   }
   if (!want_j) return;
-  double ux[3], uy[3], uz[3];  // DerivOfRotVecMult(t, v, inverse=true): d(R^T v)/d e_d (euler_converter.cc:223-239)
-  matTvec(ro.Rx, v, ux);
-  matTvec(ro.Ry, v, uy);
-  matTvec(ro.Rz, v, uz);
+  // DerivOfRotVecMult(t, v, inverse=true) = d(R^T v)/d e_d (euler_converter.cc:223-239).  With
+  // dR/d e_d = [M_d]x R (M_d = rotation axis d of the ZYX sequence = column d of M) this is R^T (v x M_d).
+  double ux[3], uy[3], uz[3];
+  {
+    const double Mx[3] = {ro.cy * ro.cz, ro.cy * ro.sz, -ro.sy}, My[3] = {-ro.sz, ro.cz, 0.0};
+    double tx[3], ty[3];
+    cross3(v, Mx, tx);
+    cross3(v, My, ty);
+    const double tz[3] = {v[1], -v[0], 0.0};  // v x e_z
+    matTvec(ro.R, tx, ux);
+    matTvec(ro.R, ty, uy);
+    matTvec(ro.R, tz, uz);
+  }
   const int nm = meta_nslots(r.meta);
   const int rs[3] = {soff, soff + 20 + nm, soff + 44 + 2 * nm};
   const int mo[3] = {20, 24, 24};
@@ -746,6 +757,12 @@ constexpr int kNodeStage = 64 * 25;
 //   A  issue the record loads of slice i+2 and (rom) the x loads of slice i+1
 //   B  stream the image of slice i to HBM with a fixed number of store instructions
 // One wave per workgroup: its LDS accesses are ordered, no barriers.
+// dynamic kernel loop.  On gfx9 a wave's loads and stores retire through ONE in-order counter, so x
+// loads issued right after a slice's stores are only seen once those stores have drained (measured: a
+// quarter of this kernel).  The slice is therefore copied out one phase late:
+//   front(i+1): x loads of slice i+1 (behind the stores of slice i-1, long gone) -> compact state
+//   copy-out(i): image of slice i -> HBM
+//   back(i+1):  Jacobian blocks of slice i+1 -> image        (single call site of each half)
 template <int NEE>
 __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ work, int n_work,
                                                     const double* __restrict__ x, double* __restrict__ g,
@@ -759,7 +776,10 @@ __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ 
   const int stride = gridDim.x;
   int i = blockIdx.x;
   if (i >= n_work) return;
-  DynWork w0 = work[i], w1 = w0, w2 = w0;
+  constexpr int NIT = (kDynStage + 2 + 127) / 128;
+  DynWork wp = work[i];   // slice whose image is waiting to be copied out (none yet)
+  bool pending = false;
+  DynWork w0 = wp, w1 = wp;
   DynShared sh0, sh1;
   DynLane ln0, ln1;
   dyn_load_rec<NEE>(w0, lane, sh0, ln0);
@@ -771,26 +791,44 @@ __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ 
   }
   for (; i < n_work; i += stride) {
     const bool has2 = i + 2 * stride < n_work;
+    DynWork w2 = w1;
     if (has2) w2 = work[i + 2 * stride];
     double* dst = jac + w0.j_off;
     const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-    {                                                   // C (the x loads of the next slice would not fit
-      DynX X;                                           //    the 256-register budget of two waves per SIMD)
+    DynFront S;
+    {
+      DynX X;
       dyn_load_x(w0, sh0, ln0, x, X);
-      dyn_quad<NEE>(w0, sh0, ln0, X, gst, stage, par, __builtin_amdgcn_readfirstlane(sh0.voff), trash, lane, want_g, want_j);
+      dyn_front<NEE>(w0, sh0, ln0, X, par, __builtin_amdgcn_readfirstlane(sh0.voff), lane, S);
     }
+    if (pending) {                                      // previous slice: image -> HBM
+      double* pdst = jac + wp.j_off;
+      const int ppar = (int)((reinterpret_cast<uintptr_t>(pdst) >> 3) & 1);
+      if (want_j) copy_out_fixed<NIT>(pdst, stage, wp.nvals, ppar, lane);
+      if (want_g) {                                     // 6 constraint values per time node, contiguous in g
+        double* go = g + wp.g_off;
+        if (lane < 6 * wp.cnt) go[lane] = gst[lane];
+        if (lane + 64 < 6 * wp.cnt) go[lane + 64] = gst[lane + 64];
+      }
+    }
+    dyn_back<NEE>(w0, ln0, S, gst, stage, trash, lane, want_g, want_j);
     DynShared sh2 = sh1;
     DynLane ln2 = ln1;
-    if (has2) dyn_load_rec<NEE>(w2, lane, sh2, ln2);    // A
-    if (want_j)                                         // B
-      copy_out_fixed<(kDynStage + 2 + 127) / 128>(dst, stage, w0.nvals, par, lane);
-    if (want_g) {                                       //   6 constraint values per time node, contiguous in g
-      double* go = g + w0.g_off;
-      if (lane < 6 * w0.cnt) go[lane] = gst[lane];
-      if (lane + 64 < 6 * w0.cnt) go[lane + 64] = gst[lane + 64];
-    }
+    if (has2) dyn_load_rec<NEE>(w2, lane, sh2, ln2);    // record of slice i+2
+    wp = w0;
+    pending = true;
     w0 = w1; sh0 = sh1; ln0 = ln1;
     w1 = w2; sh1 = sh2; ln1 = ln2;
+  }
+  {                                                     // last slice of this workgroup
+    double* pdst = jac + wp.j_off;
+    const int ppar = (int)((reinterpret_cast<uintptr_t>(pdst) >> 3) & 1);
+    if (want_j) copy_out_fixed<NIT>(pdst, stage, wp.nvals, ppar, lane);
+    if (want_g) {
+      double* go = g + wp.g_off;
+      if (lane < 6 * wp.cnt) go[lane] = gst[lane];
+      if (lane + 64 < 6 * wp.cnt) go[lane + 64] = gst[lane + 64];
+    }
   }
 }
 
