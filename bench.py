@@ -57,11 +57,11 @@ def perturbed_inputs(S, model, count, first_seed):
     return out
 
 
-def cpu_baseline(sched, params, x, budget_s=12.0):
+def cpu_baseline(sched, params, x, terrain, budget_s=12.0):
     """The oracle ("port" of the reference's Eigen CPU path) timed on this box's host cores."""
     from oracle import binding as ob
 
-    P = ob.OracleProblem("anymal", "flat", sched.durations(), sched.contact(), dt_dynamic=params.dt_dynamic,
+    P = ob.OracleProblem("anymal", terrain, sched.durations(), sched.contact(), dt_dynamic=params.dt_dynamic,
                          dt_rom=params.dt_rom, duration_base_poly=params.duration_base_poly,
                          polys_per_swing=params.polys_per_swing, polys_per_stance_force=params.polys_per_stance_force)
     t1 = P.time_callbacks(x, 3) / 3.0
@@ -90,7 +90,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=4096, help="candidates per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="candidates per GPU (default 4096, sweep: 128)")
+    ap.add_argument("--workload", choices=["c3", "sweep"], default="c3",
+                    help="c3: BASELINE config 3 (one schedule, distinct x, the headline metric); sweep: BASELINE "
+                         "configs 4-5 (enumerated gait / duration candidates on Stairs, ragged structures)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -118,16 +121,37 @@ def main():
     else:
         model = ta.model_preset("anymal", "flat")
 
-    sched, params, S = build_case(ta, model)
-    B = args.batch
-    workload = "C3 ANYmal trot (combo C1), T=2.0 s, flat, K=%d, n=%d m=%d nnz=%d, %d problems/GPU distinct x" % (
-        S.k_dynamic, S.n, S.m, S.nnz, B)
-    batch = ta.Batch([S], [0] * B, device=local_rank)
+    terrain = "flat" if args.workload == "c3" else "stairs"
+    model.terrain_id = ta.TERRAINS[terrain]  # (the broadcast blob carries the robot; the workload picks the terrain)
+    if args.workload == "c3":
+        sched, params, S = build_case(ta, model)
+        B = args.batch or 4096
+        n_all = B * world
+        workload = "C3 ANYmal trot (combo C1), T=2.0 s, flat, K=%d, n=%d m=%d nnz=%d, %d problems/GPU distinct x" % (
+            S.k_dynamic, S.n, S.m, S.nnz, B)
+        batch = ta.Batch([S], [0] * B, device=local_rank)
+        # distinct x per problem: 256 seeded perturbations per rank, tiled (contents do not change the work)
+        base = perturbed_inputs(S, model, min(B, 256), first_seed=rank * 100000)
+        reps = (B + base.shape[0] - 1) // base.shape[0]
+        x_host = np.tile(base, (reps, 1))[:B].reshape(-1)
+        bytes_per_callback = S.algorithmic_bytes
+    else:
+        # C4/C5: the canonical candidate list, contiguous shards balanced by bytes; every candidate has its
+        # own structure (SURVEY 8d enumeration, towr_amd/sweep.py)
+        from towr_amd import sweep
 
-    # distinct x per problem: 256 seeded perturbations per rank, tiled (contents do not change the work)
-    base = perturbed_inputs(S, model, min(B, 256), first_seed=rank * 100000)
-    reps = (B + base.shape[0] - 1) // base.shape[0]
-    x_host = np.tile(base, (reps, 1))[:B].reshape(-1)
+        n_all = (args.batch or 128) * world
+        cands = sweep.enumerate_candidates(n_all)
+        structs_all = [sweep.candidate_structure(model, c) for c in cands]
+        bounds = sweep.shard_bounds([s_.algorithmic_bytes for s_ in structs_all], world)
+        mine = structs_all[bounds[rank]:bounds[rank + 1]]
+        batch = ta.Batch(mine, list(range(len(mine))), device=local_rank)
+        x_host = np.concatenate([perturbed_inputs(s_, model, 1, first_seed=bounds[rank] + i_)[0]
+                                 for i_, s_ in enumerate(mine)])
+        S, sched, params = mine[0], mine[0].schedule, mine[0].params
+        B = len(mine)
+        workload = "C5 sweep: %d enumerated ANYmal candidates (combo x T x swing scale) on Stairs, K=200, ragged" % n_all
+        bytes_per_callback = batch.algorithmic_bytes // B
     x = torch.from_numpy(x_host).to(dev)
     g = torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device=dev)
     jac = torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev)
@@ -162,7 +186,7 @@ def main():
     assert bool(torch.isfinite(g).all()) and bool(torch.isfinite(jac).all())
 
     if rank == 0:
-        callbacks = B * world * args.steps
+        callbacks = n_all * args.steps
         alg_bytes = batch.algorithmic_bytes  # 8*(n+m+nnz) per problem x problems per step
         kbytes = batch.kernel_bytes()
         dom = max(kern_ms, key=kern_ms.get)  # dominant kernel by measured time
@@ -183,9 +207,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": workload, "problems_per_gpu": B, "bytes_per_callback": S.algorithmic_bytes},
+            "config": {"workload": workload, "problems_per_gpu": B, "bytes_per_callback": bytes_per_callback},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile("C3", names[dom]),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile("C3", names[dom]) if args.workload == "c3" else None,
                          "kernel": names[dom], "kernel_ms": kern_ms[dom],
                          "algorithmic_bytes_per_launch": kbytes[dom],
                          # the whole callback = the three kernels back to back (SURVEY 8d figure 8*(n+m+nnz))
@@ -194,7 +218,7 @@ def main():
                                   "algorithmic_bytes_per_step": alg_bytes}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sched, params, x_host[:S.n])
+            out["cpu_baseline"] = cpu_baseline(sched, params, x_host[:S.n], terrain)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -719,12 +719,12 @@ TWR_DEV void copy_out(double* __restrict__ dst, const double* __restrict__ stage
 // counted s_waitcnt vmcnt(N) when the persistent loop next touches its prefetched loads (on gfx9
 // loads and stores retire through one in-order counter; an unknown store count would force
 // vmcnt(0), i.e. a full store drain per slice).
-template <int NIT>
+template <int NIT, int kBatch>
 TWR_DEV void copy_out_fixed(double* __restrict__ dst, const double* __restrict__ stage, int n, int par, int lane) {
   double* al = dst - par;  // 16-byte aligned
   const int total = n + par;
   const int npairs = total >> 1;  // pairs [par, npairs) are complete; a slice has >= 20 values
-  constexpr int kBatch = 8;       // LDS reads in flight before the first store needs its data
+  // kBatch = LDS reads in flight before the first store needs its data
 #pragma unroll
   for (int it0 = 0; it0 < NIT; it0 += kBatch) {
     double2 v[kBatch];
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ 
     if (pending) {                                      // previous slice: image -> HBM
       double* pdst = jac + wp.j_off;
       const int ppar = (int)((reinterpret_cast<uintptr_t>(pdst) >> 3) & 1);
-      if (want_j) copy_out_fixed<NIT>(pdst, stage, wp.nvals, ppar, lane);
+      if (want_j) copy_out_fixed<NIT, 11>(pdst, stage, wp.nvals, ppar, lane);
       if (want_g) {                                     // 6 constraint values per time node, contiguous in g
         double* go = g + wp.g_off;
         if (lane < 6 * wp.cnt) go[lane] = gst[lane];
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ 
   {                                                     // last slice of this workgroup
     double* pdst = jac + wp.j_off;
     const int ppar = (int)((reinterpret_cast<uintptr_t>(pdst) >> 3) & 1);
-    if (want_j) copy_out_fixed<NIT>(pdst, stage, wp.nvals, ppar, lane);
+    if (want_j) copy_out_fixed<NIT, 11>(pdst, stage, wp.nvals, ppar, lane);
     if (want_g) {
       double* go = g + wp.g_off;
       if (lane < 6 * wp.cnt) go[lane] = gst[lane];
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(64, 2) void rom_kernel(const RomWork* __restrict__ 
     if (has2) r2 = rom_load_rec(w2, lane);              // A (records first: the wait for x retires them too)
     if (has1) rom_load_x(w1, r1, x, X);
     if (want_j)                                         // B
-      copy_out_fixed<(kRomStage + 2 + 127) / 128>(dst, stage, w0.nvals, par, lane);
+      copy_out_fixed<(kRomStage + 2 + 127) / 128, 13>(dst, stage, w0.nvals, par, lane);
     if (want_g) {                                       //   3 constraint values per time node, contiguous in g
       double* go = g + w0.g_off;
 #pragma unroll
