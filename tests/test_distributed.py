@@ -37,9 +37,13 @@ h = hashlib.sha256(structs[7].col_idx.tobytes() + structs[7].row_ptr.tobytes()).
 hs = [None] * world
 dist.all_gather_object(hs, h)
 assert all(x == hs[0] for x in hs)
+oks = [None] * world
+dist.all_gather_object(oks, (rank, int(a), int(b)))
 dist.barrier()
+if rank == 0:
+    sys.stdout.write("ALL RANKS OK %s\n" % sorted(oks))   # one writer: no interleaved output
+    sys.stdout.flush()
 dist.destroy_process_group()
-print("rank", rank, "ok", a, b)
 '''
 
 
@@ -55,4 +59,4 @@ def test_two_rank_gloo_broadcast_and_sharding(tmp_path):
            "--master-port", str(port), str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+    assert "ALL RANKS OK [(0, 0, " in out.stdout and "(1, " in out.stdout, out.stdout
