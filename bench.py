@@ -71,14 +71,14 @@ def cpu_baseline(sched, params, x, terrain, budget_s=12.0):
             "sample": "%d callbacks of the same ANYmal K=200 problem, single-thread C++ oracle (%.1f s)" % (iters, secs)}
 
 
-def traffic_from_profile(workload, kernel):
+def traffic_from_profile(workload, kernel, problems_per_gpu):
     """HBM bytes per launch of `kernel` from a committed rocprofv3 --pmc pass (profiles/traffic.json:
     WRITE_SIZE + 2*FETCH_SIZE in KiB, the gfx950 correction of MI355X_MICROARCH.md), or None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        if t.get("workload") == workload:
+        if t.get("workload") == workload and t.get("problems_per_gpu") == problems_per_gpu:
             return t.get("hbm_bytes_per_launch", {}).get(kernel)
     except (OSError, ValueError):
         pass
@@ -109,15 +109,22 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs (one-GPU box): TWR_BENCH_BACKEND=gloo TWR_BENCH_DEVICE=0 run every rank on one device
+    backend = os.environ.get("TWR_BENCH_BACKEND", "nccl")
+    dev_index = int(os.environ.get("TWR_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     # --- the single collective of the design: rank 0 broadcasts the POD robot/terrain model (RCCL)
     if world > 1:
         from towr_amd.dist import broadcast_model
 
-        dist.init_process_group("nccl", device_id=dev)
-        model = broadcast_model(ta.model_preset("anymal", "flat") if rank == 0 else None, src=0, device=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        model = broadcast_model(ta.model_preset("anymal", "flat") if rank == 0 else None, src=0,
+                                device=dev if backend == "nccl" else None)
     else:
         model = ta.model_preset("anymal", "flat")
 
@@ -129,7 +136,7 @@ def main():
         n_all = B * world
         workload = "C3 ANYmal trot (combo C1), T=2.0 s, flat, K=%d, n=%d m=%d nnz=%d, %d problems/GPU distinct x" % (
             S.k_dynamic, S.n, S.m, S.nnz, B)
-        batch = ta.Batch([S], [0] * B, device=local_rank)
+        batch = ta.Batch([S], [0] * B, device=dev_index)
         # distinct x per problem: 256 seeded perturbations per rank, tiled (contents do not change the work)
         base = perturbed_inputs(S, model, min(B, 256), first_seed=rank * 100000)
         reps = (B + base.shape[0] - 1) // base.shape[0]
@@ -145,7 +152,7 @@ def main():
         structs_all = [sweep.candidate_structure(model, c) for c in cands]
         bounds = sweep.shard_bounds([s_.algorithmic_bytes for s_ in structs_all], world)
         mine = structs_all[bounds[rank]:bounds[rank + 1]]
-        batch = ta.Batch(mine, list(range(len(mine))), device=local_rank)
+        batch = ta.Batch(mine, list(range(len(mine))), device=dev_index)
         x_host = np.concatenate([perturbed_inputs(s_, model, 1, first_seed=bounds[rank] + i_)[0]
                                  for i_, s_ in enumerate(mine)])
         S, sched, params = mine[0], mine[0].schedule, mine[0].params
@@ -178,7 +185,7 @@ def main():
     assert n_prof == args.steps
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else None)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -209,7 +216,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "problems_per_gpu": B, "bytes_per_callback": bytes_per_callback},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile("C3", names[dom]) if args.workload == "c3" else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile("C3", names[dom], B) if args.workload == "c3" else None,
                          "kernel": names[dom], "kernel_ms": kern_ms[dom],
                          "algorithmic_bytes_per_launch": kbytes[dom],
                          # the whole callback = the three kernels back to back (SURVEY 8d figure 8*(n+m+nnz))
