@@ -32,7 +32,10 @@ s = s.replace(b, '''    STAMP(t3)
     STAMP(t4)
     if (lane == 0 && blockIdx.x < 2048) {
       unsigned long long* o = twr_stamps + blockIdx.x * 8;
+      unsigned long long rt; asm volatile("s_memrealtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(rt) :: "memory");
+      if (o[4] == 0) { o[5] = t0; o[6] = rt; }
       o[0] += t1 - t0; o[1] += t2 - t1; o[2] += t3 - t2; o[3] += t4 - t3; o[4] += 1;
+      o[7] = ((t4 - o[5]) << 20) / (rt - o[6] + 1);   // shader cycles per 100 MHz tick, x 2^20
     }
     DynShared sh2 = sh1;''')
 s = s.replace("int dyn_stage_capacity() { return kDynStage; }", '''extern "C" void twr_debug_stamps(unsigned long long* out, int clear) {

@@ -21,4 +21,6 @@ n = b[:,4].sum()
 names=["x-load wait","front","copy-out(prev)","back"]
 tot = b[:,:4].sum()
 for k in range(4): print("%-16s %8.0f cycles/slice  %5.1f%%" % (names[k], b[:,k].sum()/n, 100*b[:,k].sum()/tot))
+clk = b[:,7].mean()/2**20*100e6
+print("in-kernel clock %.3f GHz" % (clk/1e9))
 print("sum %.0f cycles/slice over %d waves, %.1f slices/wave" % (tot/n, len(b), n/len(b)))

@@ -100,6 +100,26 @@ TWR_DEV void ee_point(uint64_t slots, bool shared, double tl, double iT, const d
       out[d] = fma(valid ? w[j] : 0.0, v[j * 3 + d], out[d]);
     }
 }
+TWR_DEV void gather12c(const double* __restrict__ xp, int xbase, const uint16_t cand[12], double v[12]) {
+#pragma unroll
+  for (int c = 0; c < 12; ++c) {
+    const int sl = cand[c] & 0xF;
+    v[c] = xp[xbase + (sl != 0xF ? sl : 0)];
+  }
+}
+TWR_DEV void ee_pointc(const uint16_t cand[12], bool shared, double tl, double iT, const double v[12], double w[4],
+                       double out[3]) {
+  hermite_pos(tl, iT, w);
+  if (shared) w[0] += w[2];
+  out[0] = out[1] = out[2] = 0.0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const bool valid = (cand[j * 3 + d] & 0xF) != 0xF;
+      out[d] = fma(valid ? w[j] : 0.0, v[j * 3 + d], out[d]);
+    }
+}
 TWR_DEV uint64_t slots_of(const uint16_t cand[12]) {
   uint64_t s = 0;
 #pragma unroll
@@ -232,8 +252,8 @@ TWR_DEV void dyn_load_x(const DynWork& w, const DynShared& sh, const DynLane& ln
     X.bl[i] = xl[i];
     X.ba[i] = xa[i];
   }
-  gather12(xp, ln.xbase_m, slots_of(ln.cand_m), X.m);
-  gather12(xp, ln.xbase_f, slots_of(ln.cand_f), X.f);
+  gather12c(xp, ln.xbase_m, ln.cand_m, X.m);
+  gather12c(xp, ln.xbase_f, ln.cand_f, X.f);
 }
 
 // Front half of the quad: consumes the x values (so their registers die before the previous slice
@@ -268,8 +288,8 @@ TWR_DEV void dyn_front(const DynWork& w, const DynShared& sh, const DynLane& ln,
   // --- this lane's end-effector: weights and spline points
   double p[3];
   double (&wm)[4] = S.wm, (&wf)[4] = S.wf, (&f)[3] = S.f, (&rv)[3] = S.rv;
-  ee_point(slots_of(ln.cand_m), meta_shared(ln.meta_m), ln.tm, ln.iTm, X.m, wm, p);
-  ee_point(slots_of(ln.cand_f), false, ln.tf, ln.iTf, X.f, wf, f);
+  ee_pointc(ln.cand_m, meta_shared(ln.meta_m), ln.tm, ln.iTm, X.m, wm, p);
+  ee_pointc(ln.cand_f, false, ln.tf, ln.iTf, X.f, wf, f);
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     rv[d] = c[d] - p[d];
