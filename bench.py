@@ -27,10 +27,10 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def build_case(ta, model, K=200, T=2.0, combo=1):
+def build_case(ta, model, K=200, T=2.0, combo=1, constraint_sets=27):
     sched = ta.gait_combo(model.n_ee, combo, T)
     dt = T / (K - 1.5)  # reference rule floor(T/dt)+2 then yields K nodes
-    params = ta.params_default(dt_dynamic=dt, dt_rom=dt)
+    params = ta.params_default(dt_dynamic=dt, dt_rom=dt, constraint_sets=constraint_sets)
     return sched, params, ta.Structure(model, sched, params)
 
 
@@ -63,7 +63,8 @@ def cpu_baseline(sched, params, x, terrain, budget_s=12.0):
 
     P = ob.OracleProblem("anymal", terrain, sched.durations(), sched.contact(), dt_dynamic=params.dt_dynamic,
                          dt_rom=params.dt_rom, duration_base_poly=params.duration_base_poly,
-                         polys_per_swing=params.polys_per_swing, polys_per_stance_force=params.polys_per_stance_force)
+                         polys_per_swing=params.polys_per_swing, polys_per_stance_force=params.polys_per_stance_force,
+                         constraint_sets=params.constraint_sets)
     t1 = P.time_callbacks(x, 3) / 3.0
     iters = max(5, int(budget_s / max(t1, 1e-6)))
     secs = P.time_callbacks(x, iters)
@@ -90,10 +91,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=None, help="candidates per GPU (default 4096, sweep: 128)")
+    ap.add_argument("--batch", type=int, default=None, help="candidates per GPU (default 8192, sweep: 128)")
     ap.add_argument("--workload", choices=["c3", "sweep"], default="c3",
                     help="c3: BASELINE config 3 (one schedule, distinct x, the headline metric); sweep: BASELINE "
                          "configs 4-5 (enumerated gait / duration candidates on Stairs, ragged structures)")
+    ap.add_argument("--sets", choices=["hot", "all"], default="hot",
+                    help="hot: the four constraint families of the headline metric (BASELINE sizes n=640 m=3866 "
+                         "nnz=102896); all: towr's whole default list (+ splineacc-base-*, swing-*), c3 only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -131,11 +135,11 @@ def main():
     terrain = "flat" if args.workload == "c3" else "stairs"
     model.terrain_id = ta.TERRAINS[terrain]  # (the broadcast blob carries the robot; the workload picks the terrain)
     if args.workload == "c3":
-        sched, params, S = build_case(ta, model)
-        B = args.batch or 4096
+        sched, params, S = build_case(ta, model, constraint_sets=27 if args.sets == "hot" else 63)
+        B = args.batch or 8192
         n_all = B * world
-        workload = "C3 ANYmal trot (combo C1), T=2.0 s, flat, K=%d, n=%d m=%d nnz=%d, %d problems/GPU distinct x" % (
-            S.k_dynamic, S.n, S.m, S.nnz, B)
+        workload = "C3 ANYmal trot (combo C1), T=2.0 s, flat, K=%d, n=%d m=%d nnz=%d, %d problems/GPU distinct x%s" % (
+            S.k_dynamic, S.n, S.m, S.nnz, B, "" if args.sets == "hot" else ", all six default constraint families")
         batch = ta.Batch([S], [0] * B, device=dev_index)
         # distinct x per problem: 256 seeded perturbations per rank, tiled (contents do not change the work)
         base = perturbed_inputs(S, model, min(B, 256), first_seed=rank * 100000)
@@ -216,7 +220,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "problems_per_gpu": B, "bytes_per_callback": bytes_per_callback},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile("C3", names[dom], B) if args.workload == "c3" else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile("C3", names[dom], B) if args.workload == "c3" and args.sets == "hot" else None,
                          "kernel": names[dom], "kernel_ms": kern_ms[dom],
                          "algorithmic_bytes_per_launch": kbytes[dom],
                          # the whole callback = the three kernels back to back (SURVEY 8d figure 8*(n+m+nnz))

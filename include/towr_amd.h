@@ -15,8 +15,10 @@
  *     "g" are the stacked constraint values and "jac" the Jacobian non-zeros in the CSR
  *     order ifopt::Problem::EvalNonzerosOfJacobian copies out (row-major, columns
  *     ascending, explicit structural zeros kept), for the constraint sets
- *        terrain-ee-motion_e.. | dynamic | rangeofmotion-e.. | force-ee-force_e..
- *     i.e. params_.constraints_ order (parameters.cc:55-60) restricted to the hot path.
+ *        terrain-ee-motion_e.. | dynamic | splineacc-base-lin | splineacc-base-ang |
+ *        rangeofmotion-e.. | force-ee-force_e.. | swing-ee-motion_e..
+ *     i.e. params_.constraints_ order (parameters.cc:55-60); twr_params.constraint_sets selects
+ *     which families exist (default: the four of the hot path).
  */
 #ifndef TOWR_AMD_H_
 #define TOWR_AMD_H_
@@ -39,6 +41,18 @@ enum { TWR_ROBOT_MONOPED = 0, TWR_ROBOT_BIPED, TWR_ROBOT_HYQ, TWR_ROBOT_ANYMAL, 
 enum { TWR_TERRAIN_FLAT = 0, TWR_TERRAIN_BLOCK, TWR_TERRAIN_STAIRS, TWR_TERRAIN_GAP, TWR_TERRAIN_SLOPE,
        TWR_TERRAIN_CHIMNEY, TWR_TERRAIN_CHIMNEY_LR };
 enum { TWR_EVAL_VALUES = 1, TWR_EVAL_JACOBIAN = 2, TWR_EVAL_BOTH = 3 };
+/* Parameters::ConstraintName entries of the default list (parameters.h:139-147, parameters.cc:55-60),
+ * as bits of twr_params.constraint_sets.  The sets always appear in this (the reference's) order. */
+enum {
+  TWR_SET_TERRAIN = 1,   /* TerrainConstraint per ee          (nlp_formulation.cc:278-289) */
+  TWR_SET_DYNAMIC = 2,   /* DynamicConstraint                 (nlp_formulation.cc:237-245) */
+  TWR_SET_BASE_ACC = 4,  /* SplineAccConstraint base-lin/-ang (nlp_formulation.cc:319-331) */
+  TWR_SET_ROM = 8,       /* RangeOfMotionConstraint per ee    (nlp_formulation.cc:247-262) */
+  TWR_SET_FORCE = 16,    /* ForceConstraint per ee            (nlp_formulation.cc:291-304) */
+  TWR_SET_SWING = 32,    /* SwingConstraint per ee            (nlp_formulation.cc:306-317) */
+  TWR_SETS_HOT_PATH = 1 | 2 | 8 | 16,
+  TWR_SETS_TOWR_DEFAULT = 63
+};
 
 /* Robot + terrain constants: the POD "model blob" that rank 0 broadcasts over RCCL.
  * Replaces towr::RobotModel {KinematicModel, DynamicModel} + HeightMap::Ptr
@@ -72,6 +86,8 @@ typedef struct twr_params {
   double duration_base_poly;    /* duration_base_polynomial_ (0.1) */
   int32_t polys_per_swing;      /* ee_polynomials_per_swing_phase_ (2) */
   int32_t polys_per_stance_force; /* force_polynomials_per_stance_phase_ (3) */
+  int32_t constraint_sets;      /* TWR_SET_* mask; twr_params_default: TWR_SETS_HOT_PATH */
+  int32_t reserved_;            /* must be 0 */
 } twr_params;
 
 typedef struct twr_sizes {

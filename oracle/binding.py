@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libtowr_oracle.so")
 _lib = None
 
+SETS_HOT_PATH = 1 | 2 | 8 | 16  # terrain, dynamic, rangeofmotion, force
+SETS_TOWR_DEFAULT = 63          # + splineacc-base-lin/-ang (4) and swing-* (32): parameters.cc:55-60
 ROBOTS = {"monoped": 0, "biped": 1, "hyq": 2, "anymal": 3, "go1": 4}
 TERRAINS = {"flat": 0, "block": 1, "stairs": 2, "gap": 3, "slope": 4, "chimney": 5, "chimney_lr": 6}
 
@@ -33,7 +35,7 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.c_int, C.c_int, C.c_int, _ip, _dp, _ip, C.c_double, C.c_double,
-                                 C.c_double, C.c_int, C.c_int, C.c_double]
+                                 C.c_double, C.c_int, C.c_int, C.c_double, C.c_int]
         L.orc_destroy.argtypes = [C.c_void_p]
         for f in ("orc_n_vars", "orc_n_rows", "orc_n_var_sets", "orc_n_con_sets"):
             getattr(L, f).argtypes = [C.c_void_p]
@@ -86,7 +88,8 @@ def gait(n_ee, combo, t_total):
 
 class OracleProblem:
     def __init__(self, robot, terrain, phase_durations, contact_at_start, dt_dynamic=0.1, dt_rom=0.08,
-                 duration_base_poly=0.1, polys_per_swing=2, polys_per_stance_force=3, force_limit=1000.0):
+                 duration_base_poly=0.1, polys_per_swing=2, polys_per_stance_force=3, force_limit=1000.0,
+                 constraint_sets=SETS_HOT_PATH):
         robot = ROBOTS[robot] if isinstance(robot, str) else robot
         terrain = TERRAINS[terrain] if isinstance(terrain, str) else terrain
         n_ee = len(phase_durations)
@@ -94,7 +97,8 @@ class OracleProblem:
         pd = np.concatenate([np.asarray(p, dtype=np.float64) for p in phase_durations])
         con = np.array(contact_at_start, dtype=np.int32)
         self._h = lib().orc_create(robot, terrain, n_ee, _i(n_ph), _d(pd), _i(con), dt_dynamic, dt_rom,
-                                   duration_base_poly, polys_per_swing, polys_per_stance_force, force_limit)
+                                   duration_base_poly, polys_per_swing, polys_per_stance_force, force_limit,
+                                   int(constraint_sets))
         if not self._h:
             raise RuntimeError("orc_create failed")
         L = lib()

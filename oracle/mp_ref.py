@@ -278,9 +278,65 @@ def unit(v):
     return [c / n for c in v]
 
 
-def constraints(L, terrain, x, fn_max=1000.0):
-    """g(x) stacked in reference order: terrain-*, dynamic, rangeofmotion-*, force-*."""
+HOT_PATH, TOWR_DEFAULT = 1 | 2 | 8 | 16, 63
+
+
+def spline_acc_rows(L, name, x):
+    """splineacc-<name> (spline_acc_constraint.cc:49-65): acceleration at the end of polynomial j minus
+    acceleration at the start of polynomial j+1, from the cubic through the node values."""
+    s = L.splines[name]
+    out = []
+    for j in range(len(s["durs"]) - 1):
+        for dm in range(3):
+            def node(k):
+                return (x[s["nodes"][k][(0, dm)]], x[s["nodes"][k][(1, dm)]])
+            Tp, Tn = mpf(s["durs"][j]), mpf(s["durs"][j + 1])
+            a_prev = hermite(node(j), node(j + 1), Tp, Tp)[2]
+            a_next = hermite(node(j + 1), node(j + 2), Tn, mpf(0))[2]
+            out.append(a_prev - a_next)
+    return out
+
+
+def swing_rows(L, ee, x, t_swing_avg=0.3):
+    """swing-ee-motion_<ee> (swing_constraint.cc:58-84): every swing node sits at the xy midpoint of its
+    neighbours with xy velocity = distance / t_swing_avg (swing_constraint.h:68)."""
+    s = L.splines["ee-motion_%d" % ee]
+    out = []
+    for nid in range(len(s["nodes"])):
+        if s["const"][nid]:
+            continue
+        for dm in (0, 1):
+            prev = x[s["nodes"][nid - 1][(0, dm)]]
+            nxt = x[s["nodes"][nid + 1][(0, dm)]]
+            out.append(x[s["nodes"][nid][(0, dm)]] - (prev + nxt) / 2)
+            out.append(x[s["nodes"][nid][(1, dm)]] - (nxt - prev) / mpf(t_swing_avg))
+    return out
+
+
+def constraints(L, terrain, x, fn_max=1000.0, sets=HOT_PATH):
+    """g(x) stacked in reference order (parameters.cc:55-60): terrain-*, dynamic, splineacc-base-{lin,ang},
+    rangeofmotion-*, force-*, swing-*; `sets` is the bit mask of oracle/towr_oracle.h."""
+    parts = _constraint_parts(L, terrain, x, fn_max)
+    g = []
+    if sets & 1:
+        g += parts["terrain"]
+    if sets & 2:
+        g += parts["dynamic"]
+    if sets & 4:
+        g += spline_acc_rows(L, "base-lin", x) + spline_acc_rows(L, "base-ang", x)
+    if sets & 8:
+        g += parts["rom"]
+    if sets & 16:
+        g += parts["force"]
+    if sets & 32:
+        for ee in range(L.n_ee):
+            g += swing_rows(L, ee, x)
+    return g
+
+
+def _constraint_parts(L, terrain, x, fn_max=1000.0):
     rb = L.rb
+    parts = {}
     g = []
     # terrain_constraint.cc:57-70 : one row per ee-motion node id>=1
     for ee in range(L.n_ee):
@@ -288,6 +344,7 @@ def constraints(L, terrain, x, fn_max=1000.0):
         for nid in range(1, len(s["nodes"])):
             p = [x[s["nodes"][nid][(0, dm)]] for dm in range(3)]
             g.append(p[2] - terrain_h(terrain, p[0], p[1])[0])
+    parts["terrain"], g = g, []
     # dynamic_constraint.cc:59-64 + single_rigid_body_dynamics.cc:76-101
     Ixx, Iyy, Izz, Ixy, Ixz, Iyz = [mpf(v) for v in rb["I"]]
     Ib = [[Ixx, -Ixy, -Ixz], [-Ixy, Iyy, -Iyz], [-Ixz, -Iyz, Izz]]
@@ -310,6 +367,7 @@ def constraints(L, terrain, x, fn_max=1000.0):
         lin = [m * c[2][i] - fsum[i] for i in range(3)]
         lin[2] += m * mpf(G)
         g += ang + lin
+    parts["dynamic"], g = g, []
     # range_of_motion_constraint.cc:58-69
     for ee in range(L.n_ee):
         for t in L.grid_rom:
@@ -319,6 +377,7 @@ def constraints(L, terrain, x, fn_max=1000.0):
             R = rot(e)
             d = [p[i] - c[i] for i in range(3)]
             g += [sum(R[j][i] * d[j] for j in range(3)) for i in range(3)]
+    parts["rom"], g = g, []
     # force_constraint.cc:62-89
     for ee in range(L.n_ee):
         sf = L.splines["ee-force_%d" % ee]
@@ -342,7 +401,8 @@ def constraints(L, terrain, x, fn_max=1000.0):
             g.append(dot(f, [a + mu * b for a, b in zip(t1, n)]))
             g.append(dot(f, [a - mu * b for a, b in zip(t2, n)]))
             g.append(dot(f, [a + mu * b for a, b in zip(t2, n)]))
-    return g
+    parts["force"] = g
+    return parts
 
 
 # ----------------------------------------------------------------- golden cases
@@ -362,6 +422,9 @@ def cases():
         "anymal_walk_stairs": dict(robot="anymal", terrain="stairs", phases=_gait(4, 0, 2.4), seed=14),
         "hyq_gallop_slope": dict(robot="hyq", terrain="slope", phases=_gait(4, 4, 2.2), seed=15),
         "go1_pace_chimney": dict(robot="go1", terrain="chimney", phases=_gait(4, 2, 1.8), seed=16),
+        # towr's whole default constraint list (adds splineacc-base-* and swing-*)
+        "full_biped_walk_block": dict(robot="biped", terrain="block", phases=_gait(2, 0, 2.0), seed=17, sets=TOWR_DEFAULT),
+        "full_anymal_trot_gap": dict(robot="anymal", terrain="gap", phases=_gait(4, 1, 2.0), seed=18, sets=TOWR_DEFAULT),
     }
 
 
@@ -385,14 +448,14 @@ _CTX = {}
 
 
 def _col(j):
-    L, terrain, x = _CTX["L"], _CTX["terrain"], _CTX["x"]
+    L, terrain, x, sets = _CTX["L"], _CTX["terrain"], _CTX["x"], _CTX["sets"]
     h = mpf(10) ** (-15)
     xp = list(x)
     xm = list(x)
     xp[j] += h
     xm[j] -= h
-    gp = constraints(L, terrain, xp)
-    gm = constraints(L, terrain, xm)
+    gp = constraints(L, terrain, xp, sets=sets)
+    gm = constraints(L, terrain, xm, sets=sets)
     col = [(a - b) / (2 * h) for a, b in zip(gp, gm)]
     return j, [(i, float(v)) for i, v in enumerate(col) if abs(v) > mpf(10) ** (-25)]
 
@@ -402,8 +465,9 @@ def generate(name, spec, outdir, procs=8):
     L = Layout(spec["robot"], pd, con)
     x64 = make_x(L, spec["seed"])
     x = [mpf(float(v)) for v in x64]
-    _CTX.update(L=L, terrain=spec["terrain"], x=x)
-    g = constraints(L, spec["terrain"], x)
+    sets = spec.get("sets", HOT_PATH)
+    _CTX.update(L=L, terrain=spec["terrain"], x=x, sets=sets)
+    g = constraints(L, spec["terrain"], x, sets=sets)
     with Pool(procs) as pool:
         cols = pool.map(_col, range(L.n), chunksize=4)
     rows, cidx, vals = [], [], []
@@ -415,7 +479,7 @@ def generate(name, spec, outdir, procs=8):
     np.savez_compressed(
         os.path.join(outdir, "mp_%s.npz" % name), robot=spec["robot"], terrain=spec["terrain"],
         n_phases=np.array([len(p) for p in pd]), phase_durations=np.concatenate([np.array(p) for p in pd]),
-        contact_at_start=np.array(con), x=x64, g=np.array([float(v) for v in g]),
+        contact_at_start=np.array(con), constraint_sets=np.int32(sets), x=x64, g=np.array([float(v) for v in g]),
         jac_row=np.array(rows, dtype=np.int32), jac_col=np.array(cidx, dtype=np.int32), jac_val=np.array(vals))
     print(name, "n", L.n, "m", len(g), "nnz(true)", len(vals), flush=True)
 

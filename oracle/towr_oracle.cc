@@ -314,11 +314,15 @@ struct NodeSpline {
     auto lt = GetLocalTime(t_global, GetPolyDurations());
     return polys.at(lt.first).GetPoint(lt.second);
   }
-  // ref: node_spline.cc:62-112
+  // ref: spline.cc:95-99
+  StateVal GetPoint(int poly_id, double t_local) const { return polys.at(poly_id).GetPoint(t_local); }
+  // ref: node_spline.cc:62-70
   SpMat GetJacobianWrtNodes(double t_global, int dxdt) const {
     auto lt = GetLocalTime(t_global, GetPolyDurations());
-    int poly_id = lt.first;
-    double t_local = lt.second;
+    return GetJacobianWrtNodes(lt.first, lt.second, dxdt);
+  }
+  // ref: node_spline.cc:72-112
+  SpMat GetJacobianWrtNodes(int poly_id, double t_local, int dxdt) const {
     SpMat jac(3, nv->rows());
     for (int idx = 0; idx < jac.c; ++idx)
       for (const NVI& nvi : nv->info[idx])
@@ -1095,6 +1099,102 @@ struct TerrainConstraint : ConSet {
   }
 };
 
+// ref: spline_acc_constraint.cc:34-88
+struct SplineAccConstraint : ConSet {
+  const NodeSpline* spline;
+  std::string node_variables_id;
+  int n_dim = 3, n_junctions = 0;
+  std::vector<double> T;
+  SplineAccConstraint(const NodeSpline* sp, const std::string& node_variable_name) : spline(sp) {
+    name = "splineacc-" + node_variable_name;
+    node_variables_id = node_variable_name;
+    n_junctions = (int)spline->polys.size() - 1;
+    T = spline->GetPolyDurations();
+    rows = n_dim * n_junctions;
+  }
+  void GetValues(double* g) const override {
+    for (int j = 0; j < n_junctions; ++j) {
+      int p_prev = j;
+      V3 acc_prev = spline->GetPoint(p_prev, T.at(p_prev)).a;
+      int p_next = j + 1;
+      V3 acc_next = spline->GetPoint(p_next, 0.0).a;
+      V3 d = acc_prev - acc_next;
+      for (int i = 0; i < n_dim; ++i) g[j * n_dim + i] = d(i);
+    }
+  }
+  void GetBounds(Bound* b) const override {
+    for (int i = 0; i < rows; ++i) b[i] = Bound{0.0, 0.0};
+  }
+  void FillJacobianBlock(const std::string& var_set, SpMat& jac) const override {
+    if (var_set != node_variables_id) return;
+    for (int j = 0; j < n_junctions; ++j) {
+      int p_prev = j;
+      SpMat acc_prev = spline->GetJacobianWrtNodes(p_prev, T.at(p_prev), kAcc);
+      int p_next = j + 1;
+      SpMat acc_next = spline->GetJacobianWrtNodes(p_next, 0.0, kAcc);
+      SpMat diff = acc_prev - acc_next;  // sparse difference: union pattern, cancelled entries stay
+      for (int i = 0; i < n_dim; ++i) jac.rows[j * n_dim + i] = diff.rows[i];
+    }
+  }
+};
+
+// ref: swing_constraint.cc:35-121, swing_constraint.h:68
+struct SwingConstraint : ConSet {
+  NodesVars* ee_motion;
+  std::vector<int> pure_swing_node_ids;
+  double t_swing_avg = 0.3;
+  SwingConstraint(const std::string& ee_motion_id, const Vars& x) {
+    name = "swing-" + ee_motion_id;
+    ee_motion = x.Get(ee_motion_id);
+    pure_swing_node_ids = ee_motion->NonConstantNodes();
+    // "assumes ... starting and ending in stance" (swing_constraint.cc:66): the reference would index
+    // nodes.at(-1) / past the end otherwise; refuse such schedules at construction.
+    for (int id : pure_swing_node_ids)
+      if (id == 0 || id == (int)ee_motion->nodes.size() - 1) throw std::runtime_error("swing: schedule must start and end in stance");
+    rows = (int)pure_swing_node_ids.size() * 2 * 2;  // Node::n_derivatives * k2D
+  }
+  void GetValues(double* g) const override {
+    int row = 0;
+    const auto& nodes = ee_motion->nodes;
+    for (int node_id : pure_swing_node_ids) {
+      const NodeVal& curr = nodes.at(node_id);
+      const NodeVal& prev = nodes.at(node_id - 1);
+      const NodeVal& next = nodes.at(node_id + 1);
+      for (int dim : {X, Y}) {
+        double distance = next.p(dim) - prev.p(dim);
+        double center = prev.p(dim) + 0.5 * distance;
+        double des_vel_center = distance / t_swing_avg;
+        g[row++] = curr.p(dim) - center;
+        g[row++] = curr.v(dim) - des_vel_center;
+      }
+    }
+  }
+  void GetBounds(Bound* b) const override {
+    for (int i = 0; i < rows; ++i) b[i] = Bound{0.0, 0.0};
+  }
+  void FillJacobianBlock(const std::string& var_set, SpMat& jac) const override {
+    if (var_set != ee_motion->name) return;
+    int row = 0;
+    auto idx = [&](int id, int deriv, int dim) {
+      int i = ee_motion->GetOptIndex(NVI{id, deriv, dim});
+      if (i < 0) throw std::runtime_error("swing: node value is not an optimisation variable");
+      return i;
+    };
+    for (int node_id : pure_swing_node_ids) {
+      for (int dim : {X, Y}) {
+        jac.coeffRef(row, idx(node_id, kPos, dim)) = 1.0;
+        jac.coeffRef(row, idx(node_id + 1, kPos, dim)) = -0.5;
+        jac.coeffRef(row, idx(node_id - 1, kPos, dim)) = -0.5;
+        row++;
+        jac.coeffRef(row, idx(node_id, kVel, dim)) = 1.0;
+        jac.coeffRef(row, idx(node_id + 1, kPos, dim)) = -1.0 / t_swing_avg;
+        jac.coeffRef(row, idx(node_id - 1, kPos, dim)) = +1.0 / t_swing_avg;
+        row++;
+      }
+    }
+  }
+};
+
 // ------------------------------------------- parameters.cc / nlp_formulation.cc
 // ref: parameters.cc:82-98
 static std::vector<double> GetBasePolyDurations(double T, double dt) {
@@ -1154,7 +1254,7 @@ extern "C" {
 
 orc_problem* orc_create(int robot, int terrain, int n_ee, const int* n_phases, const double* phase_durations,
                         const int* in_contact_at_start, double dt_dynamic, double dt_rom, double duration_base_poly,
-                        int polys_per_swing, int polys_per_stance_force, double force_limit) {
+                        int polys_per_swing, int polys_per_stance_force, double force_limit, int constraint_sets) {
   try {
     auto* P = new orc_problem();
     P->robot = MakeRobot(robot);
@@ -1203,14 +1303,26 @@ orc_problem* orc_create(int robot, int terrain, int n_ee, const int* n_phases, c
       P->sp.ee_force.push_back(add_spline(f, f->PhaseToPolyDurations(P->phase_durations[ee])));
     }
 
-    // constraints in reference order {Terrain, Dynamic, (BaseAcc), EndeffectorRom, Force, (Swing)}
-    for (int ee = 0; ee < n_ee; ++ee)
-      P->cons.emplace_back(new TerrainConstraint(P->terrain.get(), "ee-motion_" + std::to_string(ee), P->vars));
-    P->cons.emplace_back(new DynamicConstraint(P->model.get(), P->T, dt_dynamic, P->sp));
-    for (int ee = 0; ee < n_ee; ++ee)
-      P->cons.emplace_back(new RangeOfMotionConstraint(P->robot, P->T, dt_rom, ee, P->sp));
-    for (int ee = 0; ee < n_ee; ++ee)
-      P->cons.emplace_back(new ForceConstraint(P->terrain.get(), force_limit, ee, P->vars));
+    // constraints in reference order {Terrain, Dynamic, BaseAcc, EndeffectorRom, Force, Swing}
+    // (parameters.cc:55-60, nlp_formulation.cc:183-331); constraint_sets selects which are built.
+    if (constraint_sets & ORC_SET_TERRAIN)
+      for (int ee = 0; ee < n_ee; ++ee)
+        P->cons.emplace_back(new TerrainConstraint(P->terrain.get(), "ee-motion_" + std::to_string(ee), P->vars));
+    if (constraint_sets & ORC_SET_DYNAMIC)
+      P->cons.emplace_back(new DynamicConstraint(P->model.get(), P->T, dt_dynamic, P->sp));
+    if (constraint_sets & ORC_SET_BASE_ACC) {
+      P->cons.emplace_back(new SplineAccConstraint(P->sp.base_linear, "base-lin"));
+      P->cons.emplace_back(new SplineAccConstraint(P->sp.base_angular, "base-ang"));
+    }
+    if (constraint_sets & ORC_SET_ROM)
+      for (int ee = 0; ee < n_ee; ++ee)
+        P->cons.emplace_back(new RangeOfMotionConstraint(P->robot, P->T, dt_rom, ee, P->sp));
+    if (constraint_sets & ORC_SET_FORCE)
+      for (int ee = 0; ee < n_ee; ++ee)
+        P->cons.emplace_back(new ForceConstraint(P->terrain.get(), force_limit, ee, P->vars));
+    if (constraint_sets & ORC_SET_SWING)
+      for (int ee = 0; ee < n_ee; ++ee)
+        P->cons.emplace_back(new SwingConstraint("ee-motion_" + std::to_string(ee), P->vars));
     return P;
   } catch (const std::exception&) {
     return nullptr;

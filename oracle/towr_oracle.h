@@ -31,7 +31,14 @@ orc_problem* orc_create(int robot, int terrain, int n_ee, const int* n_phases,
                         const double* phase_durations, const int* in_contact_at_start,
                         double dt_dynamic, double dt_rom, double duration_base_poly,
                         int polys_per_swing, int polys_per_stance_force,
-                        double force_limit);
+                        double force_limit, int constraint_sets);
+// constraint_sets: which of the default sets (parameters.cc:55-60) to build, in that order
+enum {
+  ORC_SET_TERRAIN = 1, ORC_SET_DYNAMIC = 2, ORC_SET_BASE_ACC = 4, ORC_SET_ROM = 8, ORC_SET_FORCE = 16,
+  ORC_SET_SWING = 32,
+  ORC_SETS_HOT_PATH = 1 | 2 | 8 | 16,
+  ORC_SETS_TOWR_DEFAULT = 63
+};
 void orc_destroy(orc_problem*);
 
 int orc_n_vars(const orc_problem*);

@@ -47,7 +47,8 @@ def test_gpu_matches_mpmath_golden(path):
     for k in d["n_phases"]:
         pd.append(d["phase_durations"][o:o + k])
         o += k
-    case = Case(str(d["robot"]), str(d["terrain"]), ta.schedule(pd, list(d["contact_at_start"])))
+    sets = int(d["constraint_sets"]) if "constraint_sets" in d.files else 27
+    case = Case(str(d["robot"]), str(d["terrain"]), ta.schedule(pd, list(d["contact_at_start"])), constraint_sets=sets)
     S = case.S
     batch, g, j = _eval_case(case, [d["x"]])
     assert np.abs(g - d["g"]).max() <= 1e-12 * np.abs(d["g"]).max()
@@ -96,6 +97,30 @@ def test_other_leg_counts_and_gaits_starting_or_ending_in_flight(robot, n_ee, co
         assert_parity(case.S, *_split(batch, g, j, p), rg, rj, "%s c%d x[%d]" % (robot, combo, p))
 
 
+@pytest.mark.parametrize("spec", [
+    ("monoped", "flat", None, 2.0, dict(constraint_sets=63)),
+    ("biped", "block", 0, 2.0, dict(constraint_sets=63)),
+    ("anymal", "flat", 1, 2.0, dict(constraint_sets=63, **k_params(2.0, 200))),   # BASELINE C3 + the linear sets
+    ("hyq", "gap", 2, 2.1, dict(constraint_sets=63, polys_per_swing=3, duration_base_poly=0.13)),
+    ("go1", "slope", 0, 2.3, dict(constraint_sets=63, polys_per_swing=1)),
+    ("anymal", "stairs", 0, 2.4, dict(constraint_sets=2 | 32)),
+    ("biped", "flat", 1, 1.8, dict(constraint_sets=4)),
+    ("anymal", "chimney", 1, 2.0, dict(constraint_sets=1 | 16 | 32)),
+], ids=lambda s: "%s-%s-s%d" % (s[0], s[1], s[4]["constraint_sets"]))
+def test_whole_default_constraint_list_and_subsets(spec):
+    """towr's default constraints_ (parameters.cc:55-60) = hot path + splineacc-base-{lin,ang} + swing-*;
+    any subset keeps the reference order.  Two problems per batch so that odd value offsets occur."""
+    robot, terrain, combo, T, kw = spec
+    n_ee = ta.model_preset(robot, terrain).n_ee
+    sched = hopper_schedule() if combo is None else ta.gait_combo(n_ee, combo, T)
+    case = Case(robot, terrain, sched, **kw)
+    xs = [case.x_wild(4), case.x_perturbed(5, 2.0), case.x_guess(1.5)]
+    batch, g, j = _eval_case(case, xs)
+    for p, x in enumerate(xs):
+        rg, _, _, rj = case.P.eval(x)
+        assert_parity(case.S, *_split(batch, g, j, p), rg, rj, "%s x[%d]" % (spec[:3], p), x=x)
+
+
 def test_foot_starting_in_swing():
     """ee_in_contact_at_start = false: first polynomial of ee-motion is a swing one, force starts at zero."""
     sched = ta.schedule([[0.3, 0.5, 0.3, 0.4], [0.6, 0.3, 0.6]], [0, 1])
@@ -129,14 +154,14 @@ def test_flags_select_outputs():
 
 
 def test_full_size_batch_properties():
-    """BASELINE C3 at bench size (4096 problems): every output element is written exactly where the
+    """BASELINE C3 at bench size (8192 problems): every output element is written exactly where the
     CSR layout says, duplicates of one x give bit-identical results anywhere in the batch, sampled
     problems match the oracle, and J is the derivative of the GPU's own g (directional FD)."""
     import torch
 
     case = baseline_cases()["C3_anymal_trot_K200"]()
     S = case.S
-    B = 4096
+    B = 8192
     batch = ta.Batch([S], [0] * B, device=0)
     base = np.stack([case.x_perturbed(i) for i in range(32)])
     xh = np.tile(base, (B // 32, 1))

@@ -23,7 +23,8 @@ def load_fixture(path):
     for k in d["n_phases"]:
         pd.append(d["phase_durations"][o:o + k])
         o += k
-    P = ob.OracleProblem(str(d["robot"]), str(d["terrain"]), pd, list(d["contact_at_start"]))
+    sets = int(d["constraint_sets"]) if "constraint_sets" in d.files else ob.SETS_HOT_PATH
+    P = ob.OracleProblem(str(d["robot"]), str(d["terrain"]), pd, list(d["contact_at_start"]), constraint_sets=sets)
     return d, P
 
 
@@ -178,6 +179,92 @@ def test_static_stance_known_answers():
     assert np.array_equal(lo[sets["dynamic"][0]:sets["dynamic"][1]], np.zeros(sets["dynamic"][1] - sets["dynamic"][0]))
 
 
+def _set_rows(P):
+    out, r0 = {}, 0
+    for name, rows in P.con_sets:
+        out[name] = (r0, r0 + rows)
+        r0 += rows
+    return out
+
+
+def test_spline_acc_known_answers():
+    """spline_acc_constraint.cc:49-88: base nodes sampled from ONE global cubic have continuous
+    acceleration -> g = 0; the Jacobian rows are the kAcc weights of polynomial.cc:140-234 at t=T and t=0,
+    subtracted as sparse rows (the shared node's position entry cancels but stays in the pattern)."""
+    P = ob.OracleProblem("monoped", "flat", [[0.4, 0.2, 0.43]], [1], duration_base_poly=0.1, constraint_sets=ob.SETS_TOWR_DEFAULT)
+    sets = _set_rows(P)
+    durs = [0.1] * 10 + [0.03]               # parameters.cc:82-98: last polynomial takes the remainder
+    assert sets["splineacc-base-lin"][1] - sets["splineacc-base-lin"][0] == 3 * (len(durs) - 1)
+    t_nodes = np.concatenate([[0.0], np.cumsum(durs)])
+    x = np.random.default_rng(5).normal(size=P.n)
+    coef = np.random.default_rng(6).normal(size=(2, 3, 4))   # [lin|ang][dim][power]
+    for which in range(2):
+        for k, t in enumerate(t_nodes):
+            for d in range(3):
+                c = coef[which, d]
+                x[which * 6 * len(t_nodes) + 6 * k + d] = c @ [1, t, t * t, t**3]
+                x[which * 6 * len(t_nodes) + 6 * k + 3 + d] = c @ [0, 1, 2 * t, 3 * t * t]
+    g, rp, ci, va = P.eval(x)
+    for which, name in enumerate(("splineacc-base-lin", "splineacc-base-ang")):
+        a, b = sets[name]
+        assert np.abs(g[a:b]).max() < 1e-9            # accelerations ~ 1e1, coefficients ~ 6/T^2 = 6.7e3
+        for j in range(len(durs) - 1):
+            Tp, Tn = durs[j], durs[j + 1]
+            expect = [6 / Tp**2, 2 / Tp, -6 / Tp**2 + 6 / Tn**2, 4 / Tp + 4 / Tn, -6 / Tn**2, 2 / Tn]
+            for d in range(3):
+                r = a + 3 * j + d
+                cols = which * 6 * len(t_nodes) + 6 * j + d + 3 * np.arange(6)
+                assert np.array_equal(ci[rp[r]:rp[r + 1]], cols)
+                assert np.allclose(va[rp[r]:rp[r + 1]], expect, rtol=1e-12, atol=1e-9)
+    lo, up = P.bounds()
+    a, b = sets["splineacc-base-lin"][0], sets["splineacc-base-ang"][1]
+    assert not lo[a:b].any() and not up[a:b].any()
+    # a velocity kink at one node shows up in exactly the two junctions next to it... and at the node itself
+    x2 = x.copy()
+    x2[6 * 4 + 3 + 1] += 1.0                          # base-lin node 4, vy
+    g2 = P.values(x2)
+    a, b = sets["splineacc-base-lin"]
+    changed = np.nonzero(np.abs(g2[a:b] - g[a:b]) > 1e-9)[0]
+    assert changed.tolist() == [3 * 2 + 1, 3 * 3 + 1, 3 * 4 + 1]       # junctions 2,3,4 (nodes 3,4,5), dim y
+    assert np.allclose((g2 - g)[a:b][changed], [2 / 0.1, 8 / 0.1, 2 / 0.1], rtol=1e-9)
+
+
+def test_swing_known_answers():
+    """swing_constraint.cc:58-121: swing node at the xy midpoint of its neighbours, xy velocity =
+    distance / 0.3 s (swing_constraint.h:68)."""
+    P = ob.OracleProblem("monoped", "flat", [[0.4, 0.2, 0.4, 0.3, 0.2]], [1], constraint_sets=ob.SETS_TOWR_DEFAULT)
+    sets = _set_rows(P)
+    a, b = sets["swing-ee-motion_0"]
+    assert b - a == 2 * 4                         # two swing phases x one middle node x {x,y} x {pos,vel}
+    off = dict((n, 0) for n, _ in P.var_sets)
+    o = 0
+    for n, sz in P.var_sets:
+        off[n] = o
+        o += sz
+    m = off["ee-motion_0"]                        # stance(3) | swing node px vx py vy pz (5) | stance(3) | ...
+    x = np.zeros(P.n)
+    x[m:m + 3] = [0.0, 0.0, 0.0]
+    x[m + 8:m + 11] = [0.3, 0.6, 0.0]
+    x[m + 3:m + 8] = [0.15, 1.0, 0.3, 2.0, 0.07]  # midpoint, (0.3, 0.6) / 0.3 s
+    x[m + 16:m + 19] = [0.5, 0.5, 0.0]
+    x[m + 11:m + 16] = [0.45, 0.0, 0.5, 0.1, 0.1] # x pos off by +0.05, x vel by -(0.2/0.3), y pos by -0.05, y vel +0.1+1/3
+    g, rp, ci, va = P.eval(x)
+    assert np.abs(g[a:a + 4]).max() < 1e-15
+    assert np.allclose(g[a + 4:b], [0.05, -0.2 / 0.3, -0.05, 0.1 + 0.1 / 0.3], atol=1e-15)
+    for k in range(2):
+        base = m + 8 * k
+        rows = [va[rp[r]:rp[r + 1]] for r in range(a + 4 * k, a + 4 * k + 4)]
+        cols = [ci[rp[r]:rp[r + 1]].tolist() for r in range(a + 4 * k, a + 4 * k + 4)]
+        assert cols == [[base, base + 3, base + 8], [base, base + 4, base + 8], [base + 1, base + 5, base + 9], [base + 1, base + 6, base + 9]]
+        assert np.array_equal(rows[0], [-0.5, 1.0, -0.5]) and np.array_equal(rows[2], [-0.5, 1.0, -0.5])
+        assert np.array_equal(rows[1], [1 / 0.3, 1.0, -1 / 0.3]) and np.array_equal(rows[3], [1 / 0.3, 1.0, -1 / 0.3])
+    lo, up = P.bounds()
+    assert not lo[a:b].any() and not up[a:b].any()
+    # a foot that starts in swing has no previous node: refused (the reference would throw in at())
+    with pytest.raises(RuntimeError):
+        ob.OracleProblem("monoped", "flat", [[0.3, 0.5, 0.3, 0.5]], [0], constraint_sets=ob.SETS_TOWR_DEFAULT)
+
+
 def test_time_grid_and_sizes_follow_the_reference_rules():
     """time_discretization_constraint.cc:37-50: K = floor(T/dt)+2 with a (near-)duplicate last node;
     sizes of the BASELINE configs as derived in SURVEY App. B."""
@@ -189,6 +276,10 @@ def test_time_grid_and_sizes_follow_the_reference_rules():
     assert [len(p) for p in pd] == [7, 9, 9, 7] and con == [1, 1, 1, 1]
     Q = ob.OracleProblem("anymal", "flat", pd, con, dt_dynamic=2.0 / 198.5, dt_rom=2.0 / 198.5)
     assert (Q.n, Q.m, Q.nnz) == (640, 3866, 102896)
+    # towr's whole default list adds 2 x 3 x 19 splineacc rows (6 values each) and 4 rows (3 values) per swing node
+    Qf = ob.OracleProblem("anymal", "flat", pd, con, dt_dynamic=2.0 / 198.5, dt_rom=2.0 / 198.5, constraint_sets=ob.SETS_TOWR_DEFAULT)
+    n_swing = 3 + 4 + 4 + 3
+    assert (Qf.n, Qf.m, Qf.nnz) == (640, 3866 + 114 + 4 * n_swing, 102896 + 684 + 12 * n_swing)
     assert [s for _, s in Q.var_sets] == [126, 126, 27, 35, 35, 27, 60, 72, 72, 60]
     pd, con = ob.gait(2, 0, 2.0)
     Bp = ob.OracleProblem("biped", "flat", pd, con, dt_dynamic=2.0 / 98.5, dt_rom=2.0 / 98.5)

@@ -26,6 +26,15 @@ CONFIGS = [
     ("go1", "stairs", 0, 2.3, dict(polys_per_swing=1, polys_per_stance_force=1, duration_base_poly=0.07,
                                    dt_dynamic=0.033, dt_rom=0.05)),
     ("go1", "chimney", 3, 2.6, dict(dt_dynamic=0.25, dt_rom=0.3)),
+    # towr's whole default constraint list (parameters.cc:55-60) and odd subsets of it
+    ("monoped", "flat", None, 2.0, dict(constraint_sets=63)),
+    ("biped", "block", 0, 2.0, dict(constraint_sets=63)),
+    ("anymal", "flat", 1, 2.0, dict(constraint_sets=63, **k_params(2.0, 200))),
+    ("hyq", "gap", 2, 2.1, dict(constraint_sets=63, polys_per_swing=3, duration_base_poly=0.13)),
+    ("go1", "slope", 0, 2.3, dict(constraint_sets=63, polys_per_swing=1)),
+    ("anymal", "stairs", 0, 2.4, dict(constraint_sets=2 | 32)),
+    ("biped", "flat", 1, 1.8, dict(constraint_sets=4)),
+    ("anymal", "chimney", 1, 2.0, dict(constraint_sets=1 | 16 | 32)),
 ]
 
 
@@ -35,7 +44,7 @@ def make(robot, terrain, combo, T, kw):
     return Case(robot, terrain, sched, **kw)
 
 
-@pytest.mark.parametrize("cfg", CONFIGS, ids=["%s-%s-c%s" % (c[0], c[1], c[2]) for c in CONFIGS])
+@pytest.mark.parametrize("cfg", CONFIGS, ids=["%s-%s-c%s-s%d" % (c[0], c[1], c[2], c[4].get("constraint_sets", 27)) for c in CONFIGS])
 def test_structure_matches_oracle(cfg):
     case = make(*cfg)
     S, P = case.S, case.P
@@ -138,6 +147,15 @@ def test_error_behaviour():
         ta.Structure(ta.model_preset("anymal", "flat"), bad)
     with pytest.raises(ta.TowrError):
         ta.Structure(ta.model_preset("biped", "flat"), ta.gait_combo(2, 0, 2.0), ta.params_default(dt_dynamic=0.0))
+    for mask in (0, 64, -1):
+        with pytest.raises(ta.TowrError, match="constraint_sets"):
+            ta.Structure(ta.model_preset("biped", "flat"), ta.gait_combo(2, 0, 2.0), ta.params_default(constraint_sets=mask))
+    # SwingConstraint "assumes ... starting and ending in stance" (swing_constraint.cc:66): a foot that
+    # starts in swing has no previous node; refused at build time (the reference would throw in at())
+    flying = ta.schedule([[0.3, 0.5, 0.3, 0.5]], [0])
+    ta.Structure(ta.model_preset("monoped", "flat"), flying)  # fine without the swing set
+    with pytest.raises(ta.TowrError, match="stance"):
+        ta.Structure(ta.model_preset("monoped", "flat"), flying, ta.params_default(constraint_sets=63))
     h = C.c_void_p()
     assert L.twr_structure_create(None, None, None, C.byref(h)) == -1
     assert L.twr_batch_eval(None, None, None, None, 3, None) == -1

@@ -38,7 +38,8 @@ class Schedule(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [("dt_dynamic", C.c_double), ("dt_rom", C.c_double), ("duration_base_poly", C.c_double),
-                ("polys_per_swing", C.c_int32), ("polys_per_stance_force", C.c_int32)]
+                ("polys_per_swing", C.c_int32), ("polys_per_stance_force", C.c_int32),
+                ("constraint_sets", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class Sizes(C.Structure):

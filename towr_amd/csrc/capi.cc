@@ -101,6 +101,8 @@ int twr_params_default(twr_params* out) {
   out->duration_base_poly = 0.1;
   out->polys_per_swing = 2;
   out->polys_per_stance_force = 3;
+  out->constraint_sets = TWR_SETS_HOT_PATH;
+  out->reserved_ = 0;
   return TWR_OK;
 }
 
@@ -125,6 +127,8 @@ int twr_structure_create(const twr_model* model, const twr_schedule* schedule, c
     h->s.params = *params;
     if (params->polys_per_swing < 1 || params->polys_per_stance_force < 1)
       throw std::runtime_error("polynomials per phase must be >= 1");
+    if (params->constraint_sets <= 0 || (params->constraint_sets & ~TWR_SETS_TOWR_DEFAULT))
+      throw std::runtime_error("constraint_sets must be a non-empty mask of TWR_SET_* bits");
     h->s.Build();
     *out = h.release();
     return TWR_OK;
@@ -219,12 +223,13 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     std::vector<std::vector<std::vector<std::pair<int, int>>>> runs_rom(n_structs);
     for (int i = 0; i < n_structs; ++i) {
       const twr::Structure& S = structs[i]->s;
-      int ci = S.n_ee;  // con_sets: terrain x n_ee, dynamic, rom x n_ee, force x n_ee
-      runs_dyn[i] = chunk(S.row_ptr, S.con_sets[ci].offset, 6, (int)S.grid_dyn.size(), twr::dyn_stage_capacity(),
-                          twr::dyn_nodes_per_block());
+      // families that are switched off (twr_params.constraint_sets) simply have no work items
+      if (const twr::SetInfo* ds = S.FindSet("dynamic"))
+        runs_dyn[i] = chunk(S.row_ptr, ds->offset, 6, (int)S.grid_dyn.size(), twr::dyn_stage_capacity(),
+                            twr::dyn_nodes_per_block());
       for (int e = 0; e < S.n_ee; ++e)
-        runs_rom[i].push_back(chunk(S.row_ptr, S.con_sets[ci + 1 + e].offset, 3, (int)S.grid_rom.size(),
-                                    twr::rom_stage_capacity(), 64));
+        if (const twr::SetInfo* rs = S.FindSet("rangeofmotion-" + std::to_string(e)))
+          runs_rom[i].push_back(chunk(S.row_ptr, rs->offset, 3, (int)S.grid_rom.size(), twr::rom_stage_capacity(), 64));
     }
     for (int p = 0; p < n_problems; ++p) {
       int si = struct_of_problem[p];
@@ -234,10 +239,10 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
       b->g_off[p + 1] = b->g_off[p] + S.n_rows;
       b->j_off[p + 1] = b->j_off[p] + S.nnz;
       const uint64_t blob = reinterpret_cast<uint64_t>(b->blobs[si]);
-      const int ci = S.n_ee;
       dyn_first.push_back((int)dyn.size());
       rom_first.push_back((int)rom.size());
-      const twr::SetInfo& ds = S.con_sets[ci];
+      const twr::SetInfo* dsp = S.FindSet("dynamic");
+      const twr::SetInfo ds = dsp ? *dsp : twr::SetInfo();
       for (auto& r : runs_dyn[si]) {
         twr::DynWork w;
         std::memset(&w, 0, sizeof(w));
@@ -253,8 +258,8 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
         w.nvals = S.row_ptr[ds.offset + 6 * (r.first + r.second)] - S.row_ptr[ds.offset + 6 * r.first];
         dyn.push_back(w);
       }
-      for (int e = 0; e < S.n_ee; ++e) {
-        const twr::SetInfo& rs = S.con_sets[ci + 1 + e];
+      for (int e = 0; e < (int)runs_rom[si].size(); ++e) {
+        const twr::SetInfo& rs = *S.FindSet("rangeofmotion-" + std::to_string(e));
         for (auto& r : runs_rom[si][e]) {
           twr::RomWork w;
           std::memset(&w, 0, sizeof(w));

@@ -71,6 +71,15 @@ struct TerrainRow {  // one ee-motion node id >= 1 (terrain_constraint.cc:44-55)
   int32_t stride;    // py = idx+stride, pz = idx+2*stride (1 stance node, 2 swing node)
 };
 
+struct AccJunction {  // one base-spline junction j (spline_acc_constraint.cc:49-81)
+  double c[6];        // d(acc_end(poly j) - acc_start(poly j+1)) / d{p_j, v_j, p_j+1, v_j+1, p_j+2, v_j+2}
+};
+struct SwingNode {    // one non-constant ee-motion node (swing_constraint.cc:44-121)
+  int32_t cur;        // x index of the node's px (vx +1, py +2, vy +3)
+  int32_t prev_x, prev_y, next_x, next_y;  // x indices of the neighbours' px / py
+  int32_t pad;
+};
+
 // Blob header: model constants + what the node kernel needs.  The terrain-ee-motion_e sets are
 // adjacent in g / jac, and so are the force-ee-force_e sets, so each family is one flat node list.
 struct DevStruct {
@@ -79,7 +88,15 @@ struct DevStruct {
   int32_t row_force, nnz_force, n_force_nodes;
   uint32_t o_force_nodes;   // byte offsets inside the blob: ForceNode[n_force_nodes]
   uint32_t o_terrain_rows;  // TerrainRow[n_terrain_rows]
-  uint32_t pad_[2];
+  // splineacc-base-lin | splineacc-base-ang (adjacent, 3 rows x 6 values per junction and set) and
+  // swing-ee-motion_e (adjacent, 4 rows x 3 values per swing node); counts are 0 when a family is off
+  int32_t row_acc, nnz_acc, n_junctions;
+  int32_t row_swing, nnz_swing, n_swing_nodes;
+  int32_t off_base_ang;     // x offset of base-ang (base-lin starts at 0)
+  uint32_t o_acc;           // AccJunction[n_junctions]
+  uint32_t o_swing_nodes;   // SwingNode[n_swing_nodes]
+  uint32_t pad_[3];
+  double inv_t_swing;       // 1 / t_swing_avg_ (swing_constraint.h:68)
   double mass, gravity, mu, flat_height;
   double Ib[6];  // body inertia tensor entries (0,0),(0,1),(0,2),(1,1),(1,2),(2,2) incl. the sign of
                  // single_rigid_body_dynamics.cc:40-42

@@ -767,7 +767,6 @@ TWR_DEV void copy_out_fixed(double* __restrict__ dst, const double* __restrict__
 // seven workgroups per CU; range of motion: 64 lanes x ~84 values -> 39 KiB, four per CU.
 constexpr int kDynStage = 2654;   // + 2 + 64 + 96 doubles = 22528 B
 constexpr int kRomStage = 4856;   // + 2 + 64 + 192 doubles = 40912 B
-constexpr int kNodeStage = 64 * 25;
 
 // dynamic / range of motion: persistent workgroups, software pipelined over the strided work list.
 // Loop body for slice i (its record -- and for rom its x values -- were prefetched):
@@ -894,11 +893,13 @@ __global__ __launch_bounds__(64, 2) void rom_kernel(const RomWork* __restrict__ 
   }
 }
 
-// all terrain-ee-motion_e (terrain_constraint.cc:57-108) and force-ee-force_e sets of one
-// problem, 64 spline nodes at a time
-__global__ __launch_bounds__(64) void node_kernel(const NodeWork* __restrict__ work, const double* __restrict__ x,
-                                                  double* __restrict__ g, double* __restrict__ jac, int flags) {
-  __shared__ __attribute__((aligned(16))) double stage[kNodeStage + 2];
+// all terrain-ee-motion_e (terrain_constraint.cc:57-108), force-ee-force_e, splineacc-base-* and
+// swing-ee-motion_e sets of one problem.  One workgroup of four waves per problem, one wave per family
+// (each with its own LDS image, no barriers), 64 spline nodes / rows at a time.
+constexpr int kStageTerrain = 64 * 3 + 2, kStageForce = 64 * 25 + 2, kStageAcc = 64 * 6 + 2, kStageSwing = 64 * 12 + 2;
+__global__ __launch_bounds__(256) void node_kernel(const NodeWork* __restrict__ work, const double* __restrict__ x,
+                                                   double* __restrict__ g, double* __restrict__ jac, int flags) {
+  __shared__ __attribute__((aligned(16))) double stage_all[kStageTerrain + kStageForce + kStageAcc + kStageSwing];
   const NodeWork w = work[blockIdx.x];
   const char* blob = reinterpret_cast<const char*>(w.blob);
   const DevStruct* S = reinterpret_cast<const DevStruct*>(blob);
@@ -906,8 +907,9 @@ __global__ __launch_bounds__(64) void node_kernel(const NodeWork* __restrict__ w
   double* gp = g + w.g_off;
   double* jp = jac + w.j_off;
   const bool want_g = flags & 1, want_j = flags & 2;
-  const int lane = threadIdx.x;
-  {
+  const int lane = threadIdx.x & 63, family = threadIdx.x >> 6;  // wave-uniform
+  if (family == 0) {
+    double* stage = stage_all;
     const TerrainRow* rows = tbl<TerrainRow>(blob, S->o_terrain_rows);
     const int nr = S->n_terrain_rows;
     for (int r0 = 0; r0 < nr; r0 += 64) {
@@ -927,8 +929,8 @@ __global__ __launch_bounds__(64) void node_kernel(const NodeWork* __restrict__ w
       }
       if (want_j) copy_out(dst, stage, 3 * cnt, par, lane);  // single wave: LDS accesses are ordered
     }
-  }
-  {
+  } else if (family == 1) {
+    double* stage = stage_all + kStageTerrain;
     const ForceNode* nodes = tbl<ForceNode>(blob, S->o_force_nodes);
     const int nn = S->n_force_nodes;
     for (int i0 = 0; i0 < nn; i0 += 64) {
@@ -938,6 +940,66 @@ __global__ __launch_bounds__(64) void node_kernel(const NodeWork* __restrict__ w
       if (lane < cnt)
         force_item(S, nodes[i0 + lane], xp, gp + S->row_force + 5 * (i0 + lane), stage + par + 25 * lane, want_g, want_j);
       if (want_j) copy_out(dst, stage, 25 * cnt, par, lane);
+    }
+  } else if (family == 2) {
+    // splineacc-base-lin | splineacc-base-ang (spline_acc_constraint.cc:49-81): lane = row (set, junction j,
+    // dim d); its six variables are {p,v}_d of base nodes j, j+1, j+2 and the six Jacobian values depend on
+    // the polynomial durations only (AccJunction), so g = sum c_i x_i.
+    double* stage = stage_all + kStageTerrain + kStageForce;
+    const AccJunction* acc = tbl<AccJunction>(blob, S->o_acc);
+    const int per_set = 3 * S->n_junctions, nr = 2 * per_set;
+    for (int r0 = 0; r0 < nr; r0 += 64) {
+      const int cnt = min(64, nr - r0);
+      double* dst = jp + S->nnz_acc + 6 * r0;
+      const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+      if (lane < cnt) {
+        const int r = r0 + lane;
+        const int which = r >= per_set, rem = r - which * per_set;
+        const int j = rem / 3, d = rem - 3 * j;
+        const AccJunction a = acc[j];
+        const double* xb = xp + (which ? S->off_base_ang : 0) + 6 * j + d;
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          v += a.c[i] * xb[3 * i];
+          if (want_j) stage[par + 6 * lane + i] = a.c[i];
+        }
+        if (want_g) gp[S->row_acc + r] = v;
+      }
+      if (want_j) copy_out(dst, stage, 6 * cnt, par, lane);
+    }
+  } else {
+    // swing-ee-motion_e (swing_constraint.cc:58-121): lane = swing node, rows {x pos, x vel, y pos, y vel},
+    // columns {previous node, this node, next node}
+    double* stage = stage_all + kStageTerrain + kStageForce + kStageAcc;
+    const SwingNode* sw = tbl<SwingNode>(blob, S->o_swing_nodes);
+    const int nn = S->n_swing_nodes;
+    const double it = S->inv_t_swing;
+    for (int i0 = 0; i0 < nn; i0 += 64) {
+      const int cnt = min(64, nn - i0);
+      double* dst = jp + S->nnz_swing + 12 * i0;
+      const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+      if (lane < cnt) {
+        const SwingNode sn = sw[i0 + lane];
+        const int pi[2] = {sn.prev_x, sn.prev_y}, ni[2] = {sn.next_x, sn.next_y};
+#pragma unroll
+        for (int dim = 0; dim < 2; ++dim) {
+          const double prev = xp[pi[dim]], next = xp[ni[dim]];
+          const double pos = xp[sn.cur + 2 * dim], vel = xp[sn.cur + 2 * dim + 1];
+          const double distance = next - prev;
+          if (want_g) {
+            double* g4 = gp + S->row_swing + 4 * (i0 + lane);
+            g4[2 * dim] = pos - (prev + 0.5 * distance);
+            g4[2 * dim + 1] = vel - distance * it;
+          }
+          if (want_j) {
+            double* st = stage + par + 12 * lane + 6 * dim;
+            st[0] = -0.5; st[1] = 1.0; st[2] = -0.5;
+            st[3] = it;   st[4] = 1.0; st[5] = -it;
+          }
+        }
+      }
+      if (want_j) copy_out(dst, stage, 12 * cnt, par, lane);
     }
   }
 }
@@ -977,7 +1039,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
     hipLaunchKernelGGL(rom_kernel, grid, block, 0, stream, rom, n_rom, x, g, jac, flags);
   }
   if (ev) (void)hipEventRecord(ev[2], stream);
-  if (n_node > 0) hipLaunchKernelGGL(node_kernel, dim3(n_node), block, 0, stream, node, x, g, jac, flags);
+  if (n_node > 0) hipLaunchKernelGGL(node_kernel, dim3(n_node), dim3(256), 0, stream, node, x, g, jac, flags);
   if (ev) (void)hipEventRecord(ev[3], stream);
   return hipGetLastError();
 }

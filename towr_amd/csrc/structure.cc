@@ -267,6 +267,42 @@ void Structure::BuildTimeTables() {
       terrain_rows[e].push_back(tr);
     }
   }
+  // splineacc-base-*: the two NodeSpline::GetJacobianWrtNodes rows of spline_acc_constraint.cc:67-81 at
+  // t = T_j of polynomial j and t = 0 of polynomial j+1 (CubicHermitePolynomial::GetDerivativeWrt{Start,End}Node,
+  // polynomial.cc:140-234, kAcc); they depend on the durations only.
+  if (params.constraint_sets & TWR_SET_BASE_ACC)
+    for (size_t j = 0; j + 1 < base.durations.size(); ++j) {
+      const double Tp = base.durations[j], Tn = base.durations[j + 1];
+      const double Tp2 = std::pow(Tp, 2), Tp3 = std::pow(Tp, 3), Tn2 = std::pow(Tn, 2), Tn3 = std::pow(Tn, 3);
+      const double prev[4] = {(12 * Tp) / Tp3 - 6 / Tp2, (6 * Tp) / Tp2 - 4 / Tp, 6 / Tp2 - (12 * Tp) / Tp3, (6 * Tp) / Tp2 - 2 / Tp};
+      const double next[4] = {(12 * 0.0) / Tn3 - 6 / Tn2, (6 * 0.0) / Tn2 - 4 / Tn, 6 / Tn2 - (12 * 0.0) / Tn3, (6 * 0.0) / Tn2 - 2 / Tn};
+      AccJunction a;
+      a.c[0] = prev[0]; a.c[1] = prev[1];
+      a.c[2] = prev[2] - next[0]; a.c[3] = prev[3] - next[1];
+      a.c[4] = 0.0 - next[2]; a.c[5] = 0.0 - next[3];
+      acc_junctions.push_back(a);
+    }
+  // swing-ee-motion_e: GetIndicesOfNonConstantNodes + the neighbours' position variables
+  swing_nodes.resize(n_ee);
+  if (params.constraint_sets & TWR_SET_SWING)
+    for (int e = 0; e < n_ee; ++e) {
+      const SplineLayout& m = motion[e];
+      for (int n = 0; n < m.n_nodes; ++n) {
+        if (m.node_constant[n]) continue;
+        // "assumes ... starting and ending in stance" (swing_constraint.cc:66): the reference indexes
+        // nodes.at(node_id -+ 1) and throws otherwise
+        if (n == 0 || n == m.n_nodes - 1) throw std::runtime_error("swing constraint needs schedules that start and end in stance");
+        SwingNode sn;
+        sn.cur = m.at(n, 0, 0);
+        if (m.at(n, 1, 0) != sn.cur + 1 || m.at(n, 0, 1) != sn.cur + 2 || m.at(n, 1, 1) != sn.cur + 3)
+          throw std::runtime_error("unexpected swing node layout");
+        sn.prev_x = m.at(n - 1, 0, 0); sn.prev_y = m.at(n - 1, 0, 1);
+        sn.next_x = m.at(n + 1, 0, 0); sn.next_y = m.at(n + 1, 0, 1);
+        sn.pad = 0;
+        if (sn.prev_x < 0 || sn.prev_y < 0 || sn.next_x < 0 || sn.next_y < 0) throw std::runtime_error("swing neighbour is not a variable");
+        swing_nodes[e].push_back(sn);
+      }
+    }
 }
 
 // ------------------------------------------------------------------ CSR pattern + bounds
@@ -289,8 +325,9 @@ void Structure::BuildPattern() {
     for (int s = 0; s < nslots; ++s)
       if ((dim_of_slot[s] == want_dim) == equal) out.push_back(p.xbase + s);
   };
+  const int sets = params.constraint_sets;
   // --- terrain-ee-motion_e  (terrain_constraint.cc:90-108): [x, y, z] of node id = row+1
-  for (int e = 0; e < n_ee; ++e) {
+  for (int e = 0; e < n_ee && (sets & TWR_SET_TERRAIN); ++e) {
     begin_set("terrain-ee-motion_" + std::to_string(e), (int)terrain_rows[e].size());
     for (size_t r = 0; r < terrain_rows[e].size(); ++r) {
       const TerrainRow& tr = terrain_rows[e][r];
@@ -301,8 +338,8 @@ void Structure::BuildPattern() {
     }
   }
   // --- dynamic (dynamic_constraint.cc:73-117, single_rigid_body_dynamics.cc:103-192)
-  begin_set("dynamic", (int)grid_dyn.size() * 6);
-  for (size_t k = 0; k < grid_dyn.size(); ++k) {
+  if (sets & TWR_SET_DYNAMIC) begin_set("dynamic", (int)grid_dyn.size() * 6);
+  for (size_t k = 0; k < grid_dyn.size() && (sets & TWR_SET_DYNAMIC); ++k) {
     int q = dyn_base[k].poly;
     for (int r = 0; r < 3; ++r) {  // AX, AY, AZ
       std::vector<int> c;
@@ -326,8 +363,25 @@ void Structure::BuildPattern() {
       upper.push_back(0.0);
     }
   }
+  // --- splineacc-base-lin, splineacc-base-ang (spline_acc_constraint.cc:67-88): the sparse difference
+  // acc_prev - acc_next keeps the union pattern: both value kinds of nodes j, j+1, j+2 in dimension d
+  // (the shared node's position entry is a structural non-zero even when the durations are equal and
+  // its value cancels)
+  if (sets & TWR_SET_BASE_ACC)
+    for (int which = 0; which < 2; ++which) {
+      const int off = which == 0 ? off_base_lin : off_base_ang;
+      begin_set(which == 0 ? "splineacc-base-lin" : "splineacc-base-ang", 3 * (int)acc_junctions.size());
+      for (size_t j = 0; j < acc_junctions.size(); ++j)
+        for (int d = 0; d < 3; ++d) {
+          std::vector<int> c;
+          for (int i = 0; i < 6; ++i) c.push_back(off + 6 * (int)j + 3 * i + d);
+          rows.push_back(c);
+          lower.push_back(0.0);
+          upper.push_back(0.0);
+        }
+    }
   // --- rangeofmotion-e (range_of_motion_constraint.cc:83-109)
-  for (int e = 0; e < n_ee; ++e) {
+  for (int e = 0; e < n_ee && (sets & TWR_SET_ROM); ++e) {
     begin_set("rangeofmotion-" + std::to_string(e), (int)grid_rom.size() * 3);
     for (size_t k = 0; k < grid_rom.size(); ++k) {
       int q = rom_base[k].poly;
@@ -345,7 +399,7 @@ void Structure::BuildPattern() {
     }
   }
   // --- force-ee-force_e (force_constraint.cc:107-171)
-  for (int e = 0; e < n_ee; ++e) {
+  for (int e = 0; e < n_ee && (sets & TWR_SET_FORCE); ++e) {
     begin_set("force-ee-force_" + std::to_string(e), (int)force_nodes[e].size() * 5);
     for (const ForceNode& fn : force_nodes[e]) {
       for (int r = 0; r < 5; ++r) rows.push_back({fn.hidx, fn.hidx + 1, fn.fidx, fn.fidx + 2, fn.fidx + 4});
@@ -354,6 +408,20 @@ void Structure::BuildPattern() {
       lower.push_back(0.0);  upper.push_back(inf);
       lower.push_back(-inf); upper.push_back(0.0);
       lower.push_back(0.0);  upper.push_back(inf);
+    }
+  }
+  // --- swing-ee-motion_e (swing_constraint.cc:86-121): rows x-pos, x-vel, y-pos, y-vel per swing node
+  for (int e = 0; e < n_ee && (sets & TWR_SET_SWING); ++e) {
+    begin_set("swing-ee-motion_" + std::to_string(e), 4 * (int)swing_nodes[e].size());
+    for (const SwingNode& sn : swing_nodes[e]) {
+      rows.push_back({sn.prev_x, sn.cur, sn.next_x});
+      rows.push_back({sn.prev_x, sn.cur + 1, sn.next_x});
+      rows.push_back({sn.prev_y, sn.cur + 2, sn.next_y});
+      rows.push_back({sn.prev_y, sn.cur + 3, sn.next_y});
+      for (int r = 0; r < 4; ++r) {
+        lower.push_back(0.0);
+        upper.push_back(0.0);
+      }
     }
   }
   n_rows = (int)rows.size();
@@ -383,31 +451,49 @@ void Structure::PackBlob() {
   };
   h.n_ee = n_ee;
   h.terrain_id = model.terrain_id;
-  int ci = 0;
   std::vector<TerrainRow> all_rows;
   std::vector<ForceNode> all_nodes;
-  h.row_terrain = con_sets[0].offset;
-  h.nnz_terrain = con_sets[0].nnz_offset;
-  for (int e = 0; e < n_ee; ++e, ++ci) {
-    if (con_sets[ci].offset != h.row_terrain + (int)all_rows.size()) throw std::runtime_error("terrain sets not adjacent");
-    all_rows.insert(all_rows.end(), terrain_rows[e].begin(), terrain_rows[e].end());
-  }
+  std::vector<SwingNode> all_swing;
+  auto family = [&](const std::string& prefix, int rows_per_item, auto& per_ee, auto& all, int32_t& row0, int32_t& nnz0) {
+    // the per-ee sets of one family are adjacent in g / jac: one flat list
+    for (int e = 0; e < n_ee; ++e) {
+      const SetInfo* si = FindSet(prefix + std::to_string(e));
+      if (!si) return;
+      if (e == 0) { row0 = si->offset; nnz0 = si->nnz_offset; }
+      if (si->offset != row0 + rows_per_item * (int)all.size()) throw std::runtime_error(prefix + " sets not adjacent");
+      all.insert(all.end(), per_ee[e].begin(), per_ee[e].end());
+    }
+  };
+  family("terrain-ee-motion_", 1, terrain_rows, all_rows, h.row_terrain, h.nnz_terrain);
+  family("force-ee-force_", 5, force_nodes, all_nodes, h.row_force, h.nnz_force);
+  family("swing-ee-motion_", 4, swing_nodes, all_swing, h.row_swing, h.nnz_swing);
   h.n_terrain_rows = (int)all_rows.size();
-  const int row_dyn = con_sets[ci].offset, nnz_dyn = con_sets[ci].nnz_offset;
-  ++ci;
-  int row_rom[kMaxEE], nnz_rom[kMaxEE];
-  for (int e = 0; e < n_ee; ++e, ++ci) { row_rom[e] = con_sets[ci].offset; nnz_rom[e] = con_sets[ci].nnz_offset; }
-  h.row_force = con_sets[ci].offset;
-  h.nnz_force = con_sets[ci].nnz_offset;
-  for (int e = 0; e < n_ee; ++e, ++ci) {
-    if (con_sets[ci].offset != h.row_force + 5 * (int)all_nodes.size()) throw std::runtime_error("force sets not adjacent");
-    all_nodes.insert(all_nodes.end(), force_nodes[e].begin(), force_nodes[e].end());
-  }
   h.n_force_nodes = (int)all_nodes.size();
+  h.n_swing_nodes = (int)all_swing.size();
+  h.off_base_ang = off_base_ang;
+  h.inv_t_swing = 1.0 / 0.3;  // t_swing_avg_, swing_constraint.h:68
+  if (const SetInfo* si = FindSet("splineacc-base-lin")) {
+    const SetInfo* sa = FindSet("splineacc-base-ang");
+    if (!sa || sa->offset != si->offset + si->size || off_base_lin != 0) throw std::runtime_error("splineacc sets not adjacent");
+    h.row_acc = si->offset;
+    h.nnz_acc = si->nnz_offset;
+    h.n_junctions = (int)acc_junctions.size();
+  }
+  const SetInfo* dyn_set = FindSet("dynamic");
+  const int row_dyn = dyn_set ? dyn_set->offset : 0, nnz_dyn = dyn_set ? dyn_set->nnz_offset : 0;
+  int row_rom[kMaxEE] = {0, 0, 0, 0}, nnz_rom[kMaxEE] = {0, 0, 0, 0};
+  const bool have_rom = FindSet("rangeofmotion-0") != nullptr;
+  for (int e = 0; e < n_ee && have_rom; ++e) {
+    const SetInfo* si = FindSet("rangeofmotion-" + std::to_string(e));
+    row_rom[e] = si->offset;
+    nnz_rom[e] = si->nnz_offset;
+  }
   h.o_force_nodes = put(all_nodes.data(), all_nodes.size() * sizeof(ForceNode));
   h.o_terrain_rows = put(all_rows.data(), all_rows.size() * sizeof(TerrainRow));
+  h.o_acc = put(acc_junctions.data(), acc_junctions.size() * sizeof(AccJunction));
+  h.o_swing_nodes = put(all_swing.data(), all_swing.size() * sizeof(SwingNode));
   // --- per-lane records of the dynamic kernel
-  {
+  if (dyn_set) {
     std::vector<DynShared> sh(grid_dyn.size());
     std::vector<DynLane> ln(grid_dyn.size() * n_ee);
     for (size_t k = 0; k < grid_dyn.size(); ++k) {
@@ -433,7 +519,7 @@ void Structure::PackBlob() {
     off_dyn_lanes = put(ln.data(), ln.size() * sizeof(DynLane));
   }
   // --- per-lane records of the range-of-motion kernel
-  for (int e = 0; e < n_ee; ++e) {
+  for (int e = 0; e < n_ee && have_rom; ++e) {
     std::vector<RomRec> rc(grid_rom.size());
     for (size_t k = 0; k < grid_rom.size(); ++k) {
       RomRec& R = rc[k];
@@ -462,6 +548,12 @@ void Structure::PackBlob() {
   std::memcpy(blob.data(), &h, sizeof(h));
   if (!body.empty()) std::memcpy(blob.data() + sizeof(DevStruct), body.data(), body.size());
   blob.resize((blob.size() + 15) / 16 * 16);
+}
+
+const SetInfo* Structure::FindSet(const std::string& name) const {
+  for (const SetInfo& s : con_sets)
+    if (s.name == name) return &s;
+  return nullptr;
 }
 
 void Structure::Build() {

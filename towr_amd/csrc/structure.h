@@ -51,6 +51,8 @@ struct Structure {
   std::vector<std::vector<PolyDesc>> mpoly, fpoly;                       // [ee][poly]
   std::vector<std::vector<ForceNode>> force_nodes;                       // [ee]
   std::vector<std::vector<TerrainRow>> terrain_rows;                     // [ee]
+  std::vector<AccJunction> acc_junctions;                                // base spline junctions
+  std::vector<std::vector<SwingNode>> swing_nodes;                       // [ee]
 
   std::vector<int32_t> row_ptr, col_idx;
   std::vector<double> lower, upper;
@@ -60,6 +62,7 @@ struct Structure {
   uint32_t off_dyn_shared = 0, off_dyn_lanes = 0;
   uint32_t off_rom_recs[kMaxEE] = {0, 0, 0, 0};
 
+  const SetInfo* FindSet(const std::string& name) const;  // nullptr if the family is switched off
   void Build();            // throws std::runtime_error
   void InitialGuess(const double* lin0, const double* ang0, const double* lin1, const double* ang1,
                     const double* ee0, double* x) const;
