@@ -139,6 +139,14 @@ int twr_structure_initial_guess(const twr_structure* s, const double init_base_l
                                 const double init_base_ang[3], const double final_base_lin[3],
                                 const double final_base_ang[3], const double* init_ee_pos /* n_ee*3 */,
                                 double* x_out /* n_vars */);
+/* Variable bounds (x_l, x_u) that the same functions put on the node variables: start state of base
+ * and feet fixed, final base state fixed in the dimensions of Parameters::bounds_final_* (parameters.cc:65-69:
+ * lin pos {x,y}, lin vel, ang pos, ang vel), everything else ifopt::NoBound (+-1e20)
+ * (nlp_formulation.cc:109-122,151; nodes_variables.cc:152-181).  Base states are 12 doubles
+ * {lin pos, lin vel, ang pos, ang vel}. */
+int twr_structure_variable_bounds(const twr_structure* s, const double init_base[12], const double final_base[12],
+                                  const double* init_ee_pos /* n_ee*3 */, double* lower /* n_vars */,
+                                  double* upper /* n_vars */);
 
 /* Upload the tables of a batch: problem p uses structs[struct_of_problem[p]].  device is the HIP
  * device ordinal of this process (one process per GPU). */

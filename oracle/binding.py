@@ -47,6 +47,7 @@ def lib():
             getattr(L, f).argtypes = [C.c_void_p, C.c_int]
             getattr(L, f).restype = C.c_int
         L.orc_initial_guess.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.orc_variable_bounds.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp]
         L.orc_eval.argtypes = [C.c_void_p, _dp, _dp, _ip, _ip, _dp]
         L.orc_eval.restype = C.c_int
         L.orc_bounds.argtypes = [C.c_void_p, _dp, _dp]
@@ -122,6 +123,16 @@ class OracleProblem:
         ee = np.ascontiguousarray(ee_pos0, dtype=np.float64).reshape(-1)
         lib().orc_initial_guess(self._h, _d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), _d(ee), _d(x))
         return x
+
+    def variable_bounds(self, init_base, final_base, ee_pos0):
+        """init_base / final_base: 12 doubles {lin p, lin v, ang p, ang v}."""
+        a = np.ascontiguousarray(init_base, dtype=np.float64).reshape(-1)
+        b = np.ascontiguousarray(final_base, dtype=np.float64).reshape(-1)
+        ee = np.ascontiguousarray(ee_pos0, dtype=np.float64).reshape(-1)
+        assert a.size == 12 and b.size == 12 and ee.size == 3 * self.n_ee
+        lo, up = np.zeros(self.n), np.zeros(self.n)
+        lib().orc_variable_bounds(self._h, _d(a), _d(b), _d(ee), _d(lo), _d(up))
+        return lo, up
 
     def eval(self, x):
         """Returns g, row_ptr, col_idx, vals (CSR, explicit zeros kept)."""

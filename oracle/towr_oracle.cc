@@ -145,7 +145,14 @@ struct NodesVars {
         if (nvi.deriv == kVel) nodes.at(nvi.id).v(nvi.dim) = average_velocity(nvi.dim);
       }
   }
-  // ref: nodes_variables.cc:161-168
+  // ref: nodes_variables.cc:152-181
+  void AddBounds(int node_id, int deriv, const std::vector<int>& dimensions, const V3& val) {
+    for (int dim : dimensions) AddBound(NVI{node_id, deriv, dim}, val(dim));
+  }
+  void AddStartBound(int deriv, const std::vector<int>& dimensions, const V3& val) { AddBounds(0, deriv, dimensions, val); }
+  void AddFinalBound(int deriv, const std::vector<int>& dimensions, const V3& val) {
+    AddBounds((int)nodes.size() - 1, deriv, dimensions, val);
+  }
   void AddBound(const NVI& want, double val) {
     for (int idx = 0; idx < rows(); ++idx)
       for (const NVI& nvi : info[idx])
@@ -1371,6 +1378,32 @@ void orc_initial_guess(orc_problem* P, const double* bl0, const double* ba0, con
     v->GetValues(x_out + off);
     off += v->rows();
   }
+}
+
+// Variable bounds as NlpFormulation::Make{Base,Endeffector,Force}Variables set them
+// (nlp_formulation.cc:109-122,151, parameters.cc:65-69); base states are {lin p, lin v, ang p, ang v}.
+void orc_variable_bounds(orc_problem* P, const double* init_base, const double* final_base, const double* ee_pos0,
+                         double* lower, double* upper) {
+  auto v3 = [](const double* p) { return V3(p[0], p[1], p[2]); };
+  for (auto& v : P->var_sets) v->bounds.assign(v->rows(), Bound{-kInf, kInf});
+  NodesVars* lin = P->var_sets[0].get();
+  lin->AddStartBound(kPos, {X, Y, Z}, v3(init_base));
+  lin->AddStartBound(kVel, {X, Y, Z}, v3(init_base + 3));
+  lin->AddFinalBound(kPos, {X, Y}, v3(final_base));        // bounds_final_lin_pos_
+  lin->AddFinalBound(kVel, {X, Y, Z}, v3(final_base + 3)); // bounds_final_lin_vel_
+  NodesVars* ang = P->var_sets[1].get();
+  ang->AddStartBound(kPos, {X, Y, Z}, v3(init_base + 6));
+  ang->AddStartBound(kVel, {X, Y, Z}, v3(init_base + 9));
+  ang->AddFinalBound(kPos, {X, Y, Z}, v3(final_base + 6));
+  ang->AddFinalBound(kVel, {X, Y, Z}, v3(final_base + 9));
+  for (int ee = 0; ee < P->n_ee; ++ee) P->var_sets[2 + ee]->AddStartBound(kPos, {X, Y, Z}, v3(ee_pos0 + 3 * ee));
+  int off = 0;
+  for (auto& v : P->var_sets)
+    for (const Bound& b : v->bounds) {
+      lower[off] = b.lo;
+      upper[off] = b.up;
+      ++off;
+    }
 }
 
 // ifopt::ConstraintSet::GetJacobian + Composite row stacking + Problem::EvalNonzerosOfJacobian

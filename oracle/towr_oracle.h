@@ -55,6 +55,10 @@ void orc_initial_guess(orc_problem*, const double* base_lin0, const double* base
                        const double* base_lin1, const double* base_ang1,
                        const double* ee_pos0 /* n_ee*3 */, double* x_out);
 
+// variable bounds (x_l, x_u) of the same construction; init_base / final_base = {lin p, lin v, ang p, ang v}
+void orc_variable_bounds(orc_problem*, const double* init_base /*12*/, const double* final_base /*12*/,
+                         const double* ee_pos0 /* n_ee*3 */, double* lower, double* upper);
+
 // one full callback: SetVariables(x); g = stacked GetValues(); J = stacked GetJacobian().
 // Jacobian returned as CSR over the stacked rows (columns ascending in each row, explicit
 // zeros kept) exactly as ifopt::Problem::EvalNonzerosOfJacobian would copy it out.

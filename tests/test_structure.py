@@ -67,6 +67,15 @@ def test_structure_matches_oracle(cfg):
     ee0 = np.array([[0.1 * i, 0.05 * i, 0.0] for i in range(S.n_ee)])
     args = ([0.1, 0.2, 0.5], [0.01, 0.02, 0.3], [1.3, 0.1, 0.5], [0.0, 0.0, 0.7], ee0)
     assert np.array_equal(S.initial_guess(*args), P.initial_guess(*args))
+    # variable bounds: start state and final base state (nlp_formulation.cc:109-122,151)
+    rng = np.random.default_rng(3)
+    vb = (rng.normal(size=12), rng.normal(size=12), ee0)
+    lo, up = S.variable_bounds(*vb)
+    lo2, up2 = P.variable_bounds(*vb)
+    assert np.array_equal(lo, lo2) and np.array_equal(up, up2)
+    fixed = lo == up
+    n_fixed_ee = sum(3 for _ in range(S.n_ee))
+    assert fixed.sum() == 12 + 11 + n_fixed_ee and np.all(lo[~fixed] == -1e20) and np.all(up[~fixed] == 1e20)
 
 
 @pytest.mark.parametrize("n_ee", [1, 2, 4])

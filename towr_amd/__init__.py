@@ -104,6 +104,7 @@ def lib():
         L.twr_structure_col_idx.restype = C.POINTER(C.c_int32)
         L.twr_structure_bounds.argtypes = [C.c_void_p, _dp, _dp]
         L.twr_structure_initial_guess.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.twr_structure_variable_bounds.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp]
         L.twr_batch_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int,
                                        C.POINTER(C.c_void_p)]
         L.twr_batch_destroy.argtypes = [C.c_void_p]
@@ -215,6 +216,16 @@ class Structure:
         x = np.zeros(self.n)
         _check(lib().twr_structure_initial_guess(self._h, _d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), _d(ee), _d(x)))
         return x
+
+    def variable_bounds(self, init_base, final_base, ee_pos0):
+        """x_l, x_u of the reference's variable sets; base states = 12 doubles {lin p, lin v, ang p, ang v}."""
+        a = np.ascontiguousarray(init_base, dtype=np.float64).reshape(-1)
+        b = np.ascontiguousarray(final_base, dtype=np.float64).reshape(-1)
+        ee = np.ascontiguousarray(ee_pos0, dtype=np.float64).reshape(-1)
+        assert a.size == 12 and b.size == 12 and ee.size == 3 * self.n_ee
+        lo, up = np.zeros(self.n), np.zeros(self.n)
+        _check(lib().twr_structure_variable_bounds(self._h, _d(a), _d(b), _d(ee), _d(lo), _d(up)))
+        return lo, up
 
 
 class Batch:

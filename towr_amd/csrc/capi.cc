@@ -186,6 +186,17 @@ int twr_structure_initial_guess(const twr_structure* s, const double init_base_l
   }
 }
 
+int twr_structure_variable_bounds(const twr_structure* s, const double init_base[12], const double final_base[12],
+                                  const double* init_ee_pos, double* lower, double* upper) {
+  if (!s || !init_base || !final_base || !init_ee_pos || !lower || !upper) return fail(TWR_ERR_INVALID, "null argument");
+  try {
+    s->s.VariableBounds(init_base, final_base, init_ee_pos, lower, upper);
+    return TWR_OK;
+  } catch (const std::exception& e) {
+    return fail(TWR_ERR_INVALID, e.what());
+  }
+}
+
 int twr_batch_create(const twr_structure* const* structs, int n_structs, const int32_t* struct_of_problem,
                      int n_problems, int device, twr_batch** out) {
   if (!structs || !struct_of_problem || !out || n_structs < 1 || n_problems < 1)

@@ -653,6 +653,36 @@ void Structure::InitialGuess(const double* lin0, const double* ang0, const doubl
   }
 }
 
+// ------------------------------------------------------------------ variable bounds
+// NodesVariables::AddStartBound / AddFinalBound as called by NlpFormulation::MakeBaseVariables and
+// MakeEndeffectorVariables (src/nlp_formulation.cc:109-122,151; src/nodes_variables.cc:152-181) with the
+// bounded dimensions of src/parameters.cc:65-69.  A bound on a node value that is not an optimisation
+// variable is silently dropped (AddBound only scans existing variables).
+void Structure::VariableBounds(const double* init_base, const double* final_base, const double* ee0, double* lower,
+                               double* upper) const {
+  const double inf = 1e20;  // ifopt::NoBound
+  for (int i = 0; i < n_vars; ++i) {
+    lower[i] = -inf;
+    upper[i] = inf;
+  }
+  auto fix = [&](const SplineLayout& s, int delta, int node, int deriv, int dim, double val) {
+    int i = s.at(node, deriv, dim);
+    if (i >= 0) lower[i + delta] = upper[i + delta] = val;
+  };
+  const int last = base.n_nodes - 1;
+  for (int d = 0; d < 3; ++d) {
+    fix(base, off_base_lin, 0, 0, d, init_base[d]);
+    fix(base, off_base_lin, 0, 1, d, init_base[3 + d]);
+    if (d != 2) fix(base, off_base_lin, last, 0, d, final_base[d]);  // bounds_final_lin_pos_ = {X,Y}
+    fix(base, off_base_lin, last, 1, d, final_base[3 + d]);
+    fix(base, off_base_ang, 0, 0, d, init_base[6 + d]);
+    fix(base, off_base_ang, 0, 1, d, init_base[9 + d]);
+    fix(base, off_base_ang, last, 0, d, final_base[6 + d]);
+    fix(base, off_base_ang, last, 1, d, final_base[9 + d]);
+    for (int e = 0; e < n_ee; ++e) fix(motion[e], 0, 0, 0, d, ee0[3 * e + d]);
+  }
+}
+
 // ------------------------------------------------------------------ presets
 // RobotModel(Robot) (src/robot_model.cc:41-68) with the constants of
 // include/towr/models/examples/{monoped,biped,hyq,anymal}_model.h and models/go1/go1_model.h.

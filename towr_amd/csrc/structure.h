@@ -66,6 +66,8 @@ struct Structure {
   void Build();            // throws std::runtime_error
   void InitialGuess(const double* lin0, const double* ang0, const double* lin1, const double* ang1,
                     const double* ee0, double* x) const;
+  void VariableBounds(const double* init_base, const double* final_base, const double* ee0, double* lower,
+                      double* upper) const;
 
  private:
   void BuildVariables();
