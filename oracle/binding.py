@@ -15,6 +15,7 @@ _lib = None
 
 SETS_HOT_PATH = 1 | 2 | 8 | 16  # terrain, dynamic, rangeofmotion, force
 SETS_TOWR_DEFAULT = 63          # + splineacc-base-lin/-ang (4) and swing-* (32): parameters.cc:55-60
+SET_TOTAL_TIME = 64             # OptimizePhaseDurations(): ee-schedule_e variables, PhaseSplines, totalduration-e
 ROBOTS = {"monoped": 0, "biped": 1, "hyq": 2, "anymal": 3, "go1": 4}
 TERRAINS = {"flat": 0, "block": 1, "stairs": 2, "gap": 3, "slope": 4, "chimney": 5, "chimney_lr": 6}
 

@@ -87,7 +87,7 @@ class Layout:
     nodes_variables_all.cc:45-61, nodes_variables_phase_based.cc:38-298)."""
 
     def __init__(self, robot, phase_durations, contact_at_start, dt_dyn=0.1, dt_rom=0.08, dur_base=0.1,
-                 polys_swing=2, polys_stance=3):
+                 polys_swing=2, polys_stance=3, optimize_timings=False):
         self.rb = ROBOT[robot]
         self.n_ee = self.rb["n_ee"]
         self.T = 0.0
@@ -109,6 +109,17 @@ class Layout:
         for ee in range(self.n_ee):  # ee-force: swing phases constant (zero)
             off = self._phase_based("ee-force_%d" % ee, phase_durations[ee], not bool(contact_at_start[ee]),
                                     polys_stance, off, motion=False)
+        # ee-schedule<e> (phase_durations.cc:39-52): all phase durations but the last are variables
+        self.optimize_timings = optimize_timings
+        self.schedule = []
+        for ee in range(self.n_ee):
+            t_total = 0.0
+            for d in phase_durations[ee]:
+                t_total += d  # std::accumulate
+            self.schedule.append(dict(off=off, size=len(phase_durations[ee]) - 1, t_total=t_total,
+                                      initial=list(phase_durations[ee])))
+            if optimize_timings:
+                off += len(phase_durations[ee]) - 1
         self.n = off
         self.grid_dyn = time_grid(self.T, dt_dyn)
         self.grid_rom = time_grid(self.T, dt_rom)
@@ -155,8 +166,21 @@ class Layout:
                         nodes[i + 1][(0, dm)] = idx
                         idx += 1
                 i += 2
-        self.splines[name] = dict(durs=durs, nodes=nodes, const=consts, polys=polys, off=off, size=idx - off)
+        self.splines[name] = dict(durs=durs, nodes=nodes, const=consts, polys=polys, off=off, size=idx - off,
+                                  ee=int(name.split("_")[1]))
         return idx
+
+    def poly_durations(self, name, x):
+        """Polynomial durations of a spline: fixed (NodeSpline) or, with optimised timings, phase duration /
+        polynomials in the phase with the phase durations taken from x and the last one filling up to the
+        total time (PhaseSpline, phase_spline.cc:54-65; PhaseDurations::SetVariables, phase_durations.cc:77-103)."""
+        s = self.splines[name]
+        if not self.optimize_timings or "polys" not in s:
+            return s["durs"]
+        sc = self.schedule[s["ee"]]
+        ph = [x[sc["off"] + i] for i in range(sc["size"])]
+        ph.append(mpf(sc["t_total"]) - sum(ph))
+        return [ph[p] / n for (p, _, n) in s["polys"]]
 
 
 # ----------------------------------------------------------------- math
@@ -170,9 +194,13 @@ def hermite(n0, n1, T, t):
 
 def spline_point(L, name, x, t):
     s = L.splines[name]
-    seg, tl = locate(t, s["durs"])
-    T = mpf(s["durs"][seg])
-    tl = mpf(tl)
+    durs = L.poly_durations(name, x)
+    if durs is s["durs"]:
+        seg, tl = locate(t, durs)
+        T, tl = mpf(durs[seg]), mpf(tl)
+    else:  # x-dependent durations: the active segment by the reference's double-precision rule, the rest exact
+        seg, _ = locate(t, [float(d) for d in durs])
+        T, tl = durs[seg], mpf(t) - sum(durs[:seg])
     out = [[None] * 3 for _ in range(3)]
     for dm in range(3):
         def val(node, dv):
@@ -331,6 +359,9 @@ def constraints(L, terrain, x, fn_max=1000.0, sets=HOT_PATH):
     if sets & 32:
         for ee in range(L.n_ee):
             g += swing_rows(L, ee, x)
+    if sets & 64:  # totalduration-<ee> (total_duration_constraint.cc:50-56): sum of the optimised durations
+        for sc in L.schedule:
+            g.append(sum(x[sc["off"] + i] for i in range(sc["size"])))
     return g
 
 
@@ -425,6 +456,10 @@ def cases():
         # towr's whole default constraint list (adds splineacc-base-* and swing-*)
         "full_biped_walk_block": dict(robot="biped", terrain="block", phases=_gait(2, 0, 2.0), seed=17, sets=TOWR_DEFAULT),
         "full_anymal_trot_gap": dict(robot="anymal", terrain="gap", phases=_gait(4, 1, 2.0), seed=18, sets=TOWR_DEFAULT),
+        # optimised phase durations (Parameters::OptimizePhaseDurations): ee-schedule variables, PhaseSplines
+        "timings_hopper_flat": dict(robot="monoped", terrain="flat", phases=hop, seed=19, sets=TOWR_DEFAULT | 64),
+        "timings_biped_walk_stairs": dict(robot="biped", terrain="stairs", phases=_gait(2, 0, 2.0), seed=20, sets=TOWR_DEFAULT | 64),
+        "timings_anymal_trot_gap": dict(robot="anymal", terrain="gap", phases=_gait(4, 1, 2.0), seed=21, sets=TOWR_DEFAULT | 64),
     }
 
 
@@ -441,6 +476,11 @@ def make_x(L, seed):
         for nd in sf["nodes"]:
             for k, i in nd.items():
                 x[i] = rng.normal() * 80.0 + (200.0 if k == (0, 2) else 0.0)
+    if L.optimize_timings:  # phase durations: the given ones +-10 %, never at a grid time, sum < total time
+        for sc in L.schedule:
+            for i in range(sc["size"]):
+                x[sc["off"] + i] = sc["initial"][i] * (1.0 + 0.1 * rng.uniform(-1, 1))
+            assert x[sc["off"]:sc["off"] + sc["size"]].sum() < sc["t_total"] - 0.05
     return x
 
 
@@ -462,7 +502,7 @@ def _col(j):
 
 def generate(name, spec, outdir, procs=8):
     pd, con = spec["phases"]
-    L = Layout(spec["robot"], pd, con)
+    L = Layout(spec["robot"], pd, con, optimize_timings=bool(spec.get("sets", HOT_PATH) & 64))
     x64 = make_x(L, spec["seed"])
     x = [mpf(float(v)) for v in x64]
     sets = spec.get("sets", HOT_PATH)

@@ -83,6 +83,14 @@ struct CubicHermite {
     }
     return 0.0;
   }
+  // ref: polynomial.cc:236-257
+  V3 GetDerivativeOfPosWrtDuration(double t) const {
+    V3 x0 = n0.p, x1 = n1.p, v0 = n0.v, v1 = n1.v;
+    double t2 = std::pow(t, 2), t3 = std::pow(t, 3);
+    double T2 = std::pow(T, 2), T3 = std::pow(T, 3), T4 = std::pow(T, 4);
+    return (t3 * (v0 + v1)) / T3 - (t2 * (2.0 * v0 + v1)) / T2 - (3 * t3 * (2.0 * x0 - 2.0 * x1 + T * v0 + T * v1)) / T4 +
+           (2 * t2 * (3.0 * x0 - 3.0 * x1 + 2 * T * v0 + T * v1)) / T3;
+  }
   // ref: polynomial.cc:188-234 (end node)
   double DerivWrtEndNode(int dfdt, int node_value, double t) const {
     double t2 = std::pow(t, 2), t3 = std::pow(t, 3);
@@ -277,12 +285,17 @@ static NodesVars MakeNodesEEForce(int phase_count, bool contact_at_start, const 
 struct NodeSpline {
   NodesVars* nv = nullptr;
   std::vector<CubicHermite> polys;
+  SpMat jac_wrt_nodes_structure;  // node_spline.h:108; empty for a NodeSpline, all variables for a PhaseSpline
 
   NodeSpline(NodesVars* nodes, const std::vector<double>& durations) : nv(nodes) {
     polys.assign(durations.size(), CubicHermite());
     for (size_t i = 0; i < durations.size(); ++i) polys[i].T = durations[i];
     UpdateNodes();
+    jac_wrt_nodes_structure = SpMat(3, nv->rows());  // node_spline.cc:42
   }
+  virtual ~NodeSpline() = default;
+  // ref: node_spline.h:96-100 (only a PhaseSpline can answer)
+  virtual SpMat GetJacobianOfPosWrtDurations(double) const { throw std::runtime_error("durations are fixed"); }
   // ref: node_spline.cc:45-54, nodes_variables.cc:93-100
   void UpdateNodes() {
     for (size_t i = 0; i < polys.size(); ++i) {
@@ -328,9 +341,14 @@ struct NodeSpline {
     auto lt = GetLocalTime(t_global, GetPolyDurations());
     return GetJacobianWrtNodes(lt.first, lt.second, dxdt);
   }
-  // ref: node_spline.cc:72-112
+  // ref: node_spline.cc:72-82
   SpMat GetJacobianWrtNodes(int poly_id, double t_local, int dxdt) const {
-    SpMat jac(3, nv->rows());
+    SpMat jac = jac_wrt_nodes_structure;
+    FillJacobianWrtNodes(poly_id, t_local, dxdt, jac, false);
+    return jac;
+  }
+  // ref: node_spline.cc:84-112
+  void FillJacobianWrtNodes(int poly_id, double t_local, int dxdt, SpMat& jac, bool fill_with_zeros) const {
     for (int idx = 0; idx < jac.c; ++idx)
       for (const NVI& nvi : nv->info[idx])
         for (int side : {0, 1}) {  // Start, End
@@ -338,12 +356,100 @@ struct NodeSpline {
           if (node == nvi.id) {
             double val = side == 0 ? polys.at(poly_id).DerivWrtStartNode(dxdt, nvi.deriv, t_local)
                                    : polys.at(poly_id).DerivWrtEndNode(dxdt, nvi.deriv, t_local);
+            if (fill_with_zeros) val = 0.0;
             jac.coeffRef(nvi.dim, idx) += val;
           }
         }
+  }
+};
+
+// ------------------------------------------------ phase_durations.cc / phase_spline.cc (optimised timings)
+struct PhaseSpline;
+// ref: phase_durations.cc:39-154
+struct PhaseDurations {
+  std::string name;
+  std::vector<double> durations;
+  double t_total = 0;
+  Bound phase_duration_bounds;
+  bool initial_contact_state = true;
+  std::vector<PhaseSpline*> observers;
+
+  PhaseDurations(int ee, const std::vector<double>& timings, bool is_first_phase_in_contact, double min_duration,
+                 double max_duration) {
+    name = "ee-schedule" + std::to_string(ee);  // variable_names.h:47,60-63
+    durations = timings;
+    t_total = std::accumulate(timings.begin(), timings.end(), 0.0);
+    phase_duration_bounds = Bound{min_duration, max_duration};
+    initial_contact_state = is_first_phase_in_contact;
+  }
+  int rows() const { return (int)durations.size() - 1; }  // the last phase fills up to the total time
+  void GetValues(double* x) const {
+    for (int i = 0; i < rows(); ++i) x[i] = durations.at(i);
+  }
+  void SetVariables(const double* x);  // below (needs PhaseSpline)
+  // ref: phase_durations.cc:126-154.  Dense 3 x rows() matrix turned into a sparse one that keeps
+  // every entry, zeros included (sparseView(1.0, -1.0)).
+  SpMat GetJacobianOfPos(int current_phase, const V3& dx_dT, const V3& xd) const {
+    int n = rows();
+    std::vector<V3> col(n);
+    bool in_last_phase = (current_phase == (int)durations.size() - 1);
+    if (!in_last_phase) col.at(current_phase) = dx_dT;
+    for (int phase = 0; phase < current_phase; ++phase) {
+      col.at(phase) = -1.0 * xd;
+      if (in_last_phase) col.at(phase) = col.at(phase) - dx_dT;
+    }
+    SpMat jac(3, n);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < n; ++j) jac.coeffRef(i, j) = col[j](i);
     return jac;
   }
 };
+
+// ref: phase_spline.cc:35-93
+struct PhaseSpline : NodeSpline {
+  PhaseDurations* phase_durations;
+  PhaseSpline(NodesVars* nodes, PhaseDurations* pd)
+      : NodeSpline(nodes, nodes->PhaseToPolyDurations(pd->durations)), phase_durations(pd) {
+    pd->observers.push_back(this);
+    UpdatePolynomialDurations();
+    // "assume every global time can fall into every polynomial": the structure holds every variable
+    for (int i = 0; i < nv->poly_count(); ++i) FillJacobianWrtNodes(i, 0.0, kPos, jac_wrt_nodes_structure, true);
+  }
+  void UpdatePolynomialDurations() {
+    auto poly_durations = nv->PhaseToPolyDurations(phase_durations->durations);
+    for (size_t i = 0; i < polys.size(); ++i) polys.at(i).T = poly_durations.at(i);
+    for (auto& p : polys) p.UpdateCoeff();
+  }
+  SpMat GetJacobianOfPosWrtDurations(double t_global) const override {
+    V3 dx_dT = GetDerivativeOfPosWrtPhaseDuration(t_global);
+    V3 xd = GetPoint(t_global).v;
+    int current_phase = GetSegmentID(t_global, phase_durations->durations);
+    return phase_durations->GetJacobianOfPos(current_phase, dx_dT, xd);
+  }
+  V3 GetDerivativeOfPosWrtPhaseDuration(double t_global) const {
+    auto lt = GetLocalTime(t_global, GetPolyDurations());
+    int poly_id = lt.first;
+    double t_local = lt.second;
+    V3 vel = GetPoint(t_global).v;
+    V3 dxdT = polys.at(poly_id).GetDerivativeOfPosWrtDuration(t_local);
+    // ref: nodes_variables_phase_based.cc:86-98
+    double inner_derivative = 1. / nv->poly_info.at(poly_id).n_polys_in_phase;
+    double prev_polys_in_phase = nv->poly_info.at(poly_id).poly_in_phase;
+    return inner_derivative * (dxdT - prev_polys_in_phase * vel);
+  }
+};
+
+// ref: phase_durations.cc:77-103 (the assert t_total > sum is compiled out in Release; Eigen's x.sum()
+// is restated as a sequential sum, which can differ from its vectorised reduction in the last bit)
+void PhaseDurations::SetVariables(const double* x) {
+  double sum = 0.0;
+  for (int i = 0; i < rows(); ++i) {
+    durations.at(i) = x[i];
+    sum += x[i];
+  }
+  durations.back() = t_total - sum;
+  for (PhaseSpline* spline : observers) spline->UpdatePolynomialDurations();
+}
 
 void NodesVars::SetVariables(const double* x) {
   for (int idx = 0; idx < rows(); ++idx)
@@ -908,6 +1014,12 @@ struct DynamicConstraint : ConSet {
         SpMat jp = ee_motion[ee]->GetJacobianWrtNodes(t, kPos);
         jac_model = model->GetJacobianWrtEEPos(jp, ee);
       }
+      if (var_set == "ee-schedule" + std::to_string(ee)) {  // ref: dynamic_constraint.cc:107-113
+        SpMat jac_f_dT = ee_forces[ee]->GetJacobianOfPosWrtDurations(t);
+        jac_model = jac_model + model->GetJacobianWrtForce(jac_f_dT, ee);
+        SpMat jac_x_dT = ee_motion[ee]->GetJacobianOfPosWrtDurations(t);
+        jac_model = jac_model + model->GetJacobianWrtEEPos(jac_x_dT, ee);
+      }
     }
     for (int i = 0; i < 6; ++i) jac.rows[6 * k + i] = jac_model.rows[i];
   }
@@ -973,6 +1085,7 @@ struct RangeOfMotionConstraint : ConSet {
         set_rows(base_angular.DerivOfRotVecMult(t, r_W, true));
       }
       if (var_set == "ee-motion_" + std::to_string(ee)) set_rows(b_R_w * ee_motion->GetJacobianWrtNodes(t, kPos));
+      if (var_set == "ee-schedule" + std::to_string(ee)) set_rows(b_R_w * ee_motion->GetJacobianOfPosWrtDurations(t));
       k++;
     }
   }
@@ -1202,6 +1315,30 @@ struct SwingConstraint : ConSet {
   }
 };
 
+// ref: total_duration_constraint.cc:36-72
+struct TotalDurationConstraint : ConSet {
+  double T_total;
+  int ee;
+  const PhaseDurations* phase_durations;
+  TotalDurationConstraint(double T, int ee_, const PhaseDurations* pd) : T_total(T), ee(ee_), phase_durations(pd) {
+    name = "totalduration-" + std::to_string(ee);
+    rows = 1;
+  }
+  void GetValues(double* g) const override {
+    double sum = 0.0;  // phase_durations_->GetValues().sum(): excludes the last duration
+    for (int i = 0; i < phase_durations->rows(); ++i) sum += phase_durations->durations.at(i);
+    g[0] = sum;
+  }
+  void GetBounds(Bound* b) const override {
+    double min_duration_last_phase = 0.2;
+    b[0] = Bound{0.1, T_total - min_duration_last_phase};
+  }
+  void FillJacobianBlock(const std::string& var_set, SpMat& jac) const override {
+    if (var_set == phase_durations->name)
+      for (int col = 0; col < phase_durations->rows(); ++col) jac.coeffRef(0, col) = 1.0;
+  }
+};
+
 // ------------------------------------------- parameters.cc / nlp_formulation.cc
 // ref: parameters.cc:82-98
 static std::vector<double> GetBasePolyDurations(double T, double dt) {
@@ -1232,6 +1369,8 @@ struct orc_problem {
   int polys_swing, polys_stance;
 
   std::vector<std::unique_ptr<NodesVars>> var_sets;  // order: nlp_formulation.cc:68-82
+  std::vector<std::unique_ptr<PhaseDurations>> schedules;  // nlp_formulation.cc:183-198 (always built)
+  bool optimize_timings = false;                           // Parameters::IsOptimizeTimings, parameters.cc:128-135
   std::vector<std::unique_ptr<NodeSpline>> splines;
   Vars vars;
   Splines sp;
@@ -1240,8 +1379,16 @@ struct orc_problem {
   int n_vars() const {
     int n = 0;
     for (auto& v : var_sets) n += v->rows();
+    if (optimize_timings)
+      for (auto& s : schedules) n += s->rows();
     return n;
   }
+  // the ifopt variable sets in order (nlp_formulation.cc:63-93): node sets, then ee-schedule_e if optimised
+  int n_sets() const { return (int)var_sets.size() + (optimize_timings ? (int)schedules.size() : 0); }
+  const std::string& set_name(int i) const {
+    return i < (int)var_sets.size() ? var_sets[i]->name : schedules.at(i - var_sets.size())->name;
+  }
+  int set_rows(int i) const { return i < (int)var_sets.size() ? var_sets[i]->rows() : schedules.at(i - var_sets.size())->rows(); }
   int n_rows() const {
     int m = 0;
     for (auto& c : cons) m += c->rows;
@@ -1254,6 +1401,11 @@ struct orc_problem {
       v->SetVariables(x + off);
       off += v->rows();
     }
+    if (optimize_timings)
+      for (auto& s : schedules) {
+        s->SetVariables(x + off);
+        off += s->rows();
+      }
   }
 };
 
@@ -1293,9 +1445,17 @@ orc_problem* orc_create(int robot, int terrain, int n_ee, const int* n_phases, c
                                                               "ee-force_" + std::to_string(ee), polys_per_stance_force)));
     for (auto& v : P->var_sets) P->vars.sets.push_back(v.get());
 
-    // splines, ref: spline_holder.cc:35-61 (fixed timings -> NodeSpline)
+    // contact schedule, ref: nlp_formulation.cc:183-198, parameters.cc:52 (bound_phase_duration_)
+    P->optimize_timings = (constraint_sets & ORC_SET_TOTAL_TIME) != 0;
+    for (int ee = 0; ee < n_ee; ++ee)
+      P->schedules.emplace_back(new PhaseDurations(ee, P->phase_durations[ee], P->contact_at_start[ee] != 0, 0.2, 1.0));
+    // splines, ref: spline_holder.cc:35-61 (fixed timings -> NodeSpline, optimised -> PhaseSpline)
+    int ee_of_spline = -1;
     auto add_spline = [&](NodesVars* nv, const std::vector<double>& d) {
-      P->splines.emplace_back(new NodeSpline(nv, d));
+      if (P->optimize_timings && ee_of_spline >= 0)
+        P->splines.emplace_back(new PhaseSpline(nv, P->schedules[ee_of_spline].get()));
+      else
+        P->splines.emplace_back(new NodeSpline(nv, d));
       nv->observer = P->splines.back().get();
       return P->splines.back().get();
     };
@@ -1303,10 +1463,12 @@ orc_problem* orc_create(int robot, int terrain, int n_ee, const int* n_phases, c
     P->sp.base_angular = add_spline(P->var_sets[1].get(), base_durations);
     for (int ee = 0; ee < n_ee; ++ee) {
       NodesVars* m = P->var_sets[2 + ee].get();
+      ee_of_spline = ee;
       P->sp.ee_motion.push_back(add_spline(m, m->PhaseToPolyDurations(P->phase_durations[ee])));
     }
     for (int ee = 0; ee < n_ee; ++ee) {
       NodesVars* f = P->var_sets[2 + n_ee + ee].get();
+      ee_of_spline = ee;
       P->sp.ee_force.push_back(add_spline(f, f->PhaseToPolyDurations(P->phase_durations[ee])));
     }
 
@@ -1330,6 +1492,9 @@ orc_problem* orc_create(int robot, int terrain, int n_ee, const int* n_phases, c
     if (constraint_sets & ORC_SET_SWING)
       for (int ee = 0; ee < n_ee; ++ee)
         P->cons.emplace_back(new SwingConstraint("ee-motion_" + std::to_string(ee), P->vars));
+    if (constraint_sets & ORC_SET_TOTAL_TIME)  // Parameters::OptimizePhaseDurations appends TotalTime (parameters.cc:76-80)
+      for (int ee = 0; ee < n_ee; ++ee)
+        P->cons.emplace_back(new TotalDurationConstraint(P->T, ee, P->schedules[ee].get()));
     return P;
   } catch (const std::exception&) {
     return nullptr;
@@ -1339,10 +1504,10 @@ orc_problem* orc_create(int robot, int terrain, int n_ee, const int* n_phases, c
 void orc_destroy(orc_problem* p) { delete p; }
 int orc_n_vars(const orc_problem* p) { return p->n_vars(); }
 int orc_n_rows(const orc_problem* p) { return p->n_rows(); }
-int orc_n_var_sets(const orc_problem* p) { return (int)p->var_sets.size(); }
+int orc_n_var_sets(const orc_problem* p) { return p->n_sets(); }
 int orc_n_con_sets(const orc_problem* p) { return (int)p->cons.size(); }
-const char* orc_var_set_name(const orc_problem* p, int i) { return p->var_sets.at(i)->name.c_str(); }
-int orc_var_set_size(const orc_problem* p, int i) { return p->var_sets.at(i)->rows(); }
+const char* orc_var_set_name(const orc_problem* p, int i) { return p->set_name(i).c_str(); }
+int orc_var_set_size(const orc_problem* p, int i) { return p->set_rows(i); }
 const char* orc_con_set_name(const orc_problem* p, int i) { return p->cons.at(i)->name.c_str(); }
 int orc_con_set_rows(const orc_problem* p, int i) { return p->cons.at(i)->rows; }
 
@@ -1378,6 +1543,12 @@ void orc_initial_guess(orc_problem* P, const double* bl0, const double* ba0, con
     v->GetValues(x_out + off);
     off += v->rows();
   }
+  if (P->optimize_timings)
+    for (auto& sc : P->schedules) {  // PhaseDurations::GetValues: the given phase durations (all but the last)
+      sc->durations = P->phase_durations[&sc - &P->schedules[0]];
+      sc->GetValues(x_out + off);
+      off += sc->rows();
+    }
 }
 
 // Variable bounds as NlpFormulation::Make{Base,Endeffector,Force}Variables set them
@@ -1404,6 +1575,13 @@ void orc_variable_bounds(orc_problem* P, const double* init_base, const double* 
       upper[off] = b.up;
       ++off;
     }
+  if (P->optimize_timings)
+    for (auto& sc : P->schedules)  // PhaseDurations::GetBounds, phase_durations.cc:105-114
+      for (int i = 0; i < sc->rows(); ++i) {
+        lower[off] = sc->phase_duration_bounds.lo;
+        upper[off] = sc->phase_duration_bounds.up;
+        ++off;
+      }
 }
 
 // ifopt::ConstraintSet::GetJacobian + Composite row stacking + Problem::EvalNonzerosOfJacobian
@@ -1414,9 +1592,9 @@ int orc_eval(orc_problem* P, const double* x, double* g, int* row_ptr, int* col_
   for (auto& c : P->cons) {
     if (g) c->GetValues(g + row0);
     std::vector<SpMat> blocks;
-    for (auto& vs : P->var_sets) {
-      SpMat jac(c->rows, vs->rows());
-      c->FillJacobianBlock(vs->name, jac);
+    for (int vs = 0; vs < P->n_sets(); ++vs) {
+      SpMat jac(c->rows, P->set_rows(vs));
+      c->FillJacobianBlock(P->set_name(vs), jac);
       blocks.push_back(std::move(jac));
     }
     for (int r = 0; r < c->rows; ++r) {

@@ -36,6 +36,7 @@ orc_problem* orc_create(int robot, int terrain, int n_ee, const int* n_phases,
 enum {
   ORC_SET_TERRAIN = 1, ORC_SET_DYNAMIC = 2, ORC_SET_BASE_ACC = 4, ORC_SET_ROM = 8, ORC_SET_FORCE = 16,
   ORC_SET_SWING = 32,
+  ORC_SET_TOTAL_TIME = 64,  // Parameters::OptimizePhaseDurations (parameters.cc:76-80): timings become variables
   ORC_SETS_HOT_PATH = 1 | 2 | 8 | 16,
   ORC_SETS_TOWR_DEFAULT = 63
 };

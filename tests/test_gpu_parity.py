@@ -48,6 +48,8 @@ def test_gpu_matches_mpmath_golden(path):
         pd.append(d["phase_durations"][o:o + k])
         o += k
     sets = int(d["constraint_sets"]) if "constraint_sets" in d.files else 27
+    if sets & 64 and not getattr(ta, "SUPPORTS_OPTIMISED_TIMINGS", False):
+        pytest.skip("optimised timings (SURVEY 8f #2): oracle and fixtures exist, the device path is next")
     case = Case(str(d["robot"]), str(d["terrain"]), ta.schedule(pd, list(d["contact_at_start"])), constraint_sets=sets)
     S = case.S
     batch, g, j = _eval_case(case, [d["x"]])

@@ -265,6 +265,49 @@ def test_swing_known_answers():
         ob.OracleProblem("monoped", "flat", [[0.3, 0.5, 0.3, 0.5]], [0], constraint_sets=ob.SETS_TOWR_DEFAULT)
 
 
+def test_optimised_timings_known_answers():
+    """Parameters::OptimizePhaseDurations (parameters.cc:76-80): ee-schedule<e> variable sets of n_phases-1
+    durations bounded by [0.2, 1.0] (parameters.cc:52), every Jacobian row of an ee spline holds ALL variables
+    of its set (phase_spline.cc:44-51), totalduration-<e> = sum of the optimised durations in
+    [0.1, T - 0.2] (total_duration_constraint.cc:50-72)."""
+    pd, con = ob.gait(2, 0, 2.0)
+    F = ob.OracleProblem("biped", "flat", pd, con, constraint_sets=ob.SETS_TOWR_DEFAULT)
+    P = ob.OracleProblem("biped", "flat", pd, con, constraint_sets=ob.SETS_TOWR_DEFAULT | ob.SET_TOTAL_TIME)
+    assert P.var_sets[:-2] == F.var_sets and P.var_sets[-2:] == [("ee-schedule0", len(pd[0]) - 1), ("ee-schedule1", len(pd[1]) - 1)]
+    assert P.con_sets[:-2] == F.con_sets and P.con_sets[-2:] == [("totalduration-0", 1), ("totalduration-1", 1)]
+    ee = [[0.0, 0.2, 0.0], [0.0, -0.2, 0.0]]
+    x = P.initial_guess([0, 0, 0.65], [0, 0, 0], [1, 0, 0.65], [0, 0, 0], ee)
+    xf = F.initial_guess([0, 0, 0.65], [0, 0, 0], [1, 0, 0.65], [0, 0, 0], ee)
+    assert np.array_equal(x[:F.n], xf) and np.array_equal(x[F.n:], np.concatenate([pd[0][:-1], pd[1][:-1]]))
+    lo, up = P.variable_bounds(np.zeros(12), np.zeros(12), ee)
+    assert np.all(lo[F.n:] == 0.2) and np.all(up[F.n:] == 1.0)
+    g, rp, ci, va = P.eval(x)
+    gf, rpf, cif, vaf = F.eval(xf)
+    # same spline values at the unperturbed durations: identical g, and the last rows are the duration sums
+    assert np.abs(g[:F.m] - gf).max() < 1e-12 * np.abs(gf).max()
+    assert g[F.m] == pytest.approx(sum(pd[0][:-1]), abs=1e-15) and g[F.m + 1] == pytest.approx(sum(pd[1][:-1]), abs=1e-15)
+    clo, cup = P.bounds()
+    assert np.array_equal(clo[F.m:], [0.1, 0.1]) and np.allclose(cup[F.m:], [2.0 - 0.2] * 2, atol=1e-15)
+    r = F.m
+    assert ci[rp[r]:rp[r + 1]].tolist() == list(range(F.n, F.n + len(pd[0]) - 1)) and np.all(va[rp[r]:rp[r + 1]] == 1.0)
+    # pattern: a rangeofmotion-0 row = 12 base-lin + 12 (8 for x) base-ang + all ee-motion_0 variables + all durations
+    sets = _set_rows(P)
+    sizes = dict(P.var_sets)
+    a, _ = sets["rangeofmotion-0"]
+    assert rp[a + 2] - rp[a + 1] == 12 + 12 + sizes["ee-motion_0"] + sizes["ee-schedule0"]
+    assert rp[a + 1] - rp[a] == 12 + 8 + sizes["ee-motion_0"] + sizes["ee-schedule0"]
+    # the non-zero values of the denser rows are the fixed-timing values, everything else is an explicit zero
+    a, b = sets["dynamic"]
+    af, _ = _set_rows(F)["dynamic"]
+    for k in (0, 7, 13):
+        for i in range(6):
+            row = dict(zip(ci[rp[a + 6 * k + i]:rp[a + 6 * k + i + 1]].tolist(), va[rp[a + 6 * k + i]:rp[a + 6 * k + i + 1]]))
+            rowf = dict(zip(cif[rpf[af + 6 * k + i]:rpf[af + 6 * k + i + 1]].tolist(), vaf[rpf[af + 6 * k + i]:rpf[af + 6 * k + i + 1]]))
+            for c, v in rowf.items():
+                assert row[c] == pytest.approx(v, rel=1e-12, abs=1e-12)
+            assert all(v == 0.0 for c, v in row.items() if c < F.n and c not in rowf)
+
+
 def test_time_grid_and_sizes_follow_the_reference_rules():
     """time_discretization_constraint.cc:37-50: K = floor(T/dt)+2 with a (near-)duplicate last node;
     sizes of the BASELINE configs as derived in SURVEY App. B."""
