@@ -11,12 +11,12 @@
  *     the message of the last failure on the calling thread.  No exceptions cross the ABI.
  *   - handles are thread-compatible: distinct handles may be used from distinct threads.
  *   - "x" is the stacked ifopt variable vector in the reference order
- *        base-lin | base-ang | ee-motion_0.. | ee-force_0..      (nlp_formulation.cc:68-82)
+ *        base-lin | base-ang | ee-motion_0.. | ee-force_0.. [| ee-schedule0..]   (nlp_formulation.cc:63-93)
  *     "g" are the stacked constraint values and "jac" the Jacobian non-zeros in the CSR
  *     order ifopt::Problem::EvalNonzerosOfJacobian copies out (row-major, columns
  *     ascending, explicit structural zeros kept), for the constraint sets
  *        terrain-ee-motion_e.. | dynamic | splineacc-base-lin | splineacc-base-ang |
- *        rangeofmotion-e.. | force-ee-force_e.. | swing-ee-motion_e..
+ *        rangeofmotion-e.. | force-ee-force_e.. | swing-ee-motion_e.. | totalduration-e..
  *     i.e. params_.constraints_ order (parameters.cc:55-60); twr_params.constraint_sets selects
  *     which families exist (default: the four of the hot path).
  */
@@ -50,8 +50,15 @@ enum {
   TWR_SET_ROM = 8,       /* RangeOfMotionConstraint per ee    (nlp_formulation.cc:247-262) */
   TWR_SET_FORCE = 16,    /* ForceConstraint per ee            (nlp_formulation.cc:291-304) */
   TWR_SET_SWING = 32,    /* SwingConstraint per ee            (nlp_formulation.cc:306-317) */
+  /* Parameters::OptimizePhaseDurations() (parameters.cc:76-80): TotalDurationConstraint per ee
+   * (nlp_formulation.cc:264-276) AND, because IsOptimizeTimings() becomes true (parameters.cc:128-135),
+   * the phase durations join x as variable sets ee-schedule<e> (n_phases-1 each, after ee-force_*),
+   * the ee splines become PhaseSplines (spline_holder.cc:48-52): every Jacobian row of an ee spline
+   * holds all variables of its set, and dynamic / rangeofmotion rows gain the duration columns. */
+  TWR_SET_TOTAL_TIME = 64,
   TWR_SETS_HOT_PATH = 1 | 2 | 8 | 16,
-  TWR_SETS_TOWR_DEFAULT = 63
+  TWR_SETS_TOWR_DEFAULT = 63,
+  TWR_SETS_ALL = 127
 };
 
 /* Robot + terrain constants: the POD "model blob" that rank 0 broadcasts over RCCL.

@@ -35,6 +35,14 @@ CONFIGS = [
     ("anymal", "stairs", 0, 2.4, dict(constraint_sets=2 | 32)),
     ("biped", "flat", 1, 1.8, dict(constraint_sets=4)),
     ("anymal", "chimney", 1, 2.0, dict(constraint_sets=1 | 16 | 32)),
+    # optimised phase durations (Parameters::OptimizePhaseDurations): ee-schedule sets, all-variables rows
+    ("monoped", "flat", None, 2.0, dict(constraint_sets=127)),
+    ("biped", "stairs", 0, 2.0, dict(constraint_sets=127)),
+    ("anymal", "gap", 1, 2.0, dict(constraint_sets=127)),
+    ("anymal", "flat", 1, 2.0, dict(constraint_sets=127, **k_params(2.0, 200))),
+    ("hyq", "slope", 3, 2.2, dict(constraint_sets=127, polys_per_swing=3, polys_per_stance_force=2)),
+    ("go1", "block", 2, 1.9, dict(constraint_sets=2 | 64)),
+    ("biped", "flat", 1, 1.8, dict(constraint_sets=8 | 64)),
 ]
 
 
@@ -75,7 +83,11 @@ def test_structure_matches_oracle(cfg):
     assert np.array_equal(lo, lo2) and np.array_equal(up, up2)
     fixed = lo == up
     n_fixed_ee = sum(3 for _ in range(S.n_ee))
-    assert fixed.sum() == 12 + 11 + n_fixed_ee and np.all(lo[~fixed] == -1e20) and np.all(up[~fixed] == 1e20)
+    n_sched = sum(v["size"] for v in S.var_sets if v["name"].startswith("ee-schedule"))
+    free = ~fixed
+    free[S.n - n_sched:] = False
+    assert fixed.sum() == 12 + 11 + n_fixed_ee and np.all(lo[free] == -1e20) and np.all(up[free] == 1e20)
+    assert np.all(lo[S.n - n_sched:] == 0.2) and np.all(up[S.n - n_sched:] == 1.0)
 
 
 @pytest.mark.parametrize("n_ee", [1, 2, 4])
@@ -156,7 +168,7 @@ def test_error_behaviour():
         ta.Structure(ta.model_preset("anymal", "flat"), bad)
     with pytest.raises(ta.TowrError):
         ta.Structure(ta.model_preset("biped", "flat"), ta.gait_combo(2, 0, 2.0), ta.params_default(dt_dynamic=0.0))
-    for mask in (0, 64, -1):
+    for mask in (0, 128, -1):
         with pytest.raises(ta.TowrError, match="constraint_sets"):
             ta.Structure(ta.model_preset("biped", "flat"), ta.gait_combo(2, 0, 2.0), ta.params_default(constraint_sets=mask))
     # SwingConstraint "assumes ... starting and ending in stance" (swing_constraint.cc:66): a foot that

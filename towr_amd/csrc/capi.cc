@@ -127,7 +127,7 @@ int twr_structure_create(const twr_model* model, const twr_schedule* schedule, c
     h->s.params = *params;
     if (params->polys_per_swing < 1 || params->polys_per_stance_force < 1)
       throw std::runtime_error("polynomials per phase must be >= 1");
-    if (params->constraint_sets <= 0 || (params->constraint_sets & ~TWR_SETS_TOWR_DEFAULT))
+    if (params->constraint_sets <= 0 || (params->constraint_sets & ~TWR_SETS_ALL))
       throw std::runtime_error("constraint_sets must be a non-empty mask of TWR_SET_* bits");
     h->s.Build();
     *out = h.release();
@@ -214,6 +214,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     for (int i = 0; i < n_structs; ++i) {
       if (!structs[i]) throw std::runtime_error("null structure");
       if (structs[i]->s.n_ee != b->n_ee) throw std::runtime_error("all structures of a batch must share n_ee");
+      if (structs[i]->s.timings) throw std::runtime_error("optimised timings (TWR_SET_TOTAL_TIME): host structure only, no device path yet");
       void* d = nullptr;
       TWR_HIP(hipMalloc(&d, structs[i]->s.blob.size()));
       b->blobs.push_back(d);

@@ -80,6 +80,40 @@ struct SwingNode {    // one non-constant ee-motion node (swing_constraint.cc:44
   int32_t pad;
 };
 
+// One polynomial of a phase-based spline when the phase durations are optimised (PhaseSpline): which
+// phase it belongs to (NodesVariablesPhaseBased::PolyInfo, nodes_variables_phase_based.h:70-82), its
+// candidate descriptors as in PolyDesc, and where its variables sit inside rows that hold ALL variables
+// of the set (phase_spline.cc:44-51).
+struct PhasePoly {
+  int32_t phase, n_in_phase, poly_in_phase;
+  int32_t xbase;
+  uint32_t meta;
+  uint16_t cand[12];
+  uint16_t base_ne[3];  // set variables before xbase with dim != r   (dynamic ang row r)
+  uint16_t base_eq[3];  // set variables before xbase with dim == d   (dynamic lin row d)
+  uint16_t base_all;    // set variables before xbase                 (rangeofmotion rows)
+  uint16_t pad[3];
+};
+static_assert(sizeof(PhasePoly) == 64, "PhasePoly layout");
+
+// Tables of the optimised-timings variant (TWR_SET_TOTAL_TIME), appended to DevStruct.
+struct PhaseTables {
+  int32_t off_sched[kMaxEE];   // x offset of ee-schedule<e>
+  int32_t n_phases[kMaxEE];
+  int32_t n_mpoly[kMaxEE], n_fpoly[kMaxEE];
+  uint32_t o_mpoly[kMaxEE], o_fpoly[kMaxEE];  // PhasePoly arrays
+  int32_t mne[kMaxEE][3], fne[kMaxEE][3], feq[kMaxEE][3];  // set-wide variable counts by dim (see PhasePoly)
+  int32_t msize[kMaxEE];       // variables of ee-motion_e
+  int32_t len_ang[3], len_lin[3], node_vals;  // dynamic: row lengths and values per time node
+  int32_t rom_len[kMaxEE][3], rom_node_vals[kMaxEE];
+  int32_t row_total, nnz_total;  // totalduration-<e> rows (adjacent)
+  uint32_t o_tdyn, o_trom;     // double t_global[K] of the dynamic / rangeofmotion grids
+  int32_t k_dyn, k_rom;
+  int32_t row_dyn, nnz_dyn, row_rom[kMaxEE], nnz_rom[kMaxEE];
+  int32_t off_lin, off_ang;
+  double t_total[kMaxEE];      // PhaseDurations::t_total_
+};
+
 // Blob header: model constants + what the node kernel needs.  The terrain-ee-motion_e sets are
 // adjacent in g / jac, and so are the force-ee-force_e sets, so each family is one flat node list.
 struct DevStruct {
@@ -100,6 +134,8 @@ struct DevStruct {
   double mass, gravity, mu, flat_height;
   double Ib[6];  // body inertia tensor entries (0,0),(0,1),(0,2),(1,1),(1,2),(2,2) incl. the sign of
                  // single_rigid_body_dynamics.cc:40-42
+  int32_t timings;      // 1: optimised phase durations, PhaseTables at o_phase
+  uint32_t o_phase;
 };
 
 // Work items: one contiguous run of time nodes of one constraint set of one problem.  All

@@ -208,6 +208,16 @@ void Structure::BuildVariables() {
     var_sets.push_back({"ee-force_" + std::to_string(e), off, force.back().var_size, 0, 0});
     off += force.back().var_size;
   }
+  // MakeContactScheduleVariables (src/nlp_formulation.cc:183-198), part of x only when the timings are
+  // optimised (:78-82); PhaseDurations holds n_phases-1 variables (src/phase_durations.cc:45)
+  timings = (params.constraint_sets & TWR_SET_TOTAL_TIME) != 0;
+  if (timings)
+    for (int e = 0; e < n_ee; ++e) {
+      if (schedule.n_phases[e] < 2) throw std::runtime_error("optimised timings need at least two phases per foot");
+      off_schedule[e] = off;
+      var_sets.push_back({"ee-schedule" + std::to_string(e), off, schedule.n_phases[e] - 1, 0, 0});
+      off += schedule.n_phases[e] - 1;
+    }
   n_vars = off;
   mpoly.resize(n_ee);
   fpoly.resize(n_ee);
@@ -325,6 +335,19 @@ void Structure::BuildPattern() {
     for (int s = 0; s < nslots; ++s)
       if ((dim_of_slot[s] == want_dim) == equal) out.push_back(p.xbase + s);
   };
+  auto set_cols = [&](const SplineLayout& s, int want_dim, bool equal, std::vector<int>& out) {
+    // all variables of a phase-based set whose dim ==/!= want_dim, ascending
+    std::vector<int> dim_of(s.var_size, -1);
+    for (int n = 0; n < s.n_nodes; ++n)
+      for (int dv = 0; dv < 2; ++dv)
+        for (int d = 0; d < 3; ++d)
+          if (s.at(n, dv, d) >= 0) dim_of[s.at(n, dv, d) - s.var_offset] = d;
+    for (int i = 0; i < s.var_size; ++i)
+      if ((dim_of[i] == want_dim) == equal) out.push_back(s.var_offset + i);
+  };
+  auto sched_cols = [&](int e, std::vector<int>& out) {
+    for (int i = 0; i < schedule.n_phases[e] - 1; ++i) out.push_back(off_schedule[e] + i);
+  };
   const int sets = params.constraint_sets;
   // --- terrain-ee-motion_e  (terrain_constraint.cc:90-108): [x, y, z] of node id = row+1
   for (int e = 0; e < n_ee && (sets & TWR_SET_TERRAIN); ++e) {
@@ -348,8 +371,14 @@ void Structure::BuildPattern() {
           for (int d = 0; d < 3; ++d)
             if (d != r) c.push_back(off_base_lin + 6 * node + 3 * dv + d);
       for (int i = 0; i < 12; ++i) c.push_back(off_base_ang + 6 * q + i);  // structurally full
-      for (int e = 0; e < n_ee; ++e) slots_cols(mpoly[e][dyn_motion[e][k].poly], r, false, c);  // [f]x J_p
-      for (int e = 0; e < n_ee; ++e) slots_cols(fpoly[e][dyn_force[e][k].poly], r, false, c);   // [r]x J_f
+      if (!timings) {
+        for (int e = 0; e < n_ee; ++e) slots_cols(mpoly[e][dyn_motion[e][k].poly], r, false, c);  // [f]x J_p
+        for (int e = 0; e < n_ee; ++e) slots_cols(fpoly[e][dyn_force[e][k].poly], r, false, c);   // [r]x J_f
+      } else {  // PhaseSpline: every variable of the set (phase_spline.cc:44-51), then the duration columns
+        for (int e = 0; e < n_ee; ++e) set_cols(motion[e], r, false, c);
+        for (int e = 0; e < n_ee; ++e) set_cols(force[e], r, false, c);
+        for (int e = 0; e < n_ee; ++e) sched_cols(e, c);  // dynamic_constraint.cc:107-113
+      }
       rows.push_back(c);
       lower.push_back(0.0);
       upper.push_back(0.0);
@@ -357,7 +386,12 @@ void Structure::BuildPattern() {
     for (int d = 0; d < 3; ++d) {  // LX, LY, LZ
       std::vector<int> c;
       for (int j = 0; j < 4; ++j) c.push_back(off_base_lin + 6 * q + 3 * j + d);  // m J_acc
-      for (int e = 0; e < n_ee; ++e) slots_cols(fpoly[e][dyn_force[e][k].poly], d, true, c);  // -J_f
+      if (!timings) {
+        for (int e = 0; e < n_ee; ++e) slots_cols(fpoly[e][dyn_force[e][k].poly], d, true, c);  // -J_f
+      } else {
+        for (int e = 0; e < n_ee; ++e) set_cols(force[e], d, true, c);
+        for (int e = 0; e < n_ee; ++e) sched_cols(e, c);
+      }
       rows.push_back(c);
       lower.push_back(0.0);
       upper.push_back(0.0);
@@ -391,7 +425,12 @@ void Structure::BuildPattern() {
         for (int i = 0; i < 12; ++i) c.push_back(off_base_lin + 6 * q + i);  // -R^T J_c
         for (int i = 0; i < 12; ++i)  // DerivOfRotVecMult(inverse): row 0 does not depend on roll
           if (!(r == 0 && i % 3 == 0)) c.push_back(off_base_ang + 6 * q + i);
-        for (int s = 0; s < (int)(mp.meta & 0xF); ++s) c.push_back(mp.xbase + s);  // R^T J_p
+        if (!timings) {
+          for (int s = 0; s < (int)(mp.meta & 0xF); ++s) c.push_back(mp.xbase + s);  // R^T J_p
+        } else {  // b_R_w (dense) times the all-variables PhaseSpline rows, then the duration columns (:106-108)
+          for (int i = 0; i < motion[e].var_size; ++i) c.push_back(motion[e].var_offset + i);
+          sched_cols(e, c);
+        }
         rows.push_back(c);
         lower.push_back(model.nominal_stance[e][r] - model.max_dev[r]);  // :71-81
         upper.push_back(model.nominal_stance[e][r] + model.max_dev[r]);
@@ -423,6 +462,15 @@ void Structure::BuildPattern() {
         upper.push_back(0.0);
       }
     }
+  }
+  // --- totalduration-e (total_duration_constraint.cc:50-72): sum of the optimised durations
+  for (int e = 0; e < n_ee && (sets & TWR_SET_TOTAL_TIME); ++e) {
+    begin_set("totalduration-" + std::to_string(e), 1);
+    std::vector<int> c;
+    sched_cols(e, c);
+    rows.push_back(c);
+    lower.push_back(0.1);
+    upper.push_back(T - 0.2);  // min_duration_last_phase
   }
   n_rows = (int)rows.size();
   row_ptr.assign(n_rows + 1, 0);
@@ -540,6 +588,102 @@ void Structure::PackBlob() {
     }
     off_rom_recs[e] = put(rc.data(), rc.size() * sizeof(RomRec));
   }
+  // --- optimised timings: polynomial tables, set-wide counts, global grid times
+  if (timings) {
+    PhaseTables& pt = phase_tables;
+    std::memset(&pt, 0, sizeof(pt));
+    auto dim_table = [&](const SplineLayout& sl) {
+      std::vector<int> dim_of(sl.var_size, -1);
+      for (int n = 0; n < sl.n_nodes; ++n)
+        for (int dv = 0; dv < 2; ++dv)
+          for (int d = 0; d < 3; ++d)
+            if (sl.at(n, dv, d) >= 0) dim_of[sl.at(n, dv, d) - sl.var_offset] = d;
+      return dim_of;
+    };
+    auto poly_table = [&](const SplineLayout& sl, const std::vector<PolyDesc>& pd, int n_changing) {
+      std::vector<PhasePoly> out(pd.size());
+      std::vector<int> dim_of = dim_table(sl);
+      int in_phase = 0;
+      for (size_t q = 0; q < pd.size(); ++q) {
+        PhasePoly& pp = out[q];
+        std::memset(&pp, 0, sizeof(pp));
+        in_phase = (q > 0 && sl.poly_phase[q] == sl.poly_phase[q - 1]) ? in_phase + 1 : 0;
+        int n_in = 0;
+        for (size_t q2 = 0; q2 < pd.size(); ++q2) n_in += sl.poly_phase[q2] == sl.poly_phase[q];
+        (void)n_changing;
+        pp.phase = sl.poly_phase[q];
+        pp.n_in_phase = n_in;
+        pp.poly_in_phase = in_phase;
+        pp.xbase = pd[q].xbase;
+        pp.meta = pd[q].meta;
+        std::memcpy(pp.cand, pd[q].cand, sizeof(pp.cand));
+        const int before = (pd[q].meta & 0xF) ? pd[q].xbase - sl.var_offset : 0;
+        for (int i = 0; i < before; ++i) {
+          for (int r = 0; r < 3; ++r) {
+            if (dim_of[i] != r) pp.base_ne[r]++;
+            if (dim_of[i] == r) pp.base_eq[r]++;
+          }
+        }
+        pp.base_all = (uint16_t)before;
+      }
+      return out;
+    };
+    for (int e = 0; e < n_ee; ++e) {
+      pt.off_sched[e] = off_schedule[e];
+      pt.n_phases[e] = schedule.n_phases[e];
+      pt.t_total[e] = std::accumulate(schedule.phase_durations[e], schedule.phase_durations[e] + schedule.n_phases[e], 0.0);
+      auto mp = poly_table(motion[e], mpoly[e], params.polys_per_swing);
+      auto fp = poly_table(force[e], fpoly[e], params.polys_per_stance_force);
+      pt.n_mpoly[e] = (int)mp.size();
+      pt.n_fpoly[e] = (int)fp.size();
+      pt.o_mpoly[e] = put(mp.data(), mp.size() * sizeof(PhasePoly));
+      pt.o_fpoly[e] = put(fp.data(), fp.size() * sizeof(PhasePoly));
+      std::vector<int> dm = dim_table(motion[e]), df = dim_table(force[e]);
+      for (int r = 0; r < 3; ++r) {
+        for (int v : dm) pt.mne[e][r] += v != r;
+        for (int v : df) { pt.fne[e][r] += v != r; pt.feq[e][r] += v == r; }
+      }
+      pt.msize[e] = motion[e].var_size;
+    }
+    int sched_total = 0;
+    for (int e = 0; e < n_ee; ++e) sched_total += schedule.n_phases[e] - 1;
+    for (int r = 0; r < 3; ++r) {
+      pt.len_ang[r] = 20 + sched_total;
+      pt.len_lin[r] = 4 + sched_total;
+      for (int e = 0; e < n_ee; ++e) {
+        pt.len_ang[r] += pt.mne[e][r] + pt.fne[e][r];
+        pt.len_lin[r] += pt.feq[e][r];
+      }
+      pt.node_vals += pt.len_ang[r] + pt.len_lin[r];
+    }
+    for (int e = 0; e < n_ee; ++e) {
+      for (int r = 0; r < 3; ++r) {
+        pt.rom_len[e][r] = 12 + (r == 0 ? 8 : 12) + pt.msize[e] + schedule.n_phases[e] - 1;
+        pt.rom_node_vals[e] += pt.rom_len[e][r];
+      }
+      pt.row_rom[e] = row_rom[e];
+      pt.nnz_rom[e] = nnz_rom[e];
+    }
+    pt.o_tdyn = put(grid_dyn.data(), grid_dyn.size() * sizeof(double));
+    pt.o_trom = put(grid_rom.data(), grid_rom.size() * sizeof(double));
+    pt.k_dyn = dyn_set ? (int)grid_dyn.size() : 0;
+    pt.k_rom = have_rom ? (int)grid_rom.size() : 0;
+    pt.row_dyn = row_dyn;
+    pt.nnz_dyn = nnz_dyn;
+    pt.off_lin = off_base_lin;
+    pt.off_ang = off_base_ang;
+    if (const SetInfo* si = FindSet("totalduration-0")) {
+      pt.row_total = si->offset;
+      pt.nnz_total = si->nnz_offset;
+    }
+    // the pattern builder and these closed forms must agree
+    if (dyn_set && dyn_set->nnz != pt.node_vals * (int)grid_dyn.size()) throw std::runtime_error("dynamic row lengths inconsistent");
+    for (int e = 0; e < n_ee && have_rom; ++e)
+      if (FindSet("rangeofmotion-" + std::to_string(e))->nnz != pt.rom_node_vals[e] * (int)grid_rom.size())
+        throw std::runtime_error("rangeofmotion row lengths inconsistent");
+    h.timings = 1;
+    h.o_phase = put(&pt, sizeof(pt));
+  }
   h.mass = model.mass; h.gravity = model.gravity; h.mu = model.friction; h.flat_height = model.flat_height;
   // BuildInertiaTensor (single_rigid_body_dynamics.cc:36-44): off-diagonals are the negated products of inertia
   const double* I = model.inertia;  // Ixx,Iyy,Izz,Ixy,Ixz,Iyz
@@ -651,6 +795,9 @@ void Structure::InitialGuess(const double* lin0, const double* ang0, const doubl
     double f[3] = {0.0, 0.0, model.mass * model.gravity / n_ee};
     interpolate(force[e], 0, f, f);
   }
+  if (timings)  // PhaseDurations::GetValues (src/phase_durations.cc:66-75): the given durations but the last
+    for (int e = 0; e < n_ee; ++e)
+      for (int i = 0; i < schedule.n_phases[e] - 1; ++i) x[off_schedule[e] + i] = schedule.phase_durations[e][i];
 }
 
 // ------------------------------------------------------------------ variable bounds
@@ -681,6 +828,12 @@ void Structure::VariableBounds(const double* init_base, const double* final_base
     fix(base, off_base_ang, last, 1, d, final_base[9 + d]);
     for (int e = 0; e < n_ee; ++e) fix(motion[e], 0, 0, 0, d, ee0[3 * e + d]);
   }
+  if (timings)  // PhaseDurations::GetBounds with Parameters::bound_phase_duration_ (parameters.cc:52)
+    for (int e = 0; e < n_ee; ++e)
+      for (int i = 0; i < schedule.n_phases[e] - 1; ++i) {
+        lower[off_schedule[e] + i] = 0.2;
+        upper[off_schedule[e] + i] = 1.0;
+      }
 }
 
 // ------------------------------------------------------------------ presets

@@ -44,6 +44,9 @@ struct Structure {
   std::vector<SplineLayout> motion, force;
   std::vector<SetInfo> var_sets, con_sets;
   int n_vars = 0, n_rows = 0, nnz = 0;
+  bool timings = false;             // TWR_SET_TOTAL_TIME: phase durations are variables
+  int off_schedule[kMaxEE] = {0, 0, 0, 0};
+  PhaseTables phase_tables;         // filled by BuildPattern / PackBlob when timings
 
   std::vector<double> grid_dyn, grid_rom;
   std::vector<TimeNode> dyn_base, rom_base;
