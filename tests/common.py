@@ -101,6 +101,8 @@ class Case:
                 s = np.tile([0.2] * 3 + [0.5] * 3, vs["size"] // 6)
             elif vs["name"].startswith("ee-motion"):
                 s = np.full(vs["size"], 0.1)
+            elif vs["name"].startswith("ee-schedule"):
+                s = np.full(vs["size"], 0.3)      # phase durations: +-15 ms at sigma = 0.05
             else:
                 s = np.full(vs["size"], 50.0)
             scale[a:b] = s
@@ -116,6 +118,9 @@ class Case:
                 x[a:b] = rng.uniform(-0.5, 3.0, size=b - a)
             if vs["name"].startswith("ee-force"):
                 x[a:b] = rng.normal(size=b - a) * 150.0
+            if vs["name"].startswith("ee-schedule"):   # the given phase durations +-10 % (sum stays below T)
+                e = int(vs["name"][len("ee-schedule"):])
+                x[a:b] = np.asarray(self.sched.durations()[e][:-1]) * (1.0 + 0.1 * rng.uniform(-1, 1, size=b - a))
         return x
 
 

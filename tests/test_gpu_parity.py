@@ -123,6 +123,54 @@ def test_whole_default_constraint_list_and_subsets(spec):
         assert_parity(case.S, *_split(batch, g, j, p), rg, rj, "%s x[%d]" % (spec[:3], p), x=x)
 
 
+@pytest.mark.parametrize("spec", [
+    ("monoped", "flat", None, 2.0, dict(constraint_sets=127)),
+    ("biped", "stairs", 0, 2.0, dict(constraint_sets=127)),
+    ("anymal", "gap", 1, 2.0, dict(constraint_sets=127)),
+    ("anymal", "flat", 1, 2.0, dict(constraint_sets=127, **k_params(2.0, 200))),   # BASELINE C3 with optimised timings
+    ("hyq", "slope", 3, 2.2, dict(constraint_sets=127, polys_per_swing=3, polys_per_stance_force=2)),
+    ("go1", "block", 2, 1.9, dict(constraint_sets=2 | 64)),
+    ("biped", "flat", 1, 1.8, dict(constraint_sets=8 | 64)),
+], ids=lambda s: "%s-%s-s%d" % (s[0], s[1], s[4]["constraint_sets"]))
+def test_optimised_phase_durations(spec):
+    """Parameters::OptimizePhaseDurations: ee-schedule variables, x-dependent active polynomials, rows
+    that hold all variables of every ee set (explicit zeros), duration columns, totalduration rows."""
+    robot, terrain, combo, T, kw = spec
+    n_ee = ta.model_preset(robot, terrain).n_ee
+    sched = hopper_schedule() if combo is None else ta.gait_combo(n_ee, combo, T)
+    case = Case(robot, terrain, sched, **kw)
+    xs = [case.x_wild(6), case.x_perturbed(7, 2.0), case.x_guess(1.5), case.x_wild(8)]
+    batch, g, j = _eval_case(case, xs)
+    for p, x in enumerate(xs):
+        rg, _, _, rj = case.P.eval(x)
+        assert_parity(case.S, *_split(batch, g, j, p), rg, rj, "%s x[%d]" % (spec[:3], p), x=x)
+
+
+def test_mixed_batch_of_fixed_and_optimised_timings():
+    """Problems with and without optimised timings in one launch; stale buffer contents must not leak
+    into the explicit zeros (the device path zero-fills before storing the non-zeros)."""
+    import torch
+
+    a = Case("anymal", "gap", ta.gait_combo(4, 1, 2.0), constraint_sets=127)
+    b = Case("anymal", "gap", ta.gait_combo(4, 1, 2.0), constraint_sets=63)
+    c = Case("anymal", "stairs", ta.gait_combo(4, 0, 2.4), constraint_sets=27 | 64)
+    cases, order = [a, b, c], [0, 1, 2, 1, 0, 0, 2]
+    batch = ta.Batch([k.S for k in cases], order, device=0)
+    xs = [cases[s].x_wild(20 + i) for i, s in enumerate(order)]
+    x = torch.from_numpy(np.concatenate(xs)).cuda()
+    g = torch.full((int(batch.g_off[-1]),), float("nan"), dtype=torch.float64, device="cuda")
+    j = torch.full((int(batch.jac_off[-1]),), float("nan"), dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):  # second pass runs over the first pass's values
+        batch.eval_device(x.data_ptr(), g.data_ptr(), j.data_ptr(), ta.EVAL_BOTH, st)
+    torch.cuda.synchronize()
+    gh, jh = g.cpu().numpy(), j.cpu().numpy()
+    assert np.isfinite(gh).all() and np.isfinite(jh).all()
+    for p, s in enumerate(order):
+        rg, _, _, rj = cases[s].P.eval(xs[p])
+        assert_parity(cases[s].S, *_split(batch, gh, jh, p), rg, rj, "problem %d" % p, x=xs[p])
+
+
 def test_foot_starting_in_swing():
     """ee_in_contact_at_start = false: first polynomial of ee-motion is a swing one, force starts at zero."""
     sched = ta.schedule([[0.3, 0.5, 0.3, 0.4], [0.6, 0.3, 0.6]], [0, 1])

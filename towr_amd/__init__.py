@@ -17,6 +17,7 @@ MAX_EE, MAX_PHASES, NAME_LEN = 4, 32, 40
 ROBOTS = {"monoped": 0, "biped": 1, "hyq": 2, "anymal": 3, "go1": 4}
 TERRAINS = {"flat": 0, "block": 1, "stairs": 2, "gap": 3, "slope": 4, "chimney": 5, "chimney_lr": 6}
 EVAL_VALUES, EVAL_JACOBIAN, EVAL_BOTH = 1, 2, 3
+SUPPORTS_OPTIMISED_TIMINGS = True  # TWR_SET_TOTAL_TIME has a device path
 
 
 class Model(C.Structure):

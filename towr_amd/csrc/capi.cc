@@ -14,8 +14,9 @@
 
 namespace twr {
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
-                       const NodeWork* node, int n_node, const double* x, double* g, double* jac, int flags,
-                       hipStream_t stream, hipEvent_t* ev);
+                       const NodeWork* node, int n_node, const PhaseWork* pdyn, int n_pdyn, const PhaseWork* prom,
+                       int n_prom, const double* x, double* g, double* jac, int flags, hipStream_t stream,
+                       hipEvent_t* ev);
 int dyn_stage_capacity();
 int rom_stage_capacity();
 int dyn_nodes_per_block();
@@ -34,6 +35,10 @@ struct twr_batch {
   twr::DynWork* d_dyn = nullptr;
   twr::RomWork* d_rom = nullptr;
   twr::NodeWork* d_node = nullptr;
+  // optimised-timings problems: their own work lists and the Jacobian ranges to zero-fill before each eval
+  twr::PhaseWork *d_pdyn = nullptr, *d_prom = nullptr;
+  int n_pdyn = 0, n_prom = 0;
+  std::vector<std::pair<int64_t, int64_t>> zero_ranges;  // (first value, count), merged
   // lazily sized scratch for twr_batch_eval_host
   double *d_x = nullptr, *d_g = nullptr, *d_j = nullptr;
   // optional per-kernel timing (twr_batch_profile_begin/end): 4 events per recorded eval
@@ -214,7 +219,6 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     for (int i = 0; i < n_structs; ++i) {
       if (!structs[i]) throw std::runtime_error("null structure");
       if (structs[i]->s.n_ee != b->n_ee) throw std::runtime_error("all structures of a batch must share n_ee");
-      if (structs[i]->s.timings) throw std::runtime_error("optimised timings (TWR_SET_TOTAL_TIME): host structure only, no device path yet");
       void* d = nullptr;
       TWR_HIP(hipMalloc(&d, structs[i]->s.blob.size()));
       b->blobs.push_back(d);
@@ -229,6 +233,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     std::vector<twr::DynWork> dyn;
     std::vector<twr::RomWork> rom;
     std::vector<twr::NodeWork> node;
+    std::vector<twr::PhaseWork> pdyn, prom;
     std::vector<int> dyn_first, rom_first;  // first work item of every problem (+ end)
     // run lists are identical for problems that share a structure: build once per structure
     std::vector<std::vector<std::pair<int, int>>> runs_dyn(n_structs);
@@ -236,6 +241,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     for (int i = 0; i < n_structs; ++i) {
       const twr::Structure& S = structs[i]->s;
       // families that are switched off (twr_params.constraint_sets) simply have no work items
+      if (S.timings) continue;  // optimised timings: PhaseWork items below
       if (const twr::SetInfo* ds = S.FindSet("dynamic"))
         runs_dyn[i] = chunk(S.row_ptr, ds->offset, 6, (int)S.grid_dyn.size(), twr::dyn_stage_capacity(),
                             twr::dyn_nodes_per_block());
@@ -286,6 +292,35 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
           rom.push_back(w);
         }
       }
+      if (S.timings) {
+        twr::PhaseWork pw;
+        std::memset(&pw, 0, sizeof(pw));
+        pw.blob = blob;
+        pw.x_off = b->x_off[p];
+        pw.g_off = b->g_off[p];
+        pw.j_off = b->j_off[p];
+        if (S.FindSet("dynamic"))
+          for (int k0 = 0; k0 < (int)S.grid_dyn.size(); k0 += 16) {
+            pw.k0 = k0;
+            pw.cnt = std::min(16, (int)S.grid_dyn.size() - k0);
+            pw.ee = 0;
+            pdyn.push_back(pw);
+          }
+        for (int e = 0; e < S.n_ee; ++e)
+          if (S.FindSet("rangeofmotion-" + std::to_string(e)))
+            for (int k0 = 0; k0 < (int)S.grid_rom.size(); k0 += 64) {
+              pw.k0 = k0;
+              pw.cnt = std::min(64, (int)S.grid_rom.size() - k0);
+              pw.ee = e;
+              prom.push_back(pw);
+            }
+        // the kernels store only the non-zero values of the all-variables rows: zero-fill the rest
+        const int64_t a0 = b->j_off[p], n0 = S.nnz;
+        if (!b->zero_ranges.empty() && b->zero_ranges.back().first + b->zero_ranges.back().second == a0)
+          b->zero_ranges.back().second += n0;
+        else
+          b->zero_ranges.push_back({a0, n0});
+      }
       twr::NodeWork nw;
       nw.blob = blob;
       nw.x_off = b->x_off[p];
@@ -327,6 +362,10 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     upload(dyn.data(), dyn.size() * sizeof(twr::DynWork), reinterpret_cast<void**>(&b->d_dyn));
     upload(rom.data(), rom.size() * sizeof(twr::RomWork), reinterpret_cast<void**>(&b->d_rom));
     upload(node.data(), node.size() * sizeof(twr::NodeWork), reinterpret_cast<void**>(&b->d_node));
+    b->n_pdyn = (int)pdyn.size();
+    b->n_prom = (int)prom.size();
+    if (!pdyn.empty()) upload(pdyn.data(), pdyn.size() * sizeof(twr::PhaseWork), reinterpret_cast<void**>(&b->d_pdyn));
+    if (!prom.empty()) upload(prom.data(), prom.size() * sizeof(twr::PhaseWork), reinterpret_cast<void**>(&b->d_prom));
     *out = b.release();
     return TWR_OK;
   } catch (const std::exception& e) {
@@ -342,6 +381,8 @@ void twr_batch_destroy(twr_batch* b) {
   if (b->d_dyn) (void)hipFree(b->d_dyn);
   if (b->d_rom) (void)hipFree(b->d_rom);
   if (b->d_node) (void)hipFree(b->d_node);
+  if (b->d_pdyn) (void)hipFree(b->d_pdyn);
+  if (b->d_prom) (void)hipFree(b->d_prom);
   for (hipEvent_t e : b->prof_events) (void)hipEventDestroy(e);
   if (b->d_x) (void)hipFree(b->d_x);
   if (b->d_g) (void)hipFree(b->d_g);
@@ -367,8 +408,15 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
     return fail(TWR_ERR_INVALID, "missing output buffer");
   hipEvent_t* ev = nullptr;
   if (b->prof_count < b->prof_capacity) ev = b->prof_events.data() + 4 * b->prof_count++;
-  hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->d_rom, b->n_rom, b->d_node, b->n_node, d_x,
-                                  d_g, d_jac, flags & TWR_EVAL_BOTH, static_cast<hipStream_t>(hip_stream), ev);
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  if (flags & TWR_EVAL_JACOBIAN)
+    for (auto& zr : b->zero_ranges) {
+      hipError_t e0 = hipMemsetAsync(d_jac + zr.first, 0, (size_t)zr.second * sizeof(double), stream);
+      if (e0 != hipSuccess) return fail(TWR_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e0));
+    }
+  hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->d_rom, b->n_rom, b->d_node, b->n_node,
+                                  b->d_pdyn, b->n_pdyn, b->d_prom, b->n_prom, d_x, d_g, d_jac, flags & TWR_EVAL_BOTH,
+                                  stream, ev);
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   return TWR_OK;
 }

@@ -111,8 +111,11 @@ struct PhaseTables {
   int32_t k_dyn, k_rom;
   int32_t row_dyn, nnz_dyn, row_rom[kMaxEE], nnz_rom[kMaxEE];
   int32_t off_lin, off_ang;
+  uint32_t o_dyn_shared, o_rom_recs[kMaxEE];  // host records (their base-spline part stays x-independent)
+  int32_t pad_;
   double t_total[kMaxEE];      // PhaseDurations::t_total_
 };
+constexpr int kMaxPhasePolys = 64;  // polynomials per ee spline with optimised timings (LDS table size)
 
 // Blob header: model constants + what the node kernel needs.  The terrain-ee-motion_e sets are
 // adjacent in g / jac, and so are the force-ee-force_e sets, so each family is one flat node list.
@@ -165,5 +168,12 @@ struct NodeWork {         // all terrain-* and force-* sets of one problem
   int64_t x_off, g_off, j_off;
 };
 static_assert(sizeof(NodeWork) == 32, "NodeWork layout");
+
+struct PhaseWork {        // optimised timings: cnt time nodes (<= 16 dynamic, <= 64 rangeofmotion-<ee>) from k0
+  uint64_t blob;
+  int64_t x_off, g_off, j_off;  // the problem's x / g / jac
+  int32_t k0, cnt, ee, pad;
+};
+static_assert(sizeof(PhaseWork) == 48, "PhaseWork layout");
 
 }  // namespace twr

@@ -27,6 +27,7 @@
 namespace twr {
 
 #define TWR_DEV __device__ __forceinline__
+constexpr int TWR_MAX_PHASES_DEV = 32;  // = TWR_MAX_PHASES of include/towr_amd.h
 
 template <typename T>
 TWR_DEV const T* tbl(const char* blob, uint32_t off) {
@@ -222,6 +223,61 @@ TWR_DEV double quad_sum(double v) {
 }
 TWR_DEV double sel3(int i, double a, double b, double c) { return i == 0 ? a : (i == 1 ? b : c); }
 
+// ---------------------------------------------------------------- optimised timings helpers
+// Spline::GetSegmentID + GetLocalTime (src/spline.cc:48-78) on durations that depend on x: the same
+// double-precision accumulation, eps and sequential subtraction as the reference (and the host Locate).
+TWR_DEV int locate_segment(const double* __restrict__ d, int n, double t, double& t_local) {
+  const double eps = 1e-10;
+  double acc = 0.0;
+  int id = n - 1;  // (the reference asserts that a segment is found)
+  for (int i = 0; i < n; ++i) {
+    acc += d[i];
+    if (acc >= t - eps) {
+      id = i;
+      break;
+    }
+  }
+  t_local = t;
+  for (int i = 0; i < id; ++i) t_local -= d[i];
+  return id;
+}
+// node values (p0,v0,p1,v1)[dim] of the active polynomial from its gathered candidates: values that are
+// not optimised are the constant 0, a stance ee-motion polynomial has p1 = p0
+TWR_DEV void node_values(uint64_t slots, bool shared, const double v[12], double nv[4][3]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const bool valid = ((slots >> (4 * (j * 3 + d))) & 0xF) != 0xF;
+      nv[j][d] = valid ? v[j * 3 + d] : 0.0;
+    }
+  if (shared) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) nv[2][d] = nv[0][d];
+  }
+}
+// The two distinct columns of PhaseSpline::GetJacobianOfPosWrtDurations (src/phase_spline.cc:67-93,
+// src/phase_durations.cc:126-154): `prev` for every phase before the current one, `cur` for the
+// current phase (unused in the last phase, which is not a variable).
+//   dx/dT_phase = 1/n_polys * (dpos/dT_poly - polys_before_in_phase * vel)   (polynomial.cc:236-257)
+TWR_DEV void duration_columns(const double nv[4][3], double t, double T, double inner, double prevp, bool in_last,
+                              double prev[3], double cur[3]) {
+  const double t2 = t * t, t3 = t2 * t;
+  const double T2 = T * T, T3 = T2 * T, T4 = T3 * T;
+  double wp[4], wv[4], wa[4];
+  hermite_all(t, 1.0 / T, wp, wv, wa);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const double x0 = nv[0][d], v0 = nv[1][d], x1 = nv[2][d], v1 = nv[3][d];
+    const double vel = wv[0] * x0 + wv[1] * v0 + wv[2] * x1 + wv[3] * v1;
+    const double dxdT = (t3 * (v0 + v1)) / T3 - (t2 * (2 * v0 + v1)) / T2 - (3 * t3 * (2 * x0 - 2 * x1 + T * v0 + T * v1)) / T4 +
+                        (2 * t2 * (3 * x0 - 3 * x1 + 2 * T * v0 + T * v1)) / T3;
+    const double dph = inner * (dxdT - prevp * vel);
+    cur[d] = dph;
+    prev[d] = -vel - (in_last ? dph : 0.0);
+  }
+}
+
 // ---------------------------------------------------------------- dynamic (SRBD) quad
 // DynamicConstraint::{UpdateModel, UpdateConstraintAtInstance, UpdateJacobianAtInstance}
 // (dynamic_constraint.cc:59-137) with SingleRigidBodyDynamics::{GetDynamicViolation,
@@ -265,7 +321,9 @@ struct DynFront {
   double sx, cx, sy, cy, sz, cz;
   int rs[3], rl[3], ms[3], fs[3], ls[3];
 };
-template <int NEE>
+// PHASE (optimised timings): the row layout is given (rows hold all variables of every ee set, S.rs .. S.ls
+// are filled by the caller), otherwise it follows from the slot counts of the active polynomials.
+template <int NEE, bool PHASE = false>
 TWR_DEV void dyn_front(const DynWork& w, const DynShared& sh, const DynLane& ln, const DynX& X, int par, int vbase,
                        int lane, DynFront& S) {
   const int role = lane & 3;
@@ -303,6 +361,7 @@ TWR_DEV void dyn_front(const DynWork& w, const DynShared& sh, const DynLane& ln,
     S.F[d] = quad_sum(f[d]);
     S.tau[d] = quad_sum(t3[d]);
   }
+  if constexpr (!PHASE) {
   // slot counts of every end-effector of the quad -> row layout of this time node in the CSR slice
   const uint32_t my_mm = has_ee ? ln.meta_m : 0u, my_fm = has_ee ? ln.meta_f : 0u;
   uint32_t mmeta[4], fmeta[4];
@@ -335,6 +394,7 @@ TWR_DEV void dyn_front(const DynWork& w, const DynShared& sh, const DynLane& ln,
     S.fs[r] = rs[r] + 20 + nma[r] + pfa[r];
     S.ls[r] = rl[r] + 4 + pfl[r];
   }
+  }
   // --- rotation: lanes 0..2 of the quad evaluate one sincos each and broadcast it
   double my_s, my_c;
   sincos_fast(sel3(role, e[0], e[1], e[2]), &my_s, &my_c);
@@ -344,7 +404,17 @@ TWR_DEV void dyn_front(const DynWork& w, const DynShared& sh, const DynLane& ln,
 }
 
 // Back half: the Jacobian blocks and the constraint values, written into the LDS image.
-template <int NEE>
+// DIRECT: `stage` is global memory (expanded rows of the optimised-timings variant): candidates that are
+// not variables are skipped by a predicated store instead of being sent to an LDS trash slot.
+template <bool DIRECT>
+TWR_DEV void put_if(double* __restrict__ stage, bool valid, int idx, int trash, double v) {
+  if constexpr (DIRECT) {
+    if (valid) stage[idx] = v;
+  } else {
+    stage[valid ? idx : trash] = v;
+  }
+}
+template <int NEE, bool DIRECT = false>
 TWR_DEV void dyn_back(const DynWork& w, const DynLane& ln, const DynFront& S, double* __restrict__ gst,
                       double* __restrict__ stage, int trash, int lane, bool want_g, bool want_j) {
   const int kk = lane >> 2, role = lane & 3;
@@ -367,13 +437,13 @@ TWR_DEV void dyn_back(const DynWork& w, const DynLane& ln, const DynFront& S, do
   {                                                                                         \
     const uint32_t cm = ln.cand_m[j * 3 + D];                                               \
     const bool vm = has_ee && (cm & 0xF) != 0xF;                                            \
-    stage[vm ? ms[R1] + (int)((cm >> 4) & 0xF) : trash] = crs<R1, D>(f) * wm[j];            \
-    stage[vm ? ms[R2] + (int)((cm >> 8) & 0xF) : trash] = crs<R2, D>(f) * wm[j];            \
+    put_if<DIRECT>(stage, vm, ms[R1] + (int)((cm >> 4) & 0xF), trash, crs<R1, D>(f) * wm[j]);   \
+    put_if<DIRECT>(stage, vm, ms[R2] + (int)((cm >> 8) & 0xF), trash, crs<R2, D>(f) * wm[j]);   \
     const uint32_t cf = ln.cand_f[j * 3 + D];                                               \
     const bool vf = has_ee && (cf & 0xF) != 0xF;                                            \
-    stage[vf ? fs[R1] + (int)((cf >> 4) & 0xF) : trash] = crs<R1, D>(rv) * wf[j];           \
-    stage[vf ? fs[R2] + (int)((cf >> 8) & 0xF) : trash] = crs<R2, D>(rv) * wf[j];           \
-    stage[vf ? ls[D] + (int)((cf >> 12) & 0xF) : trash] = -wf[j];                           \
+    put_if<DIRECT>(stage, vf, fs[R1] + (int)((cf >> 4) & 0xF), trash, crs<R1, D>(rv) * wf[j]);  \
+    put_if<DIRECT>(stage, vf, fs[R2] + (int)((cf >> 8) & 0xF), trash, crs<R2, D>(rv) * wf[j]);  \
+    put_if<DIRECT>(stage, vf, ls[D] + (int)((cf >> 12) & 0xF), trash, -wf[j]);                  \
   }
       TWR_EE_TILE(0, 1, 2)
       TWR_EE_TILE(1, 2, 0)
@@ -531,8 +601,16 @@ TWR_DEV void rom_load_x(const RomWork& w, const RomRec& r, const double* __restr
   }
   gather12(xp, r.xbase, rom_slots(r), X.m);
 }
+struct RomPhase {           // optimised timings: expanded rows + duration columns of one (time node, ee)
+  int len[3];               // row lengths
+  int base_all, msize;      // ee-motion variables before the active polynomial / in the set
+  int n_sched, cur;         // duration columns, current phase
+  bool in_last;
+  double inner, prevp, T;   // 1/n_polys of the phase, polynomials before this one in the phase, its duration
+};
+template <bool PHASE = false>
 TWR_DEV void rom_item(const RomWork& w, const RomRec& r, const RomX& X, double* __restrict__ gst, double* __restrict__ stage,
-                      int par, int vbase, int trash, int lane, bool want_g, bool want_j) {
+                      int par, int vbase, int trash, int lane, bool want_g, bool want_j, const RomPhase* ph = nullptr) {
   const int soff = par + r.voff - vbase;
 #ifdef TWR_EXP_NOMATH
   { double acc = 0; for (int i2 = 0; i2 < 12; ++i2) acc += X.bl[i2] + X.ba[i2] + X.m[i2]; if (want_j) stage[soff] = acc; return; }
@@ -573,8 +651,14 @@ TWR_DEV void rom_item(const RomWork& w, const RomRec& r, const RomX& X, double* 
     matTvec(ro.R, tz, uz);
   }
   const int nm = meta_nslots(r.meta);
-  const int rs[3] = {soff, soff + 20 + nm, soff + 44 + 2 * nm};
-  const int mo[3] = {20, 24, 24};
+  int rs[3] = {soff, soff + 20 + nm, soff + 44 + 2 * nm};
+  int mo[3] = {20, 24, 24};
+  if constexpr (PHASE) {
+    rs[1] = soff + ph->len[0];
+    rs[2] = rs[1] + ph->len[1];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) mo[i] += ph->base_all;
+  }
 #pragma unroll
   for (int row = 0; row < 3; ++row) {
 #pragma unroll
@@ -592,9 +676,20 @@ TWR_DEV void rom_item(const RomWork& w, const RomRec& r, const RomX& X, double* 
 #pragma unroll
       for (int d = 0; d < 3; ++d) {  // R^T J_p
         const int sl = (int)((slots >> (4 * (j * 3 + d))) & 0xF);
-        stage[sl != 0xF ? rs[row] + mo[row] + sl : trash] = ro.R[d][row] * wm[j];
+        put_if<PHASE>(stage, sl != 0xF, rs[row] + mo[row] + sl, trash, ro.R[d][row] * wm[j]);
       }
     }
+  }
+  if constexpr (PHASE) {  // b_R_w * GetJacobianOfPosWrtDurations (range_of_motion_constraint.cc:106-108)
+    double nv[4][3], prev[3], cur[3], rp[3], rc[3];
+    node_values(slots, meta_shared(r.meta), X.m, nv);
+    duration_columns(nv, r.tm, ph->T, ph->inner, ph->prevp, ph->in_last, prev, cur);
+    matTvec(ro.R, prev, rp);
+    matTvec(ro.R, cur, rc);
+    for (int p = 0; p < ph->n_sched; ++p)
+#pragma unroll
+      for (int row = 0; row < 3; ++row)
+        stage[rs[row] + (row == 0 ? 20 : 24) + ph->msize + p] = p < ph->cur ? rp[row] : (p == ph->cur ? rc[row] : 0.0);
   }
 }
 
@@ -1001,7 +1096,213 @@ __global__ __launch_bounds__(256) void node_kernel(const NodeWork* __restrict__ 
       }
       if (want_j) copy_out(dst, stage, 12 * cnt, par, lane);
     }
+    // totalduration-<e> (total_duration_constraint.cc:50-72): sum of the optimised phase durations
+    if (S->timings) {
+      const PhaseTables* PT = tbl<PhaseTables>(blob, S->o_phase);
+      if (lane < S->n_ee) {
+        int voff = 0;
+        for (int e = 0; e < lane; ++e) voff += PT->n_phases[e] - 1;
+        const int ns = PT->n_phases[lane] - 1;
+        double sum = 0.0;
+        for (int i = 0; i < ns; ++i) {
+          sum += xp[PT->off_sched[lane] + i];
+          if (want_j) jp[PT->nnz_total + voff + i] = 1.0;
+        }
+        if (want_g) gp[PT->row_total + lane] = sum;
+      }
+    }
   }
+}
+
+// ---------------------------------------------------------------- optimised timings (PhaseSpline) kernels
+// With Parameters::OptimizePhaseDurations the active polynomial of every ee spline depends on x and every
+// Jacobian row of an ee spline holds all variables of its set (phase_spline.cc:44-51), most of them
+// explicit zeros.  The caller zero-fills the Jacobian values (hipMemsetAsync on the same stream); these
+// kernels locate the active polynomials from the durations in x, evaluate the same quad / lane math as the
+// fixed-timing kernels and store the non-zero values directly at their CSR positions, plus the duration
+// columns (dynamic_constraint.cc:107-113, range_of_motion_constraint.cc:106-108).
+// One workgroup (one wave) per run of 16 (dynamic) / 64 (rangeofmotion-<ee>) time nodes.
+TWR_DEV void phase_poly_durations(const PhaseTables* PT, const char* blob, const double* __restrict__ xp, int e,
+                                  double* ph, double* md, double* fd, bool want_force) {
+  // PhaseDurations::SetVariables (phase_durations.cc:77-103) + ConvertPhaseToPolyDurations
+  // (nodes_variables_phase_based.cc:73-84)
+  const int ns = PT->n_phases[e] - 1;
+  double sum = 0.0;
+  for (int i = 0; i < ns; ++i) {
+    const double d = xp[PT->off_sched[e] + i];
+    ph[i] = d;
+    sum += d;
+  }
+  ph[ns] = PT->t_total[e] - sum;
+  const PhasePoly* mp = tbl<PhasePoly>(blob, PT->o_mpoly[e]);
+  for (int q = 0; q < PT->n_mpoly[e]; ++q) md[q] = ph[mp[q].phase] / mp[q].n_in_phase;
+  if (want_force) {
+    const PhasePoly* fp = tbl<PhasePoly>(blob, PT->o_fpoly[e]);
+    for (int q = 0; q < PT->n_fpoly[e]; ++q) fd[q] = ph[fp[q].phase] / fp[q].n_in_phase;
+  }
+}
+
+template <int NEE>
+__global__ __launch_bounds__(64) void dyn_phase_kernel(const PhaseWork* __restrict__ work, const double* __restrict__ x,
+                                                       double* __restrict__ g, double* __restrict__ jac, int flags) {
+  __shared__ double s_ph[NEE][TWR_MAX_PHASES_DEV], s_md[NEE][kMaxPhasePolys], s_fd[NEE][kMaxPhasePolys];
+  const PhaseWork pw = work[blockIdx.x];
+  const char* blob = reinterpret_cast<const char*>(pw.blob);
+  const DevStruct* H = reinterpret_cast<const DevStruct*>(blob);
+  const PhaseTables* PT = tbl<PhaseTables>(blob, H->o_phase);
+  const double* xp = x + pw.x_off;
+  const bool want_g = flags & 1, want_j = flags & 2;
+  const int lane = threadIdx.x, kk = lane >> 2, role = lane & 3;
+  if (lane < NEE) phase_poly_durations(PT, blob, xp, lane, s_ph[lane], s_md[lane], s_fd[lane], true);
+  __syncthreads();
+  const int e = min(role, NEE - 1);
+  const bool has_ee = role < NEE;
+  const int k = pw.k0 + min(kk, pw.cnt - 1);
+  const double t = tbl<double>(blob, PT->o_tdyn)[k];
+  // active polynomials of this lane's end-effector and the current phase
+  double tlm, tlf, tlp;
+  const int qm = locate_segment(s_md[e], PT->n_mpoly[e], t, tlm);
+  const int qf = locate_segment(s_fd[e], PT->n_fpoly[e], t, tlf);
+  const int cur = locate_segment(s_ph[e], PT->n_phases[e], t, tlp);
+  const PhasePoly pm = tbl<PhasePoly>(blob, PT->o_mpoly[e])[qm];
+  const PhasePoly pf = tbl<PhasePoly>(blob, PT->o_fpoly[e])[qf];
+  const double Tm = s_md[e][qm], Tf = s_fd[e][qf];
+  DynShared sh = tbl<DynShared>(blob, PT->o_dyn_shared)[k];
+  DynLane ln;
+  ln.tm = tlm; ln.iTm = 1.0 / Tm;
+  ln.tf = tlf; ln.iTf = 1.0 / Tf;
+  ln.xbase_m = pm.xbase; ln.xbase_f = pf.xbase;
+  ln.meta_m = pm.meta;   ln.meta_f = pf.meta;
+#pragma unroll
+  for (int c = 0; c < 12; ++c) {
+    ln.cand_m[c] = pm.cand[c];
+    ln.cand_f[c] = pf.cand[c];
+  }
+  DynWork w;
+  w.shared = 0; w.lanes = 0;
+  w.hdr = pw.blob;
+  w.x_off = pw.x_off;
+  w.g_off = 0; w.j_off = 0;
+  w.off_lin = PT->off_lin; w.off_ang = PT->off_ang;
+  w.cnt = pw.cnt; w.nvals = 0;
+  // expanded row layout of this time node (relative to the first value of node k0)
+  DynFront S;
+  {
+    const int soff = min(kk, pw.cnt - 1) * PT->node_vals;
+    S.rs[0] = soff;
+    S.rs[1] = S.rs[0] + PT->len_ang[0];
+    S.rs[2] = S.rs[1] + PT->len_ang[1];
+    S.rl[0] = S.rs[2] + PT->len_ang[2];
+    S.rl[1] = S.rl[0] + PT->len_lin[0];
+    S.rl[2] = S.rl[1] + PT->len_lin[1];
+  }
+  int sa[3], sl[3];  // first duration column of this end-effector in the ang / lin rows
+  {
+    int pre_s = 0, tot_s = 0;
+#pragma unroll
+    for (int e2 = 0; e2 < NEE; ++e2) {
+      const int n = PT->n_phases[e2] - 1;
+      tot_s += n;
+      if (e2 < role) pre_s += n;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      int pre_m = 0, tot_m = 0, pre_f = 0, tot_f = 0, pre_l = 0, tot_l = 0;
+#pragma unroll
+      for (int e2 = 0; e2 < NEE; ++e2) {
+        tot_m += PT->mne[e2][r]; tot_f += PT->fne[e2][r]; tot_l += PT->feq[e2][r];
+        if (e2 < role) { pre_m += PT->mne[e2][r]; pre_f += PT->fne[e2][r]; pre_l += PT->feq[e2][r]; }
+      }
+      S.ms[r] = S.rs[r] + 20 + pre_m + pm.base_ne[r];
+      S.fs[r] = S.rs[r] + 20 + tot_m + pre_f + pf.base_ne[r];
+      S.ls[r] = S.rl[r] + 4 + pre_l + pf.base_eq[r];
+      sa[r] = S.rs[r] + 20 + tot_m + tot_f + pre_s;
+      sl[r] = S.rl[r] + 4 + tot_l + pre_s;
+    }
+  }
+  double* out = jac + pw.j_off + PT->nnz_dyn + (int64_t)pw.k0 * PT->node_vals;
+  double* gout = g + pw.g_off + PT->row_dyn + 6 * pw.k0;
+  DynX X;
+  dyn_load_x(w, sh, ln, x, X);
+  dyn_front<NEE, true>(w, sh, ln, X, 0, 0, lane, S);
+  if (want_j && has_ee && kk < pw.cnt) {
+    // duration columns: {[r]x J_f + [f]x J_p ; -J_f} with J = GetJacobianOfPosWrtDurations of the ee-force /
+    // ee-motion PhaseSpline (dynamic_constraint.cc:107-113, single_rigid_body_dynamics.cc:167-192)
+    double nv[4][3], fprev[3], fcur[3], xprev[3], xcur[3];
+    const bool in_last = cur == PT->n_phases[e] - 1;
+    node_values(slots_of(ln.cand_f), false, X.f, nv);
+    duration_columns(nv, tlf, Tf, 1.0 / pf.n_in_phase, (double)pf.poly_in_phase, in_last, fprev, fcur);
+    node_values(slots_of(ln.cand_m), meta_shared(ln.meta_m), X.m, nv);
+    duration_columns(nv, tlm, Tm, 1.0 / pm.n_in_phase, (double)pm.poly_in_phase, in_last, xprev, xcur);
+    double ap[3], ac[3], t1[3], t2[3];
+    cross3(S.rv, fprev, t1);
+    cross3(S.f, xprev, t2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ap[i] = t1[i] + t2[i];
+    cross3(S.rv, fcur, t1);
+    cross3(S.f, xcur, t2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ac[i] = t1[i] + t2[i];
+    const int ns = PT->n_phases[e] - 1;
+    for (int p = 0; p < ns; ++p)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        out[sa[r] + p] = p < cur ? ap[r] : (p == cur ? ac[r] : 0.0);
+        out[sl[r] + p] = p < cur ? -fprev[r] : (p == cur ? -fcur[r] : 0.0);
+      }
+  }
+  dyn_back<NEE, true>(w, ln, S, gout, out, 0, lane, want_g, want_j);
+}
+
+__global__ __launch_bounds__(64) void rom_phase_kernel(const PhaseWork* __restrict__ work, const double* __restrict__ x,
+                                                       double* __restrict__ g, double* __restrict__ jac, int flags) {
+  __shared__ double s_ph[TWR_MAX_PHASES_DEV], s_md[kMaxPhasePolys];
+  const PhaseWork pw = work[blockIdx.x];
+  const char* blob = reinterpret_cast<const char*>(pw.blob);
+  const DevStruct* H = reinterpret_cast<const DevStruct*>(blob);
+  const PhaseTables* PT = tbl<PhaseTables>(blob, H->o_phase);
+  const double* xp = x + pw.x_off;
+  const bool want_g = flags & 1, want_j = flags & 2;
+  const int lane = threadIdx.x, e = pw.ee;
+  if (lane == 0) phase_poly_durations(PT, blob, xp, e, s_ph, s_md, nullptr, false);
+  __syncthreads();
+  const int kl = min(lane, pw.cnt - 1), k = pw.k0 + kl;
+  const double t = tbl<double>(blob, PT->o_trom)[k];
+  double tlm, tlp;
+  const int qm = locate_segment(s_md, PT->n_mpoly[e], t, tlm);
+  const int cur = locate_segment(s_ph, PT->n_phases[e], t, tlp);
+  const PhasePoly pm = tbl<PhasePoly>(blob, PT->o_mpoly[e])[qm];
+  RomRec r = tbl<RomRec>(blob, PT->o_rom_recs[e])[k];  // base-spline part (tb, iTb, q6) is x-independent
+  r.tm = tlm;
+  r.iTm = 1.0 / s_md[qm];
+  r.xbase = pm.xbase;
+  r.meta = pm.meta;
+  const uint64_t slots = slots_of(pm.cand);
+  r.slots[0] = (uint32_t)slots;
+  r.slots[1] = (uint32_t)(slots >> 32);
+  r.voff = kl * PT->rom_node_vals[e];
+  RomWork w;
+  w.recs = 0;
+  w.x_off = pw.x_off;
+  w.g_off = 0; w.j_off = 0;
+  w.off_lin = PT->off_lin; w.off_ang = PT->off_ang;
+  w.cnt = pw.cnt; w.nvals = 0;
+  RomPhase ph;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) ph.len[i] = PT->rom_len[e][i];
+  ph.base_all = pm.base_all;
+  ph.msize = PT->msize[e];
+  ph.n_sched = PT->n_phases[e] - 1;
+  ph.cur = cur;
+  ph.in_last = cur == PT->n_phases[e] - 1;
+  ph.inner = 1.0 / pm.n_in_phase;
+  ph.prevp = (double)pm.poly_in_phase;
+  ph.T = s_md[qm];
+  double* out = jac + pw.j_off + PT->nnz_rom[e] + (int64_t)pw.k0 * PT->rom_node_vals[e];
+  double* gout = g + pw.g_off + PT->row_rom[e] + 3 * pw.k0;
+  RomX X;
+  rom_load_x(w, r, x, X);
+  if (lane < pw.cnt) rom_item<true>(w, r, X, gout, out, 0, 0, 0, lane, want_g, want_j, &ph);
 }
 
 // host-side launcher (called from capi.cc): three launches on one stream.  The dyn/rom grids are
@@ -1016,8 +1317,9 @@ static int env_int(const char* name, int dflt) {
   return v > 0 ? v : dflt;
 }
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
-                       const NodeWork* node, int n_node, const double* x, double* g, double* jac, int flags,
-                       hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */) {
+                       const NodeWork* node, int n_node, const PhaseWork* pdyn, int n_pdyn, const PhaseWork* prom,
+                       int n_prom, const double* x, double* g, double* jac, int flags, hipStream_t stream,
+                       hipEvent_t* ev /* 4 events or nullptr */) {
   static const int dyn_bpc = env_int("TWR_DYN_BPC", 7), rom_bpc = env_int("TWR_ROM_BPC", 4);
   dim3 block(64);
   if (n_ee < 1 || n_ee > 4) return hipErrorInvalidValue;
@@ -1032,7 +1334,17 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
       case 4: hipLaunchKernelGGL(dyn_kernel<4>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags); break;
     }
   }
+  if (n_pdyn > 0) {  // optimised-timings problems (their Jacobian values were zero-filled by the caller)
+    dim3 grid(n_pdyn);
+    switch (n_ee) {
+      case 1: hipLaunchKernelGGL(dyn_phase_kernel<1>, grid, block, 0, stream, pdyn, x, g, jac, flags); break;
+      case 2: hipLaunchKernelGGL(dyn_phase_kernel<2>, grid, block, 0, stream, pdyn, x, g, jac, flags); break;
+      case 3: hipLaunchKernelGGL(dyn_phase_kernel<3>, grid, block, 0, stream, pdyn, x, g, jac, flags); break;
+      case 4: hipLaunchKernelGGL(dyn_phase_kernel<4>, grid, block, 0, stream, pdyn, x, g, jac, flags); break;
+    }
+  }
   if (ev) (void)hipEventRecord(ev[1], stream);
+  if (n_prom > 0) hipLaunchKernelGGL(rom_phase_kernel, dim3(n_prom), block, 0, stream, prom, x, g, jac, flags);
   if (n_rom > 0) {
     const int res = rom_bpc * n_cu;
     dim3 grid(n_rom < res ? n_rom : res);

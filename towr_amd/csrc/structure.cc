@@ -672,6 +672,11 @@ void Structure::PackBlob() {
     pt.nnz_dyn = nnz_dyn;
     pt.off_lin = off_base_lin;
     pt.off_ang = off_base_ang;
+    pt.o_dyn_shared = off_dyn_shared;
+    for (int e = 0; e < n_ee; ++e) {
+      pt.o_rom_recs[e] = off_rom_recs[e];
+      if (pt.n_mpoly[e] > kMaxPhasePolys || pt.n_fpoly[e] > kMaxPhasePolys) throw std::runtime_error("too many polynomials per ee spline for optimised timings");
+    }
     if (const SetInfo* si = FindSet("totalduration-0")) {
       pt.row_total = si->offset;
       pt.nnz_total = si->nnz_offset;
