@@ -48,6 +48,8 @@ def perturbed_inputs(S, model, count, first_seed):
             scale[a:b] = np.tile([0.2] * 3 + [0.5] * 3, vs["size"] // 6)
         elif vs["name"].startswith("ee-motion"):
             scale[a:b] = 0.1
+        elif vs["name"].startswith("ee-schedule"):
+            scale[a:b] = 0.3  # phase durations: +-15 ms at sigma = 0.05
         else:
             scale[a:b] = 50.0
     out = np.empty((count, S.n))
@@ -95,9 +97,10 @@ def main():
     ap.add_argument("--workload", choices=["c3", "sweep"], default="c3",
                     help="c3: BASELINE config 3 (one schedule, distinct x, the headline metric); sweep: BASELINE "
                          "configs 4-5 (enumerated gait / duration candidates on Stairs, ragged structures)")
-    ap.add_argument("--sets", choices=["hot", "all"], default="hot",
+    ap.add_argument("--sets", choices=["hot", "all", "timings"], default="hot",
                     help="hot: the four constraint families of the headline metric (BASELINE sizes n=640 m=3866 "
-                         "nnz=102896); all: towr's whole default list (+ splineacc-base-*, swing-*), c3 only")
+                         "nnz=102896); all: towr's whole default list (+ splineacc-base-*, swing-*); timings: all + "
+                         "optimised phase durations (ee-schedule variables, all-variables rows); c3 only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -135,11 +138,12 @@ def main():
     terrain = "flat" if args.workload == "c3" else "stairs"
     model.terrain_id = ta.TERRAINS[terrain]  # (the broadcast blob carries the robot; the workload picks the terrain)
     if args.workload == "c3":
-        sched, params, S = build_case(ta, model, constraint_sets=27 if args.sets == "hot" else 63)
+        sched, params, S = build_case(ta, model, constraint_sets={"hot": 27, "all": 63, "timings": 127}[args.sets])
         B = args.batch or 8192
         n_all = B * world
         workload = "C3 ANYmal trot (combo C1), T=2.0 s, flat, K=%d, n=%d m=%d nnz=%d, %d problems/GPU distinct x%s" % (
-            S.k_dynamic, S.n, S.m, S.nnz, B, "" if args.sets == "hot" else ", all six default constraint families")
+            S.k_dynamic, S.n, S.m, S.nnz, B, {"hot": "", "all": ", all six default constraint families",
+                                              "timings": ", default constraints + optimised phase durations"}[args.sets])
         batch = ta.Batch([S], [0] * B, device=dev_index)
         # distinct x per problem: 256 seeded perturbations per rank, tiled (contents do not change the work)
         base = perturbed_inputs(S, model, min(B, 256), first_seed=rank * 100000)
@@ -205,6 +209,8 @@ def main():
         path_ms = sum(kern_ms.values())
         path_achieved = alg_bytes / (path_ms * 1e-3) / 1e9
         names = {"dynamic": "twr::dyn_kernel<4>", "rangeofmotion": "twr::rom_kernel", "nodes": "twr::node_kernel"}
+        if args.workload == "c3" and args.sets == "timings":
+            names.update(dynamic="twr::dyn_phase_kernel<4>", rangeofmotion="twr::rom_phase_kernel")
         out = {
             "metric": "constraint+Jacobian evals/sec (full NLP callback), 4-EE SRBD",
             "value": callbacks / elapsed,

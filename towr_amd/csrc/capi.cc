@@ -35,10 +35,9 @@ struct twr_batch {
   twr::DynWork* d_dyn = nullptr;
   twr::RomWork* d_rom = nullptr;
   twr::NodeWork* d_node = nullptr;
-  // optimised-timings problems: their own work lists and the Jacobian ranges to zero-fill before each eval
+  // optimised-timings problems have their own work lists
   twr::PhaseWork *d_pdyn = nullptr, *d_prom = nullptr;
   int n_pdyn = 0, n_prom = 0;
-  std::vector<std::pair<int64_t, int64_t>> zero_ranges;  // (first value, count), merged
   // lazily sized scratch for twr_batch_eval_host
   double *d_x = nullptr, *d_g = nullptr, *d_j = nullptr;
   // optional per-kernel timing (twr_batch_profile_begin/end): 4 events per recorded eval
@@ -314,12 +313,6 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
               pw.ee = e;
               prom.push_back(pw);
             }
-        // the kernels store only the non-zero values of the all-variables rows: zero-fill the rest
-        const int64_t a0 = b->j_off[p], n0 = S.nnz;
-        if (!b->zero_ranges.empty() && b->zero_ranges.back().first + b->zero_ranges.back().second == a0)
-          b->zero_ranges.back().second += n0;
-        else
-          b->zero_ranges.push_back({a0, n0});
       }
       twr::NodeWork nw;
       nw.blob = blob;
@@ -409,11 +402,6 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
   hipEvent_t* ev = nullptr;
   if (b->prof_count < b->prof_capacity) ev = b->prof_events.data() + 4 * b->prof_count++;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-  if (flags & TWR_EVAL_JACOBIAN)
-    for (auto& zr : b->zero_ranges) {
-      hipError_t e0 = hipMemsetAsync(d_jac + zr.first, 0, (size_t)zr.second * sizeof(double), stream);
-      if (e0 != hipSuccess) return fail(TWR_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e0));
-    }
   hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->d_rom, b->n_rom, b->d_node, b->n_node,
                                   b->d_pdyn, b->n_pdyn, b->d_prom, b->n_prom, d_x, d_g, d_jac, flags & TWR_EVAL_BOTH,
                                   stream, ev);

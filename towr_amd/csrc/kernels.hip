@@ -1117,11 +1117,22 @@ __global__ __launch_bounds__(256) void node_kernel(const NodeWork* __restrict__ 
 // ---------------------------------------------------------------- optimised timings (PhaseSpline) kernels
 // With Parameters::OptimizePhaseDurations the active polynomial of every ee spline depends on x and every
 // Jacobian row of an ee spline holds all variables of its set (phase_spline.cc:44-51), most of them
-// explicit zeros.  The caller zero-fills the Jacobian values (hipMemsetAsync on the same stream); these
-// kernels locate the active polynomials from the durations in x, evaluate the same quad / lane math as the
-// fixed-timing kernels and store the non-zero values directly at their CSR positions, plus the duration
-// columns (dynamic_constraint.cc:107-113, range_of_motion_constraint.cc:106-108).
-// One workgroup (one wave) per run of 16 (dynamic) / 64 (rangeofmotion-<ee>) time nodes.
+// explicit zeros.  A workgroup (one wave) owns a run of 16 (dynamic) / 64 (rangeofmotion-<ee>) time nodes,
+// i.e. one contiguous slice of the value array: it first streams zeros over the slice with coalesced
+// 16-byte stores, locates the active polynomials from the durations in x, evaluates the same quad / lane
+// math as the fixed-timing kernels and, once the zeros have been acknowledged, stores the non-zero values
+// directly at their CSR positions, plus the duration columns (dynamic_constraint.cc:107-113,
+// range_of_motion_constraint.cc:106-108).
+TWR_DEV void zero_fill(double* __restrict__ dst, int n, int lane) {
+  const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+  if (n <= 0) return;
+  if (par && lane == 0) dst[0] = 0.0;
+  double* al = dst + par;  // 16-byte aligned
+  const int m = n - par, npairs = m >> 1;
+  const double2 z = {0.0, 0.0};
+  for (int t = lane; t < npairs; t += 64) reinterpret_cast<double2*>(al)[t] = z;
+  if ((m & 1) && lane == 0) al[m - 1] = 0.0;
+}
 TWR_DEV void phase_poly_durations(const PhaseTables* PT, const char* blob, const double* __restrict__ xp, int e,
                                   double* ph, double* md, double* fd, bool want_force) {
   // PhaseDurations::SetVariables (phase_durations.cc:77-103) + ConvertPhaseToPolyDurations
@@ -1153,6 +1164,9 @@ __global__ __launch_bounds__(64) void dyn_phase_kernel(const PhaseWork* __restri
   const double* xp = x + pw.x_off;
   const bool want_g = flags & 1, want_j = flags & 2;
   const int lane = threadIdx.x, kk = lane >> 2, role = lane & 3;
+  double* out = jac + pw.j_off + PT->nnz_dyn + (int64_t)pw.k0 * PT->node_vals;
+  double* gout = g + pw.g_off + PT->row_dyn + 6 * pw.k0;
+  if (want_j) zero_fill(out, pw.cnt * PT->node_vals, lane);
   if (lane < NEE) phase_poly_durations(PT, blob, xp, lane, s_ph[lane], s_md[lane], s_fd[lane], true);
   __syncthreads();
   const int e = min(role, NEE - 1);
@@ -1220,11 +1234,10 @@ __global__ __launch_bounds__(64) void dyn_phase_kernel(const PhaseWork* __restri
       sl[r] = S.rl[r] + 4 + tot_l + pre_s;
     }
   }
-  double* out = jac + pw.j_off + PT->nnz_dyn + (int64_t)pw.k0 * PT->node_vals;
-  double* gout = g + pw.g_off + PT->row_dyn + 6 * pw.k0;
   DynX X;
   dyn_load_x(w, sh, ln, x, X);
   dyn_front<NEE, true>(w, sh, ln, X, 0, 0, lane, S);
+  __syncthreads();  // (s_waitcnt vmcnt(0) + barrier) the zeros of the slice are in place before any value
   if (want_j && has_ee && kk < pw.cnt) {
     // duration columns: {[r]x J_f + [f]x J_p ; -J_f} with J = GetJacobianOfPosWrtDurations of the ee-force /
     // ee-motion PhaseSpline (dynamic_constraint.cc:107-113, single_rigid_body_dynamics.cc:167-192)
@@ -1264,6 +1277,9 @@ __global__ __launch_bounds__(64) void rom_phase_kernel(const PhaseWork* __restri
   const double* xp = x + pw.x_off;
   const bool want_g = flags & 1, want_j = flags & 2;
   const int lane = threadIdx.x, e = pw.ee;
+  double* out = jac + pw.j_off + PT->nnz_rom[e] + (int64_t)pw.k0 * PT->rom_node_vals[e];
+  double* gout = g + pw.g_off + PT->row_rom[e] + 3 * pw.k0;
+  if (want_j) zero_fill(out, pw.cnt * PT->rom_node_vals[e], lane);
   if (lane == 0) phase_poly_durations(PT, blob, xp, e, s_ph, s_md, nullptr, false);
   __syncthreads();
   const int kl = min(lane, pw.cnt - 1), k = pw.k0 + kl;
@@ -1298,10 +1314,9 @@ __global__ __launch_bounds__(64) void rom_phase_kernel(const PhaseWork* __restri
   ph.inner = 1.0 / pm.n_in_phase;
   ph.prevp = (double)pm.poly_in_phase;
   ph.T = s_md[qm];
-  double* out = jac + pw.j_off + PT->nnz_rom[e] + (int64_t)pw.k0 * PT->rom_node_vals[e];
-  double* gout = g + pw.g_off + PT->row_rom[e] + 3 * pw.k0;
   RomX X;
   rom_load_x(w, r, x, X);
+  __syncthreads();  // the zeros of the slice are in place before any value
   if (lane < pw.cnt) rom_item<true>(w, r, X, gout, out, 0, 0, 0, lane, want_g, want_j, &ph);
 }
 
@@ -1334,7 +1349,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
       case 4: hipLaunchKernelGGL(dyn_kernel<4>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags); break;
     }
   }
-  if (n_pdyn > 0) {  // optimised-timings problems (their Jacobian values were zero-filled by the caller)
+  if (n_pdyn > 0) {  // optimised-timings problems
     dim3 grid(n_pdyn);
     switch (n_ee) {
       case 1: hipLaunchKernelGGL(dyn_phase_kernel<1>, grid, block, 0, stream, pdyn, x, g, jac, flags); break;
