@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/ktrace_${1:-run}
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline $BENCH_ARGS > $OUT/bench.log 2>&1
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys
