@@ -17,6 +17,8 @@ MAX_EE, MAX_PHASES, NAME_LEN = 4, 32, 40
 ROBOTS = {"monoped": 0, "biped": 1, "hyq": 2, "anymal": 3, "go1": 4}
 TERRAINS = {"flat": 0, "block": 1, "stairs": 2, "gap": 3, "slope": 4, "chimney": 5, "chimney_lr": 6}
 EVAL_VALUES, EVAL_JACOBIAN, EVAL_BOTH = 1, 2, 3
+SET_TERRAIN, SET_DYNAMIC, SET_BASE_ACC, SET_ROM, SET_FORCE, SET_SWING, SET_TOTAL_TIME = 1, 2, 4, 8, 16, 32, 64
+SETS_HOT_PATH, SETS_TOWR_DEFAULT, SETS_ALL = 27, 63, 127  # TWR_SETS_* of include/towr_amd.h
 SUPPORTS_OPTIMISED_TIMINGS = True  # TWR_SET_TOTAL_TIME has a device path
 
 

@@ -11,6 +11,12 @@
 //   towr::DynamicConstraint        "dynamic"                  towr/src/dynamic_constraint.cc:37-137
 //   towr::RangeOfMotionConstraint  "rangeofmotion-<ee>"       towr/src/range_of_motion_constraint.cc:35-109
 //   towr::ForceConstraint          "force-ee-force_<ee>"      towr/src/force_constraint.cc:37-171
+// and, when selected in twr_params.constraint_sets,
+//   towr::SplineAccConstraint      "splineacc-base-lin|ang"   towr/src/spline_acc_constraint.cc:34-88
+//   towr::SwingConstraint          "swing-ee-motion_<ee>"     towr/src/swing_constraint.cc:35-121
+//   towr::TotalDurationConstraint  "totalduration-<ee>"       towr/src/total_duration_constraint.cc:36-72
+// (with TWR_SET_TOTAL_TIME the variable composite also holds the reference's "ee-schedule<ee>" sets and
+// the dynamic / rangeofmotion sets return their duration columns for them)
 #pragma once
 #if __has_include(<ifopt/constraint_set.h>)
 #include <ifopt/constraint_set.h>
@@ -107,7 +113,7 @@ class DeviceConstraintSet : public ifopt::ConstraintSet {
     const twr_set_info* vs = nullptr;
     for (const auto& v : var_sets_)
       if (var_set == v.name) vs = &v;
-    if (!vs) return;  // e.g. "ee-schedule<i>": fixed timings, no columns
+    if (!vs) return;  // a variable set this structure does not know (e.g. "ee-schedule<i>" with fixed timings)
     const int32_t* row_ptr = twr_structure_row_ptr(problem_->structure());
     const int32_t* col_idx = twr_structure_col_idx(problem_->structure());
     const double* val = problem_->jac().data();
@@ -129,7 +135,7 @@ class DeviceConstraintSet : public ifopt::ConstraintSet {
   std::vector<twr_set_info> var_sets_;
 };
 
-// All hot-path sets of one problem, in the reference's relative order.
+// All device sets of one problem (twr_params.constraint_sets), in the reference's relative order.
 inline std::vector<ifopt::ConstraintSet::Ptr> MakeDeviceConstraints(const twr_model& model, const twr_schedule& schedule,
                                                                     const twr_params& params, int device = 0) {
   auto problem = std::make_shared<DeviceProblem>(model, schedule, params, device);
