@@ -171,6 +171,36 @@ def test_mixed_batch_of_fixed_and_optimised_timings():
         assert_parity(cases[s].S, *_split(batch, gh, jh, p), rg, rj, "problem %d" % p, x=xs[p])
 
 
+def _many_phases(n_ee, n_phases, seed):
+    rng = np.random.default_rng(seed)
+    durs = []
+    for _ in range(n_ee):
+        d = rng.uniform(0.12, 0.35, size=n_phases)
+        durs.append(d * (3.1 / d.sum()))
+    return ta.schedule(durs, [1] * n_ee)
+
+
+@pytest.mark.parametrize("name,make", [
+    ("standing_one_phase", lambda: Case("anymal", "flat", ta.schedule([[1.3]] * 4, [1] * 4))),
+    ("two_nodes_dt_gt_T", lambda: Case("biped", "slope", ta.gait_combo(2, 0, 1.1), dt_dynamic=5.0, dt_rom=7.0)),
+    ("max_phases_32", lambda: Case("anymal", "stairs", _many_phases(4, 31, 1), constraint_sets=63)),
+    ("max_phases_32_timings", lambda: Case("biped", "gap", _many_phases(2, 31, 2), constraint_sets=127)),
+    ("long_horizon_K1000", lambda: Case("hyq", "block", ta.gait_combo(4, 1, 6.0), **k_params(6.0, 1000))),
+    ("many_polys", lambda: Case("go1", "chimney_lr", ta.gait_combo(4, 2, 2.0), polys_per_swing=4, polys_per_stance_force=5)),
+    ("fine_base_spline", lambda: Case("monoped", "gap", hopper_schedule(), duration_base_poly=0.013, constraint_sets=63)),
+    ("two_phase_timings", lambda: Case("monoped", "flat", ta.schedule([[0.6, 0.5]], [1]), constraint_sets=27 | 64)),
+], ids=lambda v: v if isinstance(v, str) else "")
+def test_edge_sizes(name, make):
+    """Smallest and largest structures: a single phase, two time nodes, the maximum phase count of the ABI
+    (TWR_MAX_PHASES), a 1000-node horizon (many slices per set), many polynomials per phase."""
+    case = make()
+    xs = [case.x_wild(9), case.x_perturbed(10, 1.5)]
+    batch, g, j = _eval_case(case, xs)
+    for p, x in enumerate(xs):
+        rg, _, _, rj = case.P.eval(x)
+        assert_parity(case.S, *_split(batch, g, j, p), rg, rj, "%s x[%d]" % (name, p), x=x)
+
+
 def test_foot_starting_in_swing():
     """ee_in_contact_at_start = false: first polynomial of ee-motion is a swing one, force starts at zero."""
     sched = ta.schedule([[0.3, 0.5, 0.3, 0.4], [0.6, 0.3, 0.6]], [0, 1])
