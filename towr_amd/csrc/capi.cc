@@ -307,9 +307,9 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
           }
         for (int e = 0; e < S.n_ee; ++e)
           if (S.FindSet("rangeofmotion-" + std::to_string(e)))
-            for (int k0 = 0; k0 < (int)S.grid_rom.size(); k0 += 64) {
+            for (int k0 = 0; k0 < (int)S.grid_rom.size(); k0 += 16) {
               pw.k0 = k0;
-              pw.cnt = std::min(64, (int)S.grid_rom.size() - k0);
+              pw.cnt = std::min(16, (int)S.grid_rom.size() - k0);
               pw.ee = e;
               prom.push_back(pw);
             }

@@ -169,7 +169,7 @@ struct NodeWork {         // all terrain-* and force-* sets of one problem
 };
 static_assert(sizeof(NodeWork) == 32, "NodeWork layout");
 
-struct PhaseWork {        // optimised timings: cnt time nodes (<= 16 dynamic, <= 64 rangeofmotion-<ee>) from k0
+struct PhaseWork {        // optimised timings: cnt <= 16 time nodes of dynamic / rangeofmotion-<ee> from k0
   uint64_t blob;
   int64_t x_off, g_off, j_off;  // the problem's x / g / jac
   int32_t k0, cnt, ee, pad;

@@ -601,12 +601,10 @@ TWR_DEV void rom_load_x(const RomWork& w, const RomRec& r, const double* __restr
   }
   gather12(xp, r.xbase, rom_slots(r), X.m);
 }
-struct RomPhase {           // optimised timings: expanded rows + duration columns of one (time node, ee)
-  int len[3];               // row lengths
-  int base_all, msize;      // ee-motion variables before the active polynomial / in the set
-  int n_sched, cur;         // duration columns, current phase
-  bool in_last;
+struct RomPhase {           // optimised timings: what the duration columns of one (time node, ee) need
+  bool in_last;             // current phase is the last one (not a variable)
   double inner, prevp, T;   // 1/n_polys of the phase, polynomials before this one in the phase, its duration
+  double* sched;            // LDS: [0..2] column of the phases before the current one, [3..5] of the current one
 };
 template <bool PHASE = false>
 TWR_DEV void rom_item(const RomWork& w, const RomRec& r, const RomX& X, double* __restrict__ gst, double* __restrict__ stage,
@@ -651,14 +649,8 @@ TWR_DEV void rom_item(const RomWork& w, const RomRec& r, const RomX& X, double* 
     matTvec(ro.R, tz, uz);
   }
   const int nm = meta_nslots(r.meta);
-  int rs[3] = {soff, soff + 20 + nm, soff + 44 + 2 * nm};
-  int mo[3] = {20, 24, 24};
-  if constexpr (PHASE) {
-    rs[1] = soff + ph->len[0];
-    rs[2] = rs[1] + ph->len[1];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) mo[i] += ph->base_all;
-  }
+  const int rs[3] = {soff, soff + 20 + nm, soff + 44 + 2 * nm};
+  const int mo[3] = {20, 24, 24};
 #pragma unroll
   for (int row = 0; row < 3; ++row) {
 #pragma unroll
@@ -676,7 +668,7 @@ TWR_DEV void rom_item(const RomWork& w, const RomRec& r, const RomX& X, double* 
 #pragma unroll
       for (int d = 0; d < 3; ++d) {  // R^T J_p
         const int sl = (int)((slots >> (4 * (j * 3 + d))) & 0xF);
-        put_if<PHASE>(stage, sl != 0xF, rs[row] + mo[row] + sl, trash, ro.R[d][row] * wm[j]);
+        stage[sl != 0xF ? rs[row] + mo[row] + sl : trash] = ro.R[d][row] * wm[j];
       }
     }
   }
@@ -686,10 +678,11 @@ TWR_DEV void rom_item(const RomWork& w, const RomRec& r, const RomX& X, double* 
     duration_columns(nv, r.tm, ph->T, ph->inner, ph->prevp, ph->in_last, prev, cur);
     matTvec(ro.R, prev, rp);
     matTvec(ro.R, cur, rc);
-    for (int p = 0; p < ph->n_sched; ++p)
 #pragma unroll
-      for (int row = 0; row < 3; ++row)
-        stage[rs[row] + (row == 0 ? 20 : 24) + ph->msize + p] = p < ph->cur ? rp[row] : (p == ph->cur ? rc[row] : 0.0);
+    for (int row = 0; row < 3; ++row) {
+      ph->sched[row] = rp[row];
+      ph->sched[3 + row] = rc[row];
+    }
   }
 }
 
@@ -1117,12 +1110,12 @@ __global__ __launch_bounds__(256) void node_kernel(const NodeWork* __restrict__ 
 // ---------------------------------------------------------------- optimised timings (PhaseSpline) kernels
 // With Parameters::OptimizePhaseDurations the active polynomial of every ee spline depends on x and every
 // Jacobian row of an ee spline holds all variables of its set (phase_spline.cc:44-51), most of them
-// explicit zeros.  A workgroup (one wave) owns a run of 16 (dynamic) / 64 (rangeofmotion-<ee>) time nodes,
-// i.e. one contiguous slice of the value array: it first streams zeros over the slice with coalesced
-// 16-byte stores, locates the active polynomials from the durations in x, evaluates the same quad / lane
-// math as the fixed-timing kernels and, once the zeros have been acknowledged, stores the non-zero values
-// directly at their CSR positions, plus the duration columns (dynamic_constraint.cc:107-113,
-// range_of_motion_constraint.cc:106-108).
+// explicit zeros.  A workgroup (one wave) owns a run of 16 time nodes, i.e. one contiguous slice of the
+// value array; it locates the active polynomials from the durations in x and evaluates the same quad / lane
+// math as the fixed-timing kernels, plus the duration columns (dynamic_constraint.cc:107-113,
+// range_of_motion_constraint.cc:106-108).  dyn_phase_kernel first streams zeros over its slice with
+// coalesced 16-byte stores and, once they have been acknowledged, stores the non-zero values directly at
+// their CSR positions; rom_phase_kernel stages a compact image in LDS and streams out whole expanded rows.
 TWR_DEV void zero_fill(double* __restrict__ dst, int n, int lane) {
   const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
   if (n <= 0) return;
@@ -1151,6 +1144,23 @@ TWR_DEV void phase_poly_durations(const PhaseTables* PT, const char* blob, const
     const PhasePoly* fp = tbl<PhasePoly>(blob, PT->o_fpoly[e]);
     for (int q = 0; q < PT->n_fpoly[e]; ++q) fd[q] = ph[fp[q].phase] / fp[q].n_in_phase;
   }
+}
+
+// The same, spread over the lanes of a wave (one ee): loads in parallel, only the duration sum is serial.
+TWR_DEV void phase_poly_durations_wave(const PhaseTables* PT, const char* blob, const double* __restrict__ xp, int e,
+                                       double* ph, double* md, int lane) {
+  const int ns = PT->n_phases[e] - 1;
+  if (lane < ns) ph[lane] = xp[PT->off_sched[e] + lane];
+  __syncthreads();
+  if (lane == 0) {
+    double sum = 0.0;
+    for (int i = 0; i < ns; ++i) sum += ph[i];
+    ph[ns] = PT->t_total[e] - sum;
+  }
+  __syncthreads();
+  const PhasePoly* mp = tbl<PhasePoly>(blob, PT->o_mpoly[e]);
+  for (int q = lane; q < PT->n_mpoly[e]; q += 64) md[q] = ph[mp[q].phase] / mp[q].n_in_phase;
+  __syncthreads();
 }
 
 template <int NEE>
@@ -1267,9 +1277,18 @@ __global__ __launch_bounds__(64) void dyn_phase_kernel(const PhaseWork* __restri
   dyn_back<NEE, true>(w, ln, S, gout, out, 0, lane, want_g, want_j);
 }
 
+// rangeofmotion-<ee> with optimised timings: lane = time node.  The lanes fill a compact LDS image (the
+// fixed-timing layout at a fixed stride per node), then the wave streams out every expanded row
+// [base-lin 12 | base-ang 12 (8) | all ee-motion_e variables | all durations] as one coalesced run, taking
+// the active polynomial's values from the image and writing explicit zeros everywhere else.
+constexpr int kRomPStride = 108;  // compact values of one time node: 3 rows x (24 + <= 12 slots)
+constexpr int kRomPNodes = 16;    // time nodes per workgroup: small images keep ~10 workgroups per CU in flight
 __global__ __launch_bounds__(64) void rom_phase_kernel(const PhaseWork* __restrict__ work, const double* __restrict__ x,
                                                        double* __restrict__ g, double* __restrict__ jac, int flags) {
   __shared__ double s_ph[TWR_MAX_PHASES_DEV], s_md[kMaxPhasePolys];
+  __shared__ __attribute__((aligned(16))) double img[kRomPNodes * kRomPStride + 64];
+  __shared__ double s_sched[kRomPNodes * 6];
+  __shared__ int s_meta[kRomPNodes];  // nslots | base_all << 8 | current phase << 24
   const PhaseWork pw = work[blockIdx.x];
   const char* blob = reinterpret_cast<const char*>(pw.blob);
   const DevStruct* H = reinterpret_cast<const DevStruct*>(blob);
@@ -1279,16 +1298,14 @@ __global__ __launch_bounds__(64) void rom_phase_kernel(const PhaseWork* __restri
   const int lane = threadIdx.x, e = pw.ee;
   double* out = jac + pw.j_off + PT->nnz_rom[e] + (int64_t)pw.k0 * PT->rom_node_vals[e];
   double* gout = g + pw.g_off + PT->row_rom[e] + 3 * pw.k0;
-  if (want_j) zero_fill(out, pw.cnt * PT->rom_node_vals[e], lane);
-  if (lane == 0) phase_poly_durations(PT, blob, xp, e, s_ph, s_md, nullptr, false);
-  __syncthreads();
+  phase_poly_durations_wave(PT, blob, xp, e, s_ph, s_md, lane);
   const int kl = min(lane, pw.cnt - 1), k = pw.k0 + kl;
   const double t = tbl<double>(blob, PT->o_trom)[k];
+  RomRec r = tbl<RomRec>(blob, PT->o_rom_recs[e])[k];  // base-spline part (tb, iTb, q6) is x-independent
   double tlm, tlp;
   const int qm = locate_segment(s_md, PT->n_mpoly[e], t, tlm);
   const int cur = locate_segment(s_ph, PT->n_phases[e], t, tlp);
   const PhasePoly pm = tbl<PhasePoly>(blob, PT->o_mpoly[e])[qm];
-  RomRec r = tbl<RomRec>(blob, PT->o_rom_recs[e])[k];  // base-spline part (tb, iTb, q6) is x-independent
   r.tm = tlm;
   r.iTm = 1.0 / s_md[qm];
   r.xbase = pm.xbase;
@@ -1296,7 +1313,7 @@ __global__ __launch_bounds__(64) void rom_phase_kernel(const PhaseWork* __restri
   const uint64_t slots = slots_of(pm.cand);
   r.slots[0] = (uint32_t)slots;
   r.slots[1] = (uint32_t)(slots >> 32);
-  r.voff = kl * PT->rom_node_vals[e];
+  r.voff = kl * kRomPStride;
   RomWork w;
   w.recs = 0;
   w.x_off = pw.x_off;
@@ -1304,20 +1321,48 @@ __global__ __launch_bounds__(64) void rom_phase_kernel(const PhaseWork* __restri
   w.off_lin = PT->off_lin; w.off_ang = PT->off_ang;
   w.cnt = pw.cnt; w.nvals = 0;
   RomPhase ph;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) ph.len[i] = PT->rom_len[e][i];
-  ph.base_all = pm.base_all;
-  ph.msize = PT->msize[e];
-  ph.n_sched = PT->n_phases[e] - 1;
-  ph.cur = cur;
   ph.in_last = cur == PT->n_phases[e] - 1;
   ph.inner = 1.0 / pm.n_in_phase;
   ph.prevp = (double)pm.poly_in_phase;
   ph.T = s_md[qm];
+  ph.sched = s_sched + 6 * kl;
+  if (lane < pw.cnt) s_meta[lane] = meta_nslots(pm.meta) | ((int)pm.base_all << 8) | (cur << 24);
   RomX X;
   rom_load_x(w, r, x, X);
-  __syncthreads();  // the zeros of the slice are in place before any value
-  if (lane < pw.cnt) rom_item<true>(w, r, X, gout, out, 0, 0, 0, lane, want_g, want_j, &ph);
+  if (lane < pw.cnt) rom_item<true>(w, r, X, gout, img, 0, 0, kRomPNodes * kRomPStride + lane, lane, want_g, want_j, &ph);
+  __syncthreads();
+  if (!want_j) return;
+  const int msize = PT->msize[e], ns = PT->n_phases[e] - 1, node_vals = PT->rom_node_vals[e];
+  const int len0 = 20 + msize + ns, len1 = 24 + msize + ns;
+  // expanded values of one node, 64 at a time, four independent chunks per iteration
+  for (int node = 0; node < pw.cnt; ++node) {
+    const int meta = s_meta[node];
+    const int nm = meta & 0xFF, ba = (meta >> 8) & 0xFFFF, ncur = meta >> 24;
+    const double* im = img + node * kRomPStride;
+    const double* sc = s_sched + 6 * node;
+    double* dst = out + (int64_t)node * node_vals;
+    for (int i0 = 0; i0 < node_vals; i0 += 256) {
+      double v[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int i = min(i0 + 64 * c + lane, node_vals - 1);
+        const int row = (i >= len0) + (i >= len0 + len1);
+        const int col = i - (row == 0 ? 0 : (row == 1 ? len0 : len0 + len1));
+        const int nb = row == 0 ? 20 : 24;
+        const int rsr = row == 0 ? 0 : (row == 1 ? 20 + nm : 44 + 2 * nm);
+        const int j = col - nb - ba, p = col - nb - msize;
+        const bool in_base = col < nb, in_poly = (unsigned)j < (unsigned)nm;
+        const double vi = im[rsr + (in_base ? col : nb + (in_poly ? j : 0))];
+        const double vs = p < ncur ? sc[row] : (p == ncur ? sc[3 + row] : 0.0);
+        v[c] = (in_base || in_poly) ? vi : (p >= 0 ? vs : 0.0);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int i = i0 + 64 * c + lane;
+        if (i < node_vals) dst[i] = v[c];
+      }
+    }
+  }
 }
 
 // host-side launcher (called from capi.cc): three launches on one stream.  The dyn/rom grids are
