@@ -201,6 +201,36 @@ def test_edge_sizes(name, make):
         assert_parity(case.S, *_split(batch, g, j, p), rg, rj, "%s x[%d]" % (name, p), x=x)
 
 
+def test_optimised_timings_at_scale():
+    """512 problems with optimised phase durations (1.6 GB of Jacobian values): every value is written
+    (zeros included), copies of one x agree bit for bit wherever they sit, values-only calls leave the
+    Jacobian buffer alone, sampled problems match the oracle."""
+    import torch
+
+    case = Case("anymal", "flat", ta.gait_combo(4, 1, 2.0), constraint_sets=127, **k_params(2.0, 200))
+    S = case.S
+    B, nb = 512, 16
+    batch = ta.Batch([S], [0] * B, device=0)
+    base = np.stack([case.x_perturbed(40 + i) for i in range(nb)])
+    x = torch.from_numpy(np.tile(base, (B // nb, 1)).reshape(-1)).cuda()
+    g = torch.full((int(batch.g_off[-1]),), float("nan"), dtype=torch.float64, device="cuda")
+    j = torch.full((int(batch.jac_off[-1]),), float("nan"), dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    batch.eval_device(x.data_ptr(), g.data_ptr(), 0, ta.EVAL_VALUES, st)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(g).all()) and bool(torch.isnan(j).all())
+    for _ in range(3):
+        batch.eval_device(x.data_ptr(), g.data_ptr(), j.data_ptr(), ta.EVAL_BOTH, st)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(j).all())
+    G, J = g.view(B, S.m), j.view(B, S.nnz)
+    assert bool((G.view(B // nb, nb, S.m) == G[:nb]).all()) and bool((J.view(B // nb, nb, S.nnz) == J[:nb]).all())
+    for p in (0, 7, 15):
+        rg, _, _, rj = case.P.eval(base[p])
+        assert_parity(S, G[p + nb * 3].cpu().numpy(), J[p + nb * 20].cpu().numpy(), rg, rj, "problem %d" % p, x=base[p])
+    assert float((J[0] == 0).double().mean()) > 0.6   # most of the all-variables rows are explicit zeros
+
+
 def test_foot_starting_in_swing():
     """ee_in_contact_at_start = false: first polynomial of ee-motion is a swing one, force starts at zero."""
     sched = ta.schedule([[0.3, 0.5, 0.3, 0.4], [0.6, 0.3, 0.6]], [0, 1])

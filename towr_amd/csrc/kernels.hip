@@ -1,11 +1,14 @@
 // HIP kernels (gfx950 / CDNA4) for towr's NLP constraint + Jacobian callback.
 //
-// Three launches per callback batch (dynamic, range of motion, force/terrain nodes), one stream.
-// A workgroup is one wavefront (64 lanes); it walks a strided list of work items, each one a
+// Three launches per callback batch (dynamic, range of motion, node-based sets), one stream.
+// A dyn/rom workgroup is one wavefront (64 lanes); it walks a strided list of work items, each one a
 // *contiguous* slice of one problem's CSR value array:
 //   dyn_kernel   dynamic           : 16 consecutive time nodes k, FOUR lanes per node (6 rows each)
 //   rom_kernel   rangeofmotion-ee  : lanes = consecutive time nodes k               (3 rows each)
-//   node_kernel  force-* / terrain-* sets of the problem: lanes = spline nodes
+//   node_kernel  terrain-* / force-* / splineacc-base-* / swing-* (+ totalduration-*) of one problem:
+//                four waves, one per family, lanes = spline nodes / rows
+//   dyn_phase_kernel / rom_phase_kernel: the same math for problems with optimised phase durations
+//                (x-dependent active polynomials, rows that hold all variables of every ee set)
 // Every lane computes its rows in registers (FP64, no MFMA: the work is 3x3 algebra),
 // scatters the values into an LDS image of the slice at the CSR position they have in
 // global memory, and the wave then streams the image out with 16-byte coalesced stores.
@@ -610,9 +613,6 @@ template <bool PHASE = false>
 TWR_DEV void rom_item(const RomWork& w, const RomRec& r, const RomX& X, double* __restrict__ gst, double* __restrict__ stage,
                       int par, int vbase, int trash, int lane, bool want_g, bool want_j, const RomPhase* ph = nullptr) {
   const int soff = par + r.voff - vbase;
-#ifdef TWR_EXP_NOMATH
-  { double acc = 0; for (int i2 = 0; i2 < 12; ++i2) acc += X.bl[i2] + X.ba[i2] + X.m[i2]; if (want_j) stage[soff] = acc; return; }
-#endif
   double wP[4];
   hermite_pos(r.tb, r.iTb, wP);
   double c[3], e[3];
