@@ -1,0 +1,40 @@
+"""B=1 latency of the C3 callback (device-resident and host-buffer variants) -- numbers for DESIGN.md section 6."""
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np, torch
+import towr_amd as ta
+from bench import build_case, perturbed_inputs
+
+model = ta.model_preset("anymal", "flat")
+for sets, name in ((27, "hot path"), (63, "default list"), (127, "default + timings")):
+    sched, params, S = build_case(ta, model, constraint_sets=sets)
+    for B in (1, 64):
+        batch = ta.Batch([S], [0] * B, device=0)
+        xh = perturbed_inputs(S, model, B, 0).reshape(-1)
+        x = torch.from_numpy(xh).cuda()
+        g = torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device="cuda")
+        j = torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        for _ in range(20):
+            batch.eval_device(x.data_ptr(), g.data_ptr(), j.data_ptr(), ta.EVAL_BOTH, st)
+        torch.cuda.synchronize()
+        n = 500
+        t0 = time.perf_counter()
+        for _ in range(n):
+            batch.eval_device(x.data_ptr(), g.data_ptr(), j.data_ptr(), ta.EVAL_BOTH, st)
+        torch.cuda.synchronize()
+        dev_us = (time.perf_counter() - t0) / n * 1e6
+        # one call, synchronised each time (what an Ipopt iteration sees with device-resident buffers)
+        t0 = time.perf_counter()
+        for _ in range(200):
+            batch.eval_device(x.data_ptr(), g.data_ptr(), j.data_ptr(), ta.EVAL_BOTH, st)
+            torch.cuda.synchronize()
+        sync_us = (time.perf_counter() - t0) / 200 * 1e6
+        for _ in range(5):
+            batch.eval_host(xh)
+        t0 = time.perf_counter()
+        for _ in range(100):
+            batch.eval_host(xh)
+        host_us = (time.perf_counter() - t0) / 100 * 1e6
+        print("%-18s B=%-3d n=%d nnz=%d: back-to-back %.1f us/call, synchronised %.1f us/call, host buffers (H2D+eval+D2H) %.1f us/call"
+              % (name, B, S.n, S.nnz, dev_us, sync_us, host_us), flush=True)
