@@ -179,6 +179,11 @@ int twr_batch_profile_begin(twr_batch* b, int max_evals);
 int twr_batch_profile_end(twr_batch* b, double avg_ms[3], int* n_evals);
 /* Convenience for single-problem / adapter use: host buffers, synchronous (H2D, eval, D2H). */
 int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_jac, int flags);
+/* Page-locked host buffers owned by the batch (x, g, jac of the whole batch layout), allocated on first
+ * use.  Passing exactly these pointers to twr_batch_eval_host makes the transfers DMA directly from / into
+ * them (no staging through pageable memory): what an Ipopt callback should read g and the Jacobian
+ * values from (the ifopt adapter does). */
+int twr_batch_host_buffers(twr_batch* b, double** h_x, double** h_g, double** h_jac);
 
 #ifdef __cplusplus
 }

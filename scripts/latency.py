@@ -36,5 +36,15 @@ for sets, name in ((27, "hot path"), (63, "default list"), (127, "default + timi
         for _ in range(100):
             batch.eval_host(xh)
         host_us = (time.perf_counter() - t0) / 100 * 1e6
-        print("%-18s B=%-3d n=%d nnz=%d: back-to-back %.1f us/call, synchronised %.1f us/call, host buffers (H2D+eval+D2H) %.1f us/call"
-              % (name, B, S.n, S.nnz, dev_us, sync_us, host_us), flush=True)
+        px, pg, pj = batch.host_buffers()
+        px[:] = xh
+        for _ in range(5):
+            batch.eval_host_pinned()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            batch.eval_host_pinned()
+        pin_us = (time.perf_counter() - t0) / 100 * 1e6
+        g2, j2 = batch.eval_host(xh)
+        assert np.array_equal(g2, pg) and np.array_equal(j2, pj)
+        print("%-18s B=%-3d n=%d nnz=%d: back-to-back %.1f us/call, synchronised %.1f us/call, host buffers (H2D+eval+D2H) "
+              "pageable %.1f us/call, page-locked %.1f us/call" % (name, B, S.n, S.nnz, dev_us, sync_us, host_us, pin_us), flush=True)

@@ -231,6 +231,23 @@ def test_optimised_timings_at_scale():
     assert float((J[0] == 0).double().mean()) > 0.6   # most of the all-variables rows are explicit zeros
 
 
+def test_page_locked_host_buffers():
+    """twr_batch_host_buffers + twr_batch_eval_host: same results as the pageable path."""
+    case = baseline_cases()["C2_biped_K100"]()
+    batch = ta.Batch([case.S], [0, 0, 0], device=0)
+    xs = np.concatenate([case.x_wild(i) for i in range(3)])
+    g, j = batch.eval_host(xs)
+    px, pg, pj = batch.host_buffers()
+    assert px.size == xs.size and pg.size == g.size and pj.size == j.size
+    px[:] = xs
+    pg[:] = np.nan
+    pj[:] = np.nan
+    batch.eval_host_pinned()
+    assert np.array_equal(pg, g) and np.array_equal(pj, j)
+    px2, _, _ = batch.host_buffers()
+    assert px2.ctypes.data == px.ctypes.data   # allocated once, owned by the batch
+
+
 def test_foot_starting_in_swing():
     """ee_in_contact_at_start = false: first polynomial of ee-motion is a swing one, force starts at zero."""
     sched = ta.schedule([[0.3, 0.5, 0.3, 0.4], [0.6, 0.3, 0.6]], [0, 1])

@@ -116,6 +116,7 @@ def lib():
         L.twr_batch_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.twr_batch_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.twr_batch_eval_host.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int]
+        L.twr_batch_host_buffers.argtypes = [C.c_void_p, C.POINTER(_dp), C.POINTER(_dp), C.POINTER(_dp)]
         L.twr_batch_profile_begin.argtypes = [C.c_void_p, C.c_int]
         L.twr_batch_profile_end.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_int)]
         _lib = L
@@ -287,6 +288,19 @@ class Batch:
             for k in out:
                 out[k] += 8 * S.n
         return out
+
+    def host_buffers(self):
+        """Page-locked x / g / jac arrays owned by the batch (numpy views); eval_host_pinned() uses them."""
+        px, pg, pj = _dp(), _dp(), _dp()
+        _check(lib().twr_batch_host_buffers(self._h, C.byref(px), C.byref(pg), C.byref(pj)))
+        as_np = lambda p, n: np.ctypeslib.as_array(p, shape=(int(n),))
+        return as_np(px, self.x_off[-1]), as_np(pg, self.g_off[-1]), as_np(pj, self.jac_off[-1])
+
+    def eval_host_pinned(self, flags=EVAL_BOTH):
+        """Evaluate from / into the page-locked buffers of host_buffers() (fill x there first)."""
+        px, pg, pj = _dp(), _dp(), _dp()
+        _check(lib().twr_batch_host_buffers(self._h, C.byref(px), C.byref(pg), C.byref(pj)))
+        _check(lib().twr_batch_eval_host(self._h, px, pg, pj, flags))
 
     def eval_host(self, x, flags=EVAL_BOTH):
         x = np.ascontiguousarray(x, dtype=np.float64)

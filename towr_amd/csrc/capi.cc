@@ -40,6 +40,7 @@ struct twr_batch {
   int n_pdyn = 0, n_prom = 0;
   // lazily sized scratch for twr_batch_eval_host
   double *d_x = nullptr, *d_g = nullptr, *d_j = nullptr;
+  double *p_x = nullptr, *p_g = nullptr, *p_j = nullptr;  // page-locked host buffers (twr_batch_host_buffers)
   // optional per-kernel timing (twr_batch_profile_begin/end): 4 events per recorded eval
   std::vector<hipEvent_t> prof_events;
   int prof_capacity = 0, prof_count = 0;
@@ -380,6 +381,9 @@ void twr_batch_destroy(twr_batch* b) {
   if (b->d_x) (void)hipFree(b->d_x);
   if (b->d_g) (void)hipFree(b->d_g);
   if (b->d_j) (void)hipFree(b->d_j);
+  if (b->p_x) (void)hipHostFree(b->p_x);
+  if (b->p_g) (void)hipHostFree(b->p_g);
+  if (b->p_j) (void)hipHostFree(b->p_j);
   delete b;
 }
 
@@ -457,12 +461,33 @@ int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_
       TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_g), ng * sizeof(double)));
       TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_j), nj * sizeof(double)));
     }
-    TWR_HIP(hipMemcpy(b->d_x, h_x, nx * sizeof(double), hipMemcpyHostToDevice));
+    // one stream-ordered chain and a single synchronisation (with page-locked buffers the copies are DMA)
+    TWR_HIP(hipMemcpyAsync(b->d_x, h_x, nx * sizeof(double), hipMemcpyHostToDevice, nullptr));
     int rc = twr_batch_eval(b, b->d_x, b->d_g, b->d_j, flags, nullptr);
     if (rc != TWR_OK) return rc;
-    TWR_HIP(hipDeviceSynchronize());
-    if ((flags & TWR_EVAL_VALUES) && h_g) TWR_HIP(hipMemcpy(h_g, b->d_g, ng * sizeof(double), hipMemcpyDeviceToHost));
-    if ((flags & TWR_EVAL_JACOBIAN) && h_jac) TWR_HIP(hipMemcpy(h_jac, b->d_j, nj * sizeof(double), hipMemcpyDeviceToHost));
+    if ((flags & TWR_EVAL_VALUES) && h_g)
+      TWR_HIP(hipMemcpyAsync(h_g, b->d_g, ng * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+    if ((flags & TWR_EVAL_JACOBIAN) && h_jac)
+      TWR_HIP(hipMemcpyAsync(h_jac, b->d_j, nj * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+    TWR_HIP(hipStreamSynchronize(nullptr));
+    return TWR_OK;
+  } catch (const std::exception& e) {
+    return fail(TWR_ERR_HIP, e.what());
+  }
+}
+
+int twr_batch_host_buffers(twr_batch* b, double** h_x, double** h_g, double** h_jac) {
+  if (!b) return fail(TWR_ERR_INVALID, "null batch");
+  try {
+    TWR_HIP(hipSetDevice(b->device));
+    if (!b->p_x) {
+      TWR_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->p_x), b->x_off.back() * sizeof(double), hipHostMallocDefault));
+      TWR_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->p_g), b->g_off.back() * sizeof(double), hipHostMallocDefault));
+      TWR_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->p_j), b->j_off.back() * sizeof(double), hipHostMallocDefault));
+    }
+    if (h_x) *h_x = b->p_x;
+    if (h_g) *h_g = b->p_g;
+    if (h_jac) *h_jac = b->p_j;
     return TWR_OK;
   } catch (const std::exception& e) {
     return fail(TWR_ERR_HIP, e.what());

@@ -41,9 +41,7 @@ class DeviceProblem {
     const int32_t map[1] = {0};
     Check(twr_batch_create(list, 1, map, 1, device, &batch_));
     Check(twr_structure_sizes(structure_, &sizes_));
-    x_.assign(sizes_.n_vars, 0.0);
-    g_.assign(sizes_.n_rows, 0.0);
-    jac_.assign(sizes_.nnz, 0.0);
+    Check(twr_batch_host_buffers(batch_, &x_, &g_, &jac_));  // page-locked, owned by the batch
     lower_.resize(sizes_.n_rows);
     upper_.resize(sizes_.n_rows);
     Check(twr_structure_bounds(structure_, lower_.data(), upper_.data()));
@@ -58,15 +56,15 @@ class DeviceProblem {
   // Composite::GetValues() of the variable composite, stacked in ifopt order.
   void Update(const Eigen::VectorXd& x) {
     if (x.size() != sizes_.n_vars) throw std::runtime_error("towr_amd: variable count mismatch");
-    if (valid_ && std::memcmp(x.data(), x_.data(), sizeof(double) * x_.size()) == 0) return;
-    std::memcpy(x_.data(), x.data(), sizeof(double) * x_.size());
-    Check(twr_batch_eval_host(batch_, x_.data(), g_.data(), jac_.data(), TWR_EVAL_BOTH));
+    if (valid_ && std::memcmp(x.data(), x_, sizeof(double) * sizes_.n_vars) == 0) return;
+    std::memcpy(x_, x.data(), sizeof(double) * sizes_.n_vars);
+    Check(twr_batch_eval_host(batch_, x_, g_, jac_, TWR_EVAL_BOTH));
     valid_ = true;
   }
   const twr_structure* structure() const { return structure_; }
   const twr_sizes& sizes() const { return sizes_; }
-  const std::vector<double>& g() const { return g_; }
-  const std::vector<double>& jac() const { return jac_; }
+  const double* g() const { return g_; }
+  const double* jac() const { return jac_; }
   const std::vector<double>& lower() const { return lower_; }
   const std::vector<double>& upper() const { return upper_; }
 
@@ -77,7 +75,8 @@ class DeviceProblem {
   twr_structure* structure_ = nullptr;
   twr_batch* batch_ = nullptr;
   twr_sizes sizes_{};
-  std::vector<double> x_, g_, jac_, lower_, upper_;
+  double *x_ = nullptr, *g_ = nullptr, *jac_ = nullptr;
+  std::vector<double> lower_, upper_;
   bool valid_ = false;
 };
 
@@ -98,7 +97,7 @@ class DeviceConstraintSet : public ifopt::ConstraintSet {
 
   VectorXd GetValues() const override {
     problem_->Update(GetVariables()->GetValues());
-    return Eigen::Map<const VectorXd>(problem_->g().data() + info_.offset, info_.size);
+    return Eigen::Map<const VectorXd>(problem_->g() + info_.offset, info_.size);
   }
 
   VecBound GetBounds() const override {
@@ -116,7 +115,7 @@ class DeviceConstraintSet : public ifopt::ConstraintSet {
     if (!vs) return;  // a variable set this structure does not know (e.g. "ee-schedule<i>" with fixed timings)
     const int32_t* row_ptr = twr_structure_row_ptr(problem_->structure());
     const int32_t* col_idx = twr_structure_col_idx(problem_->structure());
-    const double* val = problem_->jac().data();
+    const double* val = problem_->jac();
     for (int r = 0; r < info_.size; ++r)
       for (int k = row_ptr[info_.offset + r]; k < row_ptr[info_.offset + r + 1]; ++k) {
         int c = col_idx[k] - vs->offset;
