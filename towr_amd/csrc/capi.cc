@@ -14,9 +14,9 @@
 
 namespace twr {
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
-                       const NodeWork* node, int n_node, const PhaseWork* pdyn, int n_pdyn, const PhaseWork* prom,
-                       int n_prom, const double* x, double* g, double* jac, int flags, hipStream_t stream,
-                       hipEvent_t* ev);
+                       const NodeWork* node, int n_node, const PhaseWork* pdyn, int n_pdyn, const LocWork* ploc,
+                       int n_ploc, const RomPhaseWork* prom, int n_prom, const double* x, double* g, double* jac,
+                       int flags, hipStream_t stream, hipEvent_t* ev);
 int dyn_stage_capacity();
 int rom_stage_capacity();
 int dyn_nodes_per_block();
@@ -36,8 +36,11 @@ struct twr_batch {
   twr::RomWork* d_rom = nullptr;
   twr::NodeWork* d_node = nullptr;
   // optimised-timings problems have their own work lists
-  twr::PhaseWork *d_pdyn = nullptr, *d_prom = nullptr;
-  int n_pdyn = 0, n_prom = 0;
+  twr::PhaseWork* d_pdyn = nullptr;
+  twr::LocWork* d_ploc = nullptr;
+  twr::RomPhaseWork* d_prom = nullptr;
+  void* d_precs = nullptr;  // scratch: x-dependent RomRec records of the optimised-timings problems
+  int n_pdyn = 0, n_ploc = 0, n_prom = 0;
   // lazily sized scratch for twr_batch_eval_host
   double *d_x = nullptr, *d_g = nullptr, *d_j = nullptr;
   double *p_x = nullptr, *p_g = nullptr, *p_j = nullptr;  // page-locked host buffers (twr_batch_host_buffers)
@@ -233,7 +236,10 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     std::vector<twr::DynWork> dyn;
     std::vector<twr::RomWork> rom;
     std::vector<twr::NodeWork> node;
-    std::vector<twr::PhaseWork> pdyn, prom;
+    std::vector<twr::PhaseWork> pdyn;
+    std::vector<twr::LocWork> ploc;
+    std::vector<twr::RomPhaseWork> prom;
+    size_t prec_bytes = 0;  // offsets into the scratch buffer are stored first and rebased after hipMalloc
     std::vector<int> dyn_first, rom_first;  // first work item of every problem (+ end)
     // run lists are identical for problems that share a structure: build once per structure
     std::vector<std::vector<std::pair<int, int>>> runs_dyn(n_structs);
@@ -307,13 +313,31 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
             pdyn.push_back(pw);
           }
         for (int e = 0; e < S.n_ee; ++e)
-          if (S.FindSet("rangeofmotion-" + std::to_string(e)))
-            for (int k0 = 0; k0 < (int)S.grid_rom.size(); k0 += 16) {
-              pw.k0 = k0;
-              pw.cnt = std::min(16, (int)S.grid_rom.size() - k0);
-              pw.ee = e;
-              prom.push_back(pw);
+          if (const twr::SetInfo* rs = S.FindSet("rangeofmotion-" + std::to_string(e))) {
+            const int K = (int)S.grid_rom.size(), nv = S.phase_tables.rom_node_vals[e];
+            twr::LocWork lw;
+            lw.blob = blob;
+            lw.recs = prec_bytes;
+            lw.x_off = b->x_off[p];
+            lw.ee = e;
+            lw.pad = 0;
+            ploc.push_back(lw);
+            for (int k0 = 0; k0 < K; k0 += 16) {
+              twr::RomPhaseWork rw;
+              rw.recs = prec_bytes + sizeof(twr::RomRec) * (size_t)k0;
+              rw.x_off = b->x_off[p];
+              rw.g_off = b->g_off[p] + rs->offset + 3 * k0;
+              rw.j_off = b->j_off[p] + rs->nnz_offset + (int64_t)k0 * nv;
+              rw.off_lin = S.off_base_lin;
+              rw.off_ang = S.off_base_ang;
+              rw.cnt = std::min(16, K - k0);
+              rw.msize = S.phase_tables.msize[e];
+              rw.ns = S.schedule.n_phases[e] - 1;
+              rw.node_vals = nv;
+              prom.push_back(rw);
             }
+            prec_bytes += sizeof(twr::RomRec) * (size_t)K;
+          }
       }
       twr::NodeWork nw;
       nw.blob = blob;
@@ -357,9 +381,17 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     upload(rom.data(), rom.size() * sizeof(twr::RomWork), reinterpret_cast<void**>(&b->d_rom));
     upload(node.data(), node.size() * sizeof(twr::NodeWork), reinterpret_cast<void**>(&b->d_node));
     b->n_pdyn = (int)pdyn.size();
+    b->n_ploc = (int)ploc.size();
     b->n_prom = (int)prom.size();
     if (!pdyn.empty()) upload(pdyn.data(), pdyn.size() * sizeof(twr::PhaseWork), reinterpret_cast<void**>(&b->d_pdyn));
-    if (!prom.empty()) upload(prom.data(), prom.size() * sizeof(twr::PhaseWork), reinterpret_cast<void**>(&b->d_prom));
+    if (!prom.empty()) {
+      TWR_HIP(hipMalloc(&b->d_precs, prec_bytes));
+      const uint64_t base = reinterpret_cast<uint64_t>(b->d_precs);
+      for (auto& lw : ploc) lw.recs += base;
+      for (auto& rw : prom) rw.recs += base;
+      upload(ploc.data(), ploc.size() * sizeof(twr::LocWork), reinterpret_cast<void**>(&b->d_ploc));
+      upload(prom.data(), prom.size() * sizeof(twr::RomPhaseWork), reinterpret_cast<void**>(&b->d_prom));
+    }
     *out = b.release();
     return TWR_OK;
   } catch (const std::exception& e) {
@@ -377,6 +409,8 @@ void twr_batch_destroy(twr_batch* b) {
   if (b->d_node) (void)hipFree(b->d_node);
   if (b->d_pdyn) (void)hipFree(b->d_pdyn);
   if (b->d_prom) (void)hipFree(b->d_prom);
+  if (b->d_ploc) (void)hipFree(b->d_ploc);
+  if (b->d_precs) (void)hipFree(b->d_precs);
   for (hipEvent_t e : b->prof_events) (void)hipEventDestroy(e);
   if (b->d_x) (void)hipFree(b->d_x);
   if (b->d_g) (void)hipFree(b->d_g);
@@ -407,8 +441,8 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
   if (b->prof_count < b->prof_capacity) ev = b->prof_events.data() + 4 * b->prof_count++;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->d_rom, b->n_rom, b->d_node, b->n_node,
-                                  b->d_pdyn, b->n_pdyn, b->d_prom, b->n_prom, d_x, d_g, d_jac, flags & TWR_EVAL_BOTH,
-                                  stream, ev);
+                                  b->d_pdyn, b->n_pdyn, b->d_ploc, b->n_ploc, b->d_prom, b->n_prom, d_x, d_g, d_jac,
+                                  flags & TWR_EVAL_BOTH, stream, ev);
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   return TWR_OK;
 }

@@ -176,4 +176,24 @@ struct PhaseWork {        // optimised timings: cnt <= 16 time nodes of dynamic 
 };
 static_assert(sizeof(PhaseWork) == 48, "PhaseWork layout");
 
+// Optimised timings, rangeofmotion-<ee>: a light pre-pass (rom_locate_kernel) turns the x-dependent segment
+// lookup into RomRec records in a scratch buffer, so that the persistent kernel sees the same two-step
+// record -> x dependency as the fixed-timing kernel.  The records carry the phase data in RomRec::pad:
+//   pad[0] = base_all | current phase << 16 | in_last_phase << 24,  pad[1] = n_in_phase | poly_in_phase << 8
+struct LocWork {          // one (problem, ee)
+  uint64_t blob;
+  uint64_t recs;          // RomRec[k_rom] (output)
+  int64_t x_off;
+  int32_t ee, pad;
+};
+static_assert(sizeof(LocWork) == 32, "LocWork layout");
+struct RomPhaseWork {     // cnt <= 32 time nodes of one (problem, ee)
+  uint64_t recs;          // RomRec[k0..] written by the pre-pass
+  int64_t x_off, g_off, j_off;  // problem's x; first constraint value / first Jacobian value of the run
+  int32_t off_lin, off_ang;
+  int32_t cnt, msize;     // time nodes; variables of ee-motion_e
+  int32_t ns, node_vals;  // duration variables of the ee; expanded values per time node
+};
+static_assert(sizeof(RomPhaseWork) == 56, "RomPhaseWork layout");
+
 }  // namespace twr

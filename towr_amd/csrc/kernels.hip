@@ -1277,91 +1277,153 @@ __global__ __launch_bounds__(64) void dyn_phase_kernel(const PhaseWork* __restri
   dyn_back<NEE, true>(w, ln, S, gout, out, 0, lane, want_g, want_j);
 }
 
-// rangeofmotion-<ee> with optimised timings: lane = time node.  The lanes fill a compact LDS image (the
-// fixed-timing layout at a fixed stride per node), then the wave streams out every expanded row
-// [base-lin 12 | base-ang 12 (8) | all ee-motion_e variables | all durations] as one coalesced run, taking
-// the active polynomial's values from the image and writing explicit zeros everywhere else.
-constexpr int kRomPStride = 108;  // compact values of one time node: 3 rows x (24 + <= 12 slots)
-constexpr int kRomPNodes = 16;    // time nodes per workgroup: small images keep ~10 workgroups per CU in flight
-__global__ __launch_bounds__(64) void rom_phase_kernel(const PhaseWork* __restrict__ work, const double* __restrict__ x,
-                                                       double* __restrict__ g, double* __restrict__ jac, int flags) {
+// rangeofmotion-<ee> with optimised timings.
+// Pre-pass: one workgroup per (problem, ee) resolves the x-dependent part of every time node -- phase and
+// polynomial durations, active polynomial, local time, current phase -- into RomRec records.
+__global__ __launch_bounds__(64) void rom_locate_kernel(const LocWork* __restrict__ work, const double* __restrict__ x) {
   __shared__ double s_ph[TWR_MAX_PHASES_DEV], s_md[kMaxPhasePolys];
-  __shared__ __attribute__((aligned(16))) double img[kRomPNodes * kRomPStride + 64];
-  __shared__ double s_sched[kRomPNodes * 6];
-  __shared__ int s_meta[kRomPNodes];  // nslots | base_all << 8 | current phase << 24
-  const PhaseWork pw = work[blockIdx.x];
-  const char* blob = reinterpret_cast<const char*>(pw.blob);
+  const LocWork lw = work[blockIdx.x];
+  const char* blob = reinterpret_cast<const char*>(lw.blob);
   const DevStruct* H = reinterpret_cast<const DevStruct*>(blob);
   const PhaseTables* PT = tbl<PhaseTables>(blob, H->o_phase);
-  const double* xp = x + pw.x_off;
+  const int lane = threadIdx.x, e = lw.ee;
+  phase_poly_durations_wave(PT, blob, x + lw.x_off, e, s_ph, s_md, lane);
+  const double* tg = tbl<double>(blob, PT->o_trom);
+  const RomRec* base = tbl<RomRec>(blob, PT->o_rom_recs[e]);  // base-spline part (tb, iTb, q6) is x-independent
+  const PhasePoly* mp = tbl<PhasePoly>(blob, PT->o_mpoly[e]);
+  RomRec* out = reinterpret_cast<RomRec*>(lw.recs);
+  for (int k = lane; k < PT->k_rom; k += 64) {
+    const double t = tg[k];
+    double tlm, tlp;
+    const int qm = locate_segment(s_md, PT->n_mpoly[e], t, tlm);
+    const int cur = locate_segment(s_ph, PT->n_phases[e], t, tlp);
+    const PhasePoly pm = mp[qm];
+    RomRec r = base[k];
+    r.tm = tlm;
+    r.iTm = 1.0 / s_md[qm];
+    r.xbase = pm.xbase;
+    r.meta = pm.meta;
+    const uint64_t slots = slots_of(pm.cand);
+    r.slots[0] = (uint32_t)slots;
+    r.slots[1] = (uint32_t)(slots >> 32);
+    r.voff = 0;
+    r.pad[0] = (uint32_t)pm.base_all | ((uint32_t)cur << 16) | ((cur == PT->n_phases[e] - 1 ? 1u : 0u) << 24);
+    r.pad[1] = (uint32_t)pm.n_in_phase | ((uint32_t)pm.poly_in_phase << 8);
+    out[k] = r;
+  }
+}
+
+// Persistent, software pipelined like rom_kernel: lane = time node (<= 32 per slice).  The lanes fill a
+// compact LDS image (the fixed-timing layout at a fixed stride per node), then the wave streams out every
+// expanded row [base-lin 12 | base-ang 12 (8) | all ee-motion_e variables | all durations] as coalesced runs,
+// taking the active polynomial's values from the image and writing explicit zeros everywhere else; the
+// record of slice i+2 and the x values of slice i+1 are in flight meanwhile.
+constexpr int kRomPStride = 108;  // compact values of one time node: 3 rows x (24 + <= 12 slots)
+constexpr int kRomPNodes = 16;    // time nodes per slice: 15 KB of LDS, eight workgroups per CU (VGPR bound)
+TWR_DEV RomRec romp_load_rec(const RomPhaseWork& w, int lane) {
+  return gptr<RomRec>(w.recs)[min(lane, w.cnt - 1)];
+}
+TWR_DEV RomWork romp_as_work(const RomPhaseWork& w) {
+  RomWork o;
+  o.recs = w.recs;
+  o.x_off = w.x_off; o.g_off = w.g_off; o.j_off = w.j_off;
+  o.off_lin = w.off_lin; o.off_ang = w.off_ang;
+  o.cnt = w.cnt; o.nvals = 0;
+  return o;
+}
+__global__ __launch_bounds__(64, 2) void rom_phase_kernel(const RomPhaseWork* __restrict__ work, int n_work,
+                                                          const double* __restrict__ x, double* __restrict__ g,
+                                                          double* __restrict__ jac, int flags) {
+  // compact image | trash slots | duration columns (6 per node): one array, so one LDS read per output value
+  __shared__ __attribute__((aligned(16))) double img[kRomPNodes * kRomPStride + 64 + kRomPNodes * 6];
+  __shared__ int s_meta[kRomPNodes];  // nslots | base_all << 8 | current phase << 24
+  double* s_sched = img + kRomPNodes * kRomPStride + 64;
   const bool want_g = flags & 1, want_j = flags & 2;
-  const int lane = threadIdx.x, e = pw.ee;
-  double* out = jac + pw.j_off + PT->nnz_rom[e] + (int64_t)pw.k0 * PT->rom_node_vals[e];
-  double* gout = g + pw.g_off + PT->row_rom[e] + 3 * pw.k0;
-  phase_poly_durations_wave(PT, blob, xp, e, s_ph, s_md, lane);
-  const int kl = min(lane, pw.cnt - 1), k = pw.k0 + kl;
-  const double t = tbl<double>(blob, PT->o_trom)[k];
-  RomRec r = tbl<RomRec>(blob, PT->o_rom_recs[e])[k];  // base-spline part (tb, iTb, q6) is x-independent
-  double tlm, tlp;
-  const int qm = locate_segment(s_md, PT->n_mpoly[e], t, tlm);
-  const int cur = locate_segment(s_ph, PT->n_phases[e], t, tlp);
-  const PhasePoly pm = tbl<PhasePoly>(blob, PT->o_mpoly[e])[qm];
-  r.tm = tlm;
-  r.iTm = 1.0 / s_md[qm];
-  r.xbase = pm.xbase;
-  r.meta = pm.meta;
-  const uint64_t slots = slots_of(pm.cand);
-  r.slots[0] = (uint32_t)slots;
-  r.slots[1] = (uint32_t)(slots >> 32);
-  r.voff = kl * kRomPStride;
-  RomWork w;
-  w.recs = 0;
-  w.x_off = pw.x_off;
-  w.g_off = 0; w.j_off = 0;
-  w.off_lin = PT->off_lin; w.off_ang = PT->off_ang;
-  w.cnt = pw.cnt; w.nvals = 0;
-  RomPhase ph;
-  ph.in_last = cur == PT->n_phases[e] - 1;
-  ph.inner = 1.0 / pm.n_in_phase;
-  ph.prevp = (double)pm.poly_in_phase;
-  ph.T = s_md[qm];
-  ph.sched = s_sched + 6 * kl;
-  if (lane < pw.cnt) s_meta[lane] = meta_nslots(pm.meta) | ((int)pm.base_all << 8) | (cur << 24);
+  const int lane = threadIdx.x;
+  const int trash = kRomPNodes * kRomPStride + lane;
+  const int stride = gridDim.x;
+  int i = blockIdx.x;
+  if (i >= n_work) return;
+  RomPhaseWork w0 = work[i], w1 = w0, w2 = w0;
+  RomRec r0 = romp_load_rec(w0, lane), r1 = r0;
   RomX X;
-  rom_load_x(w, r, x, X);
-  if (lane < pw.cnt) rom_item<true>(w, r, X, gout, img, 0, 0, kRomPNodes * kRomPStride + lane, lane, want_g, want_j, &ph);
-  __syncthreads();
-  if (!want_j) return;
-  const int msize = PT->msize[e], ns = PT->n_phases[e] - 1, node_vals = PT->rom_node_vals[e];
-  const int len0 = 20 + msize + ns, len1 = 24 + msize + ns;
-  // expanded values of one node, 64 at a time, four independent chunks per iteration
-  for (int node = 0; node < pw.cnt; ++node) {
-    const int meta = s_meta[node];
-    const int nm = meta & 0xFF, ba = (meta >> 8) & 0xFFFF, ncur = meta >> 24;
-    const double* im = img + node * kRomPStride;
-    const double* sc = s_sched + 6 * node;
-    double* dst = out + (int64_t)node * node_vals;
-    for (int i0 = 0; i0 < node_vals; i0 += 256) {
-      double v[4];
+  if (i + stride < n_work) {
+    w1 = work[i + stride];
+    r1 = romp_load_rec(w1, lane);
+  }
+  rom_load_x(romp_as_work(w0), r0, x, X);
+  for (; i < n_work; i += stride) {
+    const bool has1 = i + stride < n_work, has2 = i + 2 * stride < n_work;
+    if (has2) w2 = work[i + 2 * stride];
+    const int kl = min(lane, w0.cnt - 1);
+    r0.voff = kl * kRomPStride;
+    if (lane < w0.cnt) {
+      const int base_all = r0.pad[0] & 0xFFFF, cur = (r0.pad[0] >> 16) & 0xFF;
+      RomPhase ph;
+      ph.in_last = (r0.pad[0] >> 24) & 1;
+      ph.inner = 1.0 / (double)(r0.pad[1] & 0xFF);
+      ph.prevp = (double)((r0.pad[1] >> 8) & 0xFF);
+      ph.T = 1.0 / r0.iTm;
+      ph.sched = s_sched + 6 * lane;
+      s_meta[lane] = meta_nslots(r0.meta) | (base_all << 8) | (cur << 24);
+      rom_item<true>(romp_as_work(w0), r0, X, g + w0.g_off, img, 0, 0, trash, lane, want_g, want_j, &ph);
+    }
+    RomRec r2 = r1;
+    if (has2) r2 = romp_load_rec(w2, lane);
+    if (has1) rom_load_x(romp_as_work(w1), r1, x, X);
+    if (want_j) {
+      const int msize = w0.msize, ns = w0.ns, node_vals = w0.node_vals;
+      const int len0 = 20 + msize + ns, len1 = 24 + msize + ns;
+      double* out = jac + w0.j_off;
+      // Expanded values of one node, 64 per chunk.  What depends on the position inside the node only (row,
+      // column, which block) is computed once per slice and chunk; per node just the polynomial's offset.
+      for (int i0 = 0; i0 < node_vals; i0 += 256) {
+        int ii[4], cb[4], pp[4], ibase[4], rb[4], srow[4];
+        bool in_base[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int i = min(i0 + 64 * c + lane, node_vals - 1);
-        const int row = (i >= len0) + (i >= len0 + len1);
-        const int col = i - (row == 0 ? 0 : (row == 1 ? len0 : len0 + len1));
-        const int nb = row == 0 ? 20 : 24;
-        const int rsr = row == 0 ? 0 : (row == 1 ? 20 + nm : 44 + 2 * nm);
-        const int j = col - nb - ba, p = col - nb - msize;
-        const bool in_base = col < nb, in_poly = (unsigned)j < (unsigned)nm;
-        const double vi = im[rsr + (in_base ? col : nb + (in_poly ? j : 0))];
-        const double vs = p < ncur ? sc[row] : (p == ncur ? sc[3 + row] : 0.0);
-        v[c] = (in_base || in_poly) ? vi : (p >= 0 ? vs : 0.0);
-      }
+        for (int c = 0; c < 4; ++c) {
+          ii[c] = min(i0 + 64 * c + lane, node_vals - 1);   // clamped: the tail re-stores the last value
+          const int row = (ii[c] >= len0) + (ii[c] >= len0 + len1);
+          const int col = ii[c] - (row == 0 ? 0 : (row == 1 ? len0 : len0 + len1));
+          const int nb = row == 0 ? 20 : 24;
+          cb[c] = col - nb;                           // column inside the ee-motion block (if >= 0)
+          pp[c] = cb[c] - msize;                      // duration column (if >= 0)
+          in_base[c] = col < nb;
+          // compact row start = {0, 20, 44}[row] + row * nslots; base block at +col, polynomial at +nb+j
+          ibase[c] = (row == 0 ? 0 : (row == 1 ? 20 : 44)) + (in_base[c] ? col : nb);
+          rb[c] = row;
+          srow[c] = kRomPNodes * kRomPStride + 64 + row;   // s_sched follows img: one address space
+        }
+        int meta_next = s_meta[0];
+        for (int node = 0; node < w0.cnt; ++node) {
+          const int meta = meta_next;
+          meta_next = s_meta[min(node + 1, w0.cnt - 1)];   // next node's descriptor while this one is expanded
+          const int nm = meta & 0xFF, ba = (meta >> 8) & 0xFFFF, ncur = meta >> 24;
+          const int nbase = node * kRomPStride, sbase = 6 * node;
+          double* dst = out + (int64_t)node * node_vals;
+          int addr[4];
+          bool keep[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int i = i0 + 64 * c + lane;
-        if (i < node_vals) dst[i] = v[c];
+          for (int c = 0; c < 4; ++c) {
+            const int j = cb[c] - ba;
+            const bool in_poly = (unsigned)j < (unsigned)nm;
+            const bool from_img = in_base[c] || in_poly;
+            const bool from_sched = pp[c] >= 0 && pp[c] <= ncur;
+            const int a_img = nbase + ibase[c] + rb[c] * nm + (in_poly ? j : 0);
+            const int a_sch = sbase + srow[c] + (pp[c] == ncur ? 3 : 0);
+            addr[c] = from_img ? a_img : a_sch;
+            keep[c] = from_img || from_sched;
+          }
+          double v[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = img[addr[c]];   // four LDS reads in flight
+#pragma unroll
+          for (int c = 0; c < 4; ++c) dst[ii[c]] = keep[c] ? v[c] : 0.0;
+        }
       }
     }
+    w0 = w1; r0 = r1;
+    w1 = w2; r1 = r2;
   }
 }
 
@@ -1377,9 +1439,9 @@ static int env_int(const char* name, int dflt) {
   return v > 0 ? v : dflt;
 }
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
-                       const NodeWork* node, int n_node, const PhaseWork* pdyn, int n_pdyn, const PhaseWork* prom,
-                       int n_prom, const double* x, double* g, double* jac, int flags, hipStream_t stream,
-                       hipEvent_t* ev /* 4 events or nullptr */) {
+                       const NodeWork* node, int n_node, const PhaseWork* pdyn, int n_pdyn, const LocWork* ploc,
+                       int n_ploc, const RomPhaseWork* prom, int n_prom, const double* x, double* g, double* jac,
+                       int flags, hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */) {
   static const int dyn_bpc = env_int("TWR_DYN_BPC", 7), rom_bpc = env_int("TWR_ROM_BPC", 4);
   dim3 block(64);
   if (n_ee < 1 || n_ee > 4) return hipErrorInvalidValue;
@@ -1404,7 +1466,11 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
     }
   }
   if (ev) (void)hipEventRecord(ev[1], stream);
-  if (n_prom > 0) hipLaunchKernelGGL(rom_phase_kernel, dim3(n_prom), block, 0, stream, prom, x, g, jac, flags);
+  if (n_prom > 0) {  // pre-pass (segment lookup -> records), then the persistent kernel
+    hipLaunchKernelGGL(rom_locate_kernel, dim3(n_ploc), block, 0, stream, ploc, x);
+    const int res = 8 * n_cu;
+    hipLaunchKernelGGL(rom_phase_kernel, dim3(n_prom < res ? n_prom : res), block, 0, stream, prom, n_prom, x, g, jac, flags);
+  }
   if (n_rom > 0) {
     const int res = rom_bpc * n_cu;
     dim3 grid(n_rom < res ? n_rom : res);
