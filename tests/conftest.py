@@ -14,8 +14,11 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session", autouse=True)
 def _built():
-    """Make sure the product library and the oracle exist (both build in seconds)."""
+    """Make sure the product library and the oracle exist (both build in seconds); import torch once here
+    (the first import on a fresh box can take minutes while the image pages in -- not inside a test)."""
     import subprocess
+
+    import torch  # noqa: F401
 
     if not os.path.exists(os.path.join(ROOT, "towr_amd", "libtowr_amd.so")):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "towr_amd", "csrc")])

@@ -47,6 +47,17 @@ template <typename T>
 TWR_DEV const TWR_GLOBAL T* gptr(uint64_t addr) {
   return reinterpret_cast<const TWR_GLOBAL T*>(addr);
 }
+// Read-only tables reached through a wave-uniform address: the constant address space makes their loads
+// scalar (s_load into SGPRs) instead of one vector load per lane.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TWR_CONST __attribute__((address_space(4)))
+#else
+#define TWR_CONST
+#endif
+template <typename T>
+TWR_DEV const TWR_CONST T* cptr(uint64_t addr) {
+  return reinterpret_cast<const TWR_CONST T*>(addr);
+}
 
 // ---------------------------------------------------------------- cubic Hermite weights
 // d{pos,vel,acc}/d{p0,v0,p1,v1} of CubicHermitePolynomial (src/polynomial.cc:140-234); iT = 1/T comes
@@ -472,7 +483,7 @@ TWR_DEV void dyn_back(const DynWork& w, const DynLane& ln, const DynFront& S, do
   }
   om[2] += zd;
   omd[2] += edd[2];
-  const TWR_GLOBAL DevStruct* H = gptr<DevStruct>(w.hdr);
+  const TWR_CONST DevStruct* H = cptr<DevStruct>(w.hdr);  // uniform per work item: scalar loads
   // I_w = R I_b R^T (single_rigid_body_dynamics.cc:91), symmetric: (00,01,02,11,12,22)
   double Iw6[6];
   {
