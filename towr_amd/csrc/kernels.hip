@@ -1180,15 +1180,16 @@ __global__ __launch_bounds__(64) void dyn_phase_kernel(const PhaseWork* __restri
   __shared__ double s_ph[NEE][TWR_MAX_PHASES_DEV], s_md[NEE][kMaxPhasePolys], s_fd[NEE][kMaxPhasePolys];
   const PhaseWork pw = work[blockIdx.x];
   const char* blob = reinterpret_cast<const char*>(pw.blob);
-  const DevStruct* H = reinterpret_cast<const DevStruct*>(blob);
-  const PhaseTables* PT = tbl<PhaseTables>(blob, H->o_phase);
+  const TWR_CONST PhaseTables* PT = cptr<PhaseTables>(pw.blob + cptr<DevStruct>(pw.blob)->o_phase);  // scalar loads
   const double* xp = x + pw.x_off;
   const bool want_g = flags & 1, want_j = flags & 2;
   const int lane = threadIdx.x, kk = lane >> 2, role = lane & 3;
   double* out = jac + pw.j_off + PT->nnz_dyn + (int64_t)pw.k0 * PT->node_vals;
   double* gout = g + pw.g_off + PT->row_dyn + 6 * pw.k0;
   if (want_j) zero_fill(out, pw.cnt * PT->node_vals, lane);
-  if (lane < NEE) phase_poly_durations(PT, blob, xp, lane, s_ph[lane], s_md[lane], s_fd[lane], true);
+  if (lane < NEE)
+    phase_poly_durations(tbl<PhaseTables>(blob, cptr<DevStruct>(pw.blob)->o_phase), blob, xp, lane, s_ph[lane], s_md[lane],
+                         s_fd[lane], true);
   __syncthreads();
   const int e = min(role, NEE - 1);
   const bool has_ee = role < NEE;
