@@ -16,7 +16,7 @@
  *     order ifopt::Problem::EvalNonzerosOfJacobian copies out (row-major, columns
  *     ascending, explicit structural zeros kept), for the constraint sets
  *        terrain-ee-motion_e.. | dynamic | splineacc-base-lin | splineacc-base-ang |
- *        rangeofmotion-e.. | force-ee-force_e.. | swing-ee-motion_e.. | totalduration-e..
+ *        rangeofmotion-e.. | force-ee-force_e.. | swing-ee-motion_e.. | baseMotion | totalduration-e..
  *     i.e. params_.constraints_ order (parameters.cc:55-60); twr_params.constraint_sets selects
  *     which families exist (default: the four of the hot path).
  */
@@ -56,9 +56,14 @@ enum {
    * the ee splines become PhaseSplines (spline_holder.cc:48-52): every Jacobian row of an ee spline
    * holds all variables of its set, and dynamic / rangeofmotion rows gain the duration columns. */
   TWR_SET_TOTAL_TIME = 64,
+  /* BaseMotionConstraint "baseMotion" (nlp_formulation.cc:229-235, base_motion_constraint.cc:38-99): not in the
+   * default list; rows come after swing-* (where a caller's constraints_.push_back(BaseRom) lands) and before
+   * totalduration-*.  Needs twr_params.dt_base_motion and .base_z_init. */
+  TWR_SET_BASE_ROM = 128,
   TWR_SETS_HOT_PATH = 1 | 2 | 8 | 16,
   TWR_SETS_TOWR_DEFAULT = 63,
-  TWR_SETS_ALL = 127
+  TWR_SETS_ALL = 127,      /* default list + OptimizePhaseDurations() */
+  TWR_SETS_EVERY = 255     /* every Parameters::ConstraintName */
 };
 
 /* Robot + terrain constants: the POD "model blob" that rank 0 broadcasts over RCCL.
@@ -95,6 +100,9 @@ typedef struct twr_params {
   int32_t polys_per_stance_force; /* force_polynomials_per_stance_phase_ (3) */
   int32_t constraint_sets;      /* TWR_SET_* mask; twr_params_default: TWR_SETS_HOT_PATH */
   int32_t reserved_;            /* must be 0 */
+  double dt_base_motion;        /* dt_constraint_base_motion_ (duration_base_polynomial_/4, parameters.cc:51) */
+  double base_z_init;           /* initial base height: BaseMotionConstraint bounds z to [z-0.02, z+0.1]
+                                   (base_motion_constraint.cc:51-55, read from the spline at construction) */
 } twr_params;
 
 typedef struct twr_sizes {

@@ -15,6 +15,7 @@ _lib = None
 
 SETS_HOT_PATH = 1 | 2 | 8 | 16  # terrain, dynamic, rangeofmotion, force
 SETS_TOWR_DEFAULT = 63          # + splineacc-base-lin/-ang (4) and swing-* (32): parameters.cc:55-60
+SET_BASE_ROM = 128              # BaseMotionConstraint ("baseMotion"), only when a caller pushes Parameters::BaseRom
 SET_TOTAL_TIME = 64             # OptimizePhaseDurations(): ee-schedule_e variables, PhaseSplines, totalduration-e
 ROBOTS = {"monoped": 0, "biped": 1, "hyq": 2, "anymal": 3, "go1": 4}
 TERRAINS = {"flat": 0, "block": 1, "stairs": 2, "gap": 3, "slope": 4, "chimney": 5, "chimney_lr": 6}
@@ -36,7 +37,7 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.c_int, C.c_int, C.c_int, _ip, _dp, _ip, C.c_double, C.c_double,
-                                 C.c_double, C.c_int, C.c_int, C.c_double, C.c_int]
+                                 C.c_double, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double]
         L.orc_destroy.argtypes = [C.c_void_p]
         for f in ("orc_n_vars", "orc_n_rows", "orc_n_var_sets", "orc_n_con_sets"):
             getattr(L, f).argtypes = [C.c_void_p]
@@ -91,7 +92,7 @@ def gait(n_ee, combo, t_total):
 class OracleProblem:
     def __init__(self, robot, terrain, phase_durations, contact_at_start, dt_dynamic=0.1, dt_rom=0.08,
                  duration_base_poly=0.1, polys_per_swing=2, polys_per_stance_force=3, force_limit=1000.0,
-                 constraint_sets=SETS_HOT_PATH):
+                 constraint_sets=SETS_HOT_PATH, dt_base_motion=None, base_z_init=0.0):
         robot = ROBOTS[robot] if isinstance(robot, str) else robot
         terrain = TERRAINS[terrain] if isinstance(terrain, str) else terrain
         n_ee = len(phase_durations)
@@ -100,7 +101,9 @@ class OracleProblem:
         con = np.array(contact_at_start, dtype=np.int32)
         self._h = lib().orc_create(robot, terrain, n_ee, _i(n_ph), _d(pd), _i(con), dt_dynamic, dt_rom,
                                    duration_base_poly, polys_per_swing, polys_per_stance_force, force_limit,
-                                   int(constraint_sets))
+                                   int(constraint_sets),
+                                   float(duration_base_poly / 4.0 if dt_base_motion is None else dt_base_motion),
+                                   float(base_z_init))
         if not self._h:
             raise RuntimeError("orc_create failed")
         L = lib()

@@ -87,7 +87,7 @@ class Layout:
     nodes_variables_all.cc:45-61, nodes_variables_phase_based.cc:38-298)."""
 
     def __init__(self, robot, phase_durations, contact_at_start, dt_dyn=0.1, dt_rom=0.08, dur_base=0.1,
-                 polys_swing=2, polys_stance=3, optimize_timings=False):
+                 polys_swing=2, polys_stance=3, optimize_timings=False, dt_base_motion=None):
         self.rb = ROBOT[robot]
         self.n_ee = self.rb["n_ee"]
         self.T = 0.0
@@ -123,6 +123,7 @@ class Layout:
         self.n = off
         self.grid_dyn = time_grid(self.T, dt_dyn)
         self.grid_rom = time_grid(self.T, dt_rom)
+        self.grid_bm = time_grid(self.T, dur_base / 4.0 if dt_base_motion is None else dt_base_motion)
 
     def _phase_based(self, name, phases, first_const, n_change, off, motion):
         polys = []  # (phase, is_const)
@@ -359,6 +360,9 @@ def constraints(L, terrain, x, fn_max=1000.0, sets=HOT_PATH):
     if sets & 32:
         for ee in range(L.n_ee):
             g += swing_rows(L, ee, x)
+    if sets & 128:  # baseMotion (base_motion_constraint.cc:60-66): rows AX..AZ base-ang position, LX..LZ base-lin
+        for t in L.grid_bm:
+            g += spline_point(L, "base-ang", x, t)[0] + spline_point(L, "base-lin", x, t)[0]
     if sets & 64:  # totalduration-<ee> (total_duration_constraint.cc:50-56): sum of the optimised durations
         for sc in L.schedule:
             g.append(sum(x[sc["off"] + i] for i in range(sc["size"])))
@@ -460,6 +464,8 @@ def cases():
         "timings_hopper_flat": dict(robot="monoped", terrain="flat", phases=hop, seed=19, sets=TOWR_DEFAULT | 64),
         "timings_biped_walk_stairs": dict(robot="biped", terrain="stairs", phases=_gait(2, 0, 2.0), seed=20, sets=TOWR_DEFAULT | 64),
         "timings_anymal_trot_gap": dict(robot="anymal", terrain="gap", phases=_gait(4, 1, 2.0), seed=21, sets=TOWR_DEFAULT | 64),
+        # every Parameters::ConstraintName at once (adds baseMotion)
+        "every_biped_run_slope": dict(robot="biped", terrain="slope", phases=_gait(2, 1, 1.6), seed=22, sets=255),
     }
 
 

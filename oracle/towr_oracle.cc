@@ -1315,6 +1315,58 @@ struct SwingConstraint : ConSet {
   }
 };
 
+// ref: base_motion_constraint.cc:38-99.  z_init is base_linear_->GetPoint(0.0).p().z() at construction, i.e. the
+// initial base height of the formulation (the spline then holds the initial guess); passed in explicitly.
+struct BaseMotionConstraint : ConSet {
+  std::vector<double> dts;
+  NodeSpline* base_linear;
+  NodeSpline* base_angular;
+  Bound node_bounds[6];
+  BaseMotionConstraint(double T, double dt, const Splines& s, double z_init) {
+    name = "baseMotion";
+    dts = MakeTimeGrid(T, dt);
+    base_linear = s.base_linear;
+    base_angular = s.base_angular;
+    double dev_rad = 0.05;
+    node_bounds[AX] = Bound{-dev_rad, dev_rad};
+    node_bounds[AY] = Bound{-dev_rad, dev_rad};
+    node_bounds[AZ] = Bound{-kInf, kInf};
+    node_bounds[LX] = Bound{-kInf, kInf};
+    node_bounds[LY] = Bound{-kInf, kInf};
+    node_bounds[LZ] = Bound{z_init - 0.02, z_init + 0.1};
+    rows = (int)dts.size() * 6;
+  }
+  void GetValues(double* g) const override {
+    int k = 0;
+    for (double t : dts) {
+      V3 lin = base_linear->GetPoint(t).p, ang = base_angular->GetPoint(t).p;
+      for (int i = 0; i < 3; ++i) {
+        g[6 * k + LX + i] = lin(i);
+        g[6 * k + AX + i] = ang(i);
+      }
+      k++;
+    }
+  }
+  void GetBounds(Bound* b) const override {
+    for (size_t k = 0; k < dts.size(); ++k)
+      for (int dim = 0; dim < 6; ++dim) b[6 * k + dim] = node_bounds[dim];
+  }
+  void FillJacobianBlock(const std::string& var_set, SpMat& jac) const override {
+    int k = 0;
+    for (double t : dts) {
+      if (var_set == "base-ang") {
+        SpMat j = base_angular->GetJacobianWrtNodes(t, kPos);
+        for (int i = 0; i < 3; ++i) jac.rows[6 * k + AX + i] = j.rows[i];
+      }
+      if (var_set == "base-lin") {
+        SpMat j = base_linear->GetJacobianWrtNodes(t, kPos);
+        for (int i = 0; i < 3; ++i) jac.rows[6 * k + LX + i] = j.rows[i];
+      }
+      k++;
+    }
+  }
+};
+
 // ref: total_duration_constraint.cc:36-72
 struct TotalDurationConstraint : ConSet {
   double T_total;
@@ -1413,7 +1465,8 @@ extern "C" {
 
 orc_problem* orc_create(int robot, int terrain, int n_ee, const int* n_phases, const double* phase_durations,
                         const int* in_contact_at_start, double dt_dynamic, double dt_rom, double duration_base_poly,
-                        int polys_per_swing, int polys_per_stance_force, double force_limit, int constraint_sets) {
+                        int polys_per_swing, int polys_per_stance_force, double force_limit, int constraint_sets,
+                        double dt_base_motion, double base_z_init) {
   try {
     auto* P = new orc_problem();
     P->robot = MakeRobot(robot);
@@ -1492,6 +1545,8 @@ orc_problem* orc_create(int robot, int terrain, int n_ee, const int* n_phases, c
     if (constraint_sets & ORC_SET_SWING)
       for (int ee = 0; ee < n_ee; ++ee)
         P->cons.emplace_back(new SwingConstraint("ee-motion_" + std::to_string(ee), P->vars));
+    if (constraint_sets & ORC_SET_BASE_ROM)  // not in the default list: a caller that pushes BaseRom (nlp_formulation.cc:229-235)
+      P->cons.emplace_back(new BaseMotionConstraint(P->T, dt_base_motion, P->sp, base_z_init));
     if (constraint_sets & ORC_SET_TOTAL_TIME)  // Parameters::OptimizePhaseDurations appends TotalTime (parameters.cc:76-80)
       for (int ee = 0; ee < n_ee; ++ee)
         P->cons.emplace_back(new TotalDurationConstraint(P->T, ee, P->schedules[ee].get()));

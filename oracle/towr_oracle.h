@@ -31,11 +31,13 @@ orc_problem* orc_create(int robot, int terrain, int n_ee, const int* n_phases,
                         const double* phase_durations, const int* in_contact_at_start,
                         double dt_dynamic, double dt_rom, double duration_base_poly,
                         int polys_per_swing, int polys_per_stance_force,
-                        double force_limit, int constraint_sets);
+                        double force_limit, int constraint_sets,
+                        double dt_base_motion /* parameters.cc:51 */, double base_z_init /* base_motion_constraint.cc:51 */);
 // constraint_sets: which of the default sets (parameters.cc:55-60) to build, in that order
 enum {
   ORC_SET_TERRAIN = 1, ORC_SET_DYNAMIC = 2, ORC_SET_BASE_ACC = 4, ORC_SET_ROM = 8, ORC_SET_FORCE = 16,
   ORC_SET_SWING = 32,
+  ORC_SET_BASE_ROM = 128,   // BaseMotionConstraint "baseMotion" (not in the default list), placed before TotalTime
   ORC_SET_TOTAL_TIME = 64,  // Parameters::OptimizePhaseDurations (parameters.cc:76-80): timings become variables
   ORC_SETS_HOT_PATH = 1 | 2 | 8 | 16,
   ORC_SETS_TOWR_DEFAULT = 63

@@ -47,7 +47,7 @@ def linear_row_scale(S, ref_j, x):
     sc = np.zeros(S.m)
     terms = np.abs(ref_j * x[S.col_idx])
     for s in S.con_sets:
-        if s["name"].startswith(("splineacc-", "swing-")):
+        if s["name"].startswith(("splineacc-", "swing-", "baseMotion", "totalduration-")):
             for r in range(s["offset"], s["offset"] + s["size"]):
                 sc[r] = terms[S.row_ptr[r]:S.row_ptr[r + 1]].sum()
     return sc
@@ -76,7 +76,8 @@ class Case:
         self.P = ob.OracleProblem(robot, terrain, sched.durations(), sched.contact(), dt_dynamic=p.dt_dynamic,
                                   dt_rom=p.dt_rom, duration_base_poly=p.duration_base_poly,
                                   polys_per_swing=p.polys_per_swing, polys_per_stance_force=p.polys_per_stance_force,
-                                  constraint_sets=p.constraint_sets)
+                                  constraint_sets=p.constraint_sets, dt_base_motion=p.dt_base_motion,
+                                  base_z_init=p.base_z_init)
 
     def nominal_start(self):
         m = self.model

@@ -50,7 +50,8 @@ def test_gpu_matches_mpmath_golden(path):
     sets = int(d["constraint_sets"]) if "constraint_sets" in d.files else 27
     if sets & 64 and not getattr(ta, "SUPPORTS_OPTIMISED_TIMINGS", False):
         pytest.skip("optimised timings (SURVEY 8f #2): oracle and fixtures exist, the device path is next")
-    case = Case(str(d["robot"]), str(d["terrain"]), ta.schedule(pd, list(d["contact_at_start"])), constraint_sets=sets)
+    case = Case(str(d["robot"]), str(d["terrain"]), ta.schedule(pd, list(d["contact_at_start"])), constraint_sets=sets,
+                base_z_init=0.6)
     S = case.S
     batch, g, j = _eval_case(case, [d["x"]])
     assert np.abs(g - d["g"]).max() <= 1e-12 * np.abs(d["g"]).max()
@@ -108,6 +109,9 @@ def test_other_leg_counts_and_gaits_starting_or_ending_in_flight(robot, n_ee, co
     ("anymal", "stairs", 0, 2.4, dict(constraint_sets=2 | 32)),
     ("biped", "flat", 1, 1.8, dict(constraint_sets=4)),
     ("anymal", "chimney", 1, 2.0, dict(constraint_sets=1 | 16 | 32)),
+    ("monoped", "flat", None, 2.0, dict(constraint_sets=128, base_z_init=0.58)),                       # baseMotion alone
+    ("anymal", "stairs", 1, 2.0, dict(constraint_sets=255, base_z_init=0.42, dt_base_motion=0.031)),   # every set
+    ("biped", "gap", 0, 2.0, dict(constraint_sets=63 | 128, base_z_init=0.65)),
 ], ids=lambda s: "%s-%s-s%d" % (s[0], s[1], s[4]["constraint_sets"]))
 def test_whole_default_constraint_list_and_subsets(spec):
     """towr's default constraints_ (parameters.cc:55-60) = hot path + splineacc-base-{lin,ang} + swing-*;

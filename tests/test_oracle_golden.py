@@ -24,7 +24,8 @@ def load_fixture(path):
         pd.append(d["phase_durations"][o:o + k])
         o += k
     sets = int(d["constraint_sets"]) if "constraint_sets" in d.files else ob.SETS_HOT_PATH
-    P = ob.OracleProblem(str(d["robot"]), str(d["terrain"]), pd, list(d["contact_at_start"]), constraint_sets=sets)
+    P = ob.OracleProblem(str(d["robot"]), str(d["terrain"]), pd, list(d["contact_at_start"]), constraint_sets=sets,
+                         base_z_init=0.6)
     return d, P
 
 
@@ -306,6 +307,26 @@ def test_optimised_timings_known_answers():
             for c, v in rowf.items():
                 assert row[c] == pytest.approx(v, rel=1e-12, abs=1e-12)
             assert all(v == 0.0 for c, v in row.items() if c < F.n and c not in rowf)
+
+
+def test_base_motion_known_answers():
+    """base_motion_constraint.cc:38-99: rows 6k+{AX,AY,AZ,LX,LY,LZ} = base-ang / base-lin position at
+    t_k (dt = duration_base_polynomial_/4), roll/pitch within +-0.05 rad, z within [z_init-0.02, z_init+0.1]."""
+    P = ob.OracleProblem("monoped", "flat", [[0.4, 0.2, 0.4]], [1], constraint_sets=ob.SET_BASE_ROM, base_z_init=0.58)
+    assert P.con_sets == [("baseMotion", 6 * (int(np.floor(1.0 / 0.025)) + 2))]
+    x = P.initial_guess([0.0, 0.1, 0.58], [0.01, 0.02, 0.3], [1.0, 0.3, 0.58], [0.03, 0.0, 0.5], [[0, 0, 0]])
+    g, rp, ci, va = P.eval(x)
+    lo, up = P.bounds()
+    K = P.m // 6
+    t = np.minimum(np.arange(K) * 0.025, 1.0)   # the linear initial guess: position = start + t/T * (goal - start)
+    assert np.allclose(g.reshape(K, 6)[:, 3], t * 1.0, atol=1e-12) and np.allclose(g.reshape(K, 6)[:, 2], 0.3 + t * 0.2, atol=1e-12)
+    assert np.allclose(g.reshape(K, 6)[:, 5], 0.58, atol=1e-12)   # z: terrain height + nominal stance height
+    assert np.array_equal(lo.reshape(K, 6)[0], [-0.05, -0.05, -1e20, -1e20, -1e20, 0.58 - 0.02])
+    assert np.array_equal(up.reshape(K, 6)[0], [0.05, 0.05, 1e20, 1e20, 1e20, 0.58 + 0.1])
+    assert np.all(np.diff(rp) == 4)
+    nb = dict(P.var_sets)["base-lin"]
+    assert np.all(ci[rp[0]:rp[3]] >= nb) and np.all(ci[rp[3]:rp[6]] < nb)   # ang rows -> base-ang, lin rows -> base-lin
+    assert np.allclose(va[rp[0]:rp[1]], [1, 0, 0, 0], atol=1e-15)            # t = 0: only p0 has weight
 
 
 def test_time_grid_and_sizes_follow_the_reference_rules():

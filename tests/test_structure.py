@@ -43,6 +43,10 @@ CONFIGS = [
     ("hyq", "slope", 3, 2.2, dict(constraint_sets=127, polys_per_swing=3, polys_per_stance_force=2)),
     ("go1", "block", 2, 1.9, dict(constraint_sets=2 | 64)),
     ("biped", "flat", 1, 1.8, dict(constraint_sets=8 | 64)),
+    # baseMotion (Parameters::BaseRom), alone and with everything else
+    ("monoped", "flat", None, 2.0, dict(constraint_sets=128, base_z_init=0.58)),
+    ("anymal", "stairs", 1, 2.0, dict(constraint_sets=255, base_z_init=0.42, dt_base_motion=0.031)),
+    ("biped", "gap", 0, 2.0, dict(constraint_sets=63 | 128, base_z_init=0.65)),
 ]
 
 
@@ -168,7 +172,7 @@ def test_error_behaviour():
         ta.Structure(ta.model_preset("anymal", "flat"), bad)
     with pytest.raises(ta.TowrError):
         ta.Structure(ta.model_preset("biped", "flat"), ta.gait_combo(2, 0, 2.0), ta.params_default(dt_dynamic=0.0))
-    for mask in (0, 128, -1):
+    for mask in (0, 256, -1):
         with pytest.raises(ta.TowrError, match="constraint_sets"):
             ta.Structure(ta.model_preset("biped", "flat"), ta.gait_combo(2, 0, 2.0), ta.params_default(constraint_sets=mask))
     # SwingConstraint "assumes ... starting and ending in stance" (swing_constraint.cc:66): a foot that

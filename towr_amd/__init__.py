@@ -18,7 +18,8 @@ ROBOTS = {"monoped": 0, "biped": 1, "hyq": 2, "anymal": 3, "go1": 4}
 TERRAINS = {"flat": 0, "block": 1, "stairs": 2, "gap": 3, "slope": 4, "chimney": 5, "chimney_lr": 6}
 EVAL_VALUES, EVAL_JACOBIAN, EVAL_BOTH = 1, 2, 3
 SET_TERRAIN, SET_DYNAMIC, SET_BASE_ACC, SET_ROM, SET_FORCE, SET_SWING, SET_TOTAL_TIME = 1, 2, 4, 8, 16, 32, 64
-SETS_HOT_PATH, SETS_TOWR_DEFAULT, SETS_ALL = 27, 63, 127  # TWR_SETS_* of include/towr_amd.h
+SET_BASE_ROM = 128
+SETS_HOT_PATH, SETS_TOWR_DEFAULT, SETS_ALL, SETS_EVERY = 27, 63, 127, 255  # TWR_SETS_* of include/towr_amd.h
 SUPPORTS_OPTIMISED_TIMINGS = True  # TWR_SET_TOTAL_TIME has a device path
 
 
@@ -42,7 +43,8 @@ class Schedule(C.Structure):
 class Params(C.Structure):
     _fields_ = [("dt_dynamic", C.c_double), ("dt_rom", C.c_double), ("duration_base_poly", C.c_double),
                 ("polys_per_swing", C.c_int32), ("polys_per_stance_force", C.c_int32),
-                ("constraint_sets", C.c_int32), ("reserved_", C.c_int32)]
+                ("constraint_sets", C.c_int32), ("reserved_", C.c_int32),
+                ("dt_base_motion", C.c_double), ("base_z_init", C.c_double)]
 
 
 class Sizes(C.Structure):

@@ -111,6 +111,8 @@ int twr_params_default(twr_params* out) {
   out->polys_per_stance_force = 3;
   out->constraint_sets = TWR_SETS_HOT_PATH;
   out->reserved_ = 0;
+  out->dt_base_motion = out->duration_base_poly / 4.;  // parameters.cc:51
+  out->base_z_init = 0.0;
   return TWR_OK;
 }
 
@@ -135,7 +137,7 @@ int twr_structure_create(const twr_model* model, const twr_schedule* schedule, c
     h->s.params = *params;
     if (params->polys_per_swing < 1 || params->polys_per_stance_force < 1)
       throw std::runtime_error("polynomials per phase must be >= 1");
-    if (params->constraint_sets <= 0 || (params->constraint_sets & ~TWR_SETS_ALL))
+    if (params->constraint_sets <= 0 || (params->constraint_sets & ~TWR_SETS_EVERY))
       throw std::runtime_error("constraint_sets must be a non-empty mask of TWR_SET_* bits");
     h->s.Build();
     *out = h.release();

@@ -117,6 +117,11 @@ struct PhaseTables {
 };
 constexpr int kMaxPhasePolys = 64;  // polynomials per ee spline with optimised timings (LDS table size)
 
+struct BaseNode {     // one time node of baseMotion (base_motion_constraint.cc:60-90)
+  double t, iT;       // local time in the active base polynomial, 1/duration
+  int32_t q6, pad;    // 6 * active polynomial
+};
+
 // Blob header: model constants + what the node kernel needs.  The terrain-ee-motion_e sets are
 // adjacent in g / jac, and so are the force-ee-force_e sets, so each family is one flat node list.
 struct DevStruct {
@@ -139,6 +144,8 @@ struct DevStruct {
                  // single_rigid_body_dynamics.cc:40-42
   int32_t timings;      // 1: optimised phase durations, PhaseTables at o_phase
   uint32_t o_phase;
+  int32_t row_bm, nnz_bm, n_bm_nodes;  // baseMotion: 6 rows x 4 values per time node
+  uint32_t o_bm;        // BaseNode[n_bm_nodes]
 };
 
 // Work items: one contiguous run of time nodes of one constraint set of one problem.  All

@@ -995,7 +995,7 @@ __global__ __launch_bounds__(64, 2) void rom_kernel(const RomWork* __restrict__ 
 // all terrain-ee-motion_e (terrain_constraint.cc:57-108), force-ee-force_e, splineacc-base-* and
 // swing-ee-motion_e sets of one problem.  One workgroup of four waves per problem, one wave per family
 // (each with its own LDS image, no barriers), 64 spline nodes / rows at a time.
-constexpr int kStageTerrain = 64 * 3 + 2, kStageForce = 64 * 25 + 2, kStageAcc = 64 * 6 + 2, kStageSwing = 64 * 12 + 2;
+constexpr int kStageTerrain = 64 * 3 + 2, kStageForce = 64 * 25 + 2, kStageAcc = 64 * 24 + 2, kStageSwing = 64 * 12 + 2;
 __global__ __launch_bounds__(256) void node_kernel(const NodeWork* __restrict__ work, const double* __restrict__ x,
                                                    double* __restrict__ g, double* __restrict__ jac, int flags) {
   __shared__ __attribute__((aligned(16))) double stage_all[kStageTerrain + kStageForce + kStageAcc + kStageSwing];
@@ -1066,6 +1066,38 @@ __global__ __launch_bounds__(256) void node_kernel(const NodeWork* __restrict__ 
         if (want_g) gp[S->row_acc + r] = v;
       }
       if (want_j) copy_out(dst, stage, 6 * cnt, par, lane);
+    }
+    // baseMotion (base_motion_constraint.cc:60-90): lane = time node; rows AX..AZ = base-ang position,
+    // LX..LZ = base-lin position, every row holds the four position weights of its dimension
+    const BaseNode* bm = tbl<BaseNode>(blob, S->o_bm);
+    const int nb = S->n_bm_nodes;
+    for (int k0 = 0; k0 < nb; k0 += 64) {
+      const int cnt = min(64, nb - k0);
+      double* dst = jp + S->nnz_bm + 24 * k0;
+      const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+      if (lane < cnt) {
+        const BaseNode n = bm[k0 + lane];
+        double wP[4];
+        hermite_pos(n.t, n.iT, wP);
+        const double* xa = xp + S->off_base_ang + n.q6;
+        const double* xl = xp + n.q6;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          if (want_g) {
+            double* g6 = gp + S->row_bm + 6 * (k0 + lane);
+            g6[d] = wP[0] * xa[d] + wP[1] * xa[3 + d] + wP[2] * xa[6 + d] + wP[3] * xa[9 + d];
+            g6[3 + d] = wP[0] * xl[d] + wP[1] * xl[3 + d] + wP[2] * xl[6 + d] + wP[3] * xl[9 + d];
+          }
+          if (want_j) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              stage[par + 24 * lane + 4 * d + j] = wP[j];
+              stage[par + 24 * lane + 12 + 4 * d + j] = wP[j];
+            }
+          }
+        }
+      }
+      if (want_j) copy_out(dst, stage, 24 * cnt, par, lane);
     }
   } else {
     // swing-ee-motion_e (swing_constraint.cc:58-121): lane = swing node, rows {x pos, x vel, y pos, y vel},

@@ -245,6 +245,10 @@ void Structure::BuildTimeTables() {
     rom_base.push_back(Locate(t, base.durations));
     for (int e = 0; e < n_ee; ++e) rom_motion[e].push_back(Locate(t, motion[e].durations));
   }
+  if (params.constraint_sets & TWR_SET_BASE_ROM) {  // BaseMotionConstraint ctor, base_motion_constraint.cc:38-41
+    grid_bm = TimeGrid(T, params.dt_base_motion);
+    for (double t : grid_bm) bm_base.push_back(Locate(t, base.durations));
+  }
   // force / terrain node tables
   force_nodes.resize(n_ee);
   terrain_rows.resize(n_ee);
@@ -463,6 +467,24 @@ void Structure::BuildPattern() {
       }
     }
   }
+  // --- baseMotion (base_motion_constraint.cc:60-90): rows AX..AZ = base-ang position, LX..LZ = base-lin position
+  if (sets & TWR_SET_BASE_ROM) {
+    begin_set("baseMotion", 6 * (int)grid_bm.size());
+    const double dev_rad = 0.05, z0 = params.base_z_init;
+    for (size_t k = 0; k < grid_bm.size(); ++k) {
+      const int q = bm_base[k].poly;
+      for (int r6 = 0; r6 < 6; ++r6) {
+        const int off = r6 < 3 ? off_base_ang : off_base_lin, d = r6 % 3;
+        rows.push_back({off + 6 * q + d, off + 6 * q + 3 + d, off + 6 * q + 6 + d, off + 6 * q + 9 + d});
+      }
+      lower.push_back(-dev_rad); upper.push_back(dev_rad);   // AX
+      lower.push_back(-dev_rad); upper.push_back(dev_rad);   // AY
+      lower.push_back(-inf);     upper.push_back(inf);       // AZ
+      lower.push_back(-inf);     upper.push_back(inf);       // LX
+      lower.push_back(-inf);     upper.push_back(inf);       // LY
+      lower.push_back(z0 - 0.02); upper.push_back(z0 + 0.1); // LZ
+    }
+  }
   // --- totalduration-e (total_duration_constraint.cc:50-72): sum of the optimised durations
   for (int e = 0; e < n_ee && (sets & TWR_SET_TOTAL_TIME); ++e) {
     begin_set("totalduration-" + std::to_string(e), 1);
@@ -539,6 +561,19 @@ void Structure::PackBlob() {
   h.o_force_nodes = put(all_nodes.data(), all_nodes.size() * sizeof(ForceNode));
   h.o_terrain_rows = put(all_rows.data(), all_rows.size() * sizeof(TerrainRow));
   h.o_acc = put(acc_junctions.data(), acc_junctions.size() * sizeof(AccJunction));
+  if (const SetInfo* si = FindSet("baseMotion")) {
+    std::vector<BaseNode> bn(grid_bm.size());
+    for (size_t k = 0; k < grid_bm.size(); ++k) {
+      bn[k].t = bm_base[k].t_local;
+      bn[k].iT = 1.0 / base.durations[bm_base[k].poly];
+      bn[k].q6 = 6 * bm_base[k].poly;
+      bn[k].pad = 0;
+    }
+    h.row_bm = si->offset;
+    h.nnz_bm = si->nnz_offset;
+    h.n_bm_nodes = (int)bn.size();
+    h.o_bm = put(bn.data(), bn.size() * sizeof(BaseNode));
+  }
   h.o_swing_nodes = put(all_swing.data(), all_swing.size() * sizeof(SwingNode));
   // --- per-lane records of the dynamic kernel
   if (dyn_set) {

@@ -48,8 +48,8 @@ struct Structure {
   int off_schedule[kMaxEE] = {0, 0, 0, 0};
   PhaseTables phase_tables;         // filled by BuildPattern / PackBlob when timings
 
-  std::vector<double> grid_dyn, grid_rom;
-  std::vector<TimeNode> dyn_base, rom_base;
+  std::vector<double> grid_dyn, grid_rom, grid_bm;
+  std::vector<TimeNode> dyn_base, rom_base, bm_base;
   std::vector<std::vector<TimeNode>> dyn_motion, dyn_force, rom_motion;  // [ee][k]
   std::vector<std::vector<PolyDesc>> mpoly, fpoly;                       // [ee][poly]
   std::vector<std::vector<ForceNode>> force_nodes;                       // [ee]
