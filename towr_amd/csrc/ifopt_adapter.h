@@ -15,6 +15,7 @@
 //   towr::SplineAccConstraint      "splineacc-base-lin|ang"   towr/src/spline_acc_constraint.cc:34-88
 //   towr::SwingConstraint          "swing-ee-motion_<ee>"     towr/src/swing_constraint.cc:35-121
 //   towr::TotalDurationConstraint  "totalduration-<ee>"       towr/src/total_duration_constraint.cc:36-72
+//   towr::BaseMotionConstraint     "baseMotion"               towr/src/base_motion_constraint.cc:38-99
 // (with TWR_SET_TOTAL_TIME the variable composite also holds the reference's "ee-schedule<ee>" sets and
 // the dynamic / rangeofmotion sets return their duration columns for them)
 #pragma once
