@@ -995,7 +995,7 @@ __global__ __launch_bounds__(64, 2) void rom_kernel(const RomWork* __restrict__ 
 // all terrain-ee-motion_e (terrain_constraint.cc:57-108), force-ee-force_e, splineacc-base-* and
 // swing-ee-motion_e sets of one problem.  One workgroup of four waves per problem, one wave per family
 // (each with its own LDS image, no barriers), 64 spline nodes / rows at a time.
-constexpr int kStageTerrain = 64 * 3 + 2, kStageForce = 64 * 25 + 2, kStageAcc = 64 * 24 + 2, kStageSwing = 64 * 12 + 2;
+constexpr int kStageTerrain = 64 * 3 + 2, kStageForce = 64 * 25 + 2, kStageAcc = 64 * 6 + 2, kStageSwing = 64 * 12 + 2;
 __global__ __launch_bounds__(256) void node_kernel(const NodeWork* __restrict__ work, const double* __restrict__ x,
                                                    double* __restrict__ g, double* __restrict__ jac, int flags) {
   __shared__ __attribute__((aligned(16))) double stage_all[kStageTerrain + kStageForce + kStageAcc + kStageSwing];
@@ -1071,8 +1071,8 @@ __global__ __launch_bounds__(256) void node_kernel(const NodeWork* __restrict__ 
     // LX..LZ = base-lin position, every row holds the four position weights of its dimension
     const BaseNode* bm = tbl<BaseNode>(blob, S->o_bm);
     const int nb = S->n_bm_nodes;
-    for (int k0 = 0; k0 < nb; k0 += 64) {
-      const int cnt = min(64, nb - k0);
+    for (int k0 = 0; k0 < nb; k0 += 16) {  // 16 nodes x 24 values fit the family's 384-value image
+      const int cnt = min(16, nb - k0);
       double* dst = jp + S->nnz_bm + 24 * k0;
       const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
       if (lane < cnt) {
