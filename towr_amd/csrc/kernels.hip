@@ -304,8 +304,8 @@ TWR_DEV void duration_columns(const double nv[4][3], double t, double T, double 
 // The base-ang block is evaluated in factored form: with u = (p0,v0,p1,v1) of Euler dim d,
 //   d g_ang / d u_j = A_d wP[j] + B_d wV[j] + C_d wA[j],
 //   A_d = d g_ang/d e_d, B_d = d g_ang/d edot_d, C_d = d g_ang/d eddot_d  (3-vectors).
-struct DynX {  // the lane's slice of x: base-lin / base-ang nodes of the active polynomial, ee candidates
-  double bl[12], ba[12], m[12], f[12];
+struct DynX {  // the lane's slice of x: ONE node value (role: p0, v0, p1, v1) of base-lin / base-ang, ee candidates
+  double bl[3], ba[3], m[12], f[12];
 };
 template <int NEE>
 TWR_DEV void dyn_load_rec(const DynWork& w, int lane, DynShared& sh, DynLane& ln) {
@@ -315,10 +315,14 @@ TWR_DEV void dyn_load_rec(const DynWork& w, int lane, DynShared& sh, DynLane& ln
 }
 TWR_DEV void dyn_load_x(const DynWork& w, const DynShared& sh, const DynLane& ln, const double* __restrict__ x, DynX& X) {
   const double* xp = x + w.x_off;
-  const double* xl = xp + w.off_lin + sh.q6;  // [p0 v0 p1 v1] x 3, NodesVariablesAll order
-  const double* xa = xp + w.off_ang + sh.q6;
+  // The base nodes of the active polynomial are [p0 v0 p1 v1] x 3 (NodesVariablesAll order).  The four lanes
+  // of the quad would all load the same 24 doubles: each one loads the node value of its role only and the
+  // spline points are completed with quad sums in dyn_front.
+  const int role = threadIdx.x & 3;
+  const double* xl = xp + w.off_lin + sh.q6 + 3 * role;
+  const double* xa = xp + w.off_ang + sh.q6 + 3 * role;
 #pragma unroll
-  for (int i = 0; i < 12; ++i) {
+  for (int i = 0; i < 3; ++i) {
     X.bl[i] = xl[i];
     X.ba[i] = xa[i];
   }
@@ -347,15 +351,17 @@ TWR_DEV void dyn_front(const DynWork& w, const DynShared& sh, const DynLane& ln,
   hermite_all(sh.tb, sh.iTb, wP, wV, wA);
   double c[3], e[3];
   double (&cdd)[3] = S.cdd, (&ed)[3] = S.ed, (&edd)[3] = S.edd;
+  {  // this lane's node value times its weights, summed over the quad (Spline::GetPoint in basis form)
+    const double myP = sel3(role, wP[0], wP[1], wP[2]), myV = sel3(role, wV[0], wV[1], wV[2]), myA = sel3(role, wA[0], wA[1], wA[2]);
+    const double qP = role == 3 ? wP[3] : myP, qV = role == 3 ? wV[3] : myV, qA = role == 3 ? wA[3] : myA;
 #pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const double l0 = X.bl[d], l1 = X.bl[3 + d], l2 = X.bl[6 + d], l3 = X.bl[9 + d];
-    const double a0 = X.ba[d], a1 = X.ba[3 + d], a2 = X.ba[6 + d], a3 = X.ba[9 + d];
-    c[d] = wP[0] * l0 + wP[1] * l1 + wP[2] * l2 + wP[3] * l3;
-    cdd[d] = wA[0] * l0 + wA[1] * l1 + wA[2] * l2 + wA[3] * l3;
-    e[d] = wP[0] * a0 + wP[1] * a1 + wP[2] * a2 + wP[3] * a3;
-    ed[d] = wV[0] * a0 + wV[1] * a1 + wV[2] * a2 + wV[3] * a3;
-    edd[d] = wA[0] * a0 + wA[1] * a1 + wA[2] * a2 + wA[3] * a3;
+    for (int d = 0; d < 3; ++d) {
+      c[d] = quad_sum(qP * X.bl[d]);
+      cdd[d] = quad_sum(qA * X.bl[d]);
+      e[d] = quad_sum(qP * X.ba[d]);
+      ed[d] = quad_sum(qV * X.ba[d]);
+      edd[d] = quad_sum(qA * X.ba[d]);
+    }
   }
   // --- this lane's end-effector: weights and spline points
   double p[3];
