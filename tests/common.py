@@ -147,3 +147,31 @@ def baseline_cases():
         "C4_anymal_gap_K200": lambda: Case("anymal", "gap", ta.gait_combo(4, 2, 1.8, 0.9), **k_params(1.8, 200)),
         "C4_anymal_stairs_K200": lambda: Case("anymal", "stairs", ta.gait_combo(4, 0, 2.4, 1.1), **k_params(2.4, 200)),
     }
+
+
+def random_case(seed):
+    """Seeded random problem: robot, terrain, per-foot schedules with random phase counts and durations
+    (same total time), polynomial counts, time steps and constraint-set mask."""
+    rng = np.random.default_rng(seed)
+    robot = ["monoped", "biped", "hyq", "anymal", "go1"][rng.integers(5)]
+    terrain = list(ta.TERRAINS)[rng.integers(len(ta.TERRAINS))]
+    n_ee = ta.model_preset(robot, terrain).n_ee
+    T = float(rng.uniform(0.9, 3.0))
+    mask = int(rng.integers(1, 256))
+    durs, contact = [], []
+    for _ in range(n_ee):
+        n_ph = int(rng.integers(1, 9))
+        start_contact = bool(rng.integers(2))
+        if mask & 32:            # swing set: schedules must start and end in stance
+            start_contact = True
+            n_ph = n_ph | 1
+        if mask & 64:            # optimised timings: at least two phases
+            n_ph = max(n_ph, 3 if mask & 32 else 2)
+        d = rng.uniform(0.15, 0.6, size=n_ph)
+        durs.append(d * (T / d.sum()))
+        contact.append(int(start_contact))
+    params = dict(constraint_sets=mask, dt_dynamic=float(rng.uniform(0.03, 0.3)), dt_rom=float(rng.uniform(0.03, 0.3)),
+                  duration_base_poly=float(rng.uniform(0.05, 0.25)), polys_per_swing=int(rng.integers(1, 4)),
+                  polys_per_stance_force=int(rng.integers(1, 5)), dt_base_motion=float(rng.uniform(0.02, 0.2)),
+                  base_z_init=float(rng.uniform(0.3, 0.7)))
+    return Case(robot, terrain, ta.schedule(durs, contact), **params)

@@ -8,7 +8,7 @@ import pytest
 
 import towr_amd as ta
 from tests.common import (Case, assert_parity, baseline_cases, hopper_schedule, k_params, parity_violations,
-                          row_scale)
+                          random_case, row_scale)
 
 pytestmark = pytest.mark.gpu
 
@@ -250,6 +250,22 @@ def test_page_locked_host_buffers():
     assert np.array_equal(pg, g) and np.array_equal(pj, j)
     px2, _, _ = batch.host_buffers()
     assert px2.ctypes.data == px.ctypes.data   # allocated once, owned by the batch
+
+
+def test_random_structures_in_one_ragged_batch():
+    """Seeded fuzz: 24 random problems (robots with the same leg count share a launch), every constraint-set
+    mask, fixed and optimised timings mixed."""
+    cases = [random_case(1000 + s) for s in range(60)]
+    for n_ee in (1, 2, 4):
+        group = [c for c in cases if c.S.n_ee == n_ee][:8]
+        if not group:
+            continue
+        batch = ta.Batch([c.S for c in group], list(range(len(group))), device=0)
+        xs = [c.x_wild(50 + i) for i, c in enumerate(group)]
+        g, j = batch.eval_host(np.concatenate(xs))
+        for p, c in enumerate(group):
+            rg, _, _, rj = c.P.eval(xs[p])
+            assert_parity(c.S, *_split(batch, g, j, p), rg, rj, "n_ee %d problem %d" % (n_ee, p), x=xs[p])
 
 
 def test_foot_starting_in_swing():

@@ -9,7 +9,7 @@ import pytest
 
 import towr_amd as ta
 from oracle import binding as ob
-from tests.common import Case, hopper_schedule, k_params
+from tests.common import Case, hopper_schedule, k_params, random_case
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -92,6 +92,21 @@ def test_structure_matches_oracle(cfg):
     free[S.n - n_sched:] = False
     assert fixed.sum() == 12 + 11 + n_fixed_ee and np.all(lo[free] == -1e20) and np.all(up[free] == 1e20)
     assert np.all(lo[S.n - n_sched:] == 0.2) and np.all(up[S.n - n_sched:] == 1.0)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_structures_match_oracle(seed):
+    """Seeded fuzz over robots, terrains, phase counts, polynomial counts, time steps and set masks."""
+    case = random_case(seed)
+    S, P = case.S, case.P
+    assert (S.n, S.m, S.nnz) == (P.n, P.m, P.nnz)
+    assert [(s["name"], s["size"]) for s in S.con_sets] == P.con_sets
+    assert [(s["name"], s["size"]) for s in S.var_sets] == P.var_sets
+    _, rp, ci, _ = P.eval(case.x_wild(seed))
+    assert np.array_equal(rp, S.row_ptr) and np.array_equal(ci, S.col_idx)
+    lo, up = S.bounds()
+    lo2, up2 = P.bounds()
+    assert np.array_equal(lo, lo2) and np.array_equal(up, up2)
 
 
 @pytest.mark.parametrize("n_ee", [1, 2, 4])
