@@ -11,7 +11,8 @@
 // no network).  What pins this oracle instead (tests/test_oracle_*.py):
 //   * central finite differences of oracle g(x) vs oracle Jacobian,
 //   * an independent mpmath implementation of g(x) with 40-digit numerical
-//     differentiation (oracle/mp_ref.py -> tests/golden/*.json),
+//     differentiation (oracle/mp_ref.py -> tests/golden/mp_*.npz), for every constraint
+//     set incl. optimised phase durations,
 //   * hand known-answers derived from the cited reference lines.
 //
 // C interface (flat arrays, used from Python via ctypes).
