@@ -39,7 +39,10 @@ enum { TWR_OK = 0, TWR_ERR_INVALID = -1, TWR_ERR_HIP = -2, TWR_ERR_NO_DEVICE = -
 enum { TWR_ROBOT_MONOPED = 0, TWR_ROBOT_BIPED, TWR_ROBOT_HYQ, TWR_ROBOT_ANYMAL, TWR_ROBOT_GO1 };
 /* HeightMap::TerrainID (height_map.h:79-86) */
 enum { TWR_TERRAIN_FLAT = 0, TWR_TERRAIN_BLOCK, TWR_TERRAIN_STAIRS, TWR_TERRAIN_GAP, TWR_TERRAIN_SLOPE,
-       TWR_TERRAIN_CHIMNEY, TWR_TERRAIN_CHIMNEY_LR };
+       TWR_TERRAIN_CHIMNEY, TWR_TERRAIN_CHIMNEY_LR,
+       /* HeightMapFromCSV (include/towr/terrain/height_map_from_csv.h): a gridded terrain, heights per 0.17 m
+         * cell; needs a twr_terrain_grid handle, see twr_structure_create_with_grid */
+       TWR_TERRAIN_CSV_GRID };
 enum { TWR_EVAL_VALUES = 1, TWR_EVAL_JACOBIAN = 2, TWR_EVAL_BOTH = 3 };
 /* Parameters::ConstraintName entries of the default list (parameters.h:139-147, parameters.cc:55-60),
  * as bits of twr_params.constraint_sets.  The sets always appear in this (the reference's) order. */
@@ -118,6 +121,7 @@ typedef struct twr_set_info {
   int32_t nnz_offset, nnz;      /* constraint sets only */
 } twr_set_info;
 
+typedef struct twr_terrain_grid twr_terrain_grid; /* host copy of a gridded terrain, shared by structures */
 typedef struct twr_structure twr_structure; /* host: index maps + CSR pattern of one candidate */
 typedef struct twr_batch twr_batch;         /* device: tables of a batch of candidates */
 
@@ -139,6 +143,15 @@ int twr_gait_combo(int n_ee, int combo, double t_total, double swing_scale, twr_
  * tables and the x-independent CSR pattern of the stacked Jacobian. */
 int twr_structure_create(const twr_model* model, const twr_schedule* schedule, const twr_params* params,
                          twr_structure** out);
+/* Gridded terrain of HeightMapFromCSV (height_map_from_csv.h:16-27): heights[y_cell * cols + x_cell], i.e. the
+ * matrix the reference fills from the CSV file; cell size 0.17 m and slope window cell/50 as in :112-115.
+ * Structures keep a reference to the grid (it may be destroyed right after they are created); a batch
+ * uploads every distinct grid once. */
+int twr_terrain_grid_create(const double* heights, int rows, int cols, twr_terrain_grid** out);
+void twr_terrain_grid_destroy(twr_terrain_grid* g);
+/* As twr_structure_create for model->terrain_id == TWR_TERRAIN_CSV_GRID. */
+int twr_structure_create_with_grid(const twr_model* model, const twr_schedule* schedule, const twr_params* params,
+                                   const twr_terrain_grid* grid, twr_structure** out);
 void twr_structure_destroy(twr_structure* s);
 int twr_structure_sizes(const twr_structure* s, twr_sizes* out);
 int twr_structure_var_set(const twr_structure* s, int i, twr_set_info* out);

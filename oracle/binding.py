@@ -18,7 +18,7 @@ SETS_TOWR_DEFAULT = 63          # + splineacc-base-lin/-ang (4) and swing-* (32)
 SET_BASE_ROM = 128              # BaseMotionConstraint ("baseMotion"), only when a caller pushes Parameters::BaseRom
 SET_TOTAL_TIME = 64             # OptimizePhaseDurations(): ee-schedule_e variables, PhaseSplines, totalduration-e
 ROBOTS = {"monoped": 0, "biped": 1, "hyq": 2, "anymal": 3, "go1": 4}
-TERRAINS = {"flat": 0, "block": 1, "stairs": 2, "gap": 3, "slope": 4, "chimney": 5, "chimney_lr": 6}
+TERRAINS = {"flat": 0, "block": 1, "stairs": 2, "gap": 3, "slope": 4, "chimney": 5, "chimney_lr": 6, "csv": 7}
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -37,7 +37,8 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.c_int, C.c_int, C.c_int, _ip, _dp, _ip, C.c_double, C.c_double,
-                                 C.c_double, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double]
+                                 C.c_double, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double,
+                                 _dp, C.c_int, C.c_int]
         L.orc_destroy.argtypes = [C.c_void_p]
         for f in ("orc_n_vars", "orc_n_rows", "orc_n_var_sets", "orc_n_con_sets"):
             getattr(L, f).argtypes = [C.c_void_p]
@@ -92,7 +93,7 @@ def gait(n_ee, combo, t_total):
 class OracleProblem:
     def __init__(self, robot, terrain, phase_durations, contact_at_start, dt_dynamic=0.1, dt_rom=0.08,
                  duration_base_poly=0.1, polys_per_swing=2, polys_per_stance_force=3, force_limit=1000.0,
-                 constraint_sets=SETS_HOT_PATH, dt_base_motion=None, base_z_init=0.0):
+                 constraint_sets=SETS_HOT_PATH, dt_base_motion=None, base_z_init=0.0, grid=None):
         robot = ROBOTS[robot] if isinstance(robot, str) else robot
         terrain = TERRAINS[terrain] if isinstance(terrain, str) else terrain
         n_ee = len(phase_durations)
@@ -103,7 +104,8 @@ class OracleProblem:
                                    duration_base_poly, polys_per_swing, polys_per_stance_force, force_limit,
                                    int(constraint_sets),
                                    float(duration_base_poly / 4.0 if dt_base_motion is None else dt_base_motion),
-                                   float(base_z_init))
+                                   float(base_z_init),
+                                   *self._grid_args(grid))
         if not self._h:
             raise RuntimeError("orc_create failed")
         L = lib()
@@ -115,6 +117,12 @@ class OracleProblem:
         self.con_sets = [(L.orc_con_set_name(self._h, i).decode(), L.orc_con_set_rows(self._h, i))
                          for i in range(L.orc_n_con_sets(self._h))]
         self.nnz = L.orc_eval(self._h, _d(np.zeros(self.n)), None, None, None, None)
+
+    def _grid_args(self, grid):
+        if grid is None:
+            return None, 0, 0
+        self._grid = np.ascontiguousarray(grid, dtype=np.float64)   # grid[y_cell, x_cell] (HeightMapFromCSV)
+        return _d(self._grid), self._grid.shape[0], self._grid.shape[1]
 
     def __del__(self):
         if getattr(self, "_h", None) and lib is not None:  # (module globals are gone at interpreter exit)

@@ -757,12 +757,49 @@ struct SRBD {
 
 // -------------------------------------- height_map.cc / height_map_examples.{h,cc}
 struct HeightMap {
-  int id;  // HeightMap::TerrainID
+  int id;  // HeightMap::TerrainID; 7 = HeightMapFromCSV (include/towr/terrain/height_map_from_csv.h)
   double friction = 0.5;  // ref: height_map.h:136
+  // HeightMapFromCSV: grid_(y_cell, x_cell), 0.17 m cells, eps = cell / 50 (height_map_from_csv.h:112-115)
+  std::vector<double> grid;
+  long grid_rows = 0, grid_cols = 0;
+  double res = 0.17, eps = 0.17 / 50;
   explicit HeightMap(int id_) : id(id_) {}
+  // static_cast<size_t>(x / res) of the reference: truncation toward zero; a negative quotient <= -1 wraps to
+  // a huge size_t on x86-64 (formally undefined) and fails every range check -- restated as a signed cell
+  // index that is "invalid" when negative.  (-1, 0) truncates to cell 0 like the reference.
+  static long Cell(double v, double res_) { return (long)(v / res_); }
+  bool CellValid(long xc, long yc) const { return xc >= 0 && yc >= 0 && xc < grid_cols && yc < grid_rows; }
+  double At(long yc, long xc) const { return grid[(size_t)yc * (size_t)grid_cols + (size_t)xc]; }
+  // ref: height_map_from_csv.h:29-37
+  double CsvHeight(double x, double y) const {
+    const long xc = Cell(x, res), yc = Cell(y, res);
+    if (!CellValid(xc, yc)) return 0.0;
+    return At(yc, xc);
+  }
+  // ref: height_map_from_csv.h:40-73 (dim X) and :76-109 (dim Y): a step is smeared over eps on its lower side
+  double CsvDeriv(int dim, double x, double y) const {
+    const long xc = Cell(x, res), yc = Cell(y, res);
+    if (!CellValid(xc, yc)) return 0.0;
+    const double v = dim == X ? x : y;
+    const long c = dim == X ? xc : yc;
+    const long nxc = dim == X ? xc + 1 : xc, nyc = dim == X ? yc : yc + 1;   // next cell
+    if (CellValid(nxc, nyc)) {
+      const double diff_end = At(nyc, nxc) - At(yc, xc);
+      const double v_end = (double)(c + 1) * res;
+      if ((diff_end > 0) && (v <= v_end) && (v >= v_end - eps)) return diff_end / eps;
+    }
+    const long pxc = dim == X ? xc - 1 : xc, pyc = dim == X ? yc : yc - 1;   // previous cell
+    if (CellValid(pxc, pyc)) {
+      const double diff_start = At(yc, xc) - At(pyc, pxc);
+      const double v_start = (double)c * res;
+      if ((diff_start < 0) && (v >= v_start) && (v <= v_start + eps)) return diff_start / eps;
+    }
+    return 0.0;
+  }
 
   double GetHeight(double x, double y) const {
     switch (id) {
+      case 7: return CsvHeight(x, y);
       case 0: return 0.0;  // FlatGround(0.0)
       case 1: {            // Block, ref: height_map_examples.cc:40-53, .h:63-68
         const double block_start = 0.7, length = 3.5, height = 0.5, eps = 0.03, slope = height / eps;
@@ -821,6 +858,7 @@ struct HeightMap {
   };
   double DerivX(double x, double y) const {
     switch (id) {
+      case 7: return CsvDeriv(X, x, y);
       case 1: {  // ref: height_map_examples.cc:55-65
         const double block_start = 0.7, height = 0.5, eps = 0.03, slope = height / eps;
         return (block_start <= x && x <= block_start + eps) ? slope : 0.0;
@@ -842,6 +880,7 @@ struct HeightMap {
   }
   double DerivY(double x, double y) const {
     switch (id) {
+      case 7: return CsvDeriv(Y, x, y);
       case 5: {  // ref: height_map_examples.cc:172-181
         const double x_start = 1.0, length = 1.5, slope = 3.0, x_end = x_start + length;
         return (x_start <= x && x <= x_end) ? slope : 0.0;
@@ -1466,12 +1505,18 @@ extern "C" {
 orc_problem* orc_create(int robot, int terrain, int n_ee, const int* n_phases, const double* phase_durations,
                         const int* in_contact_at_start, double dt_dynamic, double dt_rom, double duration_base_poly,
                         int polys_per_swing, int polys_per_stance_force, double force_limit, int constraint_sets,
-                        double dt_base_motion, double base_z_init) {
+                        double dt_base_motion, double base_z_init, const double* grid, int grid_rows, int grid_cols) {
   try {
     auto* P = new orc_problem();
     P->robot = MakeRobot(robot);
     if (P->robot.n_ee != n_ee) throw std::runtime_error("n_ee mismatch with robot");
     P->terrain.reset(new HeightMap(terrain));
+    if (terrain == 7) {  // HeightMapFromCSV: the grid the reference reads with rapidcsv (height_map_from_csv.h:19-27)
+      if (!grid || grid_rows < 1 || grid_cols < 1) throw std::runtime_error("terrain 7 needs a grid");
+      P->terrain->grid.assign(grid, grid + (size_t)grid_rows * grid_cols);
+      P->terrain->grid_rows = grid_rows;
+      P->terrain->grid_cols = grid_cols;
+    }
     P->model.reset(new SRBD(P->robot));
     P->n_ee = n_ee;
     const double* pd = phase_durations;

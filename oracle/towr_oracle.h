@@ -26,14 +26,17 @@ extern "C" {
 typedef struct orc_problem orc_problem;
 
 // robot: 0 Monoped, 1 Biped, 2 Hyq, 3 Anymal, 4 Go1   (towr/src/robot_model.cc:41-68)
-// terrain: 0 Flat,1 Block,2 Stairs,3 Gap,4 Slope,5 Chimney,6 ChimneyLR (height_map.h:79-86)
+// terrain: 0 Flat,1 Block,2 Stairs,3 Gap,4 Slope,5 Chimney,6 ChimneyLR (height_map.h:79-86),
+//          7 HeightMapFromCSV with the grid passed to orc_create (terrain/height_map_from_csv.h)
 // phase_durations: concatenated per-ee phase durations, n_phases[ee] entries each.
 orc_problem* orc_create(int robot, int terrain, int n_ee, const int* n_phases,
                         const double* phase_durations, const int* in_contact_at_start,
                         double dt_dynamic, double dt_rom, double duration_base_poly,
                         int polys_per_swing, int polys_per_stance_force,
                         double force_limit, int constraint_sets,
-                        double dt_base_motion /* parameters.cc:51 */, double base_z_init /* base_motion_constraint.cc:51 */);
+                        double dt_base_motion /* parameters.cc:51 */, double base_z_init /* base_motion_constraint.cc:51 */,
+                        const double* grid /* terrain 7 (HeightMapFromCSV): rows x cols heights, grid[y_cell][x_cell] */,
+                        int grid_rows, int grid_cols);
 // constraint_sets: which of the default sets (parameters.cc:55-60) to build, in that order
 enum {
   ORC_SET_TERRAIN = 1, ORC_SET_DYNAMIC = 2, ORC_SET_BASE_ACC = 4, ORC_SET_ROM = 8, ORC_SET_FORCE = 16,

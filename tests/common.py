@@ -66,18 +66,20 @@ def assert_parity(S, got_g, got_j, ref_g, ref_j, what="", x=None):
 class Case:
     """One problem description realised both in the product (Structure) and in the oracle."""
 
-    def __init__(self, robot, terrain, sched, **params):
+    def __init__(self, robot, terrain, sched, grid=None, **params):
         self.robot, self.terrain = robot, terrain
         self.sched = sched
         self.params = ta.params_default(**params)
         self.model = ta.model_preset(robot, terrain)
-        self.S = ta.Structure(self.model, sched, self.params)
+        # gridded terrain (HeightMapFromCSV): `grid` is heights[y_cell, x_cell] or an existing ta.TerrainGrid
+        self.grid = ta.TerrainGrid(grid) if isinstance(grid, np.ndarray) else grid
+        self.S = ta.Structure(self.model, sched, self.params, grid=self.grid)
         p = self.params
         self.P = ob.OracleProblem(robot, terrain, sched.durations(), sched.contact(), dt_dynamic=p.dt_dynamic,
                                   dt_rom=p.dt_rom, duration_base_poly=p.duration_base_poly,
                                   polys_per_swing=p.polys_per_swing, polys_per_stance_force=p.polys_per_stance_force,
                                   constraint_sets=p.constraint_sets, dt_base_motion=p.dt_base_motion,
-                                  base_z_init=p.base_z_init)
+                                  base_z_init=p.base_z_init, grid=None if self.grid is None else self.grid.heights)
 
     def nominal_start(self):
         m = self.model
@@ -155,6 +157,7 @@ def random_case(seed):
     rng = np.random.default_rng(seed)
     robot = ["monoped", "biped", "hyq", "anymal", "go1"][rng.integers(5)]
     terrain = list(ta.TERRAINS)[rng.integers(len(ta.TERRAINS))]
+    grid = np.round(rng.uniform(0.0, 0.25, size=(int(rng.integers(3, 25)), int(rng.integers(3, 25)))), 2) if terrain == "csv" else None
     n_ee = ta.model_preset(robot, terrain).n_ee
     T = float(rng.uniform(0.9, 3.0))
     mask = int(rng.integers(1, 256))
@@ -174,4 +177,4 @@ def random_case(seed):
                   duration_base_poly=float(rng.uniform(0.05, 0.25)), polys_per_swing=int(rng.integers(1, 4)),
                   polys_per_stance_force=int(rng.integers(1, 5)), dt_base_motion=float(rng.uniform(0.02, 0.2)),
                   base_z_init=float(rng.uniform(0.3, 0.7)))
-    return Case(robot, terrain, ta.schedule(durs, contact), **params)
+    return Case(robot, terrain, ta.schedule(durs, contact), grid=grid, **params)

@@ -268,6 +268,39 @@ def test_random_structures_in_one_ragged_batch():
             assert_parity(c.S, *_split(batch, g, j, p), rg, rj, "n_ee %d problem %d" % (n_ee, p), x=xs[p])
 
 
+def test_gridded_terrain():
+    """HeightMapFromCSV on the device: heights and edge slopes from a grid in device memory; two structures share
+    one grid (uploaded once), a third has its own; footholds are placed on cell edges on purpose."""
+    rng = np.random.default_rng(7)
+    g1 = np.round(rng.uniform(0.0, 0.3, size=(18, 26)), 2)
+    g2 = np.round(rng.uniform(0.0, 0.2, size=(5, 7)), 2)
+    G1 = ta.TerrainGrid(g1)
+    a = Case("anymal", "csv", ta.gait_combo(4, 1, 2.0), grid=G1, constraint_sets=63)
+    b = Case("anymal", "csv", ta.gait_combo(4, 0, 2.4), grid=G1)
+    c = Case("anymal", "csv", ta.gait_combo(4, 2, 1.8), grid=g2, constraint_sets=127)
+    cases, order = [a, b, c], [0, 1, 2, 0, 2, 1]
+    batch = ta.Batch([k.S for k in cases], order, device=0)
+    xs = []
+    for i, s in enumerate(order):
+        x = cases[s].x_wild(70 + i)
+        for vs in cases[s].S.var_sets:      # snap a third of the foothold coordinates onto / next to cell edges
+            if vs["name"].startswith("ee-motion"):
+                seg = x[vs["offset"]:vs["offset"] + vs["size"]]
+                pick = rng.random(seg.size) < 0.35
+                seg[pick] = np.round(seg[pick] / 0.17) * 0.17 + rng.uniform(-0.004, 0.004, size=pick.sum())
+        xs.append(x)
+    g, j = batch.eval_host(np.concatenate(xs))
+    hit = 0
+    for p, s in enumerate(order):
+        rg, rp, ci, rj = cases[s].P.eval(xs[p])
+        assert_parity(cases[s].S, *_split(batch, g, j, p), rg, rj, "problem %d" % p, x=xs[p])
+        for cs in cases[s].S.con_sets:
+            if cs["name"].startswith("terrain-"):
+                blk = rj[rp[cs["offset"]]:rp[cs["offset"] + cs["size"]]].reshape(-1, 3)
+                hit += int((np.abs(blk[:, :2]) > 1.0).sum())
+    assert hit >= 5, "the inputs should exercise the edge slopes"
+
+
 def test_foot_starting_in_swing():
     """ee_in_contact_at_start = false: first polynomial of ee-motion is a swing one, force starts at zero."""
     sched = ta.schedule([[0.3, 0.5, 0.3, 0.4], [0.6, 0.3, 0.6]], [0, 1])

@@ -143,6 +143,44 @@ def test_terrain_known_answers():
     assert np.allclose(n, np.array([-0.7, 0, 1]) / np.hypot(0.7, 1), rtol=1e-15)
 
 
+def test_csv_grid_terrain_known_answers():
+    """HeightMapFromCSV (terrain/height_map_from_csv.h:29-109): height of the 0.17 m cell under (x, y), 0 outside
+    the grid; the slope is a step to the next / previous cell smeared over eps = cell/50 on the lower side."""
+    grid = np.array([[0.0, 0.1, 0.1], [0.2, 0.05, 0.3]])   # grid[y_cell, x_cell]
+    P = ob.OracleProblem("monoped", "csv", [[0.4, 0.2, 0.4]], [1], grid=grid)
+    off = 0
+    for name, size in P.var_sets:
+        if name == "ee-motion_0":
+            m = off
+        off += size
+    res, eps = 0.17, 0.17 / 50
+
+    def terrain_row(px, py, node=1):
+        x = np.zeros(P.n)
+        # ee-motion_0: stance (px py pz) | swing node px vx py vy pz | stance ...; terrain row 0 is node 1 = the
+        # end node of the first stance phase = the same variables as node 0
+        x[m:m + 3] = [px, py, 0.7]
+        g, rp, ci, va = P.eval(x)
+        return g[0], va[rp[0]:rp[1]]
+
+    g0, j0 = terrain_row(0.5 * res, 0.5 * res)              # cell (0,0), far from any edge
+    assert g0 == 0.7 - 0.0 and np.array_equal(j0, [-0.0, -0.0, 1.0])
+    g0, j0 = terrain_row(1.5 * res, 1.5 * res)              # cell x=1, y=1 -> 0.05
+    assert g0 == pytest.approx(0.7 - 0.05, abs=1e-15)
+    g0, j0 = terrain_row(res - 0.5 * eps, 0.5 * res)        # just below the x edge to a higher cell: slope +0.1/eps
+    assert g0 == 0.7 and np.allclose(j0, [-0.1 / eps, 0.0, 1.0], rtol=1e-14)
+    g0, j0 = terrain_row(res + 0.5 * eps, 1.5 * res)        # cell (y=1,x=1)=0.05 just after a drop from 0.2: slope -0.15/eps
+    assert np.allclose(j0, [0.15 / eps, 0.0, 1.0], rtol=1e-13)
+    g0, j0 = terrain_row(0.5 * res, res - 0.5 * eps)        # just below the y edge, next row higher (0.2): dh/dy = 0.2/eps
+    assert np.allclose(j0, [0.0, -0.2 / eps, 1.0], rtol=1e-14)
+    g0, j0 = terrain_row(3.5 * res, 0.5 * res)              # outside the grid: height 0, no slope
+    assert g0 == 0.7 and np.array_equal(j0, [-0.0, -0.0, 1.0])
+    g0, j0 = terrain_row(-0.3 * res, 0.5 * res)             # (-1, 0) * res truncates to cell 0, like static_cast<size_t>
+    assert g0 == 0.7 - 0.0
+    g0, j0 = terrain_row(-1.3 * res, 0.5 * res)             # negative cell: outside
+    assert g0 == 0.7
+
+
 def _anymal_static():
     pd, con = [[1.0]] * 4, [1] * 4          # one stance phase per foot: the robot just stands
     P = ob.OracleProblem("anymal", "flat", pd, con)

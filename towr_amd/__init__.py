@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libtowr_amd.so")
 
 MAX_EE, MAX_PHASES, NAME_LEN = 4, 32, 40
 ROBOTS = {"monoped": 0, "biped": 1, "hyq": 2, "anymal": 3, "go1": 4}
-TERRAINS = {"flat": 0, "block": 1, "stairs": 2, "gap": 3, "slope": 4, "chimney": 5, "chimney_lr": 6}
+TERRAINS = {"flat": 0, "block": 1, "stairs": 2, "gap": 3, "slope": 4, "chimney": 5, "chimney_lr": 6, "csv": 7}
 EVAL_VALUES, EVAL_JACOBIAN, EVAL_BOTH = 1, 2, 3
 SET_TERRAIN, SET_DYNAMIC, SET_BASE_ACC, SET_ROM, SET_FORCE, SET_SWING, SET_TOTAL_TIME = 1, 2, 4, 8, 16, 32, 64
 SET_BASE_ROM = 128
@@ -99,6 +99,10 @@ def lib():
         L.twr_structure_create.argtypes = [C.POINTER(Model), C.POINTER(Schedule), C.POINTER(Params),
                                            C.POINTER(C.c_void_p)]
         L.twr_structure_destroy.argtypes = [C.c_void_p]
+        L.twr_terrain_grid_create.argtypes = [_dp, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.twr_terrain_grid_destroy.argtypes = [C.c_void_p]
+        L.twr_structure_create_with_grid.argtypes = [C.POINTER(Model), C.POINTER(Schedule), C.POINTER(Params), C.c_void_p,
+                                                     C.POINTER(C.c_void_p)]
         L.twr_structure_destroy.restype = None
         L.twr_structure_sizes.argtypes = [C.c_void_p, C.POINTER(Sizes)]
         L.twr_structure_var_set.argtypes = [C.c_void_p, C.c_int, C.POINTER(SetInfo)]
@@ -172,14 +176,34 @@ def schedule(phase_durations, contact_at_start):
     return s
 
 
+class TerrainGrid:
+    """Gridded terrain of HeightMapFromCSV: heights[y_cell, x_cell] (0.17 m cells)."""
+
+    def __init__(self, heights):
+        a = np.ascontiguousarray(heights, dtype=np.float64)
+        assert a.ndim == 2
+        self._h = C.c_void_p()
+        _check(lib().twr_terrain_grid_create(_d(a), a.shape[0], a.shape[1], C.byref(self._h)))
+        self.heights = a
+
+    def __del__(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib().twr_terrain_grid_destroy(self._h)
+            self._h = None
+
+
 class Structure:
     """x-independent part of one candidate (index maps, time tables, CSR pattern)."""
 
-    def __init__(self, model, sched, params=None):
+    def __init__(self, model, sched, params=None, grid=None):
         params = params or params_default()
         self._h = C.c_void_p()
-        self.model, self.schedule, self.params = model, sched, params
-        _check(lib().twr_structure_create(C.byref(model), C.byref(sched), C.byref(params), C.byref(self._h)))
+        self.model, self.schedule, self.params, self.grid = model, sched, params, grid
+        if grid is not None:
+            _check(lib().twr_structure_create_with_grid(C.byref(model), C.byref(sched), C.byref(params), grid._h,
+                                                        C.byref(self._h)))
+        else:
+            _check(lib().twr_structure_create(C.byref(model), C.byref(sched), C.byref(params), C.byref(self._h)))
         sz = Sizes()
         _check(lib().twr_structure_sizes(self._h, C.byref(sz)))
         self.n, self.m, self.nnz = sz.n_vars, sz.n_rows, sz.nnz

@@ -25,6 +25,9 @@ int dyn_nodes_per_block();
 struct twr_structure {
   twr::Structure s;
 };
+struct twr_terrain_grid {
+  std::shared_ptr<twr::TerrainGrid> g;
+};
 
 struct twr_batch {
   int device = 0;
@@ -32,6 +35,7 @@ struct twr_batch {
   int n_dyn = 0, n_rom = 0, n_node = 0, n_cu = 0;
   std::vector<int64_t> x_off, g_off, j_off;  // n_problems+1
   std::vector<void*> blobs;                  // device blobs, one per distinct structure
+  std::vector<void*> grids;                  // device copies of the distinct gridded terrains
   twr::DynWork* d_dyn = nullptr;
   twr::RomWork* d_rom = nullptr;
   twr::NodeWork* d_node = nullptr;
@@ -127,11 +131,33 @@ int twr_gait_combo(int n_ee, int combo, double t_total, double swing_scale, twr_
   }
 }
 
+int twr_terrain_grid_create(const double* heights, int rows, int cols, twr_terrain_grid** out) {
+  if (!heights || !out || rows < 1 || cols < 1) return fail(TWR_ERR_INVALID, "bad grid");
+  try {
+    std::unique_ptr<twr_terrain_grid> h(new twr_terrain_grid());
+    h->g = std::make_shared<twr::TerrainGrid>();
+    h->g->heights.assign(heights, heights + (size_t)rows * cols);
+    h->g->rows = rows;
+    h->g->cols = cols;
+    *out = h.release();
+    return TWR_OK;
+  } catch (const std::exception& e) {
+    return fail(TWR_ERR_INVALID, e.what());
+  }
+}
+void twr_terrain_grid_destroy(twr_terrain_grid* g) { delete g; }
+
 int twr_structure_create(const twr_model* model, const twr_schedule* schedule, const twr_params* params,
                          twr_structure** out) {
+  return twr_structure_create_with_grid(model, schedule, params, nullptr, out);
+}
+
+int twr_structure_create_with_grid(const twr_model* model, const twr_schedule* schedule, const twr_params* params,
+                                   const twr_terrain_grid* grid, twr_structure** out) {
   if (!model || !schedule || !params || !out) return fail(TWR_ERR_INVALID, "null argument");
   try {
     std::unique_ptr<twr_structure> h(new twr_structure());
+    if (grid) h->s.grid = grid->g;
     h->s.model = *model;
     h->s.schedule = *schedule;
     h->s.params = *params;
@@ -221,13 +247,28 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     b->device = device;
     b->n_problems = n_problems;
     b->n_ee = structs[0]->s.n_ee;
+    std::vector<const twr::TerrainGrid*> host_grids;
     for (int i = 0; i < n_structs; ++i) {
       if (!structs[i]) throw std::runtime_error("null structure");
       if (structs[i]->s.n_ee != b->n_ee) throw std::runtime_error("all structures of a batch must share n_ee");
       void* d = nullptr;
       TWR_HIP(hipMalloc(&d, structs[i]->s.blob.size()));
       b->blobs.push_back(d);
-      TWR_HIP(hipMemcpy(d, structs[i]->s.blob.data(), structs[i]->s.blob.size(), hipMemcpyHostToDevice));
+      std::vector<char> blob = structs[i]->s.blob;
+      if (structs[i]->s.grid) {  // gridded terrain: upload every distinct grid once, patch its address into the header
+        const twr::TerrainGrid* tg = structs[i]->s.grid.get();
+        void* dg = nullptr;
+        for (size_t q = 0; q < host_grids.size(); ++q)
+          if (host_grids[q] == tg) dg = b->grids[q];
+        if (!dg) {
+          TWR_HIP(hipMalloc(&dg, tg->heights.size() * sizeof(double)));
+          TWR_HIP(hipMemcpy(dg, tg->heights.data(), tg->heights.size() * sizeof(double), hipMemcpyHostToDevice));
+          host_grids.push_back(tg);
+          b->grids.push_back(dg);
+        }
+        reinterpret_cast<twr::DevStruct*>(blob.data())->grid_ptr = reinterpret_cast<uint64_t>(dg);
+      }
+      TWR_HIP(hipMemcpy(d, blob.data(), blob.size(), hipMemcpyHostToDevice));
     }
     b->x_off.assign(n_problems + 1, 0);
     b->g_off.assign(n_problems + 1, 0);
@@ -406,6 +447,7 @@ void twr_batch_destroy(twr_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   for (void* d : b->blobs) (void)hipFree(d);
+  for (void* d : b->grids) (void)hipFree(d);
   if (b->d_dyn) (void)hipFree(b->d_dyn);
   if (b->d_rom) (void)hipFree(b->d_rom);
   if (b->d_node) (void)hipFree(b->d_node);

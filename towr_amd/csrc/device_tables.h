@@ -146,6 +146,10 @@ struct DevStruct {
   uint32_t o_phase;
   int32_t row_bm, nnz_bm, n_bm_nodes;  // baseMotion: 6 rows x 4 values per time node
   uint32_t o_bm;        // BaseNode[n_bm_nodes]
+  // gridded terrain (HeightMapFromCSV): device address of heights[rows][cols] (patched in by the batch)
+  uint64_t grid_ptr;
+  int32_t grid_rows, grid_cols;
+  double grid_res, grid_eps;
 };
 
 // Work items: one contiguous run of time nodes of one constraint set of one problem.  All

@@ -709,9 +709,43 @@ TWR_DEV void rom_item(const RomWork& w, const RomRec& r, const RomX& X, double* 
 struct Terr {
   double h, hx, hy, hxx;
 };
-TWR_DEV Terr terrain_eval(int id, double flat_height, double x, double y) {
+// HeightMapFromCSV (include/towr/terrain/height_map_from_csv.h:29-109): piecewise-constant heights per cell;
+// the "slope" is the step to the next / previous cell smeared over eps on the lower side of the step, checked
+// in the reference's order (next cell first); second derivatives are the base class's zeros.
+TWR_DEV Terr grid_eval(const DevStruct* __restrict__ S, double x, double y) {
+  Terr t = {0.0, 0.0, 0.0, 0.0};
+  const double* __restrict__ grid = reinterpret_cast<const double*>(S->grid_ptr);
+  const int rows = S->grid_rows, cols = S->grid_cols;
+  const double res = S->grid_res, eps = S->grid_eps;
+  const long xc = (long)(x / res), yc = (long)(y / res);   // truncation toward zero, like static_cast<size_t>
+  if (xc < 0 || yc < 0 || xc >= cols || yc >= rows) return t;
+  const double h0 = grid[yc * cols + xc];
+  t.h = h0;
+#pragma unroll
+  for (int dim = 0; dim < 2; ++dim) {
+    const double v = dim == 0 ? x : y;
+    const long c = dim == 0 ? xc : yc, n = dim == 0 ? cols : rows;
+    const long stride = dim == 0 ? 1 : cols;
+    double d = 0.0;
+    bool done = false;
+    if (c + 1 < n) {
+      const double diff_end = grid[yc * cols + xc + stride] - h0;
+      const double v_end = (double)(c + 1) * res;
+      if (diff_end > 0 && v <= v_end && v >= v_end - eps) { d = diff_end / eps; done = true; }
+    }
+    if (!done && c - 1 >= 0) {
+      const double diff_start = h0 - grid[yc * cols + xc - stride];
+      const double v_start = (double)c * res;
+      if (diff_start < 0 && v >= v_start && v <= v_start + eps) d = diff_start / eps;
+    }
+    if (dim == 0) t.hx = d; else t.hy = d;
+  }
+  return t;
+}
+TWR_DEV Terr terrain_eval(const DevStruct* __restrict__ S, int id, double flat_height, double x, double y) {
   Terr t = {0.0, 0.0, 0.0, 0.0};
   switch (id) {
+    case 7: return grid_eval(S, x, y);
     case 0: t.h = flat_height; break;
     case 1: {  // Block (height_map_examples.cc:40-65)
       const double start = 0.7, len = 3.5, height = 0.5, eps = 0.03, slope = height / eps;
@@ -759,7 +793,7 @@ TWR_DEV void force_item(const DevStruct* __restrict__ S, const ForceNode fn, con
                         double* __restrict__ g5, double* __restrict__ st25, bool want_g, bool want_j) {
   const double f[3] = {xp[fn.fidx], xp[fn.fidx + 2], xp[fn.fidx + 4]};
   const double px = xp[fn.hidx], py = xp[fn.hidx + 1];
-  const Terr t = terrain_eval(S->terrain_id, S->flat_height, px, py);
+  const Terr t = terrain_eval(S, S->terrain_id, S->flat_height, px, py);
   const double mu = S->mu;
   const double vb[3][3] = {{-t.hx, -t.hy, 1.0}, {1.0, 0.0, t.hx}, {0.0, 1.0, t.hy}};  // n, t1, t2 (height_map.cc:93-139)
   double nb[3][3], sq[3], nr[3];
@@ -1038,7 +1072,7 @@ __global__ __launch_bounds__(256) void node_kernel(const NodeWork* __restrict__ 
       if (lane < cnt) {
         const TerrainRow tr = rows[r0 + lane];
         const double px = xp[tr.idx], py = xp[tr.idx + tr.stride], pz = xp[tr.idx + 2 * tr.stride];
-        const Terr t = terrain_eval(S->terrain_id, S->flat_height, px, py);
+        const Terr t = terrain_eval(S, S->terrain_id, S->flat_height, px, py);
         if (want_g) gp[S->row_terrain + r0 + lane] = pz - t.h;
         if (want_j) {
           stage[par + 3 * lane + 0] = -t.hx;

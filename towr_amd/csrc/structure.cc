@@ -724,6 +724,13 @@ void Structure::PackBlob() {
     h.timings = 1;
     h.o_phase = put(&pt, sizeof(pt));
   }
+  if (model.terrain_id == TWR_TERRAIN_CSV_GRID) {
+    if (!grid) throw std::runtime_error("TWR_TERRAIN_CSV_GRID needs twr_structure_create_with_grid");
+    h.grid_rows = grid->rows;
+    h.grid_cols = grid->cols;
+    h.grid_res = grid->res;
+    h.grid_eps = grid->eps;
+  }
   h.mass = model.mass; h.gravity = model.gravity; h.mu = model.friction; h.flat_height = model.flat_height;
   // BuildInertiaTensor (single_rigid_body_dynamics.cc:36-44): off-diagonals are the negated products of inertia
   const double* I = model.inertia;  // Ixx,Iyy,Izz,Ixy,Ixz,Iyz
@@ -750,8 +757,20 @@ void Structure::Build() {
 // ------------------------------------------------------------------ terrain height (host, setup only)
 // HeightMap::GetHeight of the example terrains (src/height_map_examples.cc:35-197,
 // include/towr/terrain/examples/height_map_examples.h:45-166).
-double TerrainHeightHost(const twr_model& m, double x, double y) {
+// HeightMapFromCSV::GetHeight (include/towr/terrain/height_map_from_csv.h:29-37).  static_cast<size_t>(x / res)
+// truncates toward zero; a quotient <= -1 wraps to a huge size_t in the reference (formally undefined) and
+// fails the range check -- here a signed cell index that is invalid when negative.
+double TerrainGrid::Height(double x, double y) const {
+  const long xc = (long)(x / res), yc = (long)(y / res);
+  if (xc < 0 || yc < 0 || xc >= cols || yc >= rows) return 0.0;
+  return heights[(size_t)yc * cols + xc];
+}
+
+double TerrainHeightHost(const twr_model& m, const TerrainGrid* grid, double x, double y) {
   switch (m.terrain_id) {
+    case TWR_TERRAIN_CSV_GRID:
+      if (!grid) throw std::runtime_error("gridded terrain without a grid");
+      return grid->Height(x, y);
     case TWR_TERRAIN_FLAT: return m.flat_height;
     case TWR_TERRAIN_BLOCK: {
       const double start = 0.7, len = 3.5, height = 0.5, eps = 0.03, slope = height / eps;
@@ -815,7 +834,7 @@ void Structure::InitialGuess(const double* lin0, const double* ang0, const doubl
       }
   };
   for (int i = 0; i < n_vars; ++i) x[i] = 0.0;
-  double fl[3] = {lin1[0], lin1[1], TerrainHeightHost(model, lin1[0], lin1[1]) - model.nominal_stance[0][2]};
+  double fl[3] = {lin1[0], lin1[1], TerrainHeightHost(model, grid.get(), lin1[0], lin1[1]) - model.nominal_stance[0][2]};
   interpolate(base, off_base_lin, lin0, fl);
   interpolate(base, off_base_ang, ang0, ang1);
   for (int e = 0; e < n_ee; ++e) {
@@ -828,7 +847,7 @@ void Structure::InitialGuess(const double* lin0, const double* ang0, const doubl
                       {-s0, c0 * s0, c0 * c0}};
     double fe[3];
     for (int i = 0; i < 3; ++i) fe[i] = lin1[i] + (R[i][0] * nb[0] + R[i][1] * nb[1] + R[i][2] * nb[2]);
-    fe[2] = TerrainHeightHost(model, fe[0], fe[1]);
+    fe[2] = TerrainHeightHost(model, grid.get(), fe[0], fe[1]);
     interpolate(motion[e], 0, ee0 + 3 * e, fe);
   }
   for (int e = 0; e < n_ee; ++e) {
@@ -917,7 +936,7 @@ void ModelPreset(int robot, int terrain, twr_model* m) {
       break;
     default: throw std::runtime_error("unknown robot id");
   }
-  if (terrain < TWR_TERRAIN_FLAT || terrain > TWR_TERRAIN_CHIMNEY_LR) throw std::runtime_error("unknown terrain id");
+  if (terrain < TWR_TERRAIN_FLAT || terrain > TWR_TERRAIN_CSV_GRID) throw std::runtime_error("unknown terrain id");
   m->terrain_id = terrain;
   m->gravity = 9.80665;     // dynamic_model.cc:37
   m->friction = 0.5;        // height_map.h:136

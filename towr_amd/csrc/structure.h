@@ -3,6 +3,7 @@
 // information over NlpFormulation::GetVariableSets/GetConstraints, NodesVariables*,
 // SplineHolder and the constraint constructors (see citations in structure.cc).
 #pragma once
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -32,8 +33,16 @@ struct TimeNode {  // result of Spline::GetLocalTime for one spline at one grid 
   double t_local;
 };
 
+struct TerrainGrid {   // HeightMapFromCSV (include/towr/terrain/height_map_from_csv.h)
+  std::vector<double> heights;  // [y_cell * cols + x_cell]
+  int rows = 0, cols = 0;
+  double res = 0.17, eps = 0.17 / 50;  // :112-115
+  double Height(double x, double y) const;
+};
+
 struct Structure {
   twr_model model;
+  std::shared_ptr<const TerrainGrid> grid;  // TWR_TERRAIN_CSV_GRID only
   twr_schedule schedule;
   twr_params params;
   int n_ee = 0;
@@ -82,6 +91,6 @@ struct Structure {
 // gait tables
 void GaitCombo(int n_ee, int combo, double t_total, double swing_scale, twr_schedule* out);
 void ModelPreset(int robot, int terrain, twr_model* out);
-double TerrainHeightHost(const twr_model& m, double x, double y);
+double TerrainHeightHost(const twr_model& m, const TerrainGrid* grid, double x, double y);
 
 }  // namespace twr
