@@ -198,6 +198,15 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
  * force/terrain nodes); _end waits for the last one and returns the average duration of each. */
 int twr_batch_profile_begin(twr_batch* b, int max_evals);
 int twr_batch_profile_end(twr_batch* b, double avg_ms[3], int* n_evals);
+/* Trajectory sampling of a batch of solutions, fpowr::GetTrajectory (fpowr/include/fpowr/footstep_plan_extractor.h:
+ * 19-53): problem p's x sampled every dt while t <= T + 1e-5 (t accumulated).  One record per sample, end-effectors
+ * in towr order:  [ t | base lin p v a (9) | quaternion w x y z | omega (3) | omega_dot (3) |
+ *                  per ee: contact (0/1), ee-motion p v a (9), ee-force (3) ]   = 20 + 13 n_ee doubles.
+ * twr_structure_sample_count gives the records per problem; problem p's records start at
+ * d_out + p * problem_stride (doubles).  Asynchronous on hip_stream. */
+int twr_structure_sample_count(const twr_structure* s, double dt, int32_t* n_samples);
+int twr_batch_sample(twr_batch* b, const double* d_x, double dt, double* d_out, int64_t problem_stride, void* hip_stream);
+
 /* Convenience for single-problem / adapter use: host buffers, synchronous (H2D, eval, D2H). */
 int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_jac, int flags);
 /* Page-locked host buffers owned by the batch (x, g, jac of the whole batch layout), allocated on first

@@ -54,6 +54,8 @@ def lib():
         L.orc_eval.argtypes = [C.c_void_p, _dp, _dp, _ip, _ip, _dp]
         L.orc_eval.restype = C.c_int
         L.orc_bounds.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_sample_trajectory.argtypes = [C.c_void_p, _dp, C.c_double, _dp, C.c_int]
+        L.orc_sample_trajectory.restype = C.c_int
         L.orc_time_callbacks.argtypes = [C.c_void_p, _dp, C.c_int]
         L.orc_time_callbacks.restype = C.c_double
         L.orc_gait.argtypes = [C.c_int, C.c_int, C.c_double, _ip, _ip, _dp, C.c_int]
@@ -163,6 +165,14 @@ class OracleProblem:
         g = np.zeros(self.m)
         lib().orc_eval(self._h, _d(x), _d(g), None, None, None)
         return g
+
+    def sample_trajectory(self, x, dt=0.01):
+        """fpowr::GetTrajectory: (n_samples, 20 + 13 n_ee) array, see towr_oracle.cc for the record layout."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        n = lib().orc_sample_trajectory(self._h, _d(x), float(dt), None, 0)
+        out = np.zeros((n, 20 + 13 * self.n_ee))
+        lib().orc_sample_trajectory(self._h, _d(x), float(dt), _d(out), n)
+        return out
 
     def bounds(self):
         lo, up = np.zeros(self.m), np.zeros(self.m)

@@ -1714,6 +1714,76 @@ int orc_eval(orc_problem* P, const double* x, double* g, int* row_ptr, int* col_
   return nnz;
 }
 
+// fpowr::GetTrajectory (fpowr/include/fpowr/footstep_plan_extractor.h:19-53): the solution sampled every dt
+// while t <= T + 1e-5 (t accumulated).  One record per sample, end-effectors in towr order (the reference
+// relabels them to xpp ids, fpowr_xpp_ee_map.h:87-117):
+//   [ t | base lin p v a (9) | quaternion w x y z (4) | omega (3) | omega_dot (3) |
+//     per ee: contact (0/1), ee-motion p v a (9), ee-force p (3) ]        = 20 + 13 n_ee doubles
+// The quaternion is Eigen::Quaterniond(R) (euler_converter.cc:51-56): Eigen 3.3 Quaternion.h
+// quaternionbase_assign_impl<Matrix3d> restated (third party, not in /root/reference).
+int orc_sample_trajectory(orc_problem* P, const double* x, double dt, double* out, int max_samples) {
+  P->SetVariables(x);
+  EulerConverter base_angular;
+  base_angular.euler = P->sp.base_angular;
+  const int rec = 20 + 13 * P->n_ee;
+  double T = 0.0;  // Spline::GetTotalTime: accumulate over the polynomial durations (spline.cc:118-123)
+  for (double d : P->sp.base_linear->GetPolyDurations()) T += d;
+  int n = 0;
+  double t = 0.0;
+  while (t <= T + 1e-5) {
+    if (out && n < max_samples) {
+      double* o = out + (size_t)n * rec;
+      StateVal lin = P->sp.base_linear->GetPoint(t);
+      *o++ = t;
+      for (int i = 0; i < 3; ++i) *o++ = lin.p(i);
+      for (int i = 0; i < 3; ++i) *o++ = lin.v(i);
+      for (int i = 0; i < 3; ++i) *o++ = lin.a(i);
+      M3 m = EulerConverter::RotationDense(P->sp.base_angular->GetPoint(t).p);
+      double q[4];  // x y z w (Eigen coeffs order)
+      double tr = m(0, 0) + m(1, 1) + m(2, 2);
+      if (tr > 0) {
+        tr = std::sqrt(tr + 1.0);
+        q[3] = 0.5 * tr;
+        tr = 0.5 / tr;
+        q[0] = (m(2, 1) - m(1, 2)) * tr;
+        q[1] = (m(0, 2) - m(2, 0)) * tr;
+        q[2] = (m(1, 0) - m(0, 1)) * tr;
+      } else {
+        int i = 0;
+        if (m(1, 1) > m(0, 0)) i = 1;
+        if (m(2, 2) > m(i, i)) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        tr = std::sqrt(m(i, i) - m(j, j) - m(k, k) + 1.0);
+        q[i] = 0.5 * tr;
+        tr = 0.5 / tr;
+        q[3] = (m(k, j) - m(j, k)) * tr;
+        q[j] = (m(j, i) + m(i, j)) * tr;
+        q[k] = (m(k, i) + m(i, k)) * tr;
+      }
+      *o++ = q[3]; *o++ = q[0]; *o++ = q[1]; *o++ = q[2];
+      V3 w = base_angular.GetAngularVelocityInWorld(t), wd = base_angular.GetAngularAccelerationInWorld(t);
+      for (int i = 0; i < 3; ++i) *o++ = w(i);
+      for (int i = 0; i < 3; ++i) *o++ = wd(i);
+      for (int ee = 0; ee < P->n_ee; ++ee) {
+        // PhaseDurations::IsContactPhase (phase_durations.cc:118-124)
+        const PhaseDurations* pd = P->schedules[ee].get();
+        int phase_id = NodeSpline::GetSegmentID(t, pd->durations);
+        bool contact = phase_id % 2 == 0 ? pd->initial_contact_state : !pd->initial_contact_state;
+        *o++ = contact ? 1.0 : 0.0;
+        StateVal mo = P->sp.ee_motion[ee]->GetPoint(t);
+        for (int i = 0; i < 3; ++i) *o++ = mo.p(i);
+        for (int i = 0; i < 3; ++i) *o++ = mo.v(i);
+        for (int i = 0; i < 3; ++i) *o++ = mo.a(i);
+        V3 f = P->sp.ee_force[ee]->GetPoint(t).p;
+        for (int i = 0; i < 3; ++i) *o++ = f(i);
+      }
+    }
+    ++n;
+    t += dt;
+  }
+  return n;
+}
+
 void orc_bounds(orc_problem* P, double* lower, double* upper) {
   int row0 = 0;
   for (auto& c : P->cons) {

@@ -73,6 +73,10 @@ void orc_variable_bounds(orc_problem*, const double* init_base /*12*/, const dou
 int orc_eval(orc_problem*, const double* x, double* g, int* row_ptr, int* col_idx, double* vals);
 void orc_bounds(orc_problem*, double* lower, double* upper);
 
+// fpowr::GetTrajectory (footstep_plan_extractor.h:19-53): samples of the solution x every dt; returns the
+// number of samples (pass out = NULL to query it); record layout in towr_oracle.cc.
+int orc_sample_trajectory(orc_problem*, const double* x, double dt, double* out, int max_samples);
+
 // reference-shaped timing loop for bench.py's cpu_baseline: `iters` full callbacks on
 // x (values + Jacobian), returns seconds.
 double orc_time_callbacks(orc_problem*, const double* x, int iters);

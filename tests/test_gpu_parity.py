@@ -301,6 +301,46 @@ def test_gridded_terrain():
     assert hit >= 5, "the inputs should exercise the edge slopes"
 
 
+def test_trajectory_sampling():
+    """twr_batch_sample vs the oracle's restatement of fpowr::GetTrajectory (footstep_plan_extractor.h:19-53):
+    base state, quaternion, angular velocity / acceleration, contact flags, foot motion and forces every 10 ms,
+    for fixed and optimised timings, with large Euler angles (both quaternion branches)."""
+    import torch
+
+    a = Case("anymal", "stairs", ta.gait_combo(4, 1, 2.0))
+    b = Case("anymal", "gap", ta.gait_combo(4, 0, 2.4), constraint_sets=127)
+    c = Case("anymal", "flat", ta.gait_combo(4, 3, 1.7), polys_per_swing=3, duration_base_poly=0.13)
+    cases, order = [a, b, c], [0, 1, 2, 1, 0]
+    batch = ta.Batch([k.S for k in cases], order, device=0)
+    xs = [cases[s].x_wild(90 + i) for i, s in enumerate(order)]
+    for i, s in enumerate(order):   # large rotations: trace(R) <= 0 for some samples
+        for vs in cases[s].S.var_sets:
+            if vs["name"] == "base-ang":
+                xs[i][vs["offset"]:vs["offset"] + vs["size"]] *= 4.0
+    dt = 0.01
+    rec = 20 + 13 * 4
+    counts = [cases[s].S.sample_count(dt) for s in order]
+    stride = max(counts) * rec
+    x = torch.from_numpy(np.concatenate(xs)).cuda()
+    out = torch.full((len(order) * stride,), float("nan"), dtype=torch.float64, device="cuda")
+    batch.sample_device(x.data_ptr(), dt, out.data_ptr(), stride, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    oh = out.cpu().numpy()
+    neg_trace = 0
+    for p, s in enumerate(order):
+        ref = cases[s].P.sample_trajectory(xs[p], dt)
+        assert ref.shape == (counts[p], rec)
+        got = oh[p * stride:p * stride + counts[p] * rec].reshape(counts[p], rec)
+        scale = np.maximum(np.abs(ref).max(axis=0, keepdims=True), 1.0)
+        assert np.array_equal(got[:, 0], ref[:, 0])                       # the accumulated sample times
+        for e in range(4):
+            assert np.array_equal(got[:, 20 + 13 * e], ref[:, 20 + 13 * e])   # contact flags
+        err = np.abs(got - ref) / scale
+        assert err.max() < 1e-10, "problem %d: field %d off by %.3e" % (p, int(err.max(axis=0).argmax()), err.max())
+        neg_trace += int((4 * ref[:, 10] ** 2 - 1 <= 0).sum())          # trace(R) = 4 w^2 - 1
+    assert neg_trace > 0
+
+
 def test_foot_starting_in_swing():
     """ee_in_contact_at_start = false: first polynomial of ee-motion is a swing one, force starts at zero."""
     sched = ta.schedule([[0.3, 0.5, 0.3, 0.4], [0.6, 0.3, 0.6]], [0, 1])

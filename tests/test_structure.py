@@ -212,6 +212,18 @@ def test_no_cpu_fallback_without_a_gpu():
         ta.Batch([S], [0])
 
 
+def test_sample_counts_match_oracle():
+    """fpowr::GetTrajectory: samples while t <= T + 1e-5 with t accumulated (footstep_plan_extractor.h:27-50)."""
+    for robot, combo, T, dt in [("anymal", 1, 2.0, 0.01), ("biped", 0, 1.7, 0.013), ("monoped", 2, 0.93, 0.1), ("hyq", 4, 2.4, 0.007)]:
+        n_ee = ta.model_preset(robot, "flat").n_ee
+        case = Case(robot, "flat", ta.gait_combo(n_ee, combo, T))
+        ref = case.P.sample_trajectory(case.x_guess(), dt)
+        assert case.S.sample_count(dt) == ref.shape[0]
+        assert ref.shape[1] == 20 + 13 * n_ee and ref[0, 0] == 0.0 and abs(ref[-1, 0] - T) <= dt + 1e-5
+    with pytest.raises(ta.TowrError):
+        case.S.sample_count(0.0)
+
+
 def test_sweep_enumeration_and_sharding():
     from towr_amd import sweep
 

@@ -122,6 +122,8 @@ def lib():
         L.twr_batch_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.twr_batch_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.twr_batch_eval_host.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int]
+        L.twr_structure_sample_count.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int32)]
+        L.twr_batch_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int64, C.c_void_p]
         L.twr_batch_host_buffers.argtypes = [C.c_void_p, C.POINTER(_dp), C.POINTER(_dp), C.POINTER(_dp)]
         L.twr_batch_profile_begin.argtypes = [C.c_void_p, C.c_int]
         L.twr_batch_profile_end.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_int)]
@@ -247,6 +249,12 @@ class Structure:
         _check(lib().twr_structure_initial_guess(self._h, _d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), _d(ee), _d(x)))
         return x
 
+    def sample_count(self, dt=0.01):
+        """Records fpowr::GetTrajectory produces for this structure at step dt."""
+        n = C.c_int32()
+        _check(lib().twr_structure_sample_count(self._h, float(dt), C.byref(n)))
+        return n.value
+
     def variable_bounds(self, init_base, final_base, ee_pos0):
         """x_l, x_u of the reference's variable sets; base states = 12 doubles {lin p, lin v, ang p, ang v}."""
         a = np.ascontiguousarray(init_base, dtype=np.float64).reshape(-1)
@@ -314,6 +322,11 @@ class Batch:
             for k in out:
                 out[k] += 8 * S.n
         return out
+
+    def sample_device(self, d_x, dt, d_out, problem_stride, stream=0):
+        """twr_batch_sample: d_out[p * problem_stride + sample * (20 + 13 n_ee) + field] (device pointers)."""
+        _check(lib().twr_batch_sample(self._h, C.c_void_p(d_x), float(dt), C.c_void_p(d_out), int(problem_stride),
+                                      C.c_void_p(stream)))
 
     def host_buffers(self):
         """Page-locked x / g / jac arrays owned by the batch (numpy views); eval_host_pinned() uses them."""

@@ -17,6 +17,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
                        const NodeWork* node, int n_node, const PhaseWork* pdyn, int n_pdyn, const LocWork* ploc,
                        int n_ploc, const RomPhaseWork* prom, int n_prom, const double* x, double* g, double* jac,
                        int flags, hipStream_t stream, hipEvent_t* ev);
+hipError_t launch_sample(const SampleWork* work, int n_work, const double* x, double* out, double dt, hipStream_t stream);
 int dyn_stage_capacity();
 int rom_stage_capacity();
 int dyn_nodes_per_block();
@@ -36,6 +37,14 @@ struct twr_batch {
   std::vector<int64_t> x_off, g_off, j_off;  // n_problems+1
   std::vector<void*> blobs;                  // device blobs, one per distinct structure
   std::vector<void*> grids;                  // device copies of the distinct gridded terrains
+  // what twr_batch_sample needs of every problem (the structures need not outlive the batch)
+  std::vector<uint64_t> blob_of_problem;     // device blob address
+  std::vector<double> t_total;               // Spline::GetTotalTime of base-lin
+  std::vector<char> sample_ok;               // polynomial counts fit the sampling kernel's LDS tables
+  twr::SampleWork* d_swork = nullptr;        // work list of the last twr_batch_sample call (cached per dt / stride)
+  int n_swork = 0;
+  double swork_dt = 0.0;
+  int64_t swork_stride = -1;
   twr::DynWork* d_dyn = nullptr;
   twr::RomWork* d_rom = nullptr;
   twr::NodeWork* d_node = nullptr;
@@ -302,6 +311,13 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
       int si = struct_of_problem[p];
       if (si < 0 || si >= n_structs) throw std::runtime_error("struct_of_problem out of range");
       const twr::Structure& S = structs[si]->s;
+      b->blob_of_problem.push_back(reinterpret_cast<uint64_t>(b->blobs[si]));
+      {
+        const twr::SampleTables* st = reinterpret_cast<const twr::SampleTables*>(
+            S.blob.data() + reinterpret_cast<const twr::DevStruct*>(S.blob.data())->o_sample);
+        b->t_total.push_back(st->t_total);
+        b->sample_ok.push_back(st->n_base >= 0);
+      }
       b->x_off[p + 1] = b->x_off[p] + S.n_vars;
       b->g_off[p + 1] = b->g_off[p] + S.n_rows;
       b->j_off[p + 1] = b->j_off[p] + S.nnz;
@@ -455,6 +471,7 @@ void twr_batch_destroy(twr_batch* b) {
   if (b->d_prom) (void)hipFree(b->d_prom);
   if (b->d_ploc) (void)hipFree(b->d_ploc);
   if (b->d_precs) (void)hipFree(b->d_precs);
+  if (b->d_swork) (void)hipFree(b->d_swork);
   for (hipEvent_t e : b->prof_events) (void)hipEventDestroy(e);
   if (b->d_x) (void)hipFree(b->d_x);
   if (b->d_g) (void)hipFree(b->d_g);
@@ -548,6 +565,55 @@ int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_
     if ((flags & TWR_EVAL_JACOBIAN) && h_jac)
       TWR_HIP(hipMemcpyAsync(h_jac, b->d_j, nj * sizeof(double), hipMemcpyDeviceToHost, nullptr));
     TWR_HIP(hipStreamSynchronize(nullptr));
+    return TWR_OK;
+  } catch (const std::exception& e) {
+    return fail(TWR_ERR_HIP, e.what());
+  }
+}
+
+int twr_structure_sample_count(const twr_structure* s, double dt, int32_t* n_samples) {
+  if (!s || !n_samples) return fail(TWR_ERR_INVALID, "null argument");
+  try {
+    *n_samples = s->s.SampleCount(dt);
+    return TWR_OK;
+  } catch (const std::exception& e) {
+    return fail(TWR_ERR_INVALID, e.what());
+  }
+}
+
+int twr_batch_sample(twr_batch* b, const double* d_x, double dt, double* d_out, int64_t problem_stride, void* hip_stream) {
+  if (!b || !d_x || !d_out) return fail(TWR_ERR_INVALID, "null argument");
+  try {
+    TWR_HIP(hipSetDevice(b->device));
+    if (!b->d_swork || b->swork_dt != dt || b->swork_stride != problem_stride) {  // (re)build the work list
+      std::vector<twr::SampleWork> work;
+      for (int p = 0; p < b->n_problems; ++p) {
+        if (!(dt > 0)) throw std::runtime_error("dt must be positive");
+        int n = 0;  // fpowr GetTrajectory: while (t <= T + 1e-5) { ...; t += dt; }
+        for (double t = 0.0; t <= b->t_total[p] + 1e-5; t += dt)
+          if (++n > 10000000) throw std::runtime_error("too many samples");
+        if ((int64_t)n * (20 + 13 * b->n_ee) > problem_stride) throw std::runtime_error("problem_stride too small for the samples");
+        if (!b->sample_ok[p]) throw std::runtime_error("too many polynomials per spline for trajectory sampling");
+        for (int s0 = 0; s0 < n; s0 += 64) {
+          twr::SampleWork w;
+          w.blob = b->blob_of_problem[p];
+          w.x_off = b->x_off[p];
+          w.out_off = (int64_t)p * problem_stride;
+          w.s0 = s0;
+          w.cnt = std::min(64, n - s0);
+          work.push_back(w);
+        }
+      }
+      if (b->d_swork) TWR_HIP(hipFree(b->d_swork));
+      b->d_swork = nullptr;
+      TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_swork), work.size() * sizeof(twr::SampleWork)));
+      TWR_HIP(hipMemcpy(b->d_swork, work.data(), work.size() * sizeof(twr::SampleWork), hipMemcpyHostToDevice));
+      b->n_swork = (int)work.size();
+      b->swork_dt = dt;
+      b->swork_stride = problem_stride;
+    }
+    hipError_t e = twr::launch_sample(b->d_swork, b->n_swork, d_x, d_out, dt, static_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return TWR_OK;
   } catch (const std::exception& e) {
     return fail(TWR_ERR_HIP, e.what());

@@ -122,6 +122,27 @@ struct BaseNode {     // one time node of baseMotion (base_motion_constraint.cc:
   int32_t q6, pad;    // 6 * active polynomial
 };
 
+// Trajectory sampling (fpowr GetTrajectory, footstep_plan_extractor.h:19-53): polynomial tables of every
+// spline.  With fixed timings the durations are constants of the structure; with optimised timings the
+// kernel recomputes them from x (PhaseTables).
+struct SampleTables {
+  int32_t n_base;                         // polynomials of base-lin / base-ang
+  int32_t n_phases[kMaxEE], contact0[kMaxEE];
+  int32_t n_mpoly[kMaxEE], n_fpoly[kMaxEE];
+  uint32_t o_bdur;                        // double[n_base]
+  uint32_t o_phdur[kMaxEE];               // double[n_phases]
+  uint32_t o_mdur[kMaxEE], o_fdur[kMaxEE];    // double[n_poly]
+  uint32_t o_mdesc[kMaxEE], o_fdesc[kMaxEE];  // PolyDesc[n_poly]
+  int32_t off_lin, off_ang;
+  double t_total;                         // Spline::GetTotalTime of base-lin
+};
+struct SampleWork {       // cnt <= 64 samples of one problem from sample s0
+  uint64_t blob;
+  int64_t x_off, out_off;
+  int32_t s0, cnt;
+};
+static_assert(sizeof(SampleWork) == 32, "SampleWork layout");
+
 // Blob header: model constants + what the node kernel needs.  The terrain-ee-motion_e sets are
 // adjacent in g / jac, and so are the force-ee-force_e sets, so each family is one flat node list.
 struct DevStruct {
@@ -150,6 +171,8 @@ struct DevStruct {
   uint64_t grid_ptr;
   int32_t grid_rows, grid_cols;
   double grid_res, grid_eps;
+  uint32_t o_sample;    // SampleTables
+  uint32_t pad2_;
 };
 
 // Work items: one contiguous run of time nodes of one constraint set of one problem.  All

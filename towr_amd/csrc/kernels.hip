@@ -1525,6 +1525,138 @@ __global__ __launch_bounds__(64, 2) void rom_phase_kernel(const RomPhaseWork* __
   }
 }
 
+// ---------------------------------------------------------------- trajectory sampling
+// fpowr::GetTrajectory (fpowr/include/fpowr/footstep_plan_extractor.h:19-53) for a batch of solutions: lane =
+// sample.  Durations (constants of the structure, or recomputed from x with optimised timings) go to LDS once
+// per workgroup; every lane accumulates its sample time like the reference (t += dt), locates the active
+// polynomial of every spline and evaluates position / velocity / acceleration in Hermite basis form.
+TWR_DEV void sample_spline(const double* __restrict__ xp, const PolyDesc& pd, double tl, double T, double p[3], double v[3],
+                           double a[3]) {
+  double X[12], nv[4][3], wp[4], wv[4], wa[4];
+  gather12c(xp, pd.xbase, pd.cand, X);
+  node_values(slots_of(pd.cand), meta_shared(pd.meta), X, nv);
+  hermite_all(tl, 1.0 / T, wp, wv, wa);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    p[d] = wp[0] * nv[0][d] + wp[1] * nv[1][d] + wp[2] * nv[2][d] + wp[3] * nv[3][d];
+    v[d] = wv[0] * nv[0][d] + wv[1] * nv[1][d] + wv[2] * nv[2][d] + wv[3] * nv[3][d];
+    a[d] = wa[0] * nv[0][d] + wa[1] * nv[1][d] + wa[2] * nv[2][d] + wa[3] * nv[3][d];
+  }
+}
+__global__ __launch_bounds__(64) void sample_kernel(const SampleWork* __restrict__ work, const double* __restrict__ x,
+                                                    double* __restrict__ out, double dt) {
+  __shared__ double s_bd[2 * kMaxPhasePolys], s_ph[kMaxEE][TWR_MAX_PHASES_DEV], s_md[kMaxEE][kMaxPhasePolys],
+      s_fd[kMaxEE][kMaxPhasePolys];
+  const SampleWork sw = work[blockIdx.x];
+  const char* blob = reinterpret_cast<const char*>(sw.blob);
+  const DevStruct* H = reinterpret_cast<const DevStruct*>(blob);
+  const SampleTables* ST = tbl<SampleTables>(blob, H->o_sample);
+  const double* xp = x + sw.x_off;
+  const int lane = threadIdx.x, n_ee = H->n_ee;
+  for (int q = lane; q < ST->n_base; q += 64) s_bd[q] = tbl<double>(blob, ST->o_bdur)[q];
+  for (int e = 0; e < n_ee; ++e) {
+    if (H->timings) {  // PhaseDurations::SetVariables + ConvertPhaseToPolyDurations (phase_durations.cc:77-103)
+      const PhaseTables* PT = tbl<PhaseTables>(blob, H->o_phase);
+      phase_poly_durations_wave(PT, blob, xp, e, s_ph[e], s_md[e], lane);
+      const PhasePoly* fp = tbl<PhasePoly>(blob, PT->o_fpoly[e]);
+      for (int q = lane; q < PT->n_fpoly[e]; q += 64) s_fd[e][q] = s_ph[e][fp[q].phase] / fp[q].n_in_phase;
+    } else {
+      for (int q = lane; q < ST->n_phases[e]; q += 64) s_ph[e][q] = tbl<double>(blob, ST->o_phdur[e])[q];
+      for (int q = lane; q < ST->n_mpoly[e]; q += 64) s_md[e][q] = tbl<double>(blob, ST->o_mdur[e])[q];
+      for (int q = lane; q < ST->n_fpoly[e]; q += 64) s_fd[e][q] = tbl<double>(blob, ST->o_fdur[e])[q];
+    }
+  }
+  __syncthreads();
+  if (lane >= sw.cnt) return;
+  const int s_idx = sw.s0 + lane;
+  double t = 0.0;
+  for (int i = 0; i < s_idx; ++i) t += dt;   // the reference's accumulated sample time
+  const int rec = 20 + 13 * n_ee;
+  double* o = out + sw.out_off + (int64_t)s_idx * rec;
+  o[0] = t;
+  // base-lin / base-ang (NodesVariablesAll: [p0 v0 p1 v1] x 3 of polynomial q at 6 q)
+  double tl;
+  const int qb = locate_segment(s_bd, ST->n_base, t, tl);
+  double wp[4], wv[4], wa[4];
+  hermite_all(tl, 1.0 / s_bd[qb], wp, wv, wa);
+  const double* xl = xp + ST->off_lin + 6 * qb;
+  const double* xa = xp + ST->off_ang + 6 * qb;
+  double e3[3], ed[3], edd[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    o[1 + d] = wp[0] * xl[d] + wp[1] * xl[3 + d] + wp[2] * xl[6 + d] + wp[3] * xl[9 + d];
+    o[4 + d] = wv[0] * xl[d] + wv[1] * xl[3 + d] + wv[2] * xl[6 + d] + wv[3] * xl[9 + d];
+    o[7 + d] = wa[0] * xl[d] + wa[1] * xl[3 + d] + wa[2] * xl[6 + d] + wa[3] * xl[9 + d];
+    e3[d] = wp[0] * xa[d] + wp[1] * xa[3 + d] + wp[2] * xa[6 + d] + wp[3] * xa[9 + d];
+    ed[d] = wv[0] * xa[d] + wv[1] * xa[3 + d] + wv[2] * xa[6 + d] + wv[3] * xa[9 + d];
+    edd[d] = wa[0] * xa[d] + wa[1] * xa[3 + d] + wa[2] * xa[6 + d] + wa[3] * xa[9 + d];
+  }
+  Rot ro;
+  rotation(e3, ro);
+  {  // Eigen::Quaterniond(R) (euler_converter.cc:51-56; Eigen 3.3 Quaternion.h, quaternionbase_assign_impl)
+    const double (&m)[3][3] = ro.R;
+    double q[4];  // x y z w
+    double tr = m[0][0] + m[1][1] + m[2][2];
+    if (tr > 0) {
+      tr = sqrt(tr + 1.0);
+      q[3] = 0.5 * tr;
+      tr = 0.5 / tr;
+      q[0] = (m[2][1] - m[1][2]) * tr;
+      q[1] = (m[0][2] - m[2][0]) * tr;
+      q[2] = (m[1][0] - m[0][1]) * tr;
+    } else {
+      int i = 0;
+      if (m[1][1] > m[0][0]) i = 1;
+      if (m[2][2] > (i == 0 ? m[0][0] : m[1][1])) i = 2;
+      const int j = (i + 1) % 3, k = (j + 1) % 3;
+      auto M = [&](int r, int c) { return sel3(r, sel3(c, m[0][0], m[0][1], m[0][2]), sel3(c, m[1][0], m[1][1], m[1][2]),
+                                               sel3(c, m[2][0], m[2][1], m[2][2])); };
+      tr = sqrt(M(i, i) - M(j, j) - M(k, k) + 1.0);
+      const double qi = 0.5 * tr;
+      tr = 0.5 / tr;
+      const double qw = (M(k, j) - M(j, k)) * tr, qj = (M(j, i) + M(i, j)) * tr, qk = (M(k, i) + M(i, k)) * tr;
+      q[3] = qw;
+      q[0] = i == 0 ? qi : (j == 0 ? qj : qk);
+      q[1] = i == 1 ? qi : (j == 1 ? qj : qk);
+      q[2] = i == 2 ? qi : (j == 2 ? qj : qk);
+    }
+    o[10] = q[3]; o[11] = q[0]; o[12] = q[1]; o[13] = q[2];
+  }
+  {  // omega = M edot, omega_dot = Mdot edot + M eddot (euler_converter.cc:58-83,133-166)
+    const double sy = ro.sy, cy = ro.cy, sz = ro.sz, cz = ro.cz;
+    const double xd = ed[0], yd = ed[1], zd = ed[2];
+    const double Mx[3] = {cy * cz, cy * sz, -sy}, My[3] = {-sz, cz, 0.0};
+    const double Mdx[3] = {-cz * sy * yd - cy * sz * zd, cy * cz * zd - sy * sz * yd, -cy * yd};
+    const double Mdy[3] = {-cz * zd, -sz * zd, 0.0};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      o[14 + i] = Mx[i] * xd + My[i] * yd + (i == 2 ? zd : 0.0);
+      o[17 + i] = Mdx[i] * xd + Mdy[i] * yd + Mx[i] * edd[0] + My[i] * edd[1] + (i == 2 ? edd[2] : 0.0);
+    }
+  }
+  for (int e = 0; e < n_ee; ++e) {
+    double* oe = o + 20 + 13 * e;
+    double tlp, tlm, tlf;
+    const int phase = locate_segment(s_ph[e], ST->n_phases[e], t, tlp);   // PhaseDurations::IsContactPhase
+    oe[0] = ((phase & 1) == 0) == (ST->contact0[e] != 0) ? 1.0 : 0.0;
+    const int qm = locate_segment(s_md[e], ST->n_mpoly[e], t, tlm);
+    const int qf = locate_segment(s_fd[e], ST->n_fpoly[e], t, tlf);
+    const PolyDesc pm = tbl<PolyDesc>(blob, ST->o_mdesc[e])[qm];
+    const PolyDesc pf = tbl<PolyDesc>(blob, ST->o_fdesc[e])[qf];
+    double p[3], v[3], a[3];
+    sample_spline(xp, pm, tlm, s_md[e][qm], p, v, a);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { oe[1 + d] = p[d]; oe[4 + d] = v[d]; oe[7 + d] = a[d]; }
+    sample_spline(xp, pf, tlf, s_fd[e][qf], p, v, a);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) oe[10 + d] = p[d];
+  }
+}
+hipError_t launch_sample(const SampleWork* work, int n_work, const double* x, double* out, double dt, hipStream_t stream) {
+  if (n_work > 0) hipLaunchKernelGGL(sample_kernel, dim3(n_work), dim3(64), 0, stream, work, x, out, dt);
+  return hipGetLastError();
+}
+
 // host-side launcher (called from capi.cc): three launches on one stream.  The dyn/rom grids are
 // persistent: as many workgroups as are resident at once.  Residency is LDS bound; the occupancy API
 // over-reports it for the dynamic kernel (measured: 7 x 22.5 KB resident, an 8th starts a second

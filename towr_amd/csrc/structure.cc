@@ -731,6 +731,29 @@ void Structure::PackBlob() {
     h.grid_res = grid->res;
     h.grid_eps = grid->eps;
   }
+  {  // trajectory sampling tables
+    SampleTables st;
+    std::memset(&st, 0, sizeof(st));
+    st.n_base = (int)base.durations.size();
+    st.o_bdur = put(base.durations.data(), base.durations.size() * sizeof(double));
+    st.off_lin = off_base_lin;
+    st.off_ang = off_base_ang;
+    st.t_total = std::accumulate(base.durations.begin(), base.durations.end(), 0.0);  // spline.cc:118-123
+    for (int e = 0; e < n_ee; ++e) {
+      st.n_phases[e] = schedule.n_phases[e];
+      st.contact0[e] = schedule.in_contact_at_start[e] != 0;
+      st.n_mpoly[e] = (int)mpoly[e].size();
+      st.n_fpoly[e] = (int)fpoly[e].size();
+      st.o_phdur[e] = put(schedule.phase_durations[e], schedule.n_phases[e] * sizeof(double));
+      st.o_mdur[e] = put(motion[e].durations.data(), motion[e].durations.size() * sizeof(double));
+      st.o_fdur[e] = put(force[e].durations.data(), force[e].durations.size() * sizeof(double));
+      st.o_mdesc[e] = put(mpoly[e].data(), mpoly[e].size() * sizeof(PolyDesc));
+      st.o_fdesc[e] = put(fpoly[e].data(), fpoly[e].size() * sizeof(PolyDesc));
+      if (st.n_mpoly[e] > kMaxPhasePolys || st.n_fpoly[e] > kMaxPhasePolys) st.n_base = -1;  // sampling unsupported
+    }
+    if (st.n_base > 2 * kMaxPhasePolys) st.n_base = -1;
+    h.o_sample = put(&st, sizeof(st));
+  }
   h.mass = model.mass; h.gravity = model.gravity; h.mu = model.friction; h.flat_height = model.flat_height;
   // BuildInertiaTensor (single_rigid_body_dynamics.cc:36-44): off-diagonals are the negated products of inertia
   const double* I = model.inertia;  // Ixx,Iyy,Izz,Ixy,Ixz,Iyz
@@ -857,6 +880,18 @@ void Structure::InitialGuess(const double* lin0, const double* ang0, const doubl
   if (timings)  // PhaseDurations::GetValues (src/phase_durations.cc:66-75): the given durations but the last
     for (int e = 0; e < n_ee; ++e)
       for (int i = 0; i < schedule.n_phases[e] - 1; ++i) x[off_schedule[e] + i] = schedule.phase_durations[e][i];
+}
+
+// ------------------------------------------------------------------ trajectory sampling
+// fpowr::GetTrajectory (fpowr/include/fpowr/footstep_plan_extractor.h:19-53): `while (t <= T + 1e-5) { ...; t += dt; }`
+int Structure::SampleCount(double dt) const {
+  if (!(dt > 0)) throw std::runtime_error("dt must be positive");
+  const double Tt = std::accumulate(base.durations.begin(), base.durations.end(), 0.0);
+  int n = 0;
+  for (double t = 0.0; t <= Tt + 1e-5; t += dt) {
+    if (++n > 10000000) throw std::runtime_error("too many samples");
+  }
+  return n;
 }
 
 // ------------------------------------------------------------------ variable bounds

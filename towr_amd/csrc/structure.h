@@ -78,6 +78,7 @@ struct Structure {
   void Build();            // throws std::runtime_error
   void InitialGuess(const double* lin0, const double* ang0, const double* lin1, const double* ang1,
                     const double* ee0, double* x) const;
+  int SampleCount(double dt) const;  // fpowr GetTrajectory: samples while t <= T + 1e-5, t accumulated
   void VariableBounds(const double* init_base, const double* final_base, const double* ee0, double* lower,
                       double* upper) const;
 
