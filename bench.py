@@ -59,33 +59,143 @@ def perturbed_inputs(S, model, count, first_seed):
     return out
 
 
-def cpu_baseline(sched, params, x, terrain, budget_s=12.0):
-    """The oracle ("port" of the reference's Eigen CPU path) timed on this box's host cores."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sched, params, x, terrain, budget_s=3.0):
+    """The oracle ("port" of the reference's Eigen CPU path, reference-shaped: per time node and per variable
+    set) timed on this box's host cores, SURVEY 8d / BASELINE.md section 3: built -O3 -march=native ON THIS BOX
+    (oracle/Makefile target `native`), (i) one thread, median of 5 samples of >= 2 s each; (ii) one problem
+    instance per hardware thread, all running at once (the oracle is not re-entrant, like the reference)."""
+    import statistics
+    import subprocess
+    import threading
+
     from oracle import binding as ob
 
-    P = ob.OracleProblem("anymal", terrain, sched.durations(), sched.contact(), dt_dynamic=params.dt_dynamic,
-                         dt_rom=params.dt_rom, duration_base_poly=params.duration_base_poly,
-                         polys_per_swing=params.polys_per_swing, polys_per_stance_force=params.polys_per_stance_force,
-                         constraint_sets=params.constraint_sets)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native"])
+    ob.use_library(os.path.join(ROOT, "oracle", "_build", "libtowr_oracle_native.so"))
+
+    def make():
+        return ob.OracleProblem("anymal", terrain, sched.durations(), sched.contact(), dt_dynamic=params.dt_dynamic,
+                                dt_rom=params.dt_rom, duration_base_poly=params.duration_base_poly,
+                                polys_per_swing=params.polys_per_swing,
+                                polys_per_stance_force=params.polys_per_stance_force,
+                                constraint_sets=params.constraint_sets)
+
+    P = make()
     t1 = P.time_callbacks(x, 3) / 3.0
     iters = max(5, int(budget_s / max(t1, 1e-6)))
-    secs = P.time_callbacks(x, iters)
-    return {"value": iters / secs, "unit": "callbacks/s", "cores": 1, "kind": "port",
-            "sample": "%d callbacks of the same ANYmal K=200 problem, single-thread C++ oracle (%.1f s)" % (iters, secs)}
+    rates = sorted(iters / P.time_callbacks(x, iters) for _ in range(5))
+    single = statistics.median(rates)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    probs = [make() for _ in range(cores)]
+    secs = [0.0] * cores
+
+    def run(i):
+        secs[i] = probs[i].time_callbacks(x, iters)   # ctypes drops the GIL for the duration of the call
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=run, args=(i,)) for i in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    return {"value": single, "unit": "callbacks/s", "cores": 1, "kind": "port",
+            "sample": "median of 5 x %d callbacks (%.1f s each) of the same ANYmal K=200 problem, single-thread C++ "
+                      "oracle, g++ -O3 -march=native; min %.1f max %.1f" % (iters, iters / single, rates[0], rates[-1]),
+            "all_cores": {"value": cores * iters / wall, "unit": "callbacks/s", "cores": cores,
+                          "sample": "%d instances x %d callbacks at once (%.1f s)" % (cores, iters, wall)},
+            "nproc": cores, "cpu_model": _cpu_model()}
+
+
+def kernel_source_hash():
+    """Identity of the kernels a profile was taken on: sha256 over the device sources and their build flags."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("kernels.hip", "rom_tu.hip", "device_tables.h", "Makefile"):
+        with open(os.path.join(ROOT, "towr_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def traffic_from_profile(workload, kernel, problems_per_gpu):
     """HBM bytes per launch of `kernel` from a committed rocprofv3 --pmc pass (profiles/traffic.json:
-    WRITE_SIZE + 2*FETCH_SIZE in KiB, the gfx950 correction of MI355X_MICROARCH.md), or None."""
+    WRITE_SIZE + 2*FETCH_SIZE in KiB, the gfx950 correction of MI355X_MICROARCH.md), or None when the profile
+    is for another workload / launch size or was taken on other kernel sources than the ones in this tree."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        if t.get("workload") == workload and t.get("problems_per_gpu") == problems_per_gpu:
+        if (t.get("workload") == workload and t.get("problems_per_gpu") == problems_per_gpu
+                and t.get("kernel_source_sha256") == kernel_source_hash()):
             return t.get("hbm_bytes_per_launch", {}).get(kernel)
     except (OSError, ValueError):
         pass
     return None
+
+
+def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, stream, steps=200, n_total=1024):
+    """north_star's scaling claim: the 1024-candidate gait / phase-duration sweep on Stairs (BASELINE C5), a FIXED
+    total sharded over the ranks (strong scaling).  Every rank builds only its own contiguous shard (cheap
+    per-candidate weight, no structure needed to shard), multi-threaded in the library; the steps are timed without
+    per-kernel events."""
+    from towr_amd import sweep
+
+    m5 = ta.Model.from_buffer_copy(bytes(model))
+    m5.terrain_id = ta.TERRAINS["stairs"]
+    cands = sweep.enumerate_candidates(n_total)
+    bounds = sweep.shard_bounds([sweep.candidate_weight(c) for c in cands], world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    threads = max(1, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+    t0 = time.perf_counter()
+    mine = sweep.candidate_structures(m5, cands[lo:hi], threads=threads)
+    t1 = time.perf_counter()
+    batch = ta.Batch(mine, list(range(len(mine))), device=dev_index)
+    setup_s = time.perf_counter() - t0
+    x_host = np.concatenate([perturbed_inputs(s_, m5, 1, first_seed=lo + i_)[0] for i_, s_ in enumerate(mine)])
+    x = torch.from_numpy(x_host).to(dev)
+    g = torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device=dev)
+    jac = torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev)
+    for _ in range(10):
+        batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t2 = time.perf_counter()
+    for _ in range(steps):
+        batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t2
+    assert bool(torch.isfinite(g).all()) and bool(torch.isfinite(jac).all())
+    stats = torch.tensor([elapsed, setup_s, t1 - t0, float(batch.algorithmic_bytes)], dtype=torch.float64,
+                         device=dev if backend == "nccl" else None)
+    tot = stats.clone()
+    if world > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed, setup_max, build_max = float(stats[0]), float(stats[1]), float(stats[2])
+    bytes_total = float(tot[3])
+    return {"workload": "C5 sweep: %d enumerated ANYmal candidates (combo x T x swing scale) on Stairs, K=200, ragged"
+                        % n_total,
+            "candidates": n_total, "scaling": "strong", "steps": steps,
+            "value": n_total * steps / elapsed, "unit": "callbacks/s", "ms_per_step": elapsed / steps * 1e3,
+            "path_GBps": bytes_total * steps / elapsed / 1e9,
+            "shards": [bounds[r + 1] - bounds[r] for r in range(world)],
+            "setup_s": setup_max, "structure_build_s": build_max, "build_threads_per_rank": threads,
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1}
 
 
 def main():
@@ -102,6 +212,7 @@ def main():
                          "nnz=102896); all: towr's whole default list (+ splineacc-base-*, swing-*); timings: all + "
                          "optimised phase durations (ee-schedule variables, all-variables rows); c3 only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scale-c5", action="store_true", help="skip the strong-scaling C5 leg of the default run")
     args = ap.parse_args()
 
     import torch
@@ -137,14 +248,16 @@ def main():
 
     terrain = "flat" if args.workload == "c3" else "stairs"
     model.terrain_id = ta.TERRAINS[terrain]  # (the broadcast blob carries the robot; the workload picks the terrain)
+    t_setup = time.perf_counter()
     if args.workload == "c3":
         sched, params, S = build_case(ta, model, constraint_sets={"hot": 27, "all": 63, "timings": 127}[args.sets])
         B = args.batch or 8192
         n_all = B * world
-        workload = "C3 ANYmal trot (combo C1), T=2.0 s, flat, K=%d, n=%d m=%d nnz=%d, %d problems/GPU distinct x%s" % (
+        workload = "C3 ANYmal trot (combo C1), T=2.0 s, flat, K=%d, n=%d m=%d nnz=%d, %d problems/GPU (256 seeded x tiled)%s" % (
             S.k_dynamic, S.n, S.m, S.nnz, B, {"hot": "", "all": ", all six default constraint families",
                                               "timings": ", default constraints + optimised phase durations"}[args.sets])
         batch = ta.Batch([S], [0] * B, device=dev_index)
+        setup_s = time.perf_counter() - t_setup
         # distinct x per problem: 256 seeded perturbations per rank, tiled (contents do not change the work)
         base = perturbed_inputs(S, model, min(B, 256), first_seed=rank * 100000)
         reps = (B + base.shape[0] - 1) // base.shape[0]
@@ -157,10 +270,11 @@ def main():
 
         n_all = (args.batch or 128) * world
         cands = sweep.enumerate_candidates(n_all)
-        structs_all = [sweep.candidate_structure(model, c) for c in cands]
-        bounds = sweep.shard_bounds([s_.algorithmic_bytes for s_ in structs_all], world)
-        mine = structs_all[bounds[rank]:bounds[rank + 1]]
+        bounds = sweep.shard_bounds([sweep.candidate_weight(c) for c in cands], world)
+        t_setup = time.perf_counter()
+        mine = sweep.candidate_structures(model, cands[bounds[rank]:bounds[rank + 1]])   # this rank's shard only
         batch = ta.Batch(mine, list(range(len(mine))), device=dev_index)
+        setup_s = time.perf_counter() - t_setup
         x_host = np.concatenate([perturbed_inputs(s_, model, 1, first_seed=bounds[rank] + i_)[0]
                                  for i_, s_ in enumerate(mine)])
         S, sched, params = mine[0], mine[0].schedule, mine[0].params
@@ -224,7 +338,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": workload, "problems_per_gpu": B, "bytes_per_callback": bytes_per_callback},
+            "config": {"workload": workload, "problems_per_gpu": B, "bytes_per_callback": bytes_per_callback,
+                       "setup_s": setup_s},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile("C3", names[dom], B) if args.workload == "c3" and args.sets == "hot" else None,
                          "kernel": names[dom], "kernel_ms": kern_ms[dom],
@@ -236,6 +351,14 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sched, params, x_host[:S.n], terrain)
+    # north_star's strong-scaling claim rides on the same command: 1024 sweep candidates over all ranks
+    c5 = None
+    if args.workload == "c3" and args.sets == "hot" and not args.no_scale_c5:
+        del x, g, jac, batch
+        c5 = scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, stream)
+    if rank == 0:
+        if c5 is not None:
+            out["scale_c5"] = c5
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

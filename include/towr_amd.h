@@ -43,7 +43,9 @@ enum { TWR_TERRAIN_FLAT = 0, TWR_TERRAIN_BLOCK, TWR_TERRAIN_STAIRS, TWR_TERRAIN_
        /* HeightMapFromCSV (include/towr/terrain/height_map_from_csv.h): a gridded terrain, heights per 0.17 m
          * cell; needs a twr_terrain_grid handle, see twr_structure_create_with_grid */
        TWR_TERRAIN_CSV_GRID };
-enum { TWR_EVAL_VALUES = 1, TWR_EVAL_JACOBIAN = 2, TWR_EVAL_BOTH = 3 };
+enum { TWR_EVAL_VALUES = 1, TWR_EVAL_JACOBIAN = 2, TWR_EVAL_BOTH = 3,
+       /* also run the per-problem NaN/Inf scan over the outputs of this evaluation (twr_batch_status) */
+       TWR_EVAL_CHECK = 4 };
 /* Parameters::ConstraintName entries of the default list (parameters.h:139-147, parameters.cc:55-60),
  * as bits of twr_params.constraint_sets.  The sets always appear in this (the reference's) order. */
 enum {
@@ -105,7 +107,8 @@ typedef struct twr_params {
   int32_t reserved_;            /* must be 0 */
   double dt_base_motion;        /* dt_constraint_base_motion_ (duration_base_polynomial_/4, parameters.cc:51) */
   double base_z_init;           /* initial base height: BaseMotionConstraint bounds z to [z-0.02, z+0.1]
-                                   (base_motion_constraint.cc:51-55, read from the spline at construction) */
+                                   (base_motion_constraint.cc:51-55, read from the spline at construction).
+                                   twr_params_default leaves it NaN; TWR_SET_BASE_ROM is rejected until it is set. */
 } twr_params;
 
 typedef struct twr_sizes {
@@ -153,6 +156,11 @@ void twr_terrain_grid_destroy(twr_terrain_grid* g);
 int twr_structure_create_with_grid(const twr_model* model, const twr_schedule* schedule, const twr_params* params,
                                    const twr_terrain_grid* grid, twr_structure** out);
 void twr_structure_destroy(twr_structure* s);
+/* n candidates of one robot/terrain model at once (a sweep: SURVEY.md 8e "each rank builds descriptors for its
+ * shard only"): structure i from schedules[i] / params[i], built on up to n_threads host threads (<= 0: all
+ * hardware threads).  On failure nothing is left allocated and out[] is all NULL. */
+int twr_structure_create_many(const twr_model* model, const twr_schedule* schedules, const twr_params* params, int n,
+                              int n_threads, twr_structure** out);
 int twr_structure_sizes(const twr_structure* s, twr_sizes* out);
 int twr_structure_var_set(const twr_structure* s, int i, twr_set_info* out);
 int twr_structure_con_set(const twr_structure* s, int i, twr_set_info* out);
@@ -177,7 +185,9 @@ int twr_structure_variable_bounds(const twr_structure* s, const double init_base
                                   double* upper /* n_vars */);
 
 /* Upload the tables of a batch: problem p uses structs[struct_of_problem[p]].  device is the HIP
- * device ordinal of this process (one process per GPU). */
+ * device ordinal of this process (one process per GPU).  All structures of one batch must have the same
+ * number of end-effectors (<= TWR_MAX_EE): the dynamic kernel is specialised per n_ee and a batch is one launch
+ * of it; robots with different leg counts go into separate batches. */
 int twr_batch_create(const twr_structure* const* structs, int n_structs, const int32_t* struct_of_problem,
                      int n_problems, int device, twr_batch** out);
 void twr_batch_destroy(twr_batch* b);
@@ -191,8 +201,15 @@ int twr_batch_layout(const twr_batch* b, int64_t* x_off, int64_t* g_off, int64_t
  *   ifopt::Problem::EvalNonzerosOfJacobian(x,val) -> jac   (TWR_EVAL_JACOBIAN)
  * i.e. Composite::SetVariables + {Terrain,Dynamic,RangeOfMotion,Force}Constraint::
  * {GetValues, FillJacobianBlock}.  Asynchronous on `hip_stream` (hipStream_t, may be
- * NULL for the default stream); no host synchronisation, capturable in a hipGraph. */
+ * NULL for the default stream); no host synchronisation, capturable in a hipGraph.  The batch's device is made
+ * current and a pending sticky HIP error of the caller is cleared.  At most ONE evaluation of a given batch may
+ * be in flight at a time (batches with optimised timings keep per-batch scratch records; the profiling
+ * counters are per batch too): serialise evaluations of one batch on one stream, use one batch per stream. */
 int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, int flags, void* hip_stream);
+/* Failure detection (the reference only has Release-mode-silent asserts, spline.cc:52,65): after an evaluation with
+ * TWR_EVAL_CHECK, h_status[p] has bit 0 set if a constraint value of problem p is NaN/Inf and bit 1 if a Jacobian
+ * value is.  Waits for hip_stream (the stream of that evaluation). */
+int twr_batch_status(twr_batch* b, int32_t* h_status /* n_problems */, void* hip_stream);
 /* Measurement aid (bench.py): after _begin, the next max_evals calls of twr_batch_eval also record
  * HIP events on their launch stream around each of the three kernels (dynamic, range of motion,
  * force/terrain nodes); _end waits for the last one and returns the average duration of each. */

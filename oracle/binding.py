@@ -29,6 +29,14 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
+def use_library(path):
+    """Switch to another build of the same oracle (bench.py's cpu_baseline leg times the -O3 -march=native
+    build made on the box; the checker build stays the default)."""
+    global _lib, _LIB_PATH
+    _LIB_PATH = path
+    _lib = None
+
+
 def lib():
     global _lib
     if _lib is None:

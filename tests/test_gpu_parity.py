@@ -416,3 +416,106 @@ def test_full_size_batch_properties():
         np.add.at(Jd[p], rows, Jn[p] * d[S.col_idx])
     scale = np.maximum(np.abs(fd).max(axis=0, keepdims=True), 1.0)
     assert (np.abs(Jd - fd) / scale).max() < 1e-5
+
+
+# ---------------------------------------------------------------- BASELINE C4 / C5: the enumerated sweeps
+def _sweep_inputs(structs, model, first_seed=0):
+    from bench import perturbed_inputs
+
+    return [perturbed_inputs(S, model, 1, first_seed=first_seed + i)[0] for i, S in enumerate(structs)]
+
+
+def _oracle_for(robot, terrain, S):
+    from oracle import binding as ob
+
+    p = S.params
+    return ob.OracleProblem(robot, terrain, S.schedule.durations(), S.schedule.contact(), dt_dynamic=p.dt_dynamic,
+                            dt_rom=p.dt_rom, duration_base_poly=p.duration_base_poly, polys_per_swing=p.polys_per_swing,
+                            polys_per_stance_force=p.polys_per_stance_force, constraint_sets=p.constraint_sets)
+
+
+def _run_sweep(robot, terrain, count, sample_idx):
+    """One ragged batch of the first `count` enumerated candidates (combo x T x swing scale); every
+    output element must be written (NaN pre-fill), the sampled candidates must match the oracle."""
+    import torch
+
+    from towr_amd import sweep
+
+    model = ta.model_preset(robot, terrain)
+    cands = sweep.enumerate_candidates(count)
+    structs = sweep.candidate_structures(model, cands)
+    assert len({(S.n, S.m, S.nnz) for S in structs}) > 1, "the sweep must be ragged"
+    batch = ta.Batch(structs, list(range(count)), device=0)
+    xs = _sweep_inputs(structs, model)
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(np.concatenate(xs)).to(dev)
+    g = torch.full((int(batch.g_off[-1]),), float("nan"), dtype=torch.float64, device=dev)
+    jac = torch.full((int(batch.jac_off[-1]),), float("nan"), dtype=torch.float64, device=dev)
+    batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(g).all()), "constraint values left unwritten / non-finite"
+    assert bool(torch.isfinite(jac).all()), "Jacobian values left unwritten / non-finite"
+    gh, jh = g.cpu().numpy(), jac.cpu().numpy()
+    for p in sample_idx:
+        S = structs[p]
+        rg, rp, ci, rj = _oracle_for(robot, terrain, S).eval(xs[p])
+        assert np.array_equal(rp, S.row_ptr) and np.array_equal(ci, S.col_idx), "pattern of candidate %d" % p
+        assert_parity(S, *_split(batch, gh, jh, p), rg, rj, "%s/%s candidate %d %s" % (robot, terrain, p, cands[p]))
+    return cands
+
+
+def _c5_samples():
+    # lexicographic order: index = combo * 208 + i_T * 26 + j_scale.  Every combo at both ends of T and of the
+    # swing scale, plus interior points.
+    idx = []
+    for combo in range(5):
+        for iT, j in ((0, 0), (7, 25), (3, 13), (0, 25)):
+            k = combo * 208 + iT * 26 + j
+            if k < 1024:
+                idx.append(k)
+    return sorted(set(idx + [1023, 1000, 517]))
+
+
+@pytest.mark.parametrize("robot", ["anymal", "go1"])
+def test_sweep_c5_1024_stairs(robot):
+    """BASELINE config 5: the 1024-candidate gait / phase-duration sweep on Stairs in ONE ragged batch
+    (gait_generator.cc:54-105, quadruped_gait_generator.cc:76-87; Go1 constants go1_model.h:19-52)."""
+    idx = _c5_samples()
+    assert len(idx) >= 16
+    cands = _run_sweep(robot, "stairs", 1024, idx)
+    assert {c[0] for c in (cands[i] for i in idx)} == {0, 1, 2, 3, 4}
+
+
+@pytest.mark.parametrize("terrain", ["gap", "stairs"])
+def test_sweep_c4_64(terrain):
+    """BASELINE config 4: batch of 64 enumerated candidate contact sequences on Gap / Stairs; all 64 checked."""
+    _run_sweep("anymal", terrain, 64, list(range(64)))
+
+
+def test_eval_check_flags_nonfinite_problems():
+    """TWR_EVAL_CHECK (failure detection): per-problem NaN/Inf bits, other problems untouched."""
+    import torch
+
+    case = Case("anymal", "gap", ta.gait_combo(4, 1, 2.0))
+    S = case.S
+    xs = [case.x_perturbed(i, 2.0) for i in range(5)]
+    xs[1][S.var_sets[1]["offset"] + 7] = float("nan")            # an Euler node value: poisons g and jac
+    f0 = [v for v in S.var_sets if v["name"] == "ee-force_2"][0]
+    xs[3][f0["offset"] + 4] = float("inf")                       # a force value: g only where the force enters linearly
+    batch = ta.Batch([S], [0] * 5, device=0)
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(np.concatenate(xs)).to(dev)
+    g = torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device=dev)
+    jac = torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH | ta.EVAL_CHECK, st)
+    status = batch.status(st)
+    gh, jh = g.cpu().numpy(), jac.cpu().numpy()
+    for p in range(5):
+        want = (0 if np.isfinite(gh[batch.g_off[p]:batch.g_off[p + 1]]).all() else 1) | \
+               (0 if np.isfinite(jh[batch.jac_off[p]:batch.jac_off[p + 1]]).all() else 2)
+        assert status[p] == want, (p, status[p], want)
+    assert status[0] == 0 and status[2] == 0 and status[4] == 0 and status[1] == 3 and status[3] & 1
+    # values only: the Jacobian is neither written nor scanned
+    batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_VALUES | ta.EVAL_CHECK, st)
+    assert (batch.status(st) & 2).sum() == 0

@@ -244,4 +244,37 @@ def test_sweep_enumeration_and_sharding():
         loads = [w[b[r]:b[r + 1]].sum() for r in range(world)]
         assert max(loads) - min(loads) <= 2 * w.max()
     assert sweep.shard_bounds([5, 1, 1, 1, 1, 1], 2) == [0, 1, 6]
-    assert sweep.shard_bounds([1, 1], 4)[-1] == 2
+    with pytest.raises(ValueError):      # more ranks than candidates: every rank raises the same error
+        sweep.shard_bounds([1, 1], 4)
+    assert sweep.shard_bounds([9, 1, 1], 3) == [0, 1, 2, 3]   # never an empty shard
+    assert sweep.shard_bounds([1, 1, 50], 3) == [0, 1, 2, 3]
+
+
+def test_create_many_equals_one_by_one():
+    """twr_structure_create_many (threaded sweep setup) builds the same structures as twr_structure_create."""
+    from towr_amd import sweep
+
+    m = ta.model_preset("anymal", "stairs")
+    cands = sweep.enumerate_candidates(1040)[::37]
+    many = sweep.candidate_structures(m, cands, threads=4)
+    for c, S in zip(cands, many):
+        one = sweep.candidate_structure(m, c)
+        assert (S.n, S.m, S.nnz) == (one.n, one.m, one.nnz)
+        assert np.array_equal(S.row_ptr, one.row_ptr) and np.array_equal(S.col_idx, one.col_idx)
+        assert S.con_sets == one.con_sets and S.var_sets == one.var_sets
+    # a failing candidate fails the whole call and leaves nothing behind
+    bad = ta.params_default(constraint_sets=0)
+    with pytest.raises(ta.TowrError, match="structure 1"):
+        ta.Structure.create_many(m, [many[0].schedule, many[1].schedule], [many[0].params, bad], threads=2)
+
+
+def test_base_motion_needs_the_initial_base_height():
+    """twr_params_default leaves base_z_init unset (NaN): enabling baseMotion without it is rejected instead of
+    silently producing the infeasible bounds [-0.02, 0.1] (base_motion_constraint.cc:51-55)."""
+    m = ta.model_preset("anymal", "flat")
+    with pytest.raises(ta.TowrError, match="base_z_init"):
+        ta.Structure(m, ta.gait_combo(4, 1, 2.0), ta.params_default(constraint_sets=ta.SETS_EVERY))
+    S = ta.Structure(m, ta.gait_combo(4, 1, 2.0), ta.params_default(constraint_sets=ta.SETS_EVERY, base_z_init=0.42))
+    lo, up = S.bounds()
+    bm = [s for s in S.con_sets if s["name"] == "baseMotion"][0]
+    assert lo[bm["offset"] + 5] == pytest.approx(0.40) and up[bm["offset"] + 5] == pytest.approx(0.52)

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libtowr_amd.so")
 MAX_EE, MAX_PHASES, NAME_LEN = 4, 32, 40
 ROBOTS = {"monoped": 0, "biped": 1, "hyq": 2, "anymal": 3, "go1": 4}
 TERRAINS = {"flat": 0, "block": 1, "stairs": 2, "gap": 3, "slope": 4, "chimney": 5, "chimney_lr": 6, "csv": 7}
-EVAL_VALUES, EVAL_JACOBIAN, EVAL_BOTH = 1, 2, 3
+EVAL_VALUES, EVAL_JACOBIAN, EVAL_BOTH, EVAL_CHECK = 1, 2, 3, 4
 SET_TERRAIN, SET_DYNAMIC, SET_BASE_ACC, SET_ROM, SET_FORCE, SET_SWING, SET_TOTAL_TIME = 1, 2, 4, 8, 16, 32, 64
 SET_BASE_ROM = 128
 SETS_HOT_PATH, SETS_TOWR_DEFAULT, SETS_ALL, SETS_EVERY = 27, 63, 127, 255  # TWR_SETS_* of include/towr_amd.h
@@ -104,6 +104,8 @@ def lib():
         L.twr_structure_create_with_grid.argtypes = [C.POINTER(Model), C.POINTER(Schedule), C.POINTER(Params), C.c_void_p,
                                                      C.POINTER(C.c_void_p)]
         L.twr_structure_destroy.restype = None
+        L.twr_structure_create_many.argtypes = [C.POINTER(Model), C.POINTER(Schedule), C.POINTER(Params), C.c_int, C.c_int,
+                                                C.POINTER(C.c_void_p)]
         L.twr_structure_sizes.argtypes = [C.c_void_p, C.POINTER(Sizes)]
         L.twr_structure_var_set.argtypes = [C.c_void_p, C.c_int, C.POINTER(SetInfo)]
         L.twr_structure_con_set.argtypes = [C.c_void_p, C.c_int, C.POINTER(SetInfo)]
@@ -121,6 +123,7 @@ def lib():
         L.twr_batch_num_problems.argtypes = [C.c_void_p]
         L.twr_batch_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.twr_batch_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.twr_batch_status.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
         L.twr_batch_eval_host.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int]
         L.twr_structure_sample_count.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int32)]
         L.twr_batch_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int64, C.c_void_p]
@@ -195,36 +198,70 @@ class TerrainGrid:
 
 
 class Structure:
-    """x-independent part of one candidate (index maps, time tables, CSR pattern)."""
+    """x-independent part of one candidate (index maps, time tables, CSR pattern).  The set tables and the CSR
+    pattern are fetched from the library on first use (a sweep builds a thousand of these)."""
 
-    def __init__(self, model, sched, params=None, grid=None):
+    def __init__(self, model, sched, params=None, grid=None, _handle=None):
         params = params or params_default()
         self._h = C.c_void_p()
         self.model, self.schedule, self.params, self.grid = model, sched, params, grid
-        if grid is not None:
+        if _handle is not None:
+            self._h = _handle
+        elif grid is not None:
             _check(lib().twr_structure_create_with_grid(C.byref(model), C.byref(sched), C.byref(params), grid._h,
                                                         C.byref(self._h)))
         else:
             _check(lib().twr_structure_create(C.byref(model), C.byref(sched), C.byref(params), C.byref(self._h)))
         sz = Sizes()
         _check(lib().twr_structure_sizes(self._h, C.byref(sz)))
+        self._sz = sz
         self.n, self.m, self.nnz = sz.n_vars, sz.n_rows, sz.nnz
         self.k_dynamic, self.k_rom = sz.k_dynamic, sz.k_rom
         self.n_ee = model.n_ee
+        self._lazy = {}
 
-        def sets(fn, n):
-            out = []
-            for i in range(n):
-                si = SetInfo()
-                _check(fn(self._h, i, C.byref(si)))
-                out.append(dict(name=si.name.decode(), offset=si.offset, size=si.size, nnz_offset=si.nnz_offset,
-                                nnz=si.nnz))
-            return out
+    @classmethod
+    def create_many(cls, model, scheds, params_list, threads=0):
+        """twr_structure_create_many: the candidates of a sweep, built on `threads` host threads (0 = all)."""
+        n = len(scheds)
+        assert n == len(params_list) and n > 0
+        sa = (Schedule * n)(*scheds)
+        pa = (Params * n)(*params_list)
+        hs = (C.c_void_p * n)()
+        _check(lib().twr_structure_create_many(C.byref(model), sa, pa, n, int(threads), hs))
+        return [cls(model, scheds[i], params_list[i], _handle=C.c_void_p(hs[i])) for i in range(n)]
 
-        self.var_sets = sets(lib().twr_structure_var_set, sz.n_var_sets)
-        self.con_sets = sets(lib().twr_structure_con_set, sz.n_con_sets)
-        self.row_ptr = np.ctypeslib.as_array(lib().twr_structure_row_ptr(self._h), shape=(self.m + 1,)).copy()
-        self.col_idx = np.ctypeslib.as_array(lib().twr_structure_col_idx(self._h), shape=(self.nnz,)).copy()
+    def _sets(self, fn, n):
+        out = []
+        for i in range(n):
+            si = SetInfo()
+            _check(fn(self._h, i, C.byref(si)))
+            out.append(dict(name=si.name.decode(), offset=si.offset, size=si.size, nnz_offset=si.nnz_offset,
+                            nnz=si.nnz))
+        return out
+
+    def _get(self, key, make):
+        if key not in self._lazy:
+            self._lazy[key] = make()
+        return self._lazy[key]
+
+    @property
+    def var_sets(self):
+        return self._get("var_sets", lambda: self._sets(lib().twr_structure_var_set, self._sz.n_var_sets))
+
+    @property
+    def con_sets(self):
+        return self._get("con_sets", lambda: self._sets(lib().twr_structure_con_set, self._sz.n_con_sets))
+
+    @property
+    def row_ptr(self):
+        return self._get("row_ptr", lambda: np.ctypeslib.as_array(lib().twr_structure_row_ptr(self._h),
+                                                                  shape=(self.m + 1,)).copy())
+
+    @property
+    def col_idx(self):
+        return self._get("col_idx", lambda: np.ctypeslib.as_array(lib().twr_structure_col_idx(self._h),
+                                                                  shape=(self.nnz,)).copy())
 
     def __del__(self):
         if getattr(self, "_h", None) and lib is not None:  # (module globals are gone at interpreter exit)
@@ -296,6 +333,12 @@ class Batch:
         """Asynchronous launch on raw device pointers (ints), e.g. torch tensors' data_ptr()."""
         _check(lib().twr_batch_eval(self._h, C.c_void_p(d_x), C.c_void_p(d_g), C.c_void_p(d_jac), flags,
                                     C.c_void_p(stream)))
+
+    def status(self, stream=0):
+        """Per-problem non-finite flags of the last eval_device(..., flags | EVAL_CHECK): bit 0 g, bit 1 jac."""
+        st = np.zeros(self.n_problems, dtype=np.int32)
+        _check(lib().twr_batch_status(self._h, st.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(stream)))
+        return st
 
     def profile_begin(self, max_evals):
         """Record HIP events around each kernel of the next `max_evals` eval_device calls."""

@@ -3,10 +3,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -17,6 +20,8 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
                        const NodeWork* node, int n_node, const PhaseWork* pdyn, int n_pdyn, const LocWork* ploc,
                        int n_ploc, const RomPhaseWork* prom, int n_prom, const double* x, double* g, double* jac,
                        int flags, hipStream_t stream, hipEvent_t* ev);
+hipError_t launch_check(int n_problems, const int64_t* g_off, const int64_t* j_off, const double* g, const double* jac,
+                        int32_t* status, int flags, hipStream_t stream);
 hipError_t launch_sample(const SampleWork* work, int n_work, const double* x, double* out, double dt, hipStream_t stream);
 int dyn_stage_capacity();
 int rom_stage_capacity();
@@ -52,6 +57,8 @@ struct twr_batch {
   twr::PhaseWork* d_pdyn = nullptr;
   twr::LocWork* d_ploc = nullptr;
   twr::RomPhaseWork* d_prom = nullptr;
+  int64_t *d_goff = nullptr, *d_joff = nullptr;  // device copies of g_off / j_off (TWR_EVAL_CHECK)
+  int32_t* d_status = nullptr;                    // per-problem non-finite flags of the last checked evaluation
   void* d_precs = nullptr;  // scratch: x-dependent RomRec records of the optimised-timings problems
   int n_pdyn = 0, n_ploc = 0, n_prom = 0;
   // lazily sized scratch for twr_batch_eval_host
@@ -94,6 +101,9 @@ std::vector<std::pair<int, int>> chunk(const std::vector<int32_t>& row_ptr, int 
     while (k1 < K && k1 - k0 < max_cnt && row_ptr[row0 + rows_per_k * (k1 + 1)] - row_ptr[row0 + rows_per_k * k0] <= cap)
       ++k1;
     if (k1 == k0) throw std::runtime_error("one time node exceeds the LDS staging capacity");
+    // copy_out_fixed clamps its tail iterations to the last complete pair of the slice: a slice must hold one
+    if (row_ptr[row0 + rows_per_k * k1] - row_ptr[row0 + rows_per_k * k0] < 4)
+      throw std::runtime_error("a time-node run with fewer than 4 Jacobian values cannot be staged");
     out.push_back({k0, k1 - k0});
     k0 = k1;
   }
@@ -125,7 +135,7 @@ int twr_params_default(twr_params* out) {
   out->constraint_sets = TWR_SETS_HOT_PATH;
   out->reserved_ = 0;
   out->dt_base_motion = out->duration_base_poly / 4.;  // parameters.cc:51
-  out->base_z_init = 0.0;
+  out->base_z_init = std::nan("");  // must be set by callers that enable TWR_SET_BASE_ROM
   return TWR_OK;
 }
 
@@ -174,6 +184,9 @@ int twr_structure_create_with_grid(const twr_model* model, const twr_schedule* s
       throw std::runtime_error("polynomials per phase must be >= 1");
     if (params->constraint_sets <= 0 || (params->constraint_sets & ~TWR_SETS_EVERY))
       throw std::runtime_error("constraint_sets must be a non-empty mask of TWR_SET_* bits");
+    if ((params->constraint_sets & TWR_SET_BASE_ROM) && !std::isfinite(params->base_z_init))
+      throw std::runtime_error("TWR_SET_BASE_ROM needs twr_params.base_z_init (the initial base height; "
+                               "base_motion_constraint.cc:51-55 reads it from the spline)");
     h->s.Build();
     *out = h.release();
     return TWR_OK;
@@ -183,6 +196,36 @@ int twr_structure_create_with_grid(const twr_model* model, const twr_schedule* s
 }
 
 void twr_structure_destroy(twr_structure* s) { delete s; }
+
+int twr_structure_create_many(const twr_model* model, const twr_schedule* schedules, const twr_params* params, int n,
+                              int n_threads, twr_structure** out) {
+  if (!model || !schedules || !params || !out || n < 1) return fail(TWR_ERR_INVALID, "bad arguments");
+  if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+  n_threads = std::max(1, std::min(n_threads, n));
+  for (int i = 0; i < n; ++i) out[i] = nullptr;
+  std::vector<std::string> errs(n_threads);
+  std::atomic<int> next(0);
+  auto worker = [&](int tid) {
+    for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+      // the error string of the failing call lives in the worker's thread_local slot: carry it out
+      if (twr_structure_create(model, &schedules[i], &params[i], &out[i]) != TWR_OK && errs[tid].empty())
+        errs[tid] = "structure " + std::to_string(i) + ": " + twr_last_error();
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker, t);
+  worker(0);
+  for (auto& t : pool) t.join();
+  for (const std::string& e : errs)
+    if (!e.empty()) {
+      for (int i = 0; i < n; ++i) {
+        twr_structure_destroy(out[i]);
+        out[i] = nullptr;
+      }
+      return fail(TWR_ERR_INVALID, e);
+    }
+  return TWR_OK;
+}
 
 int twr_structure_sizes(const twr_structure* s, twr_sizes* out) {
   if (!s || !out) return fail(TWR_ERR_INVALID, "null argument");
@@ -439,6 +482,10 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     upload(dyn.data(), dyn.size() * sizeof(twr::DynWork), reinterpret_cast<void**>(&b->d_dyn));
     upload(rom.data(), rom.size() * sizeof(twr::RomWork), reinterpret_cast<void**>(&b->d_rom));
     upload(node.data(), node.size() * sizeof(twr::NodeWork), reinterpret_cast<void**>(&b->d_node));
+    upload(b->g_off.data(), b->g_off.size() * sizeof(int64_t), reinterpret_cast<void**>(&b->d_goff));
+    upload(b->j_off.data(), b->j_off.size() * sizeof(int64_t), reinterpret_cast<void**>(&b->d_joff));
+    TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_status), sizeof(int32_t) * (size_t)n_problems));
+    TWR_HIP(hipMemset(b->d_status, 0, sizeof(int32_t) * (size_t)n_problems));
     b->n_pdyn = (int)pdyn.size();
     b->n_ploc = (int)ploc.size();
     b->n_prom = (int)prom.size();
@@ -471,6 +518,9 @@ void twr_batch_destroy(twr_batch* b) {
   if (b->d_prom) (void)hipFree(b->d_prom);
   if (b->d_ploc) (void)hipFree(b->d_ploc);
   if (b->d_precs) (void)hipFree(b->d_precs);
+  if (b->d_goff) (void)hipFree(b->d_goff);
+  if (b->d_joff) (void)hipFree(b->d_joff);
+  if (b->d_status) (void)hipFree(b->d_status);
   if (b->d_swork) (void)hipFree(b->d_swork);
   for (hipEvent_t e : b->prof_events) (void)hipEventDestroy(e);
   if (b->d_x) (void)hipFree(b->d_x);
@@ -498,6 +548,10 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
   if ((flags & TWR_EVAL_BOTH) == 0) return fail(TWR_ERR_INVALID, "flags select nothing");
   if (((flags & TWR_EVAL_VALUES) && !d_g) || ((flags & TWR_EVAL_JACOBIAN) && !d_jac))
     return fail(TWR_ERR_INVALID, "missing output buffer");
+  // one process may drive several devices: make the batch's device current (as every other entry point does),
+  // and drop a sticky error the host application may have left behind so that it is not reported as ours
+  if (hipSetDevice(b->device) != hipSuccess) return fail(TWR_ERR_HIP, "hipSetDevice failed");
+  (void)hipGetLastError();
   hipEvent_t* ev = nullptr;
   if (b->prof_count < b->prof_capacity) ev = b->prof_events.data() + 4 * b->prof_count++;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
@@ -505,7 +559,24 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
                                   b->d_pdyn, b->n_pdyn, b->d_ploc, b->n_ploc, b->d_prom, b->n_prom, d_x, d_g, d_jac,
                                   flags & TWR_EVAL_BOTH, stream, ev);
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  if (flags & TWR_EVAL_CHECK) {
+    e = twr::launch_check(b->n_problems, b->d_goff, b->d_joff, d_g, d_jac, b->d_status, flags & TWR_EVAL_BOTH, stream);
+    if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("check kernel launch: ") + hipGetErrorString(e));
+  }
   return TWR_OK;
+}
+
+int twr_batch_status(twr_batch* b, int32_t* h_status, void* hip_stream) {
+  if (!b || !h_status) return fail(TWR_ERR_INVALID, "null argument");
+  try {
+    TWR_HIP(hipSetDevice(b->device));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    TWR_HIP(hipMemcpyAsync(h_status, b->d_status, sizeof(int32_t) * (size_t)b->n_problems, hipMemcpyDeviceToHost, stream));
+    TWR_HIP(hipStreamSynchronize(stream));
+    return TWR_OK;
+  } catch (const std::exception& e) {
+    return fail(TWR_ERR_HIP, e.what());
+  }
 }
 
 int twr_batch_profile_begin(twr_batch* b, int max_evals) {

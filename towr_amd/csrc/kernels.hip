@@ -1345,7 +1345,10 @@ __global__ __launch_bounds__(64) void dyn_phase_kernel(const PhaseWork* __restri
   DynX X;
   dyn_load_x(w, sh, ln, x, X);
   dyn_front<NEE, true>(w, sh, ln, X, 0, 0, lane, S);
-  __syncthreads();  // (s_waitcnt vmcnt(0) + barrier) the zeros of the slice are in place before any value
+  // The values below overwrite zeros written by OTHER lanes of this wave: the zero stores must have been
+  // acknowledged first.  A single-wave workgroup gets no s_barrier from __syncthreads(), so the dependency is
+  // made explicit (on gfx9 loads and stores retire through the one in-order vmcnt counter).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (want_j && has_ee && kk < pw.cnt) {
     // duration columns: {[r]x J_f + [f]x J_p ; -J_f} with J = GetJacobianOfPosWrtDurations of the ee-force /
     // ee-motion PhaseSpline (dynamic_constraint.cc:107-113, single_rigid_body_dynamics.cc:167-192)
@@ -1654,6 +1657,37 @@ __global__ __launch_bounds__(64) void sample_kernel(const SampleWork* __restrict
 }
 hipError_t launch_sample(const SampleWork* work, int n_work, const double* x, double* out, double dt, hipStream_t stream) {
   if (n_work > 0) hipLaunchKernelGGL(sample_kernel, dim3(n_work), dim3(64), 0, stream, work, x, out, dt);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- TWR_EVAL_CHECK
+// Per-problem non-finite flags (failure detection): a separate pass over the outputs of one
+// evaluation, off the hot path (it re-reads g and jac once).  status[p] |= 1 if a constraint value of problem p is
+// NaN/Inf, |= 2 if a Jacobian value is.  Sixteen workgroups per problem, each scanning a contiguous share.
+constexpr int kCheckParts = 16;
+TWR_DEV bool non_finite(double v) { return (__double2hiint(v) & 0x7ff00000) == 0x7ff00000; }
+__global__ __launch_bounds__(256) void check_kernel(const int64_t* __restrict__ g_off, const int64_t* __restrict__ j_off,
+                                                    const double* __restrict__ g, const double* __restrict__ jac,
+                                                    int32_t* __restrict__ status, int flags) {
+  const int p = blockIdx.x / kCheckParts, part = blockIdx.x % kCheckParts;
+  int bad = 0;
+  if (flags & 1) {
+    const int64_t a = g_off[p], n = g_off[p + 1] - a;
+    const int64_t lo = a + n * part / kCheckParts, hi = a + n * (part + 1) / kCheckParts;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) bad |= non_finite(g[i]) ? 1 : 0;
+  }
+  if (flags & 2) {
+    const int64_t a = j_off[p], n = j_off[p + 1] - a;
+    const int64_t lo = a + n * part / kCheckParts, hi = a + n * (part + 1) / kCheckParts;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) bad |= non_finite(jac[i]) ? 2 : 0;
+  }
+  if (bad) atomicOr(&status[p], bad);
+}
+hipError_t launch_check(int n_problems, const int64_t* g_off, const int64_t* j_off, const double* g, const double* jac,
+                        int32_t* status, int flags, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(status, 0, sizeof(int32_t) * (size_t)n_problems, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(check_kernel, dim3(n_problems * kCheckParts), dim3(256), 0, stream, g_off, j_off, g, jac, status, flags);
   return hipGetLastError();
 }
 

@@ -322,15 +322,28 @@ void Structure::BuildTimeTables() {
 // ------------------------------------------------------------------ CSR pattern + bounds
 void Structure::BuildPattern() {
   const double inf = 1e20;
-  std::vector<std::vector<int>> rows;
+  // rows are emitted straight into col_idx / row_ptr (no per-row containers: this runs once per candidate of a
+  // sweep)
+  row_ptr.assign(1, 0);
+  col_idx.clear();
+  col_idx.reserve(1 << 17);
+  std::vector<int32_t>& c = col_idx;
+  auto end_row = [&]() {
+    if (!std::is_sorted(col_idx.begin() + row_ptr.back(), col_idx.end())) throw std::runtime_error("row not sorted");
+    row_ptr.push_back((int32_t)col_idx.size());
+  };
+  auto emit = [&](std::initializer_list<int> cols) {
+    col_idx.insert(col_idx.end(), cols.begin(), cols.end());
+    end_row();
+  };
   auto begin_set = [&](const std::string& name, int n) {
     SetInfo s;
     s.name = name;
-    s.offset = (int)rows.size();
+    s.offset = (int)row_ptr.size() - 1;
     s.size = n;
     con_sets.push_back(s);
   };
-  auto slots_cols = [&](const PolyDesc& p, int want_dim, bool equal, std::vector<int>& out) {
+  auto slots_cols = [&](const PolyDesc& p, int want_dim, bool equal, std::vector<int32_t>& out) {
     // columns of the slots whose dim ==/!= want_dim, ascending
     int dim_of_slot[12];
     for (int c = 0; c < 12; ++c)
@@ -339,7 +352,7 @@ void Structure::BuildPattern() {
     for (int s = 0; s < nslots; ++s)
       if ((dim_of_slot[s] == want_dim) == equal) out.push_back(p.xbase + s);
   };
-  auto set_cols = [&](const SplineLayout& s, int want_dim, bool equal, std::vector<int>& out) {
+  auto set_cols = [&](const SplineLayout& s, int want_dim, bool equal, std::vector<int32_t>& out) {
     // all variables of a phase-based set whose dim ==/!= want_dim, ascending
     std::vector<int> dim_of(s.var_size, -1);
     for (int n = 0; n < s.n_nodes; ++n)
@@ -349,7 +362,7 @@ void Structure::BuildPattern() {
     for (int i = 0; i < s.var_size; ++i)
       if ((dim_of[i] == want_dim) == equal) out.push_back(s.var_offset + i);
   };
-  auto sched_cols = [&](int e, std::vector<int>& out) {
+  auto sched_cols = [&](int e, std::vector<int32_t>& out) {
     for (int i = 0; i < schedule.n_phases[e] - 1; ++i) out.push_back(off_schedule[e] + i);
   };
   const int sets = params.constraint_sets;
@@ -358,7 +371,7 @@ void Structure::BuildPattern() {
     begin_set("terrain-ee-motion_" + std::to_string(e), (int)terrain_rows[e].size());
     for (size_t r = 0; r < terrain_rows[e].size(); ++r) {
       const TerrainRow& tr = terrain_rows[e][r];
-      rows.push_back({tr.idx, tr.idx + tr.stride, tr.idx + 2 * tr.stride});
+      emit({tr.idx, tr.idx + tr.stride, tr.idx + 2 * tr.stride});
       bool constant = motion[e].node_constant[r + 1];
       lower.push_back(0.0);
       upper.push_back(constant ? 0.0 : inf);  // terrain_constraint.cc:72-88
@@ -369,7 +382,6 @@ void Structure::BuildPattern() {
   for (size_t k = 0; k < grid_dyn.size() && (sets & TWR_SET_DYNAMIC); ++k) {
     int q = dyn_base[k].poly;
     for (int r = 0; r < 3; ++r) {  // AX, AY, AZ
-      std::vector<int> c;
       for (int node = q; node <= q + 1; ++node)  // -sum [f]x J_pos: dims != r, pos then vel per node
         for (int dv = 0; dv < 2; ++dv)
           for (int d = 0; d < 3; ++d)
@@ -383,12 +395,11 @@ void Structure::BuildPattern() {
         for (int e = 0; e < n_ee; ++e) set_cols(force[e], r, false, c);
         for (int e = 0; e < n_ee; ++e) sched_cols(e, c);  // dynamic_constraint.cc:107-113
       }
-      rows.push_back(c);
+      end_row();
       lower.push_back(0.0);
       upper.push_back(0.0);
     }
     for (int d = 0; d < 3; ++d) {  // LX, LY, LZ
-      std::vector<int> c;
       for (int j = 0; j < 4; ++j) c.push_back(off_base_lin + 6 * q + 3 * j + d);  // m J_acc
       if (!timings) {
         for (int e = 0; e < n_ee; ++e) slots_cols(fpoly[e][dyn_force[e][k].poly], d, true, c);  // -J_f
@@ -396,7 +407,7 @@ void Structure::BuildPattern() {
         for (int e = 0; e < n_ee; ++e) set_cols(force[e], d, true, c);
         for (int e = 0; e < n_ee; ++e) sched_cols(e, c);
       }
-      rows.push_back(c);
+      end_row();
       lower.push_back(0.0);
       upper.push_back(0.0);
     }
@@ -411,9 +422,8 @@ void Structure::BuildPattern() {
       begin_set(which == 0 ? "splineacc-base-lin" : "splineacc-base-ang", 3 * (int)acc_junctions.size());
       for (size_t j = 0; j < acc_junctions.size(); ++j)
         for (int d = 0; d < 3; ++d) {
-          std::vector<int> c;
           for (int i = 0; i < 6; ++i) c.push_back(off + 6 * (int)j + 3 * i + d);
-          rows.push_back(c);
+          end_row();
           lower.push_back(0.0);
           upper.push_back(0.0);
         }
@@ -425,7 +435,6 @@ void Structure::BuildPattern() {
       int q = rom_base[k].poly;
       const PolyDesc& mp = mpoly[e][rom_motion[e][k].poly];
       for (int r = 0; r < 3; ++r) {
-        std::vector<int> c;
         for (int i = 0; i < 12; ++i) c.push_back(off_base_lin + 6 * q + i);  // -R^T J_c
         for (int i = 0; i < 12; ++i)  // DerivOfRotVecMult(inverse): row 0 does not depend on roll
           if (!(r == 0 && i % 3 == 0)) c.push_back(off_base_ang + 6 * q + i);
@@ -435,7 +444,7 @@ void Structure::BuildPattern() {
           for (int i = 0; i < motion[e].var_size; ++i) c.push_back(motion[e].var_offset + i);
           sched_cols(e, c);
         }
-        rows.push_back(c);
+        end_row();
         lower.push_back(model.nominal_stance[e][r] - model.max_dev[r]);  // :71-81
         upper.push_back(model.nominal_stance[e][r] + model.max_dev[r]);
       }
@@ -445,7 +454,7 @@ void Structure::BuildPattern() {
   for (int e = 0; e < n_ee && (sets & TWR_SET_FORCE); ++e) {
     begin_set("force-ee-force_" + std::to_string(e), (int)force_nodes[e].size() * 5);
     for (const ForceNode& fn : force_nodes[e]) {
-      for (int r = 0; r < 5; ++r) rows.push_back({fn.hidx, fn.hidx + 1, fn.fidx, fn.fidx + 2, fn.fidx + 4});
+      for (int r = 0; r < 5; ++r) emit({fn.hidx, fn.hidx + 1, fn.fidx, fn.fidx + 2, fn.fidx + 4});
       lower.push_back(0.0);  upper.push_back(model.force_limit);  // :91-105
       lower.push_back(-inf); upper.push_back(0.0);
       lower.push_back(0.0);  upper.push_back(inf);
@@ -457,10 +466,10 @@ void Structure::BuildPattern() {
   for (int e = 0; e < n_ee && (sets & TWR_SET_SWING); ++e) {
     begin_set("swing-ee-motion_" + std::to_string(e), 4 * (int)swing_nodes[e].size());
     for (const SwingNode& sn : swing_nodes[e]) {
-      rows.push_back({sn.prev_x, sn.cur, sn.next_x});
-      rows.push_back({sn.prev_x, sn.cur + 1, sn.next_x});
-      rows.push_back({sn.prev_y, sn.cur + 2, sn.next_y});
-      rows.push_back({sn.prev_y, sn.cur + 3, sn.next_y});
+      emit({sn.prev_x, sn.cur, sn.next_x});
+      emit({sn.prev_x, sn.cur + 1, sn.next_x});
+      emit({sn.prev_y, sn.cur + 2, sn.next_y});
+      emit({sn.prev_y, sn.cur + 3, sn.next_y});
       for (int r = 0; r < 4; ++r) {
         lower.push_back(0.0);
         upper.push_back(0.0);
@@ -475,7 +484,7 @@ void Structure::BuildPattern() {
       const int q = bm_base[k].poly;
       for (int r6 = 0; r6 < 6; ++r6) {
         const int off = r6 < 3 ? off_base_ang : off_base_lin, d = r6 % 3;
-        rows.push_back({off + 6 * q + d, off + 6 * q + 3 + d, off + 6 * q + 6 + d, off + 6 * q + 9 + d});
+        emit({off + 6 * q + d, off + 6 * q + 3 + d, off + 6 * q + 6 + d, off + 6 * q + 9 + d});
       }
       lower.push_back(-dev_rad); upper.push_back(dev_rad);   // AX
       lower.push_back(-dev_rad); upper.push_back(dev_rad);   // AY
@@ -488,19 +497,12 @@ void Structure::BuildPattern() {
   // --- totalduration-e (total_duration_constraint.cc:50-72): sum of the optimised durations
   for (int e = 0; e < n_ee && (sets & TWR_SET_TOTAL_TIME); ++e) {
     begin_set("totalduration-" + std::to_string(e), 1);
-    std::vector<int> c;
     sched_cols(e, c);
-    rows.push_back(c);
+    end_row();
     lower.push_back(0.1);
     upper.push_back(T - 0.2);  // min_duration_last_phase
   }
-  n_rows = (int)rows.size();
-  row_ptr.assign(n_rows + 1, 0);
-  for (int r = 0; r < n_rows; ++r) {
-    if (!std::is_sorted(rows[r].begin(), rows[r].end())) throw std::runtime_error("row not sorted");
-    row_ptr[r + 1] = row_ptr[r] + (int)rows[r].size();
-    col_idx.insert(col_idx.end(), rows[r].begin(), rows[r].end());
-  }
+  n_rows = (int)row_ptr.size() - 1;
   nnz = row_ptr[n_rows];
   for (auto& s : con_sets) {
     s.nnz_offset = row_ptr[s.offset];
