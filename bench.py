@@ -70,6 +70,21 @@ def _cpu_model():
     return "unknown"
 
 
+def host_cores():
+    """Host threads this process may actually keep busy: the affinity mask, cut down by a cgroup CPU quota when
+    one is set, and by the GPU pool's per-GPU CPU share (16 host threads per GPU; a 256-thread pool on such a box
+    is time-sliced onto that share).  TWR_HOST_CORES overrides."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("TWR_HOST_CORES", "16"))))
+
+
 def cpu_baseline(sched, params, x, terrain, budget_s=3.0):
     """The oracle ("port" of the reference's Eigen CPU path, reference-shaped: per time node and per variable
     set) timed on this box's host cores, SURVEY 8d / BASELINE.md section 3: built -O3 -march=native ON THIS BOX
@@ -96,7 +111,7 @@ def cpu_baseline(sched, params, x, terrain, budget_s=3.0):
     iters = max(5, int(budget_s / max(t1, 1e-6)))
     rates = sorted(iters / P.time_callbacks(x, iters) for _ in range(5))
     single = statistics.median(rates)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     probs = [make() for _ in range(cores)]
     secs = [0.0] * cores
 
@@ -115,7 +130,7 @@ def cpu_baseline(sched, params, x, terrain, budget_s=3.0):
                       "oracle, g++ -O3 -march=native; min %.1f max %.1f" % (iters, iters / single, rates[0], rates[-1]),
             "all_cores": {"value": cores * iters / wall, "unit": "callbacks/s", "cores": cores,
                           "sample": "%d instances x %d callbacks at once (%.1f s)" % (cores, iters, wall)},
-            "nproc": cores, "cpu_model": _cpu_model()}
+            "nproc": os.cpu_count(), "cpu_model": _cpu_model()}
 
 
 def kernel_source_hash():
@@ -157,7 +172,7 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
     cands = sweep.enumerate_candidates(n_total)
     bounds = sweep.shard_bounds([sweep.candidate_weight(c) for c in cands], world)
     lo, hi = bounds[rank], bounds[rank + 1]
-    threads = max(1, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+    threads = host_cores()   # per rank: the pool gives every GPU its own CPU share
     t0 = time.perf_counter()
     mine = sweep.candidate_structures(m5, cands[lo:hi], threads=threads)
     t1 = time.perf_counter()

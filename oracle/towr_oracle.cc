@@ -764,6 +764,67 @@ struct HeightMap {
   long grid_rows = 0, grid_cols = 0;
   double res = 0.17, eps = 0.17 / 50;
   explicit HeightMap(int id_) : id(id_) {}
+
+  // ---- id 8: the fork's `Grid` height map (include/towr/terrain/grid_height_map.h:15-60), the terrain fpowr hands
+  // the solver (fpowr/src/footstep_plan_server.cc:155): the "elevation" layer of a ROS grid_map sampled with
+  // grid_map::InterpolationMethods::INTER_LINEAR into a FLOAT, out of range -> numeric_limits<float>::max()
+  // (:33-46); slopes are central differences of those floats over eps = resolution / 6 (:25,48-60); second
+  // derivatives are the base class's zeros.  grid_map itself is a third-party dependency that is neither in
+  // /root/reference nor in this image and is not version-pinned by the reference (Dockerfile installs the
+  // distro's ros-noetic-grid-map): its published algorithm (grid_map_core GridMap::atPosition,
+  // atPositionLinearInterpolated, GridMapMath getIndexFromPosition / getPositionFromIndex /
+  // checkIfPositionWithinMap) is restated here for a map with start index (0,0):
+  //   cell (i,j) centre = map position + length/2 - (index + 1/2) resolution  (x falls with i, y falls with j)
+  //   index of a position = trunc((map position + length/2 - position) / resolution)
+  //   bilinear over the 2x2 cells around the position, origin cell = the one with the smaller x and y, evaluated
+  //   in double and rounded to float; if one of the four cells is outside the map: nearest cell if the position
+  //   is inside the map, else std::out_of_range.
+  std::vector<float> gm;   // column-major like grid_map's Eigen::MatrixXf: gm[i + j * gm_sx]
+  int gm_sx = 0, gm_sy = 0;
+  double gm_res = 0, gm_px = 0, gm_py = 0, gm_eps = 0;
+  bool GmIn(long i, long j) const { return i >= 0 && j >= 0 && i < gm_sx && j < gm_sy; }
+  float GmAt(long i, long j) const { return gm[(size_t)i + (size_t)j * (size_t)gm_sx]; }
+  bool GmAtPosition(double x, double y, float& value) const {   // false = std::out_of_range
+    const double lx = gm_sx * gm_res, ly = gm_sy * gm_res;
+    // getIndexFromPosition: indexVector = (position - length/2 - mapPosition) / resolution, index = -indexVector
+    // converted to int (truncation toward zero)
+    const double vx = (x - 0.5 * lx - gm_px) / gm_res, vy = (y - 0.5 * ly - gm_py) / gm_res;
+    const long i0 = (long)(-vx), j0 = (long)(-vy);
+    // checkIfPositionWithinMap: transformed = mapPosition + length/2 - position in [0, length)
+    const double tx = gm_px + 0.5 * lx - x, ty = gm_py + 0.5 * ly - y;
+    const bool inside = tx >= 0.0 && ty >= 0.0 && tx < lx && ty < ly;
+    // atPositionLinearInterpolated
+    const double cx0 = gm_px + 0.5 * lx - 0.5 * gm_res - gm_res * (double)i0;   // getPositionFromIndex
+    const double cy0 = gm_py + 0.5 * ly - 0.5 * gm_res - gm_res * (double)j0;
+    const long ia = x >= cx0 ? i0 : i0 + 1, ja = y >= cy0 ? j0 : j0 + 1;        // origin cell: smaller x, smaller y
+    const long ib = ia - 1, jb = ja - 1;
+    if (GmIn(ia, ja) && GmIn(ib, jb)) {
+      const float f0 = GmAt(ia, ja), f1 = GmAt(ib, ja), f2 = GmAt(ia, jb), f3 = GmAt(ib, jb);
+      const double px = gm_px + 0.5 * lx - 0.5 * gm_res - gm_res * (double)ia;
+      const double py = gm_py + 0.5 * ly - 0.5 * gm_res - gm_res * (double)ja;
+      const double rx = (x - px) / gm_res, ry = (y - py) / gm_res, fx = 1.0 - rx, fy = 1.0 - ry;
+      value = (float)(f0 * fx * fy + f1 * rx * fy + f2 * fx * ry + f3 * rx * ry);
+      return true;
+    }
+    if (inside && GmIn(i0, j0)) {   // INTER_NEAREST fallback
+      value = GmAt(i0, j0);
+      return true;
+    }
+    return false;
+  }
+  // ref: grid_height_map.h:29-46 (the value travels as float)
+  float GridHeight(double x, double y) const {
+    float h;
+    if (!GmAtPosition(x, y, h)) h = std::numeric_limits<float>::max();
+    return h;
+  }
+  // ref: grid_height_map.h:48-60: float difference, double quotient
+  double GridDeriv(int dim, double x, double y) const {
+    const float hp = dim == X ? GridHeight(x + gm_eps, y) : GridHeight(x, y + gm_eps);
+    const float hm = dim == X ? GridHeight(x - gm_eps, y) : GridHeight(x, y - gm_eps);
+    return (hp - hm) / (2 * gm_eps);
+  }
+
   // static_cast<size_t>(x / res) of the reference: truncation toward zero; a negative quotient <= -1 wraps to
   // a huge size_t on x86-64 (formally undefined) and fails every range check -- restated as a signed cell
   // index that is "invalid" when negative.  (-1, 0) truncates to cell 0 like the reference.
@@ -800,6 +861,7 @@ struct HeightMap {
   double GetHeight(double x, double y) const {
     switch (id) {
       case 7: return CsvHeight(x, y);
+      case 8: return GridHeight(x, y);
       case 0: return 0.0;  // FlatGround(0.0)
       case 1: {            // Block, ref: height_map_examples.cc:40-53, .h:63-68
         const double block_start = 0.7, length = 3.5, height = 0.5, eps = 0.03, slope = height / eps;
@@ -859,6 +921,7 @@ struct HeightMap {
   double DerivX(double x, double y) const {
     switch (id) {
       case 7: return CsvDeriv(X, x, y);
+      case 8: return GridDeriv(X, x, y);
       case 1: {  // ref: height_map_examples.cc:55-65
         const double block_start = 0.7, height = 0.5, eps = 0.03, slope = height / eps;
         return (block_start <= x && x <= block_start + eps) ? slope : 0.0;
@@ -881,6 +944,7 @@ struct HeightMap {
   double DerivY(double x, double y) const {
     switch (id) {
       case 7: return CsvDeriv(Y, x, y);
+      case 8: return GridDeriv(Y, x, y);
       case 5: {  // ref: height_map_examples.cc:172-181
         const double x_start = 1.0, length = 1.5, slope = 3.0, x_end = x_start + length;
         return (x_start <= x && x <= x_end) ? slope : 0.0;

@@ -1,0 +1,138 @@
+// TEST INFRASTRUCTURE ONLY -- BASELINE config 1 ("plumbing"): the hopper problem of towr/test/hopper_example.cc:45-90
+// (monoped, flat ground, phases {0.4,0.2,0.4,0.2,0.4,0.2,0.2}, in contact at start) driven through the ifopt surface
+// the way Ipopt's adapter drives it: AddVariableSet / AddConstraintSet (-> LinkWithVariables), EvaluateConstraints(x),
+// EvalNonzerosOfJacobian(x, values), GetBoundsOnConstraints -- with towr_amd's device sets behind
+// ifopt::ConstraintSet (towr_amd/csrc/ifopt_adapter.h).  Compiled against tests/ifopt_stub (this image has neither
+// ifopt nor Eigen).  The result must equal a direct twr_batch_eval_host call bit for bit, in ifopt's stacking order.
+//   hopper_adapter_test            -> needs a GPU, exit 0 on success
+//   hopper_adapter_test --no-gpu   -> everything up to the device: expects TWR_ERR_NO_DEVICE to surface as an exception
+#include <ifopt/problem.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../towr_amd/csrc/ifopt_adapter.h"
+
+namespace {
+// a towr NodesVariables stand-in: a named block of x (nodes_variables.cc:52-72 keeps exactly this state)
+class PlainVariables : public ifopt::VariableSet {
+ public:
+  PlainVariables(const std::string& name, const double* x0, int n) : ifopt::VariableSet(n, name), x_(n) {
+    for (int i = 0; i < n; ++i) x_[i] = x0[i];
+  }
+  VectorXd GetValues() const override { return x_; }
+  void SetVariables(const VectorXd& x) override { x_ = x; }
+  VecBound GetBounds() const override { return VecBound(static_cast<size_t>(GetRows()), ifopt::NoBound); }
+
+ private:
+  VectorXd x_;
+};
+int fails = 0;
+void expect(bool ok, const char* what) {
+  if (!ok) {
+    std::fprintf(stderr, "FAILED: %s\n", what);
+    ++fails;
+  }
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+  const bool no_gpu = argc > 1 && std::string(argv[1]) == "--no-gpu";
+  const int sets = argc > 2 ? std::atoi(argv[2]) : TWR_SETS_TOWR_DEFAULT;
+  twr_model model;
+  twr_model_preset(TWR_ROBOT_MONOPED, TWR_TERRAIN_FLAT, &model);
+  twr_schedule sched;
+  std::memset(&sched, 0, sizeof(sched));
+  sched.n_ee = 1;
+  sched.n_phases[0] = 7;
+  sched.in_contact_at_start[0] = 1;
+  const double ph[7] = {0.4, 0.2, 0.4, 0.2, 0.4, 0.2, 0.2};  // hopper_example.cc:67
+  for (int i = 0; i < 7; ++i) sched.phase_durations[0][i] = ph[i];
+  twr_params prm;
+  twr_params_default(&prm);
+  prm.constraint_sets = sets;  // towr's default constraints_ (parameters.cc:55-60), or + TotalTime
+
+  std::vector<ifopt::ConstraintSet::Ptr> device_sets;
+  try {
+    device_sets = towr_amd::MakeDeviceConstraints(model, sched, prm, /*device=*/0);
+  } catch (const std::exception& e) {
+    std::printf("MakeDeviceConstraints: %s\n", e.what());
+    if (no_gpu) return std::strstr(e.what(), "no HIP device") ? 0 : 2;
+    return 2;
+  }
+  if (no_gpu) {
+    std::printf("a GPU is visible: --no-gpu has nothing to check\n");
+    return 0;
+  }
+
+  // reference data straight from the C ABI (what the adapter must reproduce)
+  twr_structure* S = nullptr;
+  twr_structure_create(&model, &sched, &prm, &S);
+  twr_sizes sz;
+  twr_structure_sizes(S, &sz);
+  const double lin0[3] = {0, 0, 0.5}, ang0[3] = {0, 0, 0}, lin1[3] = {1.0, 0, 0.5}, ee0[3] = {0, 0, 0};  // hopper_example.cc:53-59
+  std::vector<double> x(sz.n_vars);
+  twr_structure_initial_guess(S, lin0, ang0, lin1, ang0, ee0, x.data());
+  for (int i = 0; i < sz.n_vars; ++i) x[i] += 0.01 * std::sin(1.0 + 0.37 * i);  // off the trivial guess
+  const twr_structure* list[1] = {S};
+  const int32_t map[1] = {0};
+  twr_batch* B = nullptr;
+  expect(twr_batch_create(list, 1, map, 1, 0, &B) == TWR_OK, "twr_batch_create");
+  std::vector<double> g_ref(sz.n_rows), j_ref(sz.nnz), lo(sz.n_rows), up(sz.n_rows);
+  expect(twr_batch_eval_host(B, x.data(), g_ref.data(), j_ref.data(), TWR_EVAL_BOTH) == TWR_OK, "twr_batch_eval_host");
+  twr_structure_bounds(S, lo.data(), up.data());
+
+  // the ifopt problem: variable sets in the reference order (nlp_formulation.cc:63-93), then the device sets
+  ifopt::Problem nlp;
+  for (int i = 0; i < sz.n_var_sets; ++i) {
+    twr_set_info v;
+    twr_structure_var_set(S, i, &v);
+    nlp.AddVariableSet(std::make_shared<PlainVariables>(v.name, x.data() + v.offset, v.size));
+  }
+  for (auto& c : device_sets) nlp.AddConstraintSet(c);
+  expect(nlp.GetNumberOfOptimizationVariables() == sz.n_vars, "variable count");
+  expect(nlp.GetNumberOfConstraints() == sz.n_rows, "constraint count");
+  expect(static_cast<int>(device_sets.size()) == sz.n_con_sets, "one ifopt set per constraint set");
+  for (int i = 0; i < sz.n_con_sets; ++i) {
+    twr_set_info c;
+    twr_structure_con_set(S, i, &c);
+    expect(device_sets[i]->GetName() == c.name && device_sets[i]->GetRows() == c.size, "component name / rows");
+  }
+
+  // Ipopt: eval_g
+  x[3] += 1e-3;  // a new x through Problem::SetVariables, not the one the sets were created at
+  expect(twr_batch_eval_host(B, x.data(), g_ref.data(), j_ref.data(), TWR_EVAL_BOTH) == TWR_OK, "twr_batch_eval_host");
+  ifopt::Problem::VectorXd g = nlp.EvaluateConstraints(x.data());
+  double dg = 0;
+  for (int i = 0; i < sz.n_rows; ++i) dg = std::fmax(dg, std::fabs(g[i] - g_ref[i]));
+  expect(dg == 0.0, "stacked GetValues equals the direct evaluation");
+  // Ipopt: eval_jac_g structure + values
+  ifopt::Problem::Jacobian jac = nlp.GetJacobianOfConstraints();
+  jac.makeCompressed();
+  expect(jac.nonZeros() == sz.nnz, "nnz of the stacked Jacobian (explicit zeros kept)");
+  const int32_t* rp = twr_structure_row_ptr(S);
+  const int32_t* ci = twr_structure_col_idx(S);
+  bool pattern = jac.nonZeros() == sz.nnz;
+  for (int r = 0; pattern && r <= sz.n_rows; ++r) pattern = jac.outerIndexPtr()[r] == rp[r];
+  for (int k = 0; pattern && k < sz.nnz; ++k) pattern = jac.innerIndexPtr()[k] == ci[k];
+  expect(pattern, "CSR pattern equals twr_structure_row_ptr / col_idx");
+  std::vector<double> vals(sz.nnz);
+  nlp.EvalNonzerosOfJacobian(x.data(), vals.data());
+  double dj = 0;
+  for (int k = 0; k < sz.nnz; ++k) dj = std::fmax(dj, std::fabs(vals[k] - j_ref[k]));
+  expect(dj == 0.0, "EvalNonzerosOfJacobian equals the direct evaluation");
+  // bounds
+  ifopt::Problem::VecBound b = nlp.GetBoundsOnConstraints();
+  bool bounds = static_cast<int>(b.size()) == sz.n_rows;
+  for (int r = 0; bounds && r < sz.n_rows; ++r) bounds = b[r].lower_ == lo[r] && b[r].upper_ == up[r];
+  expect(bounds, "GetBounds equals twr_structure_bounds");
+
+  std::printf("hopper through ifopt: n=%d m=%d nnz=%d sets=%d  max|dg|=%g max|dJ|=%g  %s\n", sz.n_vars, sz.n_rows, sz.nnz,
+              sz.n_con_sets, dg, dj, fails ? "FAILED" : "ok");
+  twr_batch_destroy(B);
+  twr_structure_destroy(S);
+  return fails ? 1 : 0;
+}

@@ -1,0 +1,44 @@
+"""BASELINE config 1 (towr/test/hopper_example.cc: monoped hop, flat terrain, CPU-Ipopt plumbing) through the ifopt
+adapter.  ifopt and Eigen are absent from this image, so towr_amd/csrc/ifopt_adapter.h is compiled against
+tests/ifopt_stub/ -- stand-ins for exactly the surface SURVEY.md App. C lists (test infrastructure) -- and driven the
+way ifopt::Problem drives constraint sets for Ipopt (tests/ifopt_stub/hopper_adapter_test.cc)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUB = os.path.join(ROOT, "tests", "ifopt_stub")
+EXE = os.path.join(ROOT, "tests", "ifopt_stub", "_build", "hopper_adapter_test")
+
+
+def _build():
+    os.makedirs(os.path.dirname(EXE), exist_ok=True)
+    src = os.path.join(STUB, "hopper_adapter_test.cc")
+    deps = [src, os.path.join(ROOT, "towr_amd", "csrc", "ifopt_adapter.h"), os.path.join(ROOT, "include", "towr_amd.h"),
+            os.path.join(ROOT, "towr_amd", "libtowr_amd.so")]
+    if os.path.exists(EXE) and all(os.path.getmtime(EXE) >= os.path.getmtime(d) for d in deps):
+        return
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + STUB,
+                           "-I" + os.path.join(ROOT, "include"), "-o", EXE, src, "-L" + os.path.join(ROOT, "towr_amd"),
+                           "-ltowr_amd", "-Wl,-rpath," + os.path.join(ROOT, "towr_amd")])
+
+
+def test_adapter_compiles_warning_free_and_fails_loudly_without_a_gpu():
+    import torch
+
+    _build()
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    r = subprocess.run([EXE, "--no-gpu"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "no HIP device" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sets", [63, 127, 27], ids=["towr_default", "optimised_timings", "hot_path"])
+def test_hopper_through_the_ifopt_surface(sets):
+    """MakeDeviceConstraints -> GetValues / GetBounds / GetJacobian of every set == twr_batch_eval_host, stacked."""
+    _build()
+    r = subprocess.run([EXE, "--gpu", str(sets)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "max|dg|=0 max|dJ|=0" in r.stdout and " ok" in r.stdout, r.stdout

@@ -3,8 +3,10 @@
 // it instantiates (INTEGRATION.md shows the three-line change in nlp_formulation.cc).
 //
 // COMPILE-GATED: needs <ifopt/constraint_set.h> and Eigen, which this build image does not have
-// (SURVEY.md section 0); the core library and its tests do not depend on this header.  It is the only
-// C++/Eigen-typed code on top of the C ABI of include/towr_amd.h.
+// (SURVEY.md section 0); the core library does not depend on this header.  It is the only C++/Eigen-typed
+// code on top of the C ABI of include/towr_amd.h.  In this image it is compiled (-Wall -Werror) and run on the
+// hopper problem against tests/ifopt_stub/ (stand-ins for exactly the ifopt/Eigen surface of SURVEY App. C):
+// tests/test_ifopt_adapter.py.
 //
 // Replaces (same component names, same row order, same Jacobian pattern incl. explicit zeros):
 //   towr::TerrainConstraint        "terrain-ee-motion_<ee>"   towr/src/terrain_constraint.cc:36-108
@@ -94,6 +96,21 @@ class DeviceConstraintSet : public ifopt::ConstraintSet {
       twr_structure_var_set(problem_->structure(), i, &v);
       var_sets_.push_back(v);
     }
+    // Where the values of (this set's row r) x (variable set v) sit in the CSR value array: the columns of a
+    // row ascend and a variable set is a contiguous column range, so it is one sub-range per row, found once
+    // here instead of re-walking the whole pattern on every FillJacobianBlock call.
+    const int32_t* row_ptr = twr_structure_row_ptr(problem_->structure());
+    const int32_t* col_idx = twr_structure_col_idx(problem_->structure());
+    ranges_.assign(var_sets_.size(), std::vector<int32_t>(2 * (size_t)info_.size, 0));
+    for (int r = 0; r < info_.size; ++r) {
+      int k = row_ptr[info_.offset + r];
+      const int end = row_ptr[info_.offset + r + 1];
+      for (size_t v = 0; v < var_sets_.size(); ++v) {
+        ranges_[v][2 * r] = k;
+        while (k < end && col_idx[k] < var_sets_[v].offset + var_sets_[v].size) ++k;
+        ranges_[v][2 * r + 1] = k;
+      }
+    }
   }
 
   VectorXd GetValues() const override {
@@ -110,18 +127,15 @@ class DeviceConstraintSet : public ifopt::ConstraintSet {
 
   void FillJacobianBlock(std::string var_set, Jacobian& jac) const override {
     problem_->Update(GetVariables()->GetValues());
-    const twr_set_info* vs = nullptr;
-    for (const auto& v : var_sets_)
-      if (var_set == v.name) vs = &v;
-    if (!vs) return;  // a variable set this structure does not know (e.g. "ee-schedule<i>" with fixed timings)
-    const int32_t* row_ptr = twr_structure_row_ptr(problem_->structure());
+    size_t v = 0;
+    while (v < var_sets_.size() && var_set != var_sets_[v].name) ++v;
+    if (v == var_sets_.size()) return;  // a variable set this structure does not know (e.g. "ee-schedule<i>" with fixed timings)
     const int32_t* col_idx = twr_structure_col_idx(problem_->structure());
     const double* val = problem_->jac();
+    const int32_t* range = ranges_[v].data();
     for (int r = 0; r < info_.size; ++r)
-      for (int k = row_ptr[info_.offset + r]; k < row_ptr[info_.offset + r + 1]; ++k) {
-        int c = col_idx[k] - vs->offset;
-        if (c >= 0 && c < vs->size) jac.coeffRef(r, c) = val[k];  // explicit zeros kept, like the reference
-      }
+      for (int k = range[2 * r]; k < range[2 * r + 1]; ++k)
+        jac.coeffRef(r, col_idx[k] - var_sets_[v].offset) = val[k];  // explicit zeros kept, like the reference
   }
 
  private:
@@ -133,6 +147,7 @@ class DeviceConstraintSet : public ifopt::ConstraintSet {
   std::shared_ptr<DeviceProblem> problem_;
   twr_set_info info_{};
   std::vector<twr_set_info> var_sets_;
+  std::vector<std::vector<int32_t>> ranges_;  // [variable set][2 * row + {begin, end}] into the CSR value array
 };
 
 // All device sets of one problem (twr_params.constraint_sets), in the reference's relative order.
