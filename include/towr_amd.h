@@ -42,7 +42,12 @@ enum { TWR_TERRAIN_FLAT = 0, TWR_TERRAIN_BLOCK, TWR_TERRAIN_STAIRS, TWR_TERRAIN_
        TWR_TERRAIN_CHIMNEY, TWR_TERRAIN_CHIMNEY_LR,
        /* HeightMapFromCSV (include/towr/terrain/height_map_from_csv.h): a gridded terrain, heights per 0.17 m
          * cell; needs a twr_terrain_grid handle, see twr_structure_create_with_grid */
-       TWR_TERRAIN_CSV_GRID };
+       TWR_TERRAIN_CSV_GRID,
+       /* Grid (include/towr/terrain/grid_height_map.h:15-60): the perception-driven terrain fpowr hands the solver
+        * (fpowr/src/footstep_plan_server.cc:155) -- the float "elevation" layer of a ROS grid_map, bilinear
+        * sample, central-difference slopes over resolution/6, FLT_MAX outside the map; needs a handle made by
+        * twr_terrain_grid_map_create, see twr_structure_create_with_grid */
+       TWR_TERRAIN_GRID_MAP };
 enum { TWR_EVAL_VALUES = 1, TWR_EVAL_JACOBIAN = 2, TWR_EVAL_BOTH = 3,
        /* also run the per-problem NaN/Inf scan over the outputs of this evaluation (twr_batch_status) */
        TWR_EVAL_CHECK = 4 };
@@ -151,8 +156,17 @@ int twr_structure_create(const twr_model* model, const twr_schedule* schedule, c
  * Structures keep a reference to the grid (it may be destroyed right after they are created); a batch
  * uploads every distinct grid once. */
 int twr_terrain_grid_create(const double* heights, int rows, int cols, twr_terrain_grid** out);
+/* The "elevation" layer of a grid_map::GridMap for TWR_TERRAIN_GRID_MAP: elevation[i + j * size_x] is cell (i, j)
+ * (the column-major float matrix grid_map keeps; i runs along -x, j along -y from the corner with the largest x
+ * and y), cell size `resolution`, map centre (pos_x, pos_y) = GridMap::getPosition(); the map must have start
+ * index (0,0) (GridMap::convertToDefaultStartIndex()).  Sampling follows grid_map's published
+ * atPosition(..., INTER_LINEAR): bilinear over the 2x2 cells around the position, nearest cell in the half-cell
+ * border band, std::out_of_range (-> FLT_MAX in Grid::GetHeight) outside the map. */
+int twr_terrain_grid_map_create(const float* elevation, int size_x, int size_y, double resolution, double pos_x,
+                                double pos_y, twr_terrain_grid** out);
 void twr_terrain_grid_destroy(twr_terrain_grid* g);
-/* As twr_structure_create for model->terrain_id == TWR_TERRAIN_CSV_GRID. */
+/* As twr_structure_create for model->terrain_id == TWR_TERRAIN_CSV_GRID / TWR_TERRAIN_GRID_MAP (the grid must be
+ * of the matching kind). */
 int twr_structure_create_with_grid(const twr_model* model, const twr_schedule* schedule, const twr_params* params,
                                    const twr_terrain_grid* grid, twr_structure** out);
 void twr_structure_destroy(twr_structure* s);

@@ -18,7 +18,8 @@ SETS_TOWR_DEFAULT = 63          # + splineacc-base-lin/-ang (4) and swing-* (32)
 SET_BASE_ROM = 128              # BaseMotionConstraint ("baseMotion"), only when a caller pushes Parameters::BaseRom
 SET_TOTAL_TIME = 64             # OptimizePhaseDurations(): ee-schedule_e variables, PhaseSplines, totalduration-e
 ROBOTS = {"monoped": 0, "biped": 1, "hyq": 2, "anymal": 3, "go1": 4}
-TERRAINS = {"flat": 0, "block": 1, "stairs": 2, "gap": 3, "slope": 4, "chimney": 5, "chimney_lr": 6, "csv": 7}
+TERRAINS = {"flat": 0, "block": 1, "stairs": 2, "gap": 3, "slope": 4, "chimney": 5, "chimney_lr": 6, "csv": 7,
+            "grid_map": 8}
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -68,6 +69,9 @@ def lib():
         L.orc_time_callbacks.restype = C.c_double
         L.orc_gait.argtypes = [C.c_int, C.c_int, C.c_double, _ip, _ip, _dp, C.c_int]
         L.orc_gait.restype = C.c_int
+        L.orc_set_grid_map.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
+        L.orc_set_grid_map.restype = C.c_int
+        L.orc_terrain_probe.argtypes = [C.c_void_p, C.c_double, C.c_double, _dp]
         L.orc_hermite_weights.argtypes = [C.c_double, C.c_double, _dp]
         L.orc_terrain_height.argtypes = [C.c_int, C.c_double, C.c_double]
         L.orc_terrain_height.restype = C.c_double
@@ -103,7 +107,7 @@ def gait(n_ee, combo, t_total):
 class OracleProblem:
     def __init__(self, robot, terrain, phase_durations, contact_at_start, dt_dynamic=0.1, dt_rom=0.08,
                  duration_base_poly=0.1, polys_per_swing=2, polys_per_stance_force=3, force_limit=1000.0,
-                 constraint_sets=SETS_HOT_PATH, dt_base_motion=None, base_z_init=0.0, grid=None):
+                 constraint_sets=SETS_HOT_PATH, dt_base_motion=None, base_z_init=0.0, grid=None, grid_map=None):
         robot = ROBOTS[robot] if isinstance(robot, str) else robot
         terrain = TERRAINS[terrain] if isinstance(terrain, str) else terrain
         n_ee = len(phase_durations)
@@ -119,6 +123,12 @@ class OracleProblem:
         if not self._h:
             raise RuntimeError("orc_create failed")
         L = lib()
+        if grid_map is not None:   # (elevation[size_x, size_y] float32, resolution, (pos_x, pos_y)) of the `Grid` terrain
+            elev, res, pos = grid_map
+            self._gm = np.asfortranarray(elev, dtype=np.float32)   # grid_map's column-major storage
+            if L.orc_set_grid_map(self._h, self._gm.ctypes.data_as(C.POINTER(C.c_float)), self._gm.shape[0],
+                                  self._gm.shape[1], float(res), float(pos[0]), float(pos[1])) != 0:
+                raise RuntimeError("orc_set_grid_map failed")
         self.n_ee = n_ee
         self.n = L.orc_n_vars(self._h)
         self.m = L.orc_n_rows(self._h)
@@ -181,6 +191,12 @@ class OracleProblem:
         out = np.zeros((n, 20 + 13 * self.n_ee))
         lib().orc_sample_trajectory(self._h, _d(x), float(dt), _d(out), n)
         return out
+
+    def terrain_probe(self, x, y):
+        """(height, dh/dx, dh/dy) of the problem's terrain."""
+        o = np.zeros(3)
+        lib().orc_terrain_probe(self._h, float(x), float(y), _d(o))
+        return o
 
     def bounds(self):
         lo, up = np.zeros(self.m), np.zeros(self.m)

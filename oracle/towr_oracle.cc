@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <memory>
 #include <numeric>
@@ -2042,6 +2043,21 @@ void orc_hermite_weights(double t, double T, double w[12]) {
     w[i++] = p.DerivWrtEndNode(d, kPos, t);
     w[i++] = p.DerivWrtEndNode(d, kVel, t);
   }
+}
+int orc_set_grid_map(orc_problem* P, const float* elevation, int size_x, int size_y, double resolution, double pos_x,
+                     double pos_y) {
+  if (!P || !elevation || size_x < 1 || size_y < 1 || !(resolution > 0) || P->terrain->id != 8) return -1;
+  HeightMap& t = *P->terrain;
+  t.gm.assign(elevation, elevation + (size_t)size_x * size_y);
+  t.gm_sx = size_x; t.gm_sy = size_y;
+  t.gm_res = resolution; t.gm_px = pos_x; t.gm_py = pos_y;
+  t.gm_eps = resolution / 6.0;   // ref: grid_height_map.h:25
+  return 0;
+}
+void orc_terrain_probe(const orc_problem* P, double x, double y, double out[3]) {
+  out[0] = P->terrain->GetHeight(x, y);
+  out[1] = P->terrain->GetDerivativeOfHeightWrt(X, x, y);
+  out[2] = P->terrain->GetDerivativeOfHeightWrt(Y, x, y);
 }
 double orc_terrain_height(int terrain, double x, double y) { return HeightMap(terrain).GetHeight(x, y); }
 void orc_terrain_basis(int terrain, int which, double x, double y, double out[3]) {

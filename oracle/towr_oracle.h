@@ -28,6 +28,7 @@ typedef struct orc_problem orc_problem;
 // robot: 0 Monoped, 1 Biped, 2 Hyq, 3 Anymal, 4 Go1   (towr/src/robot_model.cc:41-68)
 // terrain: 0 Flat,1 Block,2 Stairs,3 Gap,4 Slope,5 Chimney,6 ChimneyLR (height_map.h:79-86),
 //          7 HeightMapFromCSV with the grid passed to orc_create (terrain/height_map_from_csv.h)
+//          8 Grid (terrain/grid_height_map.h), see orc_set_grid_map
 // phase_durations: concatenated per-ee phase durations, n_phases[ee] entries each.
 orc_problem* orc_create(int robot, int terrain, int n_ee, const int* n_phases,
                         const double* phase_durations, const int* in_contact_at_start,
@@ -37,6 +38,14 @@ orc_problem* orc_create(int robot, int terrain, int n_ee, const int* n_phases,
                         double dt_base_motion /* parameters.cc:51 */, double base_z_init /* base_motion_constraint.cc:51 */,
                         const double* grid /* terrain 7 (HeightMapFromCSV): rows x cols heights, grid[y_cell][x_cell] */,
                         int grid_rows, int grid_cols);
+// terrain 8 = the fork's `Grid` height map (include/towr/terrain/grid_height_map.h:15-60): create the problem with
+// terrain 8, then hand over the "elevation" layer of the grid_map before the first evaluation / initial guess:
+// elevation[i + j * size_x] (column-major float matrix, as grid_map stores it; start index (0,0)), cell size
+// `resolution`, map centre (pos_x, pos_y).  Returns 0, or -1 on bad arguments.
+int orc_set_grid_map(orc_problem*, const float* elevation, int size_x, int size_y, double resolution, double pos_x,
+                     double pos_y);
+// height and the two slopes of the problem's terrain at (x, y)
+void orc_terrain_probe(const orc_problem*, double x, double y, double out[3]);
 // constraint_sets: which of the default sets (parameters.cc:55-60) to build, in that order
 enum {
   ORC_SET_TERRAIN = 1, ORC_SET_DYNAMIC = 2, ORC_SET_BASE_ACC = 4, ORC_SET_ROM = 8, ORC_SET_FORCE = 16,

@@ -72,6 +72,8 @@ class Case:
         self.params = ta.params_default(**params)
         self.model = ta.model_preset(robot, terrain)
         # gridded terrain (HeightMapFromCSV): `grid` is heights[y_cell, x_cell] or an existing ta.TerrainGrid
+        if isinstance(grid, tuple):       # (elevation[size_x, size_y], resolution, (pos_x, pos_y)): the `Grid` terrain
+            grid = ta.GridMap(*grid)
         self.grid = ta.TerrainGrid(grid) if isinstance(grid, np.ndarray) else grid
         self.S = ta.Structure(self.model, sched, self.params, grid=self.grid)
         p = self.params
@@ -79,7 +81,10 @@ class Case:
                                   dt_rom=p.dt_rom, duration_base_poly=p.duration_base_poly,
                                   polys_per_swing=p.polys_per_swing, polys_per_stance_force=p.polys_per_stance_force,
                                   constraint_sets=p.constraint_sets, dt_base_motion=p.dt_base_motion,
-                                  base_z_init=p.base_z_init, grid=None if self.grid is None else self.grid.heights)
+                                  base_z_init=p.base_z_init,
+                                  grid=None if self.grid is None else self.grid.heights,
+                                  grid_map=(self.grid.elevation, self.grid.resolution, self.grid.position)
+                                  if isinstance(self.grid, ta.GridMap) else None)
 
     def nominal_start(self):
         m = self.model
@@ -158,6 +163,10 @@ def random_case(seed):
     robot = ["monoped", "biped", "hyq", "anymal", "go1"][rng.integers(5)]
     terrain = list(ta.TERRAINS)[rng.integers(len(ta.TERRAINS))]
     grid = np.round(rng.uniform(0.0, 0.25, size=(int(rng.integers(3, 25)), int(rng.integers(3, 25)))), 2) if terrain == "csv" else None
+    if terrain == "grid_map":   # a perception-like elevation patch; small enough that wild footholds also leave it
+        sx, sy = int(rng.integers(8, 60)), int(rng.integers(8, 40))
+        grid = (rng.uniform(-0.05, 0.3, size=(sx, sy)).astype(np.float32), float(rng.uniform(0.03, 0.12)),
+                (float(rng.uniform(0.5, 1.5)), float(rng.uniform(-0.3, 0.3))))
     n_ee = ta.model_preset(robot, terrain).n_ee
     T = float(rng.uniform(0.9, 3.0))
     mask = int(rng.integers(1, 256))

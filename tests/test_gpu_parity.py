@@ -519,3 +519,35 @@ def test_eval_check_flags_nonfinite_problems():
     # values only: the Jacobian is neither written nor scanned
     batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_VALUES | ta.EVAL_CHECK, st)
     assert (batch.status(st) & 2).sum() == 0
+
+
+def test_grid_map_terrain():
+    """`Grid` (grid_height_map.h:15-60), the terrain fpowr feeds the solver: float bilinear sample of the grid_map
+    elevation layer, central-difference slopes, FLT_MAX outside -- terrain and force rows vs the oracle, with footholds
+    in the interior, in the border band and outside the map (x_wild spreads them over [-0.5, 3] m)."""
+    from tests.test_oracle_golden import _planar_grid_map
+
+    rng = np.random.default_rng(5)
+    rough = (rng.uniform(-0.05, 0.3, size=(48, 36)).astype(np.float32), 0.05, (1.0, 0.1))
+    for gm, sets in ((_planar_grid_map(), 27), (rough, 63), (rough, 127)):
+        case = Case("go1", "grid_map", ta.gait_combo(4, 1, 2.0), grid=gm, constraint_sets=sets)
+        xs = [case.x_guess(1.6), case.x_perturbed(0, 1.6), case.x_perturbed(1, 1.2), case.x_wild(0), case.x_wild(1)]
+        batch, g, j = _eval_case(case, xs)
+        hit_outside = False
+        for p, x in enumerate(xs):
+            rg, _, _, rj = case.P.eval(x)
+            assert_parity(case.S, *_split(batch, g, j, p), rg, rj, "grid_map sets %d x[%d]" % (sets, p), x=x)
+            hit_outside |= bool((np.abs(rg) > 1e37).any())
+        assert hit_outside, "the out-of-range branch (FLT_MAX) must be exercised"
+    # two structures that share one map and one that has another: every distinct map is uploaded once
+    other = (rough[0][::-1].copy(), 0.05, (1.0, 0.1))
+    c1 = Case("anymal", "grid_map", ta.gait_combo(4, 0, 1.6), grid=rough)
+    c2 = Case("anymal", "grid_map", ta.gait_combo(4, 2, 2.2), grid=c1.grid)
+    c3 = Case("anymal", "grid_map", ta.gait_combo(4, 1, 2.0), grid=other)
+    cases = [c1, c2, c3]
+    batch = ta.Batch([c.S for c in cases], [0, 1, 2, 1], device=0)
+    xs = [cases[s].x_perturbed(7 + i, 1.5) for i, s in enumerate([0, 1, 2, 1])]
+    g, j = batch.eval_host(np.concatenate(xs))
+    for p, s in enumerate([0, 1, 2, 1]):
+        rg, _, _, rj = cases[s].P.eval(xs[p])
+        assert_parity(cases[s].S, *_split(batch, g, j, p), rg, rj, "shared map problem %d" % p)

@@ -413,3 +413,48 @@ def test_oracle_jacobian_vs_finite_differences(robot, terrain, n_ee, combo, T):
     qm[rows[qk], ci[qk]] = True
     err = np.abs(J - Jfd) / np.maximum(1.0, np.abs(Jfd))
     assert err[~qm].max() < 2e-5
+
+
+def _planar_grid_map(sx=40, sy=30, res=0.05, pos=(1.0, 0.2), a=0.3, b=-0.2, c=0.1):
+    """elevation[i, j] of the plane h = a x + b y + c at grid_map's cell centres (x falls with i, y falls with j)."""
+    i = np.arange(sx)[:, None]
+    j = np.arange(sy)[None, :]
+    cx = pos[0] + 0.5 * sx * res - (i + 0.5) * res
+    cy = pos[1] + 0.5 * sy * res - (j + 0.5) * res
+    return (a * cx + b * cy + c).astype(np.float32), res, pos
+
+
+def test_grid_map_terrain_known_answers():
+    """`Grid` (include/towr/terrain/grid_height_map.h:15-60) over grid_map's published atPosition(INTER_LINEAR):
+    bilinear sampling reproduces a plane exactly (up to the float the reference stores the height in), cell centres
+    return the cell, the half-cell border band falls back to the nearest cell, outside is FLT_MAX; slopes are central
+    float differences over eps = resolution / 6."""
+    el, res, pos = _planar_grid_map()
+    P = ob.OracleProblem("anymal", "grid_map", *ob.gait(4, 1, 2.0), grid_map=(el, res, pos))
+    f32 = np.float32
+    # interior: the plane, rounded to float; slopes exact to float resolution of the heights / (2 eps)
+    for x, y in [(1.0, 0.2), (0.3, 0.0), (1.93, 0.5), (0.52, -0.31), (1.2345, 0.4321)]:
+        h, hx, hy = P.terrain_probe(x, y)
+        want = 0.3 * x - 0.2 * y + 0.1
+        assert abs(h - want) <= 1e-6 and h == float(f32(h))          # a float, widened
+        assert abs(hx - 0.3) <= 2e-5 and abs(hy + 0.2) <= 2e-5
+    # a cell centre returns that cell's value (weights 1,0,0,0)
+    cx = pos[0] + 0.5 * 40 * res - (7 + 0.5) * res
+    cy = pos[1] + 0.5 * 30 * res - (11 + 0.5) * res
+    assert abs(P.terrain_probe(cx, cy)[0] - float(el[7, 11])) <= 1e-7
+    # border band (less than half a cell from the map edge): nearest cell, hence zero slope (eps < half a cell)
+    h, hx, hy = P.terrain_probe(0.01, -0.54)
+    assert h == float(el[39, 29]) and hx == 0.0 and hy == 0.0
+    h, hx, hy = P.terrain_probe(1.99, 0.94)
+    assert h == float(el[0, 0]) and hx == 0.0 and hy == 0.0
+    # outside: numeric_limits<float>::max(); FLT_MAX - FLT_MAX = 0 slope; at the edge one side is inside
+    fmax = float(np.finfo(np.float32).max)
+    assert tuple(P.terrain_probe(2.1, 0.0)) == (fmax, 0.0, 0.0)
+    h, hx, hy = P.terrain_probe(0.0, 0.0)        # x = lower edge: position - length/2 hits the half-open bound
+    assert h == fmax and hx < -1e39 and hy == 0.0
+    # a 2x2 map: the bilinear weights at the centre are 1/4 each, evaluated in double, rounded to float
+    el2 = np.array([[1.0, 2.0], [4.0, 8.0]], dtype=np.float32)
+    P2 = ob.OracleProblem("monoped", "grid_map", [[0.4, 0.2, 0.4]], [1], grid_map=(el2, 1.0, (0.0, 0.0)))
+    assert P2.terrain_probe(0.0, 0.0)[0] == 3.75
+    # x = 0.25: cells i=0 (x centre +0.5) and i=1 (x centre -0.5): rx = 0.75 towards i=0
+    assert P2.terrain_probe(0.25, 0.0)[0] == float(f32(0.5 * (0.75 * (1 + 2) + 0.25 * (4 + 8))))

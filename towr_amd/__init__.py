@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libtowr_amd.so")
 
 MAX_EE, MAX_PHASES, NAME_LEN = 4, 32, 40
 ROBOTS = {"monoped": 0, "biped": 1, "hyq": 2, "anymal": 3, "go1": 4}
-TERRAINS = {"flat": 0, "block": 1, "stairs": 2, "gap": 3, "slope": 4, "chimney": 5, "chimney_lr": 6, "csv": 7}
+TERRAINS = {"flat": 0, "block": 1, "stairs": 2, "gap": 3, "slope": 4, "chimney": 5, "chimney_lr": 6, "csv": 7,
+            "grid_map": 8}
 EVAL_VALUES, EVAL_JACOBIAN, EVAL_BOTH, EVAL_CHECK = 1, 2, 3, 4
 SET_TERRAIN, SET_DYNAMIC, SET_BASE_ACC, SET_ROM, SET_FORCE, SET_SWING, SET_TOTAL_TIME = 1, 2, 4, 8, 16, 32, 64
 SET_BASE_ROM = 128
@@ -100,6 +101,8 @@ def lib():
                                            C.POINTER(C.c_void_p)]
         L.twr_structure_destroy.argtypes = [C.c_void_p]
         L.twr_terrain_grid_create.argtypes = [_dp, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.twr_terrain_grid_map_create.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                                  C.POINTER(C.c_void_p)]
         L.twr_terrain_grid_destroy.argtypes = [C.c_void_p]
         L.twr_structure_create_with_grid.argtypes = [C.POINTER(Model), C.POINTER(Schedule), C.POINTER(Params), C.c_void_p,
                                                      C.POINTER(C.c_void_p)]
@@ -195,6 +198,22 @@ class TerrainGrid:
         if getattr(self, "_h", None) and lib is not None:
             lib().twr_terrain_grid_destroy(self._h)
             self._h = None
+
+
+class GridMap(TerrainGrid):
+    """The "elevation" layer of a ROS grid_map for the `Grid` terrain (TWR_TERRAIN_GRID_MAP):
+    elevation[i, j] float32 with i along -x and j along -y (grid_map's index convention, start index (0,0)),
+    cell size `resolution`, map centre `position`."""
+
+    def __init__(self, elevation, resolution, position=(0.0, 0.0)):
+        a = np.asfortranarray(elevation, dtype=np.float32)   # grid_map's Eigen::MatrixXf is column-major
+        assert a.ndim == 2
+        self._h = C.c_void_p()
+        _check(lib().twr_terrain_grid_map_create(a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[0], a.shape[1],
+                                                 float(resolution), float(position[0]), float(position[1]),
+                                                 C.byref(self._h)))
+        self.elevation, self.resolution, self.position = a, float(resolution), (float(position[0]), float(position[1]))
+        self.heights = None
 
 
 class Structure:

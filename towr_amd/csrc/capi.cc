@@ -164,6 +164,27 @@ int twr_terrain_grid_create(const double* heights, int rows, int cols, twr_terra
     return fail(TWR_ERR_INVALID, e.what());
   }
 }
+int twr_terrain_grid_map_create(const float* elevation, int size_x, int size_y, double resolution, double pos_x,
+                                double pos_y, twr_terrain_grid** out) {
+  if (!elevation || !out || size_x < 1 || size_y < 1 || !(resolution > 0) || !std::isfinite(pos_x) || !std::isfinite(pos_y))
+    return fail(TWR_ERR_INVALID, "bad grid map");
+  try {
+    std::unique_ptr<twr_terrain_grid> h(new twr_terrain_grid());
+    h->g = std::make_shared<twr::TerrainGrid>();
+    h->g->grid_map = true;
+    h->g->elevation.assign(elevation, elevation + (size_t)size_x * size_y);
+    h->g->rows = size_x;
+    h->g->cols = size_y;
+    h->g->res = resolution;
+    h->g->eps = resolution / 6.0;  // grid_height_map.h:25
+    h->g->pos_x = pos_x;
+    h->g->pos_y = pos_y;
+    *out = h.release();
+    return TWR_OK;
+  } catch (const std::exception& e) {
+    return fail(TWR_ERR_INVALID, e.what());
+  }
+}
 void twr_terrain_grid_destroy(twr_terrain_grid* g) { delete g; }
 
 int twr_structure_create(const twr_model* model, const twr_schedule* schedule, const twr_params* params,
@@ -313,8 +334,10 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
         for (size_t q = 0; q < host_grids.size(); ++q)
           if (host_grids[q] == tg) dg = b->grids[q];
         if (!dg) {
-          TWR_HIP(hipMalloc(&dg, tg->heights.size() * sizeof(double)));
-          TWR_HIP(hipMemcpy(dg, tg->heights.data(), tg->heights.size() * sizeof(double), hipMemcpyHostToDevice));
+          const void* src = tg->grid_map ? (const void*)tg->elevation.data() : (const void*)tg->heights.data();
+          const size_t bytes = tg->grid_map ? tg->elevation.size() * sizeof(float) : tg->heights.size() * sizeof(double);
+          TWR_HIP(hipMalloc(&dg, bytes));
+          TWR_HIP(hipMemcpy(dg, src, bytes, hipMemcpyHostToDevice));
           host_grids.push_back(tg);
           b->grids.push_back(dg);
         }

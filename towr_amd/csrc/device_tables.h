@@ -167,12 +167,14 @@ struct DevStruct {
   uint32_t o_phase;
   int32_t row_bm, nnz_bm, n_bm_nodes;  // baseMotion: 6 rows x 4 values per time node
   uint32_t o_bm;        // BaseNode[n_bm_nodes]
-  // gridded terrain (HeightMapFromCSV): device address of heights[rows][cols] (patched in by the batch)
+  // gridded terrain: device address of the cell data (patched in by the batch) -- HeightMapFromCSV: double
+  // heights[rows][cols]; Grid (grid_map): float elevation[i + j * rows], rows = size_x, cols = size_y
   uint64_t grid_ptr;
   int32_t grid_rows, grid_cols;
   double grid_res, grid_eps;
   uint32_t o_sample;    // SampleTables
   uint32_t pad2_;
+  double grid_px, grid_py;  // Grid: map centre
 };
 
 // Work items: one contiguous run of time nodes of one constraint set of one problem.  All

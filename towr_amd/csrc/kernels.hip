@@ -742,10 +742,49 @@ TWR_DEV Terr grid_eval(const DevStruct* __restrict__ S, double x, double y) {
   }
   return t;
 }
+// Grid (include/towr/terrain/grid_height_map.h:15-60) over the float "elevation" layer of a ROS grid_map.
+// gridmap_sample = grid_map's published GridMap::atPosition(layer, position, INTER_LINEAR) for a map with start
+// index (0,0) (third party, absent and unpinned in the reference: restated from its published algorithm --
+// atPositionLinearInterpolated, GridMapMath getIndexFromPosition / getPositionFromIndex / checkIfPositionWithinMap):
+// cell (i,j) centre = map position + length/2 - (index + 1/2) res; index = trunc((position + length/2 - p) / res);
+// bilinear over the 2x2 cells around p evaluated in double and rounded to FLOAT; if one of the four cells lies outside
+// the map: the nearest cell when p is inside the map, otherwise std::out_of_range, which Grid::GetHeight turns into
+// numeric_limits<float>::max() (:41-45).
+TWR_DEV float gridmap_sample(const DevStruct* __restrict__ S, double x, double y) {
+  const float* __restrict__ el = reinterpret_cast<const float*>(S->grid_ptr);
+  const int sx = S->grid_rows, sy = S->grid_cols;
+  const double res = S->grid_res, lx = sx * res, ly = sy * res, mx = S->grid_px, my = S->grid_py;
+  const long i0 = (long)(-((x - 0.5 * lx - mx) / res)), j0 = (long)(-((y - 0.5 * ly - my) / res));
+  const double tx = mx + 0.5 * lx - x, ty = my + 0.5 * ly - y;
+  const bool inside = tx >= 0.0 && ty >= 0.0 && tx < lx && ty < ly;
+  const double cx0 = mx + 0.5 * lx - 0.5 * res - res * (double)i0, cy0 = my + 0.5 * ly - 0.5 * res - res * (double)j0;
+  const long ia = x >= cx0 ? i0 : i0 + 1, ja = y >= cy0 ? j0 : j0 + 1, ib = ia - 1, jb = ja - 1;
+  if (ib >= 0 && jb >= 0 && ia < sx && ja < sy) {
+    const double px = mx + 0.5 * lx - 0.5 * res - res * (double)ia, py = my + 0.5 * ly - 0.5 * res - res * (double)ja;
+    const double rx = (x - px) / res, ry = (y - py) / res, fx = 1.0 - rx, fy = 1.0 - ry;
+    const double f0 = el[ia + ja * (long)sx], f1 = el[ib + ja * (long)sx], f2 = el[ia + jb * (long)sx], f3 = el[ib + jb * (long)sx];
+    // no FMA contraction: the reference's products and sums are separately rounded doubles
+    return (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(__dmul_rn(f0, fx), fy), __dmul_rn(__dmul_rn(f1, rx), fy)),
+                                      __dmul_rn(__dmul_rn(f2, fx), ry)),
+                            __dmul_rn(__dmul_rn(f3, rx), ry));
+  }
+  if (inside && i0 >= 0 && j0 >= 0 && i0 < sx && j0 < sy) return el[i0 + j0 * (long)sx];
+  return 3.402823466e+38f;  // numeric_limits<float>::max()
+}
+TWR_DEV Terr gridmap_eval(const DevStruct* __restrict__ S, double x, double y) {
+  Terr t = {0.0, 0.0, 0.0, 0.0};
+  const double eps = S->grid_eps;
+  t.h = (double)gridmap_sample(S, x, y);
+  // grid_height_map.h:48-60: the two heights are floats, their difference is a float, the quotient a double
+  t.hx = (double)(gridmap_sample(S, x + eps, y) - gridmap_sample(S, x - eps, y)) / (2 * eps);
+  t.hy = (double)(gridmap_sample(S, x, y + eps) - gridmap_sample(S, x, y - eps)) / (2 * eps);
+  return t;
+}
 TWR_DEV Terr terrain_eval(const DevStruct* __restrict__ S, int id, double flat_height, double x, double y) {
   Terr t = {0.0, 0.0, 0.0, 0.0};
   switch (id) {
     case 7: return grid_eval(S, x, y);
+    case 8: return gridmap_eval(S, x, y);
     case 0: t.h = flat_height; break;
     case 1: {  // Block (height_map_examples.cc:40-65)
       const double start = 0.7, len = 3.5, height = 0.5, eps = 0.03, slope = height / eps;

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <limits>
 #include <numeric>
 #include <stdexcept>
 
@@ -726,12 +727,16 @@ void Structure::PackBlob() {
     h.timings = 1;
     h.o_phase = put(&pt, sizeof(pt));
   }
-  if (model.terrain_id == TWR_TERRAIN_CSV_GRID) {
-    if (!grid) throw std::runtime_error("TWR_TERRAIN_CSV_GRID needs twr_structure_create_with_grid");
+  if (model.terrain_id == TWR_TERRAIN_CSV_GRID || model.terrain_id == TWR_TERRAIN_GRID_MAP) {
+    if (!grid) throw std::runtime_error("gridded terrains need twr_structure_create_with_grid");
+    if (grid->grid_map != (model.terrain_id == TWR_TERRAIN_GRID_MAP))
+      throw std::runtime_error("the grid handle is of the other kind (CSV heights vs grid_map elevation layer)");
     h.grid_rows = grid->rows;
     h.grid_cols = grid->cols;
     h.grid_res = grid->res;
     h.grid_eps = grid->eps;
+    h.grid_px = grid->pos_x;
+    h.grid_py = grid->pos_y;
   }
   {  // trajectory sampling tables
     SampleTables st;
@@ -785,7 +790,30 @@ void Structure::Build() {
 // HeightMapFromCSV::GetHeight (include/towr/terrain/height_map_from_csv.h:29-37).  static_cast<size_t>(x / res)
 // truncates toward zero; a quotient <= -1 wraps to a huge size_t in the reference (formally undefined) and
 // fails the range check -- here a signed cell index that is invalid when negative.
+// Grid::GetHeight (include/towr/terrain/grid_height_map.h:29-46) over grid_map's published
+// atPosition(INTER_LINEAR) (restated in the device code, kernels.hip gridmap_sample; this host copy serves the
+// initial guess only): bilinear in double, rounded to float; nearest cell in the border band; FLT_MAX outside.
+static float GridMapSample(const TerrainGrid& g, double x, double y) {
+  const int sx = g.rows, sy = g.cols;
+  const double res = g.res, lx = sx * res, ly = sy * res;
+  auto in = [&](long i, long j) { return i >= 0 && j >= 0 && i < sx && j < sy; };
+  auto at = [&](long i, long j) { return g.elevation[(size_t)i + (size_t)j * (size_t)sx]; };
+  const long i0 = (long)(-((x - 0.5 * lx - g.pos_x) / res)), j0 = (long)(-((y - 0.5 * ly - g.pos_y) / res));
+  const double tx = g.pos_x + 0.5 * lx - x, ty = g.pos_y + 0.5 * ly - y;
+  const bool inside = tx >= 0.0 && ty >= 0.0 && tx < lx && ty < ly;
+  const double cx0 = g.pos_x + 0.5 * lx - 0.5 * res - res * (double)i0, cy0 = g.pos_y + 0.5 * ly - 0.5 * res - res * (double)j0;
+  const long ia = x >= cx0 ? i0 : i0 + 1, ja = y >= cy0 ? j0 : j0 + 1, ib = ia - 1, jb = ja - 1;
+  if (in(ia, ja) && in(ib, jb)) {
+    const double px = g.pos_x + 0.5 * lx - 0.5 * res - res * (double)ia, py = g.pos_y + 0.5 * ly - 0.5 * res - res * (double)ja;
+    const double rx = (x - px) / res, ry = (y - py) / res, fx = 1.0 - rx, fy = 1.0 - ry;
+    return (float)(at(ia, ja) * fx * fy + at(ib, ja) * rx * fy + at(ia, jb) * fx * ry + at(ib, jb) * rx * ry);
+  }
+  if (inside && in(i0, j0)) return at(i0, j0);
+  return std::numeric_limits<float>::max();
+}
+
 double TerrainGrid::Height(double x, double y) const {
+  if (grid_map) return GridMapSample(*this, x, y);
   const long xc = (long)(x / res), yc = (long)(y / res);
   if (xc < 0 || yc < 0 || xc >= cols || yc >= rows) return 0.0;
   return heights[(size_t)yc * cols + xc];
@@ -794,6 +822,7 @@ double TerrainGrid::Height(double x, double y) const {
 double TerrainHeightHost(const twr_model& m, const TerrainGrid* grid, double x, double y) {
   switch (m.terrain_id) {
     case TWR_TERRAIN_CSV_GRID:
+    case TWR_TERRAIN_GRID_MAP:
       if (!grid) throw std::runtime_error("gridded terrain without a grid");
       return grid->Height(x, y);
     case TWR_TERRAIN_FLAT: return m.flat_height;
@@ -973,7 +1002,7 @@ void ModelPreset(int robot, int terrain, twr_model* m) {
       break;
     default: throw std::runtime_error("unknown robot id");
   }
-  if (terrain < TWR_TERRAIN_FLAT || terrain > TWR_TERRAIN_CSV_GRID) throw std::runtime_error("unknown terrain id");
+  if (terrain < TWR_TERRAIN_FLAT || terrain > TWR_TERRAIN_GRID_MAP) throw std::runtime_error("unknown terrain id");
   m->terrain_id = terrain;
   m->gravity = 9.80665;     // dynamic_model.cc:37
   m->friction = 0.5;        // height_map.h:136

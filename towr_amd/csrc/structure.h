@@ -33,10 +33,13 @@ struct TimeNode {  // result of Spline::GetLocalTime for one spline at one grid 
   double t_local;
 };
 
-struct TerrainGrid {   // HeightMapFromCSV (include/towr/terrain/height_map_from_csv.h)
-  std::vector<double> heights;  // [y_cell * cols + x_cell]
-  int rows = 0, cols = 0;
-  double res = 0.17, eps = 0.17 / 50;  // :112-115
+struct TerrainGrid {   // HeightMapFromCSV (include/towr/terrain/height_map_from_csv.h) or Grid (grid_height_map.h)
+  std::vector<double> heights;  // CSV: [y_cell * cols + x_cell]
+  int rows = 0, cols = 0;       // CSV: rows x cols; grid_map: size_x x size_y cells
+  double res = 0.17, eps = 0.17 / 50;  // CSV :112-115; grid_map: resolution, resolution / 6 (grid_height_map.h:25)
+  bool grid_map = false;        // Grid: float elevation layer, column-major [i + j * size_x]
+  std::vector<float> elevation;
+  double pos_x = 0, pos_y = 0;  // GridMap::getPosition()
   double Height(double x, double y) const;
 };
 
