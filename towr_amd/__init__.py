@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtowr_amd.so")
+LIB_PATH = os.environ.get("TWR_AMD_LIB") or os.path.join(_HERE, "libtowr_amd.so")   # (override: diagnostic builds)
 
 MAX_EE, MAX_PHASES, NAME_LEN = 4, 32, 40
 ROBOTS = {"monoped": 0, "biped": 1, "hyq": 2, "anymal": 3, "go1": 4}

@@ -23,9 +23,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
 hipError_t launch_check(int n_problems, const int64_t* g_off, const int64_t* j_off, const double* g, const double* jac,
                         int32_t* status, int flags, hipStream_t stream);
 hipError_t launch_sample(const SampleWork* work, int n_work, const double* x, double* out, double dt, hipStream_t stream);
-int dyn_stage_capacity();
 int rom_stage_capacity();
-int dyn_nodes_per_block();
 }  // namespace twr
 
 struct twr_structure {
@@ -360,15 +358,11 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     size_t prec_bytes = 0;  // offsets into the scratch buffer are stored first and rebased after hipMalloc
     std::vector<int> dyn_first, rom_first;  // first work item of every problem (+ end)
     // run lists are identical for problems that share a structure: build once per structure
-    std::vector<std::vector<std::pair<int, int>>> runs_dyn(n_structs);
     std::vector<std::vector<std::vector<std::pair<int, int>>>> runs_rom(n_structs);
     for (int i = 0; i < n_structs; ++i) {
       const twr::Structure& S = structs[i]->s;
       // families that are switched off (twr_params.constraint_sets) simply have no work items
       if (S.timings) continue;  // optimised timings: PhaseWork items below
-      if (const twr::SetInfo* ds = S.FindSet("dynamic"))
-        runs_dyn[i] = chunk(S.row_ptr, ds->offset, 6, (int)S.grid_dyn.size(), twr::dyn_stage_capacity(),
-                            twr::dyn_nodes_per_block());
       for (int e = 0; e < S.n_ee; ++e)
         if (const twr::SetInfo* rs = S.FindSet("rangeofmotion-" + std::to_string(e)))
           runs_rom[i].push_back(chunk(S.row_ptr, rs->offset, 3, (int)S.grid_rom.size(), twr::rom_stage_capacity(), 64));
@@ -392,19 +386,19 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
       rom_first.push_back((int)rom.size());
       const twr::SetInfo* dsp = S.FindSet("dynamic");
       const twr::SetInfo ds = dsp ? *dsp : twr::SetInfo();
-      for (auto& r : runs_dyn[si]) {
+      for (const auto& sl : S.dyn_slices) {   // fixed timings only (empty otherwise)
         twr::DynWork w;
         std::memset(&w, 0, sizeof(w));
-        w.shared = blob + S.off_dyn_shared + sizeof(twr::DynShared) * (size_t)r.first;
-        w.lanes = blob + S.off_dyn_lanes + sizeof(twr::DynLane) * (size_t)r.first * S.n_ee;
+        w.nodes = blob + S.off_dyn_nodes + sizeof(twr::DynNode) * (size_t)sl.k0;
+        w.gather = blob + S.off_dyn_gather + sizeof(twr::DynGather) * (size_t)sl.k0 * 4;
+        w.put = blob + S.off_dyn_put + sizeof(twr::DynPut) * (size_t)sl.k0 * 4;
+        w.map = blob + sl.map;
         w.hdr = blob;
         w.x_off = b->x_off[p];
-        w.g_off = b->g_off[p] + ds.offset + 6 * r.first;
-        w.j_off = b->j_off[p] + S.row_ptr[ds.offset + 6 * r.first];
-        w.off_lin = S.off_base_lin;
-        w.off_ang = S.off_base_ang;
-        w.cnt = r.second;
-        w.nvals = S.row_ptr[ds.offset + 6 * (r.first + r.second)] - S.row_ptr[ds.offset + 6 * r.first];
+        w.g_off = b->g_off[p] + ds.offset + 6 * sl.k0;
+        w.j_off = b->j_off[p] + S.row_ptr[ds.offset + 6 * sl.k0];
+        w.cnt = sl.cnt;
+        w.nvals = sl.nvals;
         dyn.push_back(w);
       }
       for (int e = 0; e < (int)runs_rom[si].size(); ++e) {

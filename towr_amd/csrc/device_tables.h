@@ -62,6 +62,43 @@ struct DynLane {
 };
 static_assert(sizeof(DynLane) == 96, "DynLane layout");
 
+// ---- dynamic, fixed timings (dyn_kernel): everything index-like is resolved on the host, down to LDS byte offsets.
+// A slice (work item) is a run of <= 16 time nodes.  The wave first stages the slice's part of x in LDS ("xs":
+// a zero pair followed by <= 254 doubles, filled cooperatively from a per-slice index map), so that a lane
+// gets its node values with LDS reads instead of ~30 scattered global loads, and a value that is not an
+// optimisation variable simply reads the zero slot (no selects).
+constexpr int kDynImage = 2654;    // Jacobian values of one slice (LDS image, doubles)
+constexpr int kDynNodes = 16;      // time nodes per slice: four lanes each
+constexpr int kDynTrash0 = kDynImage + 2;   // image + parity slack, then a trash PAIR per lane (either parity)
+constexpr int kDynXsCap = 254;     // staged doubles per slice (8-bit staging indices 2..255; 0/1 = the zero pair)
+// per time node, shared by the four lanes of the quad (32 B)
+struct DynNode {
+  double tb, iTb;        // base spline: local time in the active polynomial, 1/duration
+  uint16_t sb_lin;       // byte offset inside xs of the active base-lin polynomial's first node value ([p0 v0 p1 v1] x 3)
+  uint16_t sb_ang;
+  uint16_t nb;           // byte offset of the node's first Jacobian value inside the slice image
+  uint16_t rs1, rs2;     // byte offsets of rows AY, AZ relative to the node's first value (AX = 0)
+  uint16_t rl[3];        // rows LX, LY, LZ
+};
+static_assert(sizeof(DynNode) == 32, "DynNode layout");
+// per (time node, role): what the front half needs (64 B).  Roles >= n_ee get a dummy record: every candidate reads
+// the zero slot and every store goes to the lane's trash pair.
+struct DynGather {
+  double tm, iTm, tf, iTf;
+  uint8_t idx_m[12], idx_f[12];  // staging index of candidate c = j*3+d (0 = constant zero)
+  uint32_t flags;                // bit 0: stance ee-motion polynomial (p1 shares p0's variable: w_p1 folds into w_p0)
+  uint32_t pad;
+};
+static_assert(sizeof(DynGather) == 64, "DynGather layout");
+// per (time node, role): where the end-effector tiles go (128 B).  Byte offsets relative to the node's first value;
+// a candidate that is not a variable points at the lane's trash pair behind the image.
+struct DynPut {
+  uint16_t m[12][2];   // [f]x J_p : rows (d+1)%3 and (d+2)%3 of the angular block
+  uint16_t f[12][3];   // {[r]x J_f ; -J_f}: the same two angular rows, then linear row d
+  uint16_t pad[4];
+};
+static_assert(sizeof(DynPut) == 128, "DynPut layout");
+
 struct ForceNode {   // one non-constant ee-force node (force_constraint.cc:50-60)
   int32_t fidx;      // x index of the node's force px (py = +2, pz = +4)
   int32_t hidx;      // x index of the stance foothold x (y = +1)
@@ -180,16 +217,18 @@ struct DevStruct {
 // Work items: one contiguous run of time nodes of one constraint set of one problem.  All
 // pointers / offsets are absolute so that a workgroup needs no header lookup.
 struct DynWork {          // cnt <= 16 time nodes of "dynamic"
-  uint64_t shared;        // DynShared[k0..]
-  uint64_t lanes;         // DynLane[k0 * n_ee ..]
+  uint64_t nodes;         // DynNode[k0..]
+  uint64_t gather;        // DynGather[k0 * 4 ..]
+  uint64_t put;           // DynPut[k0 * 4 ..]
+  uint64_t map;           // uint16_t[64][4]: lane l stages x[map[l][c]] at xs[2 + 64 c + l]
   uint64_t hdr;           // DevStruct (mass, gravity, inertia)
   int64_t x_off;          // problem's x
   int64_t g_off;          // first constraint value of the run (row 6*k0 of the set)
   int64_t j_off;          // first Jacobian value of the run
-  int32_t off_lin, off_ang;  // x offsets of base-lin / base-ang inside the problem
   int32_t cnt, nvals;     // time nodes, Jacobian values of the run
+  int64_t pad;
 };
-static_assert(sizeof(DynWork) == 64, "DynWork layout");
+static_assert(sizeof(DynWork) == 80, "DynWork layout");
 
 struct RomWork {          // cnt <= 64 time nodes of "rangeofmotion-<ee>"
   uint64_t recs;          // RomRec[k0..] of that ee

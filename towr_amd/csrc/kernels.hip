@@ -307,13 +307,15 @@ TWR_DEV void duration_columns(const double nv[4][3], double t, double T, double 
 struct DynX {  // the lane's slice of x: ONE node value (role: p0, v0, p1, v1) of base-lin / base-ang, ee candidates
   double bl[3], ba[3], m[12], f[12];
 };
-template <int NEE>
-TWR_DEV void dyn_load_rec(const DynWork& w, int lane, DynShared& sh, DynLane& ln) {
-  const int kk = min(lane >> 2, w.cnt - 1), role = min(lane & 3, NEE - 1);
-  sh = gptr<DynShared>(w.shared)[kk];
-  ln = gptr<DynLane>(w.lanes)[kk * NEE + role];
-}
-TWR_DEV void dyn_load_x(const DynWork& w, const DynShared& sh, const DynLane& ln, const double* __restrict__ x, DynX& X) {
+// (the optimised-timings kernel builds its per-lane records on the fly and drives the quad math below through this
+// local descriptor; the fixed-timing kernel has its own, fully pre-resolved path: dyn2_front / dyn2_back)
+struct DynWorkP {
+  uint64_t hdr;            // DevStruct (mass, gravity, inertia)
+  int64_t x_off;           // problem's x
+  int32_t off_lin, off_ang;  // x offsets of base-lin / base-ang inside the problem
+  int32_t cnt;             // time nodes of the run
+};
+TWR_DEV void dyn_load_x(const DynWorkP& w, const DynShared& sh, const DynLane& ln, const double* __restrict__ x, DynX& X) {
   const double* xp = x + w.x_off;
   // The base nodes of the active polynomial are [p0 v0 p1 v1] x 3 (NodesVariablesAll order).  The four lanes
   // of the quad would all load the same 24 doubles: each one loads the node value of its role only and the
@@ -342,7 +344,7 @@ struct DynFront {
 // PHASE (optimised timings): the row layout is given (rows hold all variables of every ee set, S.rs .. S.ls
 // are filled by the caller), otherwise it follows from the slot counts of the active polynomials.
 template <int NEE, bool PHASE = false>
-TWR_DEV void dyn_front(const DynWork& w, const DynShared& sh, const DynLane& ln, const DynX& X, int par, int vbase,
+TWR_DEV void dyn_front(const DynWorkP& w, const DynShared& sh, const DynLane& ln, const DynX& X, int par, int vbase,
                        int lane, DynFront& S) {
   const int role = lane & 3;
   const bool has_ee = role < NEE;
@@ -435,7 +437,7 @@ TWR_DEV void put_if(double* __restrict__ stage, bool valid, int idx, int trash, 
   }
 }
 template <int NEE, bool DIRECT = false>
-TWR_DEV void dyn_back(const DynWork& w, const DynLane& ln, const DynFront& S, double* __restrict__ gst,
+TWR_DEV void dyn_back(const DynWorkP& w, const DynLane& ln, const DynFront& S, double* __restrict__ gst,
                       double* __restrict__ stage, int trash, int lane, bool want_g, bool want_j) {
   const int kk = lane >> 2, role = lane & 3;
   if (kk >= w.cnt) return;
@@ -919,31 +921,34 @@ TWR_DEV void copy_out(double* __restrict__ dst, const double* __restrict__ stage
 // vmcnt(0), i.e. a full store drain per slice).
 template <int NIT, int kBatch>
 TWR_DEV void copy_out_fixed(double* __restrict__ dst, const double* __restrict__ stage, int n, int par, int lane) {
-  double* al = dst - par;  // 16-byte aligned
+  // byte offsets as unsigned 32-bit values: one VGPR addresses both the LDS read and the global store (wave-uniform
+  // base + 32-bit offset), two VALU instructions per store instead of a 64-bit address computation
+  char* al = reinterpret_cast<char*>(dst - par);  // 16-byte aligned
+  const char* st = reinterpret_cast<const char*>(stage);
   const int total = n + par;
-  const int npairs = total >> 1;  // pairs [par, npairs) are complete; a slice has >= 20 values
+  const uint32_t last = (uint32_t)((total >> 1) - 1) * 16u;  // last complete pair; pairs [par, npairs) are complete
+  const uint32_t first = (uint32_t)(par + lane) * 16u;
   // kBatch = LDS reads in flight before the first store needs its data
 #pragma unroll
   for (int it0 = 0; it0 < NIT; it0 += kBatch) {
     double2 v[kBatch];
-    int t[kBatch];
+    uint32_t off[kBatch];
 #pragma unroll
     for (int b = 0; b < kBatch; ++b)
       if (it0 + b < NIT) {
-        t[b] = min(par + lane + 64 * (it0 + b), npairs - 1);
-        v[b] = *reinterpret_cast<const double2*>(stage + 2 * t[b]);
+        off[b] = min(first + 1024u * (uint32_t)(it0 + b), last);
+        v[b] = *reinterpret_cast<const double2*>(st + off[b]);
       }
 #pragma unroll
     for (int b = 0; b < kBatch; ++b)
-      if (it0 + b < NIT) *reinterpret_cast<double2*>(al + 2 * t[b]) = v[b];
+      if (it0 + b < NIT) *reinterpret_cast<double2*>(al + off[b]) = v[b];
   }
-  if (par && lane == 0 && n > 0) al[1] = stage[1];
-  if ((total & 1) && lane == 0 && total - 1 > par) al[total - 1] = stage[total - 1];
+  if (par && lane == 0 && n > 0) dst[0] = stage[1];
+  if ((total & 1) && lane == 0 && total - 1 > par) dst[n - 1] = stage[total - 1];
 }
 
 // LDS image sizes (doubles).  dynamic: 16 time nodes per wave (~170 values each at 4 ee) -> 22.5 KiB,
 // seven workgroups per CU; range of motion: 64 lanes x ~84 values -> 39 KiB, four per CU.
-constexpr int kDynStage = 2654;   // + 2 + 64 + 96 doubles = 22528 B
 constexpr int kRomStage = 4856;   // + 2 + 64 + 192 doubles = 40912 B
 
 // dynamic / range of motion: persistent workgroups, software pipelined over the strided work list.
@@ -961,67 +966,365 @@ constexpr int kRomStage = 4856;   // + 2 + 64 + 192 doubles = 40912 B
 //   copy-out(i): image of slice i -> HBM
 //   back(i+1):  Jacobian blocks of slice i+1 -> image        (single call site of each half)
 #ifndef TWR_TU_ROM
-template <int NEE>
+// ---------------------------------------------------------------- dynamic, fixed timings (dyn_kernel)
+// Same math as dyn_front / dyn_back above (DynamicConstraint + SingleRigidBodyDynamics + EulerConverter for one
+// time node on a quad of lanes), but every index is an LDS byte offset prepared on the host (device_tables.h
+// DynNode / DynGather / DynPut): the slice's part of x sits in LDS ("xs"), values that are not optimisation
+// variables read its zero slot, and a Jacobian value is stored at node base + a 16-bit offset from the record.
+constexpr int kDynG0 = kDynTrash0 + 128;   // constraint values of the slice (6 x 16)
+constexpr int kDynX0 = kDynG0 + 96;        // xs: zero pair, then <= 254 staged doubles of x
+constexpr int kDynLds = kDynX0 + 256;      // 3136 doubles = 25088 B: six workgroups per CU
+#ifndef TWR_DYN_COPY_BATCH
+#define TWR_DYN_COPY_BATCH 8
+#endif
+constexpr int kDynCopyBatch = TWR_DYN_COPY_BATCH;   // LDS reads in flight before the first store of the copy-out
+struct Dyn2Front {   // (the base-spline weights are recomputed in the back half: 48 registers less across the copy-out)
+  double cdd[3], ed[3], edd[3];
+  double wm[4], wf[4], f[3], rv[3], F[3], tau[3];
+  double sx, cx, sy, cy, sz, cz;
+};
+TWR_DEV double lds_f64(const char* __restrict__ lds, uint32_t byte_off) {
+  return *reinterpret_cast<const double*>(lds + byte_off);
+}
+#if defined(TWR_ABLATE) && TWR_ABLATE == 2   // diagnostic: the image fill replaced by an accumulation (math kept, LDS stores gone)
+__device__ double g_abl_sink;
+TWR_DEV void lds_put(char* __restrict__ lds, uint32_t byte_off, double v) {
+  if (v == 1.2345e-300 + byte_off) g_abl_sink = v;
+}
+#else
+TWR_DEV void lds_put(char* __restrict__ lds, uint32_t byte_off, double v) { *reinterpret_cast<double*>(lds + byte_off) = v; }
+#endif
+// staged candidate c of a spline: xs[idx[c]]
+TWR_DEV void gather12s(const char* __restrict__ xs, const uint8_t idx[12], double v[12]) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(idx);
+#pragma unroll
+  for (int c = 0; c < 12; ++c) v[c] = lds_f64(xs, ((w[c >> 2] >> (8 * (c & 3))) & 0xFFu) << 3);
+}
+TWR_DEV void dyn2_load_rec(const DynWork& w, int lane, DynNode& nd, DynGather& ga) {
+  const int kk = min(lane >> 2, w.cnt - 1);
+  nd = gptr<DynNode>(w.nodes)[kk];
+  ga = gptr<DynGather>(w.gather)[kk * 4 + (lane & 3)];
+}
+TWR_DEV void dyn2_front(const DynNode& nd, const DynGather& ga, const char* __restrict__ xs, int lane, Dyn2Front& S) {
+  const int role = lane & 3;
+  double wP[4], wV[4], wA[4];
+  hermite_all(nd.tb, nd.iTb, wP, wV, wA);
+  double c[3], e[3];
+  {  // base spline points (Spline::GetPoint in basis form): the active polynomial's [p0 v0 p1 v1] x 3
+    double bl[12], ba[12];
+    const double2* pl = reinterpret_cast<const double2*>(__builtin_assume_aligned(xs + nd.sb_lin, 16));
+    const double2* pa = reinterpret_cast<const double2*>(__builtin_assume_aligned(xs + nd.sb_ang, 16));
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double2 a = pl[i], b = pa[i];
+      bl[2 * i] = a.x; bl[2 * i + 1] = a.y;
+      ba[2 * i] = b.x; ba[2 * i + 1] = b.y;
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      c[d] = wP[0] * bl[d] + wP[1] * bl[3 + d] + wP[2] * bl[6 + d] + wP[3] * bl[9 + d];
+      S.cdd[d] = wA[0] * bl[d] + wA[1] * bl[3 + d] + wA[2] * bl[6 + d] + wA[3] * bl[9 + d];
+      e[d] = wP[0] * ba[d] + wP[1] * ba[3 + d] + wP[2] * ba[6 + d] + wP[3] * ba[9 + d];
+      S.ed[d] = wV[0] * ba[d] + wV[1] * ba[3 + d] + wV[2] * ba[6 + d] + wV[3] * ba[9 + d];
+      S.edd[d] = wA[0] * ba[d] + wA[1] * ba[3 + d] + wA[2] * ba[6 + d] + wA[3] * ba[9 + d];
+    }
+  }
+  // this lane's end-effector: weights and spline points (absent candidates read the zero slot)
+  double vm[12], vf[12], p[3];
+  gather12s(xs, ga.idx_m, vm);
+  gather12s(xs, ga.idx_f, vf);
+  hermite_pos(ga.tm, ga.iTm, S.wm);
+  hermite_pos(ga.tf, ga.iTf, S.wf);
+  S.wm[0] += (ga.flags & 1) ? S.wm[2] : 0.0;   // stance polynomial: p1 is the same variable as p0
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    p[d] = S.wm[0] * vm[d] + S.wm[1] * vm[3 + d] + S.wm[2] * vm[6 + d] + S.wm[3] * vm[9 + d];
+    S.f[d] = S.wf[0] * vf[d] + S.wf[1] * vf[3 + d] + S.wf[2] * vf[6 + d] + S.wf[3] * vf[9 + d];
+    S.rv[d] = c[d] - p[d];
+  }
+  // force and torque sums over the end-effectors (single_rigid_body_dynamics.cc:81-88); dummy roles carry f = 0
+  double t3[3];
+  cross3(S.f, S.rv, t3);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    S.F[d] = quad_sum(S.f[d]);
+    S.tau[d] = quad_sum(t3[d]);
+  }
+  // rotation: lanes 0..2 of the quad evaluate one sincos each and broadcast it
+  double my_s, my_c;
+  sincos_fast(sel3(role, e[0], e[1], e[2]), &my_s, &my_c);
+  S.sx = quad_perm<0x00>(my_s); S.cx = quad_perm<0x00>(my_c);
+  S.sy = quad_perm<0x55>(my_s); S.cy = quad_perm<0x55>(my_c);
+  S.sz = quad_perm<0xAA>(my_s); S.cz = quad_perm<0xAA>(my_c);
+}
+
+// Back half: Jacobian blocks and constraint values into the LDS image.  `img` is the byte address of the image
+// (parity shift included), node base and row offsets come from DynNode, tile offsets from DynPut.
+TWR_DEV void dyn2_back(const DynWork& w, const DynNode& nd, const DynPut& pu, const Dyn2Front& S, double* __restrict__ gst,
+                       char* __restrict__ img, int lane, bool want_g, bool want_j) {
+  const int kk = lane >> 2, role = lane & 3;
+  if (kk >= w.cnt) return;
+  const double (&cdd)[3] = S.cdd, (&ed)[3] = S.ed, (&edd)[3] = S.edd;
+  const double (&wm)[4] = S.wm, (&wf)[4] = S.wf, (&f)[3] = S.f, (&rv)[3] = S.rv, (&F)[3] = S.F, (&tau)[3] = S.tau;
+  const double sx = S.sx, cx = S.cx, sy = S.sy, cy = S.cy, sz = S.sz, cz = S.cz;
+  char* nb = img + nd.nb;   // first value of this time node
+  // --- ee-motion block [f]x J_p (:181-192) and ee-force block {[r]x J_f ; -J_f} (:167-179) of this lane's
+  // end-effector; a candidate that is not a variable carries the offset of the lane's trash pair
+  if (want_j) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#define TWR_EE_TILE2(D, R1, R2)                                       \
+  {                                                                   \
+    lds_put(nb, pu.m[j * 3 + D][0], crs<R1, D>(f) * wm[j]);          \
+    lds_put(nb, pu.m[j * 3 + D][1], crs<R2, D>(f) * wm[j]);          \
+    lds_put(nb, pu.f[j * 3 + D][0], crs<R1, D>(rv) * wf[j]);         \
+    lds_put(nb, pu.f[j * 3 + D][1], crs<R2, D>(rv) * wf[j]);         \
+    lds_put(nb, pu.f[j * 3 + D][2], -wf[j]);                         \
+  }
+      TWR_EE_TILE2(0, 1, 2)
+      TWR_EE_TILE2(1, 2, 0)
+      TWR_EE_TILE2(2, 0, 1)
+#undef TWR_EE_TILE2
+    }
+  }
+  // --- angular quantities (euler_converter.cc:58-83,133-166,207-221)
+  double R[3][3];
+  R[0][0] = cy * cz; R[0][1] = cz * sx * sy - cx * sz; R[0][2] = sx * sz + cx * cz * sy;
+  R[1][0] = cy * sz; R[1][1] = cx * cz + sx * sy * sz; R[1][2] = cx * sy * sz - cz * sx;
+  R[2][0] = -sy;     R[2][1] = cy * sx;                R[2][2] = cx * cy;
+  const double xd = ed[0], yd = ed[1], zd = ed[2];
+  const double Mx[3] = {cy * cz, cy * sz, -sy}, My[3] = {-sz, cz, 0.0};
+  const double Mdx[3] = {-cz * sy * yd - cy * sz * zd, cy * cz * zd - sy * sz * yd, -cy * yd};
+  const double Mdy[3] = {-cz * zd, -sz * zd, 0.0};
+  double om[3], omd[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    om[i] = Mx[i] * xd + My[i] * yd;
+    omd[i] = Mdx[i] * xd + Mdy[i] * yd + Mx[i] * edd[0] + My[i] * edd[1];
+  }
+  om[2] += zd;
+  omd[2] += edd[2];
+  const TWR_CONST DevStruct* H = cptr<DevStruct>(w.hdr);  // uniform per work item: scalar loads
+  double Iw6[6];  // I_w = R I_b R^T (single_rigid_body_dynamics.cc:91), symmetric: (00,01,02,11,12,22)
+  {
+    double Ib[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Ib[i] = H->Ib[i];
+    double T[3][3];  // R I_b
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      T[i][0] = R[i][0] * Ib[0] + R[i][1] * Ib[1] + R[i][2] * Ib[2];
+      T[i][1] = R[i][0] * Ib[1] + R[i][1] * Ib[3] + R[i][2] * Ib[4];
+      T[i][2] = R[i][0] * Ib[2] + R[i][1] * Ib[4] + R[i][2] * Ib[5];
+    }
+    Iw6[0] = T[0][0] * R[0][0] + T[0][1] * R[0][1] + T[0][2] * R[0][2];
+    Iw6[1] = T[0][0] * R[1][0] + T[0][1] * R[1][1] + T[0][2] * R[1][2];
+    Iw6[2] = T[0][0] * R[2][0] + T[0][1] * R[2][1] + T[0][2] * R[2][2];
+    Iw6[3] = T[1][0] * R[1][0] + T[1][1] * R[1][1] + T[1][2] * R[1][2];
+    Iw6[4] = T[1][0] * R[2][0] + T[1][1] * R[2][1] + T[1][2] * R[2][2];
+    Iw6[5] = T[2][0] * R[2][0] + T[2][1] * R[2][1] + T[2][2] * R[2][2];
+  }
+  double Iw_wd[3], Iw_w[3];
+  symmul(Iw6, omd, Iw_wd);
+  symmul(Iw6, om, Iw_w);
+  const double m = H->mass;
+  double wP[4], wV[4], wA[4];
+  {
+    double tb = nd.tb;
+    asm volatile("" : "+v"(tb));   // a fresh evaluation: do not carry the front half's twelve weights across the copy-out
+    hermite_all(tb, nd.iTb, wP, wV, wA);
+  }
+  char* row[3] = {nb, nb + nd.rs1, nb + nd.rs2};
+
+  if (role == 3) {
+    if (want_g) {  // GetDynamicViolation, single_rigid_body_dynamics.cc:76-101
+      double wxIw[3];
+      cross3(om, Iw_w, wxIw);
+      double* go = gst + 6 * kk;  // staged in LDS, written out coalesced with the Jacobian slice
+#pragma unroll
+      for (int i = 0; i < 3; ++i) go[i] = Iw_wd[i] + wxIw[i] - tau[i];
+      go[3] = m * cdd[0] - F[0];
+      go[4] = m * cdd[1] - F[1];
+      go[5] = m * cdd[2] - F[2] + m * H->gravity;
+    }
+    if (want_j) {  // base-lin block: ang rows -sum_i [f_i]x J_pos, lin rows m J_acc (:103-121)
+      char* lin[3] = {nb + nd.rl[0], nb + nd.rl[1], nb + nd.rl[2]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lds_put(row[0], 8 * (2 * j + 0), -crs<0, 1>(F) * wP[j]);
+        lds_put(row[0], 8 * (2 * j + 1), -crs<0, 2>(F) * wP[j]);
+        lds_put(row[1], 8 * (2 * j + 0), -crs<1, 0>(F) * wP[j]);
+        lds_put(row[1], 8 * (2 * j + 1), -crs<1, 2>(F) * wP[j]);
+        lds_put(row[2], 8 * (2 * j + 0), -crs<2, 0>(F) * wP[j]);
+        lds_put(row[2], 8 * (2 * j + 1), -crs<2, 1>(F) * wP[j]);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) lds_put(lin[d], 8 * j, m * wA[j]);
+      }
+    }
+  } else if (want_j) {
+    // --- base-ang block (:123-165), Euler dimension d = role, factored (see dyn_back)
+    const double dMx_dy[3] = {-sy * cz, -sy * sz, -cy};
+    const double dMx_dz[3] = {-cy * sz, cy * cz, 0.0};
+    const double dMy_dz[3] = {-cz, -sz, 0.0};
+    const double dMdx_dy[3] = {-cz * cy * yd + sy * sz * zd, -sy * cz * zd - cy * sz * yd, sy * yd};
+    const double dMdx_dz[3] = {sz * sy * yd - cy * cz * zd, -cy * sz * zd - sy * cz * yd, 0.0};
+    const double dMdy_dz[3] = {sz * zd, -cz * zd, 0.0};
+    double Md[3], dwd_ed[3], dw[3], dwd[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      Md[i] = sel3(role, Mx[i], My[i], i == 2 ? 1.0 : 0.0);  // column d of M (euler_converter.cc:133-148)
+      dwd_ed[i] = sel3(role, Mdx[i], Mdy[i] + xd * dMx_dy[i], xd * dMx_dz[i] + yd * dMy_dz[i]);
+      dw[i] = sel3(role, 0.0, xd * dMx_dy[i], xd * dMx_dz[i] + yd * dMy_dz[i]);
+      dwd[i] = sel3(role, 0.0, xd * dMdx_dy[i] + edd[0] * dMx_dy[i],
+                    xd * dMdx_dz[i] + yd * dMdy_dz[i] + edd[0] * dMx_dz[i] + edd[1] * dMy_dz[i]);
+    }
+    auto dIw = [&](const double v[3], const double Iwv[3], double o[3]) {
+      double t1[3], t2[3], t3b[3];
+      cross3(Md, Iwv, t1);
+      cross3(v, Md, t2);
+      symmul(Iw6, t2, t3b);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) o[i] = t1[i] + t3b[i];
+    };
+    double A[3], B[3], C[3];
+    symmul(Iw6, Md, C);
+    {
+      double t1[3], t2[3], t3b[3];
+      symmul(Iw6, dwd_ed, t1);
+      cross3(Md, Iw_w, t2);
+      cross3(om, C, t3b);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) B[i] = t1[i] + t2[i] + t3b[i];
+    }
+    {
+      double t1[3], t2[3], t3b[3], t4[3], t5[3], t6[3], t7[3];
+      dIw(omd, Iw_wd, t1);
+      symmul(Iw6, dwd, t2);
+      cross3(dw, Iw_w, t3b);
+      dIw(om, Iw_w, t4);
+      symmul(Iw6, dw, t5);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) t6[i] = t4[i] + t5[i];
+      cross3(om, t6, t7);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) A[i] = t1[i] + t2[i] + t3b[i] + t7[i];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lds_put(row[r], 8 * (8 + 3 * j + role), A[r] * wP[j] + B[r] * wV[j] + C[r] * wA[j]);
+  }
+}
+
+// Loop of one persistent single-wave workgroup over its strided slices.  State at the top of iteration i: xs holds
+// x(i); `xr` (registers) holds x(i+1), gathered one iteration ago; mapr holds the staging map of slice i+2;
+// the front records of slices i and i+1 are in registers.
+//   F  front(i): LDS reads of xs + the front record -> compact state
+//   P  issue the load of slice i's put record (needed by the back half only; it lands during the copy-out)
+//   O  copy-out(i-1): image -> HBM (one phase late: the x gathers of the previous iteration were issued before
+//      these stores, so waiting for them never waits for a store)
+//   B  back(i): Jacobian blocks -> image
+//   S  xs <- xr (x(i+1));  then issue: front record of slice i+2, xr <- gather x(i+2), mapr <- map(i+3)
 __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ work, int n_work,
                                                     const double* __restrict__ x, double* __restrict__ g,
                                                     double* __restrict__ jac, int flags) {
-  // Jacobian image + parity slack + trash slots + constraint values of the slice
-  __shared__ __attribute__((aligned(16))) double stage[kDynStage + 2 + 64 + 96];
+  __shared__ __attribute__((aligned(16))) double stage[kDynLds];
   const bool want_g = flags & 1, want_j = flags & 2;
   const int lane = threadIdx.x;
-  const int trash = kDynStage + 2 + lane;
-  double* gst = stage + kDynStage + 2 + 64;
+  double* gst = stage + kDynG0;
+  char* xs = reinterpret_cast<char*>(stage + kDynX0);
   const int stride = gridDim.x;
   int i = blockIdx.x;
   if (i >= n_work) return;
-  constexpr int NIT = (kDynStage + 2 + 127) / 128;
+  constexpr int NIT = (kDynImage + 2 + 127) / 128;
+  if (lane < 2) stage[kDynX0 + lane] = 0.0;   // the zero pair
+  auto load_map = [&](const DynWork& w) { return gptr<uint2>(w.map)[lane]; };   // four 16-bit x indices per lane
+  auto gather_x = [&](const DynWork& w, uint2 m, double xr[4]) {
+    const double* xp = x + w.x_off;
+    xr[0] = xp[m.x & 0xFFFFu];
+    xr[1] = xp[m.x >> 16];
+    xr[2] = xp[m.y & 0xFFFFu];
+    xr[3] = xp[m.y >> 16];
+  };
+  auto stage_x = [&](const double xr[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) stage[kDynX0 + 2 + 64 * c + lane] = xr[c];
+  };
   DynWork wp = work[i];   // slice whose image is waiting to be copied out (none yet)
   bool pending = false;
-  DynWork w0 = wp, w1 = wp;
-  DynShared sh0, sh1;
-  DynLane ln0, ln1;
-  dyn_load_rec<NEE>(w0, lane, sh0, ln0);
-  sh1 = sh0;
-  ln1 = ln0;
+  DynWork w0 = wp, w1 = wp, w2 = wp;
+  DynNode nd0, nd1;
+  DynGather ga0, ga1;
+  double xr[4];
+  uint2 mapr = load_map(w0);
+  dyn2_load_rec(w0, lane, nd0, ga0);
+  gather_x(w0, mapr, xr);
+  stage_x(xr);                                           // x(first slice): the only exposed gather
+  nd1 = nd0;
+  ga1 = ga0;
   if (i + stride < n_work) {
     w1 = work[i + stride];
-    dyn_load_rec<NEE>(w1, lane, sh1, ln1);
+    mapr = load_map(w1);
+    dyn2_load_rec(w1, lane, nd1, ga1);
+    gather_x(w1, mapr, xr);
+  }
+  if (i + 2 * stride < n_work) {
+    w2 = work[i + 2 * stride];
+    mapr = load_map(w2);
   }
   for (; i < n_work; i += stride) {
-    const bool has2 = i + 2 * stride < n_work;
-    DynWork w2 = w1;
-    if (has2) w2 = work[i + 2 * stride];
+    const bool has1 = i + stride < n_work, has2 = i + 2 * stride < n_work, has3 = i + 3 * stride < n_work;
+    DynWork w3 = w2;
+    if (has3) w3 = work[i + 3 * stride];
     double* dst = jac + w0.j_off;
     const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-    DynFront S;
-    {
-      DynX X;
-      dyn_load_x(w0, sh0, ln0, x, X);
-      dyn_front<NEE>(w0, sh0, ln0, X, par, __builtin_amdgcn_readfirstlane(sh0.voff), lane, S);
-    }
-    if (pending) {                                      // previous slice: image -> HBM
+    Dyn2Front S;
+#ifdef TWR_ABLATE   // diagnostic build only (make ablate): runtime switches in flags bits 8.. (scripts/ablate.py)
+    if (flags & 0x400) {
+      double* sp = reinterpret_cast<double*>(&S);
+      for (int q = 0; q < (int)(sizeof(S) / 8); ++q) sp[q] = 0.25 + q;
+    } else
+#endif
+    dyn2_front(nd0, ga0, xs, lane, S);                                                       // F
+    const DynPut pu = gptr<DynPut>(w0.put)[min(lane >> 2, w0.cnt - 1) * 4 + (lane & 3)];   // P
+#ifdef TWR_ABLATE
+    if (pending && !(flags & 0x100)) {
+#else
+    if (pending) {                                                                           // O
+#endif
       double* pdst = jac + wp.j_off;
       const int ppar = (int)((reinterpret_cast<uintptr_t>(pdst) >> 3) & 1);
-      if (want_j) copy_out_fixed<NIT, 11>(pdst, stage, wp.nvals, ppar, lane);
+      if (want_j) copy_out_fixed<NIT, kDynCopyBatch>(pdst, stage, wp.nvals, ppar, lane);
       if (want_g) {                                     // 6 constraint values per time node, contiguous in g
         double* go = g + wp.g_off;
         if (lane < 6 * wp.cnt) go[lane] = gst[lane];
         if (lane + 64 < 6 * wp.cnt) go[lane + 64] = gst[lane + 64];
       }
     }
-    dyn_back<NEE>(w0, ln0, S, gst, stage, trash, lane, want_g, want_j);
-    DynShared sh2 = sh1;
-    DynLane ln2 = ln1;
-    if (has2) dyn_load_rec<NEE>(w2, lane, sh2, ln2);    // record of slice i+2
+#ifdef TWR_ABLATE
+    if (!(flags & 0x200))
+      dyn2_back(w0, nd0, pu, S, gst, reinterpret_cast<char*>(stage + par), lane, want_g, want_j && !(flags & 0x1000));
+#else
+    dyn2_back(w0, nd0, pu, S, gst, reinterpret_cast<char*>(stage + par), lane, want_g, want_j);   // B
+#endif
+    if (has1) stage_x(xr);                                                                   // S
+    DynNode nd2 = nd1;
+    DynGather ga2 = ga1;
+    if (has2) {
+      dyn2_load_rec(w2, lane, nd2, ga2);
+      gather_x(w2, mapr, xr);
+    }
+    if (has3) mapr = load_map(w3);
     wp = w0;
     pending = true;
-    w0 = w1; sh0 = sh1; ln0 = ln1;
-    w1 = w2; sh1 = sh2; ln1 = ln2;
+    w0 = w1; nd0 = nd1; ga0 = ga1;
+    w1 = w2; nd1 = nd2; ga1 = ga2;
+    w2 = w3;
   }
   {                                                     // last slice of this workgroup
     double* pdst = jac + wp.j_off;
     const int ppar = (int)((reinterpret_cast<uintptr_t>(pdst) >> 3) & 1);
-    if (want_j) copy_out_fixed<NIT, 11>(pdst, stage, wp.nvals, ppar, lane);
+    if (want_j) copy_out_fixed<NIT, kDynCopyBatch>(pdst, stage, wp.nvals, ppar, lane);
     if (want_g) {
       double* go = g + wp.g_off;
       if (lane < 6 * wp.cnt) go[lane] = gst[lane];
@@ -1339,13 +1642,11 @@ __global__ __launch_bounds__(64) void dyn_phase_kernel(const PhaseWork* __restri
     ln.cand_m[c] = pm.cand[c];
     ln.cand_f[c] = pf.cand[c];
   }
-  DynWork w;
-  w.shared = 0; w.lanes = 0;
+  DynWorkP w;
   w.hdr = pw.blob;
   w.x_off = pw.x_off;
-  w.g_off = 0; w.j_off = 0;
   w.off_lin = PT->off_lin; w.off_ang = PT->off_ang;
-  w.cnt = pw.cnt; w.nvals = 0;
+  w.cnt = pw.cnt;
   // expanded row layout of this time node (relative to the first value of node k0)
   DynFront S;
   {
@@ -1359,11 +1660,10 @@ __global__ __launch_bounds__(64) void dyn_phase_kernel(const PhaseWork* __restri
   }
   int sa[3], sl[3];  // first duration column of this end-effector in the ang / lin rows
   {
-    int pre_s = 0, tot_s = 0;
+    int pre_s = 0;
 #pragma unroll
     for (int e2 = 0; e2 < NEE; ++e2) {
       const int n = PT->n_phases[e2] - 1;
-      tot_s += n;
       if (e2 < role) pre_s += n;
     }
 #pragma unroll
@@ -1745,19 +2045,17 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
                        const NodeWork* node, int n_node, const PhaseWork* pdyn, int n_pdyn, const LocWork* ploc,
                        int n_ploc, const RomPhaseWork* prom, int n_prom, const double* x, double* g, double* jac,
                        int flags, hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */) {
-  static const int dyn_bpc = env_int("TWR_DYN_BPC", 7), rom_bpc = env_int("TWR_ROM_BPC", 4);
+  static const int dyn_bpc = env_int("TWR_DYN_BPC", 6), rom_bpc = env_int("TWR_ROM_BPC", 4);
+#ifdef TWR_ABLATE
+  flags |= env_int("TWR_DEBUG_FLAGS", 0) & ~0xFF;
+#endif
   dim3 block(64);
   if (n_ee < 1 || n_ee > 4) return hipErrorInvalidValue;
   if (ev) (void)hipEventRecord(ev[0], stream);
   if (n_dyn > 0) {
     const int res = dyn_bpc * n_cu;
     dim3 grid(n_dyn < res ? n_dyn : res);
-    switch (n_ee) {
-      case 1: hipLaunchKernelGGL(dyn_kernel<1>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags); break;
-      case 2: hipLaunchKernelGGL(dyn_kernel<2>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags); break;
-      case 3: hipLaunchKernelGGL(dyn_kernel<3>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags); break;
-      case 4: hipLaunchKernelGGL(dyn_kernel<4>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags); break;
-    }
+    hipLaunchKernelGGL(dyn_kernel, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags);
   }
   if (n_pdyn > 0) {  // optimised-timings problems
     dim3 grid(n_pdyn);
@@ -1785,9 +2083,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
   return hipGetLastError();
 }
 
-int dyn_stage_capacity() { return kDynStage; }
 int rom_stage_capacity() { return kRomStage; }
-int dyn_nodes_per_block() { return 16; }
 #endif  // !TWR_TU_ROM
 
 }  // namespace twr

@@ -578,31 +578,146 @@ void Structure::PackBlob() {
     h.o_bm = put(bn.data(), bn.size() * sizeof(BaseNode));
   }
   h.o_swing_nodes = put(all_swing.data(), all_swing.size() * sizeof(SwingNode));
-  // --- per-lane records of the dynamic kernel
-  if (dyn_set) {
+  // --- dynamic, optimised timings: the base-spline part of the per-node record (the rest depends on x)
+  if (dyn_set && timings) {
     std::vector<DynShared> sh(grid_dyn.size());
-    std::vector<DynLane> ln(grid_dyn.size() * n_ee);
     for (size_t k = 0; k < grid_dyn.size(); ++k) {
       std::memset(&sh[k], 0, sizeof(DynShared));
       sh[k].tb = dyn_base[k].t_local;
       sh[k].iTb = 1.0 / base.durations[dyn_base[k].poly];
       sh[k].q6 = 6 * dyn_base[k].poly;
       sh[k].voff = row_ptr[row_dyn + 6 * k] - nnz_dyn;
-      for (int e = 0; e < n_ee; ++e) {
-        DynLane& L = ln[k * n_ee + e];
-        std::memset(&L, 0, sizeof(L));
-        const PolyDesc& mp = mpoly[e][dyn_motion[e][k].poly];
-        const PolyDesc& fp = fpoly[e][dyn_force[e][k].poly];
-        L.tm = dyn_motion[e][k].t_local; L.iTm = mp.iT;
-        L.tf = dyn_force[e][k].t_local;  L.iTf = fp.iT;
-        L.xbase_m = mp.xbase; L.xbase_f = fp.xbase;
-        L.meta_m = mp.meta;   L.meta_f = fp.meta;
-        std::memcpy(L.cand_m, mp.cand, sizeof(L.cand_m));
-        std::memcpy(L.cand_f, fp.cand, sizeof(L.cand_f));
-      }
     }
     off_dyn_shared = put(sh.data(), sh.size() * sizeof(DynShared));
-    off_dyn_lanes = put(ln.data(), ln.size() * sizeof(DynLane));
+  }
+  // --- dynamic, fixed timings: slices, staging maps and per-lane records with every index resolved to an LDS
+  // byte offset (device_tables.h).  The put offsets are read off the CSR pattern itself, so kernel and
+  // pattern cannot disagree.
+  if (dyn_set && !timings) {
+    const int K = (int)grid_dyn.size();
+    auto poly_range = [&](const std::vector<PolyDesc>& pd, int qa, int qb, int& lo, int& hi) {
+      lo = 1 << 30;
+      hi = -1;
+      for (int q = qa; q <= qb; ++q) {
+        const int ns = (int)(pd[q].meta & 0xF);
+        if (!ns) continue;
+        lo = std::min(lo, pd[q].xbase);
+        hi = std::max(hi, pd[q].xbase + ns);
+      }
+      if (hi < 0) lo = hi = 0;
+    };
+    auto stage_count = [&](int k0, int k1) {  // doubles of x the nodes [k0, k1) read
+      int n = 2 * 6 * (dyn_base[k1 - 1].poly - dyn_base[k0].poly + 2);
+      for (int e = 0; e < n_ee; ++e) {
+        int lo, hi;
+        poly_range(mpoly[e], dyn_motion[e][k0].poly, dyn_motion[e][k1 - 1].poly, lo, hi);
+        n += hi - lo;
+        poly_range(fpoly[e], dyn_force[e][k0].poly, dyn_force[e][k1 - 1].poly, lo, hi);
+        n += hi - lo;
+      }
+      return n;
+    };
+    auto nvals_of = [&](int k0, int k1) { return row_ptr[row_dyn + 6 * k1] - row_ptr[row_dyn + 6 * k0]; };
+    std::vector<DynNode> nodes(K);
+    std::vector<DynGather> gather((size_t)K * 4);
+    std::vector<DynPut> putv((size_t)K * 4);
+    dyn_slices.clear();
+    for (int k0 = 0; k0 < K;) {
+      int k1 = k0;
+      while (k1 < K && k1 - k0 < kDynNodes && nvals_of(k0, k1 + 1) <= kDynImage && stage_count(k0, k1 + 1) <= kDynXsCap) ++k1;
+      if (k1 == k0) throw std::runtime_error("one time node of the dynamic set exceeds the LDS staging capacity");
+      if (nvals_of(k0, k1) < 4) throw std::runtime_error("a time-node run with fewer than 4 Jacobian values cannot be staged");
+      // staging layout of the slice: xs index 2 + e
+      std::vector<uint16_t> map(256, 0);   // lane-transposed below; unused entries stage x[0] (harmless)
+      std::vector<int> xidx;               // x index of staging entry e
+      const int qmin = dyn_base[k0].poly, nbase = 6 * (dyn_base[k1 - 1].poly - qmin + 2);
+      for (int i = 0; i < nbase; ++i) xidx.push_back(off_base_lin + 6 * qmin + i);
+      for (int i = 0; i < nbase; ++i) xidx.push_back(off_base_ang + 6 * qmin + i);
+      int mlo[kMaxEE], mst[kMaxEE], flo[kMaxEE], fst[kMaxEE];   // first x index / staging entry of every ee range
+      for (int e = 0; e < n_ee; ++e) {
+        int hi;
+        poly_range(mpoly[e], dyn_motion[e][k0].poly, dyn_motion[e][k1 - 1].poly, mlo[e], hi);
+        mst[e] = (int)xidx.size();
+        for (int i = mlo[e]; i < hi; ++i) xidx.push_back(i);
+        poly_range(fpoly[e], dyn_force[e][k0].poly, dyn_force[e][k1 - 1].poly, flo[e], hi);
+        fst[e] = (int)xidx.size();
+        for (int i = flo[e]; i < hi; ++i) xidx.push_back(i);
+      }
+      if ((int)xidx.size() > kDynXsCap) throw std::runtime_error("staging count inconsistent");
+      for (size_t e = 0; e < xidx.size(); ++e) {
+        if (xidx[e] < 0 || xidx[e] > 0xFFFF) throw std::runtime_error("x index does not fit the staging map");
+        map[(e % 64) * 4 + e / 64] = (uint16_t)xidx[e];
+      }
+      DynSlice sl;
+      sl.k0 = k0;
+      sl.cnt = k1 - k0;
+      sl.nvals = nvals_of(k0, k1);
+      sl.map = put(map.data(), map.size() * sizeof(uint16_t));
+      dyn_slices.push_back(sl);
+      for (int k = k0; k < k1; ++k) {
+        const int row0 = row_dyn + 6 * k, v0 = row_ptr[row0];
+        DynNode& N = nodes[k];
+        std::memset(&N, 0, sizeof(N));
+        N.tb = dyn_base[k].t_local;
+        N.iTb = 1.0 / base.durations[dyn_base[k].poly];
+        N.sb_lin = (uint16_t)(8 * (2 + 6 * (dyn_base[k].poly - qmin)));
+        N.sb_ang = (uint16_t)(8 * (2 + nbase + 6 * (dyn_base[k].poly - qmin)));
+        const int node_rel = v0 - row_ptr[row_dyn + 6 * k0];
+        N.nb = (uint16_t)(8 * node_rel);
+        N.rs1 = (uint16_t)(8 * (row_ptr[row0 + 1] - v0));
+        N.rs2 = (uint16_t)(8 * (row_ptr[row0 + 2] - v0));
+        for (int d = 0; d < 3; ++d) N.rl[d] = (uint16_t)(8 * (row_ptr[row0 + 3 + d] - v0));
+        auto find = [&](int row, int col) -> int {  // position of `col` in row `row`, relative to the node's first value
+          const int32_t* b = col_idx.data() + row_ptr[row0 + row];
+          const int32_t* e2 = col_idx.data() + row_ptr[row0 + row + 1];
+          const int32_t* it = std::lower_bound(b, e2, col);
+          if (it == e2 || *it != col) throw std::runtime_error("dynamic pattern lacks an expected column");
+          return (int)(it - col_idx.data()) - v0;
+        };
+        for (int role = 0; role < 4; ++role) {
+          DynGather& G = gather[(size_t)k * 4 + role];
+          DynPut& P = putv[(size_t)k * 4 + role];
+          std::memset(&G, 0, sizeof(G));
+          const int lane = (k - k0) * 4 + role;
+          const int trash = 8 * (kDynTrash0 + 2 * lane - node_rel);   // relative to the node, like every put offset
+          if (trash < 0 || trash > 0xFFFF) throw std::runtime_error("trash offset out of range");
+          for (int c = 0; c < 12; ++c) {
+            P.m[c][0] = P.m[c][1] = (uint16_t)trash;
+            P.f[c][0] = P.f[c][1] = P.f[c][2] = (uint16_t)trash;
+          }
+          for (int i = 0; i < 4; ++i) P.pad[i] = 0;
+          G.tm = G.tf = 0.0;
+          G.iTm = G.iTf = 1.0;   // dummy roles evaluate finite weights on zeros
+          if (role >= n_ee) continue;
+          const int e = role;
+          const PolyDesc& mp = mpoly[e][dyn_motion[e][k].poly];
+          const PolyDesc& fp = fpoly[e][dyn_force[e][k].poly];
+          G.tm = dyn_motion[e][k].t_local; G.iTm = mp.iT;
+          G.tf = dyn_force[e][k].t_local;  G.iTf = fp.iT;
+          G.flags = (mp.meta >> 16) & 1;
+          for (int c = 0; c < 12; ++c) {
+            const int d = c % 3, r1 = (d + 1) % 3, r2 = (d + 2) % 3;
+            if (mp.cand[c] != 0xFFFF) {
+              const int col = mp.xbase + (mp.cand[c] & 0xF);
+              G.idx_m[c] = (uint8_t)(2 + mst[e] + col - mlo[e]);
+              P.m[c][0] = (uint16_t)(8 * find(r1, col));
+              P.m[c][1] = (uint16_t)(8 * find(r2, col));
+            }
+            if (fp.cand[c] != 0xFFFF) {
+              const int col = fp.xbase + (fp.cand[c] & 0xF);
+              G.idx_f[c] = (uint8_t)(2 + fst[e] + col - flo[e]);
+              P.f[c][0] = (uint16_t)(8 * find(r1, col));
+              P.f[c][1] = (uint16_t)(8 * find(r2, col));
+              P.f[c][2] = (uint16_t)(8 * find(3 + d, col));
+            }
+          }
+        }
+      }
+      k0 = k1;
+    }
+    off_dyn_nodes = put(nodes.data(), nodes.size() * sizeof(DynNode));
+    off_dyn_gather = put(gather.data(), gather.size() * sizeof(DynGather));
+    off_dyn_put = put(putv.data(), putv.size() * sizeof(DynPut));
   }
   // --- per-lane records of the range-of-motion kernel
   for (int e = 0; e < n_ee && have_rom; ++e) {

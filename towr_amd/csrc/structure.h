@@ -74,7 +74,14 @@ struct Structure {
 
   std::vector<char> blob;  // packed DevStruct + tables (device_tables.h)
   // byte offsets of the per-lane record arrays inside the blob
-  uint32_t off_dyn_shared = 0, off_dyn_lanes = 0;
+  uint32_t off_dyn_shared = 0, off_dyn_lanes = 0;   // optimised timings: DynShared[k] (base-spline part)
+  // fixed timings: slices of the dynamic set and their tables (device_tables.h DynNode / DynGather / DynPut)
+  struct DynSlice {
+    int k0, cnt, nvals;
+    uint32_t map;        // byte offset of the slice's staging map inside the blob
+  };
+  std::vector<DynSlice> dyn_slices;
+  uint32_t off_dyn_nodes = 0, off_dyn_gather = 0, off_dyn_put = 0;
   uint32_t off_rom_recs[kMaxEE] = {0, 0, 0, 0};
 
   const SetInfo* FindSet(const std::string& name) const;  // nullptr if the family is switched off
