@@ -393,6 +393,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
         w.gather = blob + S.off_dyn_gather + sizeof(twr::DynGather) * (size_t)sl.k0 * 4;
         w.put = blob + S.off_dyn_put + sizeof(twr::DynPut) * (size_t)sl.k0 * 4;
         w.map = blob + sl.map;
+        w.desc = blob + sl.desc;
         w.hdr = blob;
         w.x_off = b->x_off[p];
         w.g_off = b->g_off[p] + ds.offset + 6 * sl.k0;

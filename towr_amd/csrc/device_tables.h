@@ -99,6 +99,18 @@ struct DynPut {
 };
 static_assert(sizeof(DynPut) == 128, "DynPut layout");
 
+// dyn kernel, "table + emit" form (dyn_emit_kernel): instead of scattering every Jacobian value into an LDS image of
+// the slice, the quad writes a small operand table per time node, and the wave then EMITS the slice in CSR order --
+// every value is (+-) table[a] * table[b], the pair (a, b) coming from a per-slice descriptor array built on the host.
+// Table of one time node (kDynTabNode doubles): F[3] | wP[4] | m wA[4] | - | BA[36] (row r, base-ang column 3j+d) |
+// per role e: f[3] rv[3] wm[4] wf[4].  The slice's table region starts with the constants 1.0 and -1.0.
+constexpr int kDynTabNode = 104;
+constexpr int kDynTabConst = 2;
+constexpr int kDynTabF = 0, kDynTabWP = 3, kDynTabMWA = 7, kDynTabBA = 12, kDynTabEE = 48, kDynTabEEStride = 14;
+// descriptor of one Jacobian value: bits 0-15 byte offset of a, bits 16-30 byte offset of b (both inside the slice's
+// table region), bit 31 = negate.  The array of a slice has one leading and seven trailing pad entries.
+constexpr int kDynDescLead = 1, kDynDescTail = 7;
+
 struct ForceNode {   // one non-constant ee-force node (force_constraint.cc:50-60)
   int32_t fidx;      // x index of the node's force px (py = +2, pz = +4)
   int32_t hidx;      // x index of the stance foothold x (y = +1)
@@ -226,7 +238,7 @@ struct DynWork {          // cnt <= 16 time nodes of "dynamic"
   int64_t g_off;          // first constraint value of the run (row 6*k0 of the set)
   int64_t j_off;          // first Jacobian value of the run
   int32_t cnt, nvals;     // time nodes, Jacobian values of the run
-  int64_t pad;
+  uint64_t desc;          // uint32_t[kDynDescLead + nvals + kDynDescTail]: emit descriptors of the slice
 };
 static_assert(sizeof(DynWork) == 80, "DynWork layout");
 
