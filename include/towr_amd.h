@@ -238,6 +238,26 @@ int twr_batch_profile_end(twr_batch* b, double avg_ms[3], int* n_evals);
 int twr_structure_sample_count(const twr_structure* s, double dt, int32_t* n_samples);
 int twr_batch_sample(twr_batch* b, const double* d_x, double dt, double* d_out, int64_t problem_stride, void* hip_stream);
 
+/* Candidate scoring of a sweep (new; the reference solves one NLP per goal and lets Ipopt judge feasibility): for
+ * problem p and constraint family f -- the bit index of its TWR_SET_* flag: 0 terrain, 1 dynamic, 2 splineacc, 3
+ * rangeofmotion, 4 force, 5 swing, 6 totalduration, 7 baseMotion -- over the family's rows, with the bounds of
+ * ConstraintSet::GetBounds (twr_structure_bounds):
+ *   d_scores[16 p + 2 f]     = max_i max(lower_i - g_i, g_i - upper_i, 0)        (inf-norm of the violation)
+ *   d_scores[16 p + 2 f + 1] = sum_i max(lower_i - g_i, g_i - upper_i, 0)        (1-norm)
+ * (0 for families the structure does not build; NaN if a constraint value of the family is NaN).  d_g is the output of
+ * twr_batch_eval with TWR_EVAL_VALUES.  Asynchronous on hip_stream. */
+int twr_batch_score(twr_batch* b, const double* d_g, double* d_scores /* 16 * n_problems */, void* hip_stream);
+/* fpowr::ExtractFootstepPlan (fpowr/include/fpowr/footstep_plan_extractor.h:69-133) for every problem of the batch,
+ * minus the nearest-plane lookup (boost::geometry over ROS messages -- the caller's): the solution x sampled every dt
+ * (GetTrajectory, :19-53), a footstep state at the first sample and wherever HasEndEffectorContactChanged (:55-67)
+ * against the previous sample; duration = time to the next footstep state, the last one lasts until time_horizon.
+ * Problem p's records start at d_out + p * max_steps * (2 + 4 n_ee):
+ *   [ t_global | duration | contact flag per ee | ee-motion position (3) per ee ]
+ * and d_counts[p] is their number (never more than twr_structure_contact_steps_max).  Asynchronous on hip_stream. */
+int twr_structure_contact_steps_max(const twr_structure* s, int32_t* max_steps);
+int twr_batch_contact_plan(twr_batch* b, const double* d_x, double dt, double time_horizon, double* d_out, int32_t max_steps,
+                           int32_t* d_counts, void* hip_stream);
+
 /* Convenience for single-problem / adapter use: host buffers, synchronous (H2D, eval, D2H). */
 int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_jac, int flags);
 /* Page-locked host buffers owned by the batch (x, g, jac of the whole batch layout), allocated on first

@@ -65,6 +65,8 @@ def lib():
         L.orc_bounds.argtypes = [C.c_void_p, _dp, _dp]
         L.orc_sample_trajectory.argtypes = [C.c_void_p, _dp, C.c_double, _dp, C.c_int]
         L.orc_sample_trajectory.restype = C.c_int
+        L.orc_contact_plan.argtypes = [C.c_void_p, _dp, C.c_double, C.c_double, _dp, C.c_int]
+        L.orc_contact_plan.restype = C.c_int
         L.orc_time_callbacks.argtypes = [C.c_void_p, _dp, C.c_int]
         L.orc_time_callbacks.restype = C.c_double
         L.orc_gait.argtypes = [C.c_int, C.c_int, C.c_double, _ip, _ip, _dp, C.c_int]
@@ -190,6 +192,14 @@ class OracleProblem:
         n = lib().orc_sample_trajectory(self._h, _d(x), float(dt), None, 0)
         out = np.zeros((n, 20 + 13 * self.n_ee))
         lib().orc_sample_trajectory(self._h, _d(x), float(dt), _d(out), n)
+        return out
+
+    def contact_plan(self, x, dt=0.01, time_horizon=2.0):
+        """fpowr::ExtractFootstepPlan: (n_steps, 2 + 4 n_ee) array [t, duration, contact flags, ee positions]."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        n = lib().orc_contact_plan(self._h, _d(x), float(dt), float(time_horizon), None, 0)
+        out = np.zeros((n, 2 + 4 * self.n_ee))
+        lib().orc_contact_plan(self._h, _d(x), float(dt), float(time_horizon), _d(out), n)
         return out
 
     def terrain_probe(self, x, y):

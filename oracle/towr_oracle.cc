@@ -1786,6 +1786,36 @@ int orc_eval(orc_problem* P, const double* x, double* g, int* row_ptr, int* col_
 //     per ee: contact (0/1), ee-motion p v a (9), ee-force p (3) ]        = 20 + 13 n_ee doubles
 // The quaternion is Eigen::Quaterniond(R) (euler_converter.cc:51-56): Eigen 3.3 Quaternion.h
 // quaternionbase_assign_impl<Matrix3d> restated (third party, not in /root/reference).
+// fpowr::ExtractFootstepPlan (fpowr/include/fpowr/footstep_plan_extractor.h:69-133) without the ROS / boost::geometry
+// nearest-plane lookup: the trajectory sampled every dt (GetTrajectory, :19-53), a footstep state wherever it is the
+// first state or HasEndEffectorContactChanged (:55-67) against the previous state; duration = time to the next
+// footstep state, the last one lasts until time_horizon (:121-128).  Record per footstep state:
+//   [ t_global | duration | contact flag per ee | ee-motion position (3) per ee ]  = 2 + 4 n_ee doubles
+int orc_contact_plan(orc_problem* P, const double* x, double dt, double time_horizon, double* out, int max_steps) {
+  const int n = orc_sample_trajectory(P, x, dt, nullptr, 0);
+  const int rec = 20 + 13 * P->n_ee, srec = 2 + 4 * P->n_ee;
+  std::vector<double> traj((size_t)n * rec);
+  orc_sample_trajectory(P, x, dt, traj.data(), n);
+  std::vector<int> steps;
+  for (int i = 0; i < n; ++i) {
+    bool changed = i == 0;
+    for (int ee = 0; ee < P->n_ee && !changed; ++ee)
+      changed = traj[(size_t)i * rec + 20 + 13 * ee] != traj[(size_t)(i - 1) * rec + 20 + 13 * ee];
+    if (changed) steps.push_back(i);
+  }
+  for (size_t s = 0; s < steps.size() && out && (int)s < max_steps; ++s) {
+    const double* st = traj.data() + (size_t)steps[s] * rec;
+    double* o = out + s * srec;
+    o[0] = st[0];
+    o[1] = s + 1 < steps.size() ? traj[(size_t)steps[s + 1] * rec] - st[0] : time_horizon - st[0];
+    for (int ee = 0; ee < P->n_ee; ++ee) {
+      o[2 + ee] = st[20 + 13 * ee];
+      for (int d = 0; d < 3; ++d) o[2 + P->n_ee + 3 * ee + d] = st[20 + 13 * ee + 1 + d];
+    }
+  }
+  return (int)steps.size();
+}
+
 int orc_sample_trajectory(orc_problem* P, const double* x, double dt, double* out, int max_samples) {
   P->SetVariables(x);
   EulerConverter base_angular;

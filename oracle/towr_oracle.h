@@ -86,6 +86,10 @@ void orc_bounds(orc_problem*, double* lower, double* upper);
 // number of samples (pass out = NULL to query it); record layout in towr_oracle.cc.
 int orc_sample_trajectory(orc_problem*, const double* x, double dt, double* out, int max_samples);
 
+// fpowr::ExtractFootstepPlan (footstep_plan_extractor.h:69-133) minus the nearest-plane lookup: footstep states
+// [t | duration | contact per ee | ee position per ee]; returns their number (out = NULL to query it).
+int orc_contact_plan(orc_problem*, const double* x, double dt, double time_horizon, double* out, int max_steps);
+
 // reference-shaped timing loop for bench.py's cpu_baseline: `iters` full callbacks on
 // x (values + Jacobian), returns seconds.
 double orc_time_callbacks(orc_problem*, const double* x, int iters);

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""A/B of library builds on one box: scripts/ab.py lib1.so[:ENV=VAL,...] lib2.so ...  (kernel times of the default bench)."""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for rep in range(2):
+    for spec in sys.argv[1:]:
+        lib, _, envs = spec.partition(":")
+        env = dict(os.environ, TWR_AMD_LIB=os.path.join(ROOT, "towr_amd", lib))
+        for kv in filter(None, envs.split(",")):
+            k, v = kv.split("=")
+            env[k] = v
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "3", "--no-cpu-baseline",
+                            "--no-scale-c5"], env=env, capture_output=True, text=True)
+        try:
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            k = d["roofline"]["path"]["kernel_ms"]
+            print("%-40s %.3f M cb/s  " % (spec, d["value"] / 1e6) + "  ".join("%s %.3f" % (n.split("::")[1][:10], v) for n, v in k.items()), flush=True)
+        except Exception as e:  # noqa: BLE001
+            print(spec, "failed", e, r.stderr[-400:], flush=True)

@@ -10,10 +10,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = os.path.join(ROOT, "towr_amd", os.environ.get("ABL_LIB", "libtowr_amd_ablate.so"))
 cases = [("full", 0), ("no copy-out", 0x100), ("no back", 0x200), ("no front", 0x400), ("no front/back", 0x600),
-         ("back without LDS stores", 0x1000), ("nothing", 0x700),
+         ("back without LDS stores", 0x1000), ("nothing", 0x700), ("no x loads (rom)", 0x400 | 0x2000),
+         ("clamped overshoot stores (old)", 0x8000), ("copy-out only, old clamp", 0x8600), ("copy-out only, const data", 0x4600),
          ("no copy-out, no front", 0x500), ("no copy-out, no back", 0x300), ("no copy-out, back w/o LDS stores", 0x1100)]
 if os.environ.get("ABL_CASES"):
-    want = os.environ["ABL_CASES"].split(",")
+    want = os.environ["ABL_CASES"].split(";")
     cases = [c for c in cases if c[0] in want]
 extra = sys.argv[1:]
 for name, fl in cases:

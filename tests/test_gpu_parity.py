@@ -551,3 +551,64 @@ def test_grid_map_terrain():
     for p, s in enumerate([0, 1, 2, 1]):
         rg, _, _, rj = cases[s].P.eval(xs[p])
         assert_parity(cases[s].S, *_split(batch, g, j, p), rg, rj, "shared map problem %d" % p)
+
+
+def test_candidate_scores_and_contact_plans():
+    """Sweep post-processing on the device: per-family bound violations (twr_batch_score) against numpy on the oracle's
+    g and bounds, and fpowr::ExtractFootstepPlan (footstep_plan_extractor.h:69-133, minus the plane lookup) against
+    the oracle restatement -- fixed and optimised timings, ragged batch."""
+    import torch
+
+    cases = [Case("anymal", "stairs", ta.gait_combo(4, 1, 2.0), constraint_sets=63),
+             Case("anymal", "gap", ta.gait_combo(4, 0, 2.4, 0.9), constraint_sets=255, base_z_init=0.42),
+             Case("go1", "flat", ta.gait_combo(4, 4, 1.8), constraint_sets=127),
+             Case("anymal", "block", ta.gait_combo(4, 3, 2.2), constraint_sets=27)]
+    order = [0, 1, 2, 3, 2, 0]
+    batch = ta.Batch([c.S for c in cases], order, device=0)
+    xs = [cases[s].x_perturbed(i, 1.5) if i % 2 else cases[s].x_wild(i) for i, s in enumerate(order)]
+    xs[4][cases[2].S.var_sets[0]["offset"] + 2] = float("nan")     # one problem with a poisoned base height
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.from_numpy(np.concatenate(xs)).to(dev)
+    g = torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device=dev)
+    scores = torch.full((len(order), 16), -1.0, dtype=torch.float64, device=dev)
+    batch.eval_device(x.data_ptr(), g.data_ptr(), 0, ta.EVAL_VALUES, st)
+    batch.score_device(g.data_ptr(), scores.data_ptr(), st)
+    torch.cuda.synchronize()
+    sc = scores.cpu().numpy()
+    for p, s in enumerate(order):
+        S = cases[s].S
+        rg = cases[s].P.values(xs[p])
+        lo, up = cases[s].P.bounds()
+        viol = np.maximum(np.maximum(lo - rg, rg - up), 0.0)
+        viol[np.isnan(rg)] = np.nan
+        want = np.zeros((8, 2))
+        for cs in S.con_sets:
+            fam = [i for i, f in enumerate(ta.FAMILIES) if cs["name"].startswith(f)][0]
+            v = viol[cs["offset"]:cs["offset"] + cs["size"]]
+            want[fam, 0] = np.nan if (np.isnan(v).any() or np.isnan(want[fam, 0])) else max(want[fam, 0], v.max(initial=0.0))
+            want[fam, 1] += v.sum()
+        got = sc[p].reshape(8, 2)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), (p, got, want)
+        ok = ~np.isnan(want)
+        assert np.all(np.abs(got[ok] - want[ok]) <= 1e-9 * np.abs(want[ok]) + 1e-9), (p, got, want)
+    assert np.isnan(sc[4]).any() and not np.isnan(sc[[0, 1, 2, 3, 5]]).any()
+    # contact plans (dt = 0.01 and the time horizon of fpowr, footstep_plan_server.cc:31)
+    for dt, horizon in ((0.01, 2.0), (0.037, 3.0)):
+        max_steps = max(c.S.contact_steps_max() for c in cases)
+        n_ee = 4
+        rec = 2 + 4 * n_ee
+        out = torch.full((len(order), max_steps, rec), float("nan"), dtype=torch.float64, device=dev)
+        counts = torch.zeros(len(order), dtype=torch.int32, device=dev)
+        batch.contact_plan_device(x.data_ptr(), dt, horizon, out.data_ptr(), max_steps, counts.data_ptr(), st)
+        torch.cuda.synchronize()
+        oh, ch = out.cpu().numpy(), counts.cpu().numpy()
+        for p, s in enumerate(order):
+            if p == 4:
+                continue   # (NaN durations in x: locate_segment is undefined there, like the reference's assert)
+            ref = cases[s].P.contact_plan(xs[p], dt, horizon)
+            assert ch[p] == ref.shape[0] and 2 <= ch[p] <= max_steps, (p, ch[p], ref.shape)
+            got = oh[p, :ch[p]]
+            assert np.array_equal(got[:, 2:2 + n_ee], ref[:, 2:2 + n_ee])          # contact flags
+            assert np.abs(got[:, :2] - ref[:, :2]).max() <= 1e-12                    # t, duration
+            assert np.abs(got[:, 2 + n_ee:] - ref[:, 2 + n_ee:]).max() <= 1e-9 * max(1.0, np.abs(ref).max())

@@ -458,3 +458,19 @@ def test_grid_map_terrain_known_answers():
     assert P2.terrain_probe(0.0, 0.0)[0] == 3.75
     # x = 0.25: cells i=0 (x centre +0.5) and i=1 (x centre -0.5): rx = 0.75 towards i=0
     assert P2.terrain_probe(0.25, 0.0)[0] == float(f32(0.5 * (0.75 * (1 + 2) + 0.25 * (4 + 8))))
+
+
+def test_contact_plan_known_answer():
+    """fpowr::ExtractFootstepPlan (footstep_plan_extractor.h:69-133): footstep states where the contact flags change.
+    Hopper phases {0.4,0.2,0.4,0.2,0.4,0.2,0.2} starting in contact, sampled every 0.01 s: states start at the first
+    sample at or after every phase boundary (t accumulated, IsContactPhase uses the previous phase at a junction)."""
+    P = ob.OracleProblem("monoped", "flat", [[0.4, 0.2, 0.4, 0.2, 0.4, 0.2, 0.2]], [1])
+    x = P.initial_guess([0, 0, 0.5], [0, 0, 0], [1, 0, 0.5], [0, 0, 0], [[0, 0, 0]])
+    plan = P.contact_plan(x, 0.01, 2.0)
+    assert plan.shape == (7, 6)
+    assert list(plan[:, 2]) == [1, 0, 1, 0, 1, 0, 1]
+    bounds = np.cumsum([0.4, 0.2, 0.4, 0.2, 0.4, 0.2])
+    # GetSegmentID: the previous phase still holds AT the boundary (eps 1e-10) -> the change shows one sample later
+    assert plan[0, 0] == 0.0 and np.all(plan[1:, 0] > bounds - 1e-9) and np.all(plan[1:, 0] < bounds + 0.0101)
+    assert np.allclose(plan[:-1, 1], np.diff(plan[:, 0])) and plan[-1, 1] == pytest.approx(2.0 - plan[-1, 0])
+    assert np.allclose(plan[:, 3:], [[xx, 0, 0] for xx in plan[:, 3]])   # flat ground: the foot stays at z = 0

@@ -21,6 +21,7 @@ EVAL_VALUES, EVAL_JACOBIAN, EVAL_BOTH, EVAL_CHECK = 1, 2, 3, 4
 SET_TERRAIN, SET_DYNAMIC, SET_BASE_ACC, SET_ROM, SET_FORCE, SET_SWING, SET_TOTAL_TIME = 1, 2, 4, 8, 16, 32, 64
 SET_BASE_ROM = 128
 SETS_HOT_PATH, SETS_TOWR_DEFAULT, SETS_ALL, SETS_EVERY = 27, 63, 127, 255  # TWR_SETS_* of include/towr_amd.h
+FAMILIES = ("terrain", "dynamic", "splineacc", "rangeofmotion", "force", "swing", "totalduration", "baseMotion")  # twr_batch_score
 SUPPORTS_OPTIMISED_TIMINGS = True  # TWR_SET_TOTAL_TIME has a device path
 
 
@@ -130,6 +131,10 @@ def lib():
         L.twr_batch_eval_host.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int]
         L.twr_structure_sample_count.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int32)]
         L.twr_batch_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int64, C.c_void_p]
+        L.twr_batch_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.twr_structure_contact_steps_max.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        L.twr_batch_contact_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_int32, C.c_void_p,
+                                             C.c_void_p]
         L.twr_batch_host_buffers.argtypes = [C.c_void_p, C.POINTER(_dp), C.POINTER(_dp), C.POINTER(_dp)]
         L.twr_batch_profile_begin.argtypes = [C.c_void_p, C.c_int]
         L.twr_batch_profile_end.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_int)]
@@ -305,6 +310,12 @@ class Structure:
         _check(lib().twr_structure_initial_guess(self._h, _d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), _d(ee), _d(x)))
         return x
 
+    def contact_steps_max(self):
+        """Upper bound of the footstep states twr_batch_contact_plan can produce for this structure."""
+        n = C.c_int32()
+        _check(lib().twr_structure_contact_steps_max(self._h, C.byref(n)))
+        return n.value
+
     def sample_count(self, dt=0.01):
         """Records fpowr::GetTrajectory produces for this structure at step dt."""
         n = C.c_int32()
@@ -389,6 +400,15 @@ class Batch:
         """twr_batch_sample: d_out[p * problem_stride + sample * (20 + 13 n_ee) + field] (device pointers)."""
         _check(lib().twr_batch_sample(self._h, C.c_void_p(d_x), float(dt), C.c_void_p(d_out), int(problem_stride),
                                       C.c_void_p(stream)))
+
+    def score_device(self, d_g, d_scores, stream=0):
+        """twr_batch_score: d_scores[16 p + 2 f + {0: inf-norm, 1: 1-norm}] of the bound violation per family f."""
+        _check(lib().twr_batch_score(self._h, C.c_void_p(d_g), C.c_void_p(d_scores), C.c_void_p(stream)))
+
+    def contact_plan_device(self, d_x, dt, time_horizon, d_out, max_steps, d_counts, stream=0):
+        """twr_batch_contact_plan (fpowr ExtractFootstepPlan without the plane lookup)."""
+        _check(lib().twr_batch_contact_plan(self._h, C.c_void_p(d_x), float(dt), float(time_horizon), C.c_void_p(d_out),
+                                            int(max_steps), C.c_void_p(d_counts), C.c_void_p(stream)))
 
     def host_buffers(self):
         """Page-locked x / g / jac arrays owned by the batch (numpy views); eval_host_pinned() uses them."""

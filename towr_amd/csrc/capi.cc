@@ -22,6 +22,9 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
                        int flags, hipStream_t stream, hipEvent_t* ev);
 hipError_t launch_check(int n_problems, const int64_t* g_off, const int64_t* j_off, const double* g, const double* jac,
                         int32_t* status, int flags, hipStream_t stream);
+hipError_t launch_score(const NodeWork* work, int n_problems, const double* g, double* scores, hipStream_t stream);
+hipError_t launch_contact_plan(const NodeWork* work, int n_problems, const double* x, double* out, int32_t* counts, double dt,
+                               double time_horizon, int n_samples_max, int max_steps, hipStream_t stream);
 hipError_t launch_sample(const SampleWork* work, int n_work, const double* x, double* out, double dt, hipStream_t stream);
 int rom_stage_capacity();
 }  // namespace twr
@@ -393,7 +396,6 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
         w.gather = blob + S.off_dyn_gather + sizeof(twr::DynGather) * (size_t)sl.k0 * 4;
         w.put = blob + S.off_dyn_put + sizeof(twr::DynPut) * (size_t)sl.k0 * 4;
         w.map = blob + sl.map;
-        w.desc = blob + sl.desc;
         w.hdr = blob;
         w.x_off = b->x_off[p];
         w.g_off = b->g_off[p] + ds.offset + 6 * sl.k0;
@@ -702,6 +704,46 @@ int twr_batch_sample(twr_batch* b, const double* d_x, double dt, double* d_out, 
       b->swork_stride = problem_stride;
     }
     hipError_t e = twr::launch_sample(b->d_swork, b->n_swork, d_x, d_out, dt, static_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return TWR_OK;
+  } catch (const std::exception& e) {
+    return fail(TWR_ERR_HIP, e.what());
+  }
+}
+
+int twr_batch_score(twr_batch* b, const double* d_g, double* d_scores, void* hip_stream) {
+  if (!b || !d_g || !d_scores) return fail(TWR_ERR_INVALID, "null argument");
+  if (hipSetDevice(b->device) != hipSuccess) return fail(TWR_ERR_HIP, "hipSetDevice failed");
+  (void)hipGetLastError();
+  hipError_t e = twr::launch_score(b->d_node, b->n_problems, d_g, d_scores, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  return TWR_OK;
+}
+
+int twr_structure_contact_steps_max(const twr_structure* s, int32_t* max_steps) {
+  if (!s || !max_steps) return fail(TWR_ERR_INVALID, "null argument");
+  int n = 1;   // the first sample, then at most one footstep state per phase change of any foot
+  for (int e = 0; e < s->s.n_ee; ++e) n += s->s.schedule.n_phases[e] - 1;
+  *max_steps = n;
+  return TWR_OK;
+}
+
+int twr_batch_contact_plan(twr_batch* b, const double* d_x, double dt, double time_horizon, double* d_out, int32_t max_steps,
+                           int32_t* d_counts, void* hip_stream) {
+  if (!b || !d_x || !d_out || !d_counts || max_steps < 1 || !(dt > 0)) return fail(TWR_ERR_INVALID, "bad arguments");
+  try {
+    TWR_HIP(hipSetDevice(b->device));
+    (void)hipGetLastError();
+    int n_max = 0;
+    for (int p = 0; p < b->n_problems; ++p) {
+      if (!b->sample_ok[p]) throw std::runtime_error("too many polynomials per spline for trajectory sampling");
+      int n = 0;  // fpowr GetTrajectory: while (t <= T + 1e-5) { ...; t += dt; }
+      for (double t = 0.0; t <= b->t_total[p] + 1e-5; t += dt)
+        if (++n > 10000000) throw std::runtime_error("too many samples");
+      n_max = std::max(n_max, n);
+    }
+    hipError_t e = twr::launch_contact_plan(b->d_node, b->n_problems, d_x, d_out, d_counts, dt, time_horizon, n_max, max_steps,
+                                            static_cast<hipStream_t>(hip_stream));
     if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return TWR_OK;
   } catch (const std::exception& e) {

@@ -67,10 +67,20 @@ static_assert(sizeof(DynLane) == 96, "DynLane layout");
 // a zero pair followed by <= 254 doubles, filled cooperatively from a per-slice index map), so that a lane
 // gets its node values with LDS reads instead of ~30 scattered global loads, and a value that is not an
 // optimisation variable simply reads the zero slot (no selects).
-constexpr int kDynImage = 2654;    // Jacobian values of one slice (LDS image, doubles)
+#ifndef TWR_DYN_IMAGE
+#define TWR_DYN_IMAGE 2206
+#endif
+#ifndef TWR_DYN_XS
+#define TWR_DYN_XS 222
+#endif
+// Sized for EIGHT single-wave workgroups per CU (20 KB each; the kernel's 253 VGPRs allow no more): measured on one box
+// 0.637 ms per 8192 C3 problems against 0.692 ms with 2654-value images at six per CU.
+constexpr int kDynImage = TWR_DYN_IMAGE;    // Jacobian values of one slice (LDS image, doubles)
 constexpr int kDynNodes = 16;      // time nodes per slice: four lanes each
-constexpr int kDynTrash0 = kDynImage + 2;   // image + parity slack, then a trash PAIR per lane (either parity)
-constexpr int kDynXsCap = 254;     // staged doubles per slice (8-bit staging indices 2..255; 0/1 = the zero pair)
+// image + parity slack, then a trash PAIR per lane (either parity).  The constraint values of the slice (6 per node,
+// written by role 3 AFTER all tile stores of the wave) are staged in the same 128 doubles.
+constexpr int kDynTrash0 = kDynImage + 2;
+constexpr int kDynXsCap = TWR_DYN_XS;     // staged doubles per slice (8-bit staging indices 2..255; 0/1 = the zero pair)
 // per time node, shared by the four lanes of the quad (32 B)
 struct DynNode {
   double tb, iTb;        // base spline: local time in the active polynomial, 1/duration
@@ -98,18 +108,6 @@ struct DynPut {
   uint16_t pad[4];
 };
 static_assert(sizeof(DynPut) == 128, "DynPut layout");
-
-// dyn kernel, "table + emit" form (dyn_emit_kernel): instead of scattering every Jacobian value into an LDS image of
-// the slice, the quad writes a small operand table per time node, and the wave then EMITS the slice in CSR order --
-// every value is (+-) table[a] * table[b], the pair (a, b) coming from a per-slice descriptor array built on the host.
-// Table of one time node (kDynTabNode doubles): F[3] | wP[4] | m wA[4] | - | BA[36] (row r, base-ang column 3j+d) |
-// per role e: f[3] rv[3] wm[4] wf[4].  The slice's table region starts with the constants 1.0 and -1.0.
-constexpr int kDynTabNode = 104;
-constexpr int kDynTabConst = 2;
-constexpr int kDynTabF = 0, kDynTabWP = 3, kDynTabMWA = 7, kDynTabBA = 12, kDynTabEE = 48, kDynTabEEStride = 14;
-// descriptor of one Jacobian value: bits 0-15 byte offset of a, bits 16-30 byte offset of b (both inside the slice's
-// table region), bit 31 = negate.  The array of a slice has one leading and seven trailing pad entries.
-constexpr int kDynDescLead = 1, kDynDescTail = 7;
 
 struct ForceNode {   // one non-constant ee-force node (force_constraint.cc:50-60)
   int32_t fidx;      // x index of the node's force px (py = +2, pz = +4)
@@ -192,6 +190,16 @@ struct SampleWork {       // cnt <= 64 samples of one problem from sample s0
 };
 static_assert(sizeof(SampleWork) == 32, "SampleWork layout");
 
+// Candidate scoring (twr_batch_score): the bounds of every row and which constraint family a set belongs to.
+constexpr int kMaxConSets = 24;   // 4 terrain + dynamic + 2 splineacc + 4 rangeofmotion + 4 force + 4 swing + baseMotion + 4 totalduration
+struct ScoreTables {
+  int32_t n_sets, n_rows;
+  uint32_t o_lower, o_upper;       // double[n_rows] (twr_structure_bounds)
+  struct {
+    int32_t row0, row1, family, pad;   // family = bit index of the set's TWR_SET_* flag (0 terrain .. 7 baseMotion, 6 totalduration)
+  } sets[kMaxConSets];
+};
+
 // Blob header: model constants + what the node kernel needs.  The terrain-ee-motion_e sets are
 // adjacent in g / jac, and so are the force-ee-force_e sets, so each family is one flat node list.
 struct DevStruct {
@@ -224,6 +232,8 @@ struct DevStruct {
   uint32_t o_sample;    // SampleTables
   uint32_t pad2_;
   double grid_px, grid_py;  // Grid: map centre
+  uint32_t o_score;         // ScoreTables
+  uint32_t pad3_;
 };
 
 // Work items: one contiguous run of time nodes of one constraint set of one problem.  All
@@ -238,7 +248,7 @@ struct DynWork {          // cnt <= 16 time nodes of "dynamic"
   int64_t g_off;          // first constraint value of the run (row 6*k0 of the set)
   int64_t j_off;          // first Jacobian value of the run
   int32_t cnt, nvals;     // time nodes, Jacobian values of the run
-  uint64_t desc;          // uint32_t[kDynDescLead + nvals + kDynDescTail]: emit descriptors of the slice
+  int64_t pad;
 };
 static_assert(sizeof(DynWork) == 80, "DynWork layout");
 

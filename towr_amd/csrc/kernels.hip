@@ -920,7 +920,7 @@ TWR_DEV void copy_out(double* __restrict__ dst, const double* __restrict__ stage
 // loads and stores retire through one in-order counter; an unknown store count would force
 // vmcnt(0), i.e. a full store drain per slice).
 template <int NIT, int kBatch>
-TWR_DEV void copy_out_fixed(double* __restrict__ dst, const double* __restrict__ stage, int n, int par, int lane) {
+TWR_DEV void copy_out_fixed(double* __restrict__ dst, const double* __restrict__ stage, int n, int par, int lane, int abl = 0) {
   // byte offsets as unsigned 32-bit values: one VGPR addresses both the LDS read and the global store (wave-uniform
   // base + 32-bit offset), two VALU instructions per store instead of a 64-bit address computation
   char* al = reinterpret_cast<char*>(dst - par);  // 16-byte aligned
@@ -936,12 +936,22 @@ TWR_DEV void copy_out_fixed(double* __restrict__ dst, const double* __restrict__
 #pragma unroll
     for (int b = 0; b < kBatch; ++b)
       if (it0 + b < NIT) {
-        off[b] = min(first + 1024u * (uint32_t)(it0 + b), last);
-        v[b] = *reinterpret_cast<const double2*>(st + off[b]);
+        off[b] = first + 1024u * (uint32_t)(it0 + b);
+#ifdef TWR_ABLATE
+        if (abl & 0x4000) v[b] = make_double2(1.0, 2.0); else
+#endif
+        v[b] = *reinterpret_cast<const double2*>(st + min(off[b], last));
       }
+    // lanes past the end of the slice store nothing, but the instruction is issued all the same: the count of
+    // vector-memory instructions stays a compile-time constant (counted s_waitcnt for the prefetched loads)
 #pragma unroll
     for (int b = 0; b < kBatch; ++b)
-      if (it0 + b < NIT) *reinterpret_cast<double2*>(al + off[b]) = v[b];
+      if (it0 + b < NIT) {
+#ifdef TWR_ABLATE
+        if (abl & 0x8000) { *reinterpret_cast<double2*>(al + min(off[b], last)) = v[b]; continue; }
+#endif
+        if (off[b] <= last) *reinterpret_cast<double2*>(al + off[b]) = v[b];
+      }
   }
   if (par && lane == 0 && n > 0) dst[0] = stage[1];
   if ((total & 1) && lane == 0 && total - 1 > par) dst[n - 1] = stage[total - 1];
@@ -971,14 +981,14 @@ constexpr int kRomStage = 4856;   // + 2 + 64 + 192 doubles = 40912 B
 // time node on a quad of lanes), but every index is an LDS byte offset prepared on the host (device_tables.h
 // DynNode / DynGather / DynPut): the slice's part of x sits in LDS ("xs"), values that are not optimisation
 // variables read its zero slot, and a Jacobian value is stored at node base + a 16-bit offset from the record.
-constexpr int kDynG0 = kDynTrash0 + 128;   // constraint values of the slice (6 x 16)
-constexpr int kDynX0 = kDynG0 + 96;        // xs: zero pair, then <= 254 staged doubles of x
-constexpr int kDynLds = kDynX0 + 256;      // 3136 doubles = 25088 B: six workgroups per CU
+constexpr int kDynG0 = kDynTrash0;         // constraint values of the slice (6 x 16), sharing the trash pairs' space
+constexpr int kDynX0 = kDynG0 + 128;       // xs: zero pair, then <= kDynXsCap staged doubles of x
+constexpr int kDynLds = kDynX0 + 2 + kDynXsCap;   // 2560 doubles = 20480 B: eight workgroups per CU (the VGPR limit too)
+static_assert(kDynLds * 8 <= 20480, "dyn_kernel: eight workgroups of 20 KB per CU");
 #ifndef TWR_DYN_COPY_BATCH
 #define TWR_DYN_COPY_BATCH 8
 #endif
 constexpr int kDynCopyBatch = TWR_DYN_COPY_BATCH;   // LDS reads in flight before the first store of the copy-out
-#define TWR_STAGE() __builtin_amdgcn_sched_barrier(0)
 struct Dyn2Front {   // (the base-spline weights are recomputed in the back half: 48 registers less across the copy-out)
   double cdd[3], ed[3], edd[3];
   double wm[4], wf[4], f[3], rv[3], F[3], tau[3];
@@ -1030,9 +1040,7 @@ TWR_DEV void dyn2_front(const DynNode& nd, const DynGather& ga, const char* __re
       S.edd[d] = wA[0] * ba[d] + wA[1] * ba[3 + d] + wA[2] * ba[6 + d] + wA[3] * ba[9 + d];
     }
   }
-  // this lane's end-effector: weights and spline points (absent candidates read the zero slot); one spline after
-  // the other (TWR_STAGE: scheduling fences that keep the stages' live ranges apart -- register budget)
-  TWR_STAGE();
+  // this lane's end-effector: weights and spline points (absent candidates read the zero slot)
   {
     double vm[12], p[3];
     gather12s(xs, ga.idx_m, vm);
@@ -1044,7 +1052,6 @@ TWR_DEV void dyn2_front(const DynNode& nd, const DynGather& ga, const char* __re
       S.rv[d] = c[d] - p[d];
     }
   }
-  TWR_STAGE();
   {
     double vf[12];
     gather12s(xs, ga.idx_f, vf);
@@ -1052,7 +1059,6 @@ TWR_DEV void dyn2_front(const DynNode& nd, const DynGather& ga, const char* __re
 #pragma unroll
     for (int d = 0; d < 3; ++d) S.f[d] = S.wf[0] * vf[d] + S.wf[1] * vf[3 + d] + S.wf[2] * vf[6 + d] + S.wf[3] * vf[9 + d];
   }
-  TWR_STAGE();
   // force and torque sums over the end-effectors (single_rigid_body_dynamics.cc:81-88); dummy roles carry f = 0
   double t3[3];
   cross3(S.f, S.rv, t3);
@@ -1259,7 +1265,8 @@ __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ 
   };
   auto stage_x = [&](const double xr[4]) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) stage[kDynX0 + 2 + 64 * c + lane] = xr[c];
+    for (int c = 0; c < 4; ++c)
+      if (64 * c + lane < kDynXsCap) stage[kDynX0 + 2 + 64 * c + lane] = xr[c];
   };
   DynWork wp = work[i];   // slice whose image is waiting to be copied out (none yet)
   bool pending = false;
@@ -1305,7 +1312,11 @@ __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ 
 #endif
       double* pdst = jac + wp.j_off;
       const int ppar = (int)((reinterpret_cast<uintptr_t>(pdst) >> 3) & 1);
+#ifdef TWR_ABLATE
+      if (want_j) copy_out_fixed<NIT, kDynCopyBatch>(pdst, stage, wp.nvals, ppar, lane, flags);
+#else
       if (want_j) copy_out_fixed<NIT, kDynCopyBatch>(pdst, stage, wp.nvals, ppar, lane);
+#endif
       if (want_g) {                                     // 6 constraint values per time node, contiguous in g
         double* go = g + wp.g_off;
         if (lane < 6 * wp.cnt) go[lane] = gst[lane];
@@ -1344,283 +1355,12 @@ __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ 
   }
 }
 
-// ---------------------------------------------------------------- dynamic, fixed timings: table + emit
-// The image form above is bound by its structure, not by the math (scripts/ablate.py): ~85 scattered, bank-conflicted
-// ds_write_b64 per lane and slice (more than half of the tile stores go to trash for end-effectors in swing), and
-// 25 KB of LDS per single-wave workgroup, i.e. six waves per CU.  Here the quad only writes the node's OPERANDS
-// (kDynTabNode doubles, device_tables.h), 13 KB per slice, and the wave then produces the slice in CSR order, four
-// consecutive values per lane: value = (+-) table[a] * table[b] with (a, b) from the slice's descriptor array.
-// Stores are coalesced 16-byte stores straight from registers; nothing is written that is not a Jacobian value.
-constexpr int kEmitTab = kDynTabConst + kDynNodes * kDynTabNode;   // 1666 doubles
-constexpr int kEmitG0 = kEmitTab;                                  // constraint values of the slice (6 x 16)
-constexpr int kEmitX0 = kEmitG0 + 96;                              // xs: zero pair + <= 254 staged doubles
-constexpr int kEmitLds = kEmitX0 + 256;                            // 2018 doubles = 16144 B: ten workgroups per CU
-constexpr int kEmitIters = (kDynImage + 1 + 255) / 256;            // chunks of 4 values per lane
-
-// all of dyn2_front + the math of dyn2_back for one time node; results go to the node's table and to gst
-TWR_DEV void dyn3_tables(const DynWork& w, const DynNode& nd, const DynGather& ga, const char* __restrict__ xs,
-                         double* __restrict__ tab, double* __restrict__ gst, int lane, bool want_g, bool want_j) {
-  const int kk = lane >> 2, role = lane & 3;
-  Dyn2Front S;
-  dyn2_front(nd, ga, xs, lane, S);
-  if (kk >= w.cnt) return;
-  const double (&cdd)[3] = S.cdd, (&ed)[3] = S.ed, (&edd)[3] = S.edd;
-  const double (&F)[3] = S.F, (&tau)[3] = S.tau;
-  const double sx = S.sx, cx = S.cx, sy = S.sy, cy = S.cy, sz = S.sz, cz = S.cz;
-  double* nt = tab + kDynTabConst + kk * kDynTabNode;
-  if (want_j) {  // this role's operands: f[3] rv[3] wm[4] wf[4], seven aligned 16-byte stores
-    double2* ee = reinterpret_cast<double2*>(nt + kDynTabEE + kDynTabEEStride * role);
-    ee[0] = make_double2(S.f[0], S.f[1]);
-    ee[1] = make_double2(S.f[2], S.rv[0]);
-    ee[2] = make_double2(S.rv[1], S.rv[2]);
-    ee[3] = make_double2(S.wm[0], S.wm[1]);
-    ee[4] = make_double2(S.wm[2], S.wm[3]);
-    ee[5] = make_double2(S.wf[0], S.wf[1]);
-    ee[6] = make_double2(S.wf[2], S.wf[3]);
-  }
-  TWR_STAGE();
-  // --- angular quantities (euler_converter.cc:58-83,133-166,207-221), as in dyn2_back
-  const double xd = ed[0], yd = ed[1], zd = ed[2];
-  const double Mx[3] = {cy * cz, cy * sz, -sy}, My[3] = {-sz, cz, 0.0};
-  const double Mdx[3] = {-cz * sy * yd - cy * sz * zd, cy * cz * zd - sy * sz * yd, -cy * yd};
-  const double Mdy[3] = {-cz * zd, -sz * zd, 0.0};
-  double om[3], omd[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    om[i] = Mx[i] * xd + My[i] * yd;
-    omd[i] = Mdx[i] * xd + Mdy[i] * yd + Mx[i] * edd[0] + My[i] * edd[1];
-  }
-  om[2] += zd;
-  omd[2] += edd[2];
-  const TWR_CONST DevStruct* H = cptr<DevStruct>(w.hdr);  // uniform per work item: scalar loads
-  double Iw6[6];  // I_w = R I_b R^T (single_rigid_body_dynamics.cc:91), symmetric: (00,01,02,11,12,22)
-  {
-    double R[3][3];
-    R[0][0] = cy * cz; R[0][1] = cz * sx * sy - cx * sz; R[0][2] = sx * sz + cx * cz * sy;
-    R[1][0] = cy * sz; R[1][1] = cx * cz + sx * sy * sz; R[1][2] = cx * sy * sz - cz * sx;
-    R[2][0] = -sy;     R[2][1] = cy * sx;                R[2][2] = cx * cy;
-    double Ib[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) Ib[i] = H->Ib[i];
-    double T[3][3];  // R I_b
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      T[i][0] = R[i][0] * Ib[0] + R[i][1] * Ib[1] + R[i][2] * Ib[2];
-      T[i][1] = R[i][0] * Ib[1] + R[i][1] * Ib[3] + R[i][2] * Ib[4];
-      T[i][2] = R[i][0] * Ib[2] + R[i][1] * Ib[4] + R[i][2] * Ib[5];
-    }
-    Iw6[0] = T[0][0] * R[0][0] + T[0][1] * R[0][1] + T[0][2] * R[0][2];
-    Iw6[1] = T[0][0] * R[1][0] + T[0][1] * R[1][1] + T[0][2] * R[1][2];
-    Iw6[2] = T[0][0] * R[2][0] + T[0][1] * R[2][1] + T[0][2] * R[2][2];
-    Iw6[3] = T[1][0] * R[1][0] + T[1][1] * R[1][1] + T[1][2] * R[1][2];
-    Iw6[4] = T[1][0] * R[2][0] + T[1][1] * R[2][1] + T[1][2] * R[2][2];
-    Iw6[5] = T[2][0] * R[2][0] + T[2][1] * R[2][1] + T[2][2] * R[2][2];
-  }
-  TWR_STAGE();
-  double Iw_wd[3], Iw_w[3];
-  symmul(Iw6, omd, Iw_wd);
-  symmul(Iw6, om, Iw_w);
-  const double m = H->mass;
-  double wP[4], wV[4], wA[4];
-  if (role == 3) {
-    hermite_all(nd.tb, nd.iTb, wP, wV, wA);
-    if (want_g) {  // GetDynamicViolation, single_rigid_body_dynamics.cc:76-101
-      double wxIw[3];
-      cross3(om, Iw_w, wxIw);
-      double* go = gst + 6 * kk;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) go[i] = Iw_wd[i] + wxIw[i] - tau[i];
-      go[3] = m * cdd[0] - F[0];
-      go[4] = m * cdd[1] - F[1];
-      go[5] = m * cdd[2] - F[2] + m * H->gravity;
-    }
-    if (want_j) {  // operands of the base-lin block: -[F]x J_pos and m J_acc (:103-121)
-#pragma unroll
-      for (int i = 0; i < 3; ++i) nt[kDynTabF + i] = F[i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        nt[kDynTabWP + j] = wP[j];
-        nt[kDynTabMWA + j] = m * wA[j];
-      }
-    }
-  } else if (want_j) {
-    // --- base-ang block (:123-165), Euler dimension d = role, factored (see dyn_back)
-    const double dMx_dy[3] = {-sy * cz, -sy * sz, -cy};
-    const double dMx_dz[3] = {-cy * sz, cy * cz, 0.0};
-    const double dMy_dz[3] = {-cz, -sz, 0.0};
-    const double dMdx_dy[3] = {-cz * cy * yd + sy * sz * zd, -sy * cz * zd - cy * sz * yd, sy * yd};
-    const double dMdx_dz[3] = {sz * sy * yd - cy * cz * zd, -cy * sz * zd - sy * cz * yd, 0.0};
-    const double dMdy_dz[3] = {sz * zd, -cz * zd, 0.0};
-    double Md[3], dwd_ed[3], dw[3], dwd[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      Md[i] = sel3(role, Mx[i], My[i], i == 2 ? 1.0 : 0.0);  // column d of M (euler_converter.cc:133-148)
-      dwd_ed[i] = sel3(role, Mdx[i], Mdy[i] + xd * dMx_dy[i], xd * dMx_dz[i] + yd * dMy_dz[i]);
-      dw[i] = sel3(role, 0.0, xd * dMx_dy[i], xd * dMx_dz[i] + yd * dMy_dz[i]);
-      dwd[i] = sel3(role, 0.0, xd * dMdx_dy[i] + edd[0] * dMx_dy[i],
-                    xd * dMdx_dz[i] + yd * dMdy_dz[i] + edd[0] * dMx_dz[i] + edd[1] * dMy_dz[i]);
-    }
-    auto dIw = [&](const double v[3], const double Iwv[3], double o[3]) {
-      double t1[3], t2[3], t3b[3];
-      cross3(Md, Iwv, t1);
-      cross3(v, Md, t2);
-      symmul(Iw6, t2, t3b);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) o[i] = t1[i] + t3b[i];
-    };
-    double A[3], B[3], C[3];
-    symmul(Iw6, Md, C);
-    {
-      double t1[3], t2[3], t3b[3];
-      symmul(Iw6, dwd_ed, t1);
-      cross3(Md, Iw_w, t2);
-      cross3(om, C, t3b);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) B[i] = t1[i] + t2[i] + t3b[i];
-    }
-    {
-      double t1[3], t2[3], t3b[3], t4[3], t5[3], t6[3], t7[3];
-      dIw(omd, Iw_wd, t1);
-      symmul(Iw6, dwd, t2);
-      cross3(dw, Iw_w, t3b);
-      dIw(om, Iw_w, t4);
-      symmul(Iw6, dw, t5);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) t6[i] = t4[i] + t5[i];
-      cross3(om, t6, t7);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) A[i] = t1[i] + t2[i] + t3b[i] + t7[i];
-    }
-    {
-      double tb = nd.tb;
-      asm volatile("" : "+v"(tb));   // a fresh evaluation here: twelve weights less across the A/B/C algebra
-      hermite_all(tb, nd.iTb, wP, wV, wA);
-    }
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) nt[kDynTabBA + r * 12 + 3 * j + role] = A[r] * wP[j] + B[r] * wV[j] + C[r] * wA[j];
-  }
-}
-
-// one emitted value: (+-) table[a] * table[b]
-TWR_DEV double emit_value(const char* __restrict__ tab, uint32_t d) {
-  const double a = lds_f64(tab, d & 0xFFFFu), b = lds_f64(tab, (d >> 16) & 0x7FFFu);
-  const double v = a * b;
-  return __hiloint2double(__double2hiint(v) ^ (int)(d & 0x80000000u), __double2loint(v));
-}
-
-// Persistent single-wave workgroups, strided slices.  Per slice:
-//   T  tables(i): xs + front record -> operand tables, constraint values           (LDS writes: ~26 per lane)
-//   X  xs <- xr (x(i+1), gathered during the previous emit phase)
-//   L  issue the loads of the NEXT slice that the next table phase needs at once (front record, x gather): they are
-//      older than every store of this slice, so waiting for them never waits for a store
-//   E  emit(i): descriptors -> products -> 16-byte stores, four values per lane and step; constraint values
-__global__ __launch_bounds__(64, 3) void dyn_emit_kernel(const DynWork* __restrict__ work, int n_work,
-                                                         const double* __restrict__ x, double* __restrict__ g,
-                                                         double* __restrict__ jac, int flags) {
-  __shared__ __attribute__((aligned(16))) double lds[kEmitLds];
-  const bool want_g = flags & 1, want_j = flags & 2;
-  const int lane = threadIdx.x;
-  double* tab = lds;
-  double* gst = lds + kEmitG0;
-  char* xs = reinterpret_cast<char*>(lds + kEmitX0);
-  const char* tabc = reinterpret_cast<const char*>(lds);
-  const int stride = gridDim.x;
-  int i = blockIdx.x;
-  if (i >= n_work) return;
-  if (lane < 2) {
-    lds[kEmitX0 + lane] = 0.0;              // the zero pair of xs
-    lds[lane] = lane == 0 ? 1.0 : -1.0;     // table constants
-  }
-  auto load_map = [&](const DynWork& w) { return gptr<uint2>(w.map)[lane]; };
-  auto gather_x = [&](const DynWork& w, uint2 m, double xr[4]) {
-    const double* xp = x + w.x_off;
-    xr[0] = xp[m.x & 0xFFFFu];
-    xr[1] = xp[m.x >> 16];
-    xr[2] = xp[m.y & 0xFFFFu];
-    xr[3] = xp[m.y >> 16];
-  };
-  auto stage_x = [&](const double xr[4]) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) lds[kEmitX0 + 2 + 64 * c + lane] = xr[c];
-  };
-  DynWork w0 = work[i], w1 = w0, w2 = w0;
-  DynNode nd0, nd1;
-  DynGather ga0, ga1;
-  double xr[4];
-  uint2 mapr = load_map(w0);
-  dyn2_load_rec(w0, lane, nd0, ga0);
-  gather_x(w0, mapr, xr);
-  stage_x(xr);                                           // x of the first slice: the only exposed gather
-  nd1 = nd0;
-  ga1 = ga0;
-  if (i + stride < n_work) {
-    w1 = work[i + stride];
-    mapr = load_map(w1);
-  }
-  for (; i < n_work; i += stride) {
-    const bool has1 = i + stride < n_work, has2 = i + 2 * stride < n_work;
-    if (has2) w2 = work[i + 2 * stride];
-    dyn3_tables(w0, nd0, ga0, xs, tab, gst, lane, want_g, want_j);                          // T
-    if (has1) {                                                                               // L
-      dyn2_load_rec(w1, lane, nd1, ga1);
-      gather_x(w1, mapr, xr);
-    }
-    if (has2) mapr = load_map(w2);
-    if (want_j) {                                                                             // E
-      double* dst = jac + w0.j_off;
-      const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-      char* al = reinterpret_cast<char*>(dst - par);                  // 16-byte aligned
-      const int total = w0.nvals + par;                               // values of the slice, counted from al
-      const uint32_t* desc = gptr<uint32_t>(w0.desc) + kDynDescLead - par;   // desc[t] describes al[t]
-      // chunks of four values [4c, 4c+4): complete ones are c in [cfirst, clast]; lanes past the end redo the last
-      // complete chunk (idempotent); the incomplete head (par = 1) and tail are done value by value below
-      const int cfirst = par, clast = (total >> 2) - 1;
-      // descriptors two steps ahead of their use, nothing else kept in flight (register budget: three waves per SIMD)
-      auto load_desc = [&](int it) {
-        const int c = min(max(lane + 64 * it, cfirst), clast);
-        return *reinterpret_cast<const uint4*>(desc + 4 * c);   // 4-byte aligned 16-byte load
-      };
-      uint4 d0 = load_desc(0), d1 = load_desc(1);
-#pragma unroll 1
-      for (int it = 0; it < kEmitIters; ++it) {
-        const uint4 d = d0;
-        d0 = d1;
-        d1 = load_desc(min(it + 2, kEmitIters - 1));
-        const int c = min(max(lane + 64 * it, cfirst), clast);
-        double2 v0, v1;
-        v0.x = emit_value(tabc, d.x);
-        v0.y = emit_value(tabc, d.y);
-        v1.x = emit_value(tabc, d.z);
-        v1.y = emit_value(tabc, d.w);
-        double2* o = reinterpret_cast<double2*>(al + 32u * (uint32_t)c);
-        o[0] = v0;
-        o[1] = v1;
-      }
-      if (lane < 8) {   // head: al[1..3] when par = 1; tail: al[4 (clast + 1) ..  total)
-        const int t = lane < 4 ? lane : 4 * (clast + 1) + (lane - 4);
-        const bool mine = lane < 4 ? (par == 1 && t >= 1) : (t < total);
-        if (mine) reinterpret_cast<double*>(al)[t] = emit_value(tabc, desc[t]);
-      }
-    }
-    if (want_g) {                                       // 6 constraint values per time node, contiguous in g
-      double* go = g + w0.g_off;
-      if (lane < 6 * w0.cnt) go[lane] = gst[lane];
-      if (lane + 64 < 6 * w0.cnt) go[lane + 64] = gst[lane + 64];
-    }
-    if (has1) stage_x(xr);                                                                    // X (for the next T)
-    w0 = w1; nd0 = nd1; ga0 = ga1;
-    w1 = w2;
-  }
-}
-
 #endif  // !TWR_TU_ROM
 
 // rom_kernel is compiled in its own translation unit (rom_tu.hip) with a different instruction scheduling
 // strategy: it is store bound and gains 4-5 % from clause-oriented scheduling, the VALU-bound kernels lose.
 #ifdef TWR_TU_ROM
-__global__ __launch_bounds__(64, 2) void rom_kernel(const RomWork* __restrict__ work, int n_work,
+__global__ __launch_bounds__(64, 1) void rom_kernel(const RomWork* __restrict__ work, int n_work,
                                                     const double* __restrict__ x, double* __restrict__ g,
                                                     double* __restrict__ jac, int flags) {
   __shared__ __attribute__((aligned(16))) double stage[kRomStage + 2 + 64 + 192];
@@ -1645,12 +1385,28 @@ __global__ __launch_bounds__(64, 2) void rom_kernel(const RomWork* __restrict__ 
     double* dst = jac + w0.j_off;
     const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
     const int vbase = __builtin_amdgcn_readfirstlane(r0.voff);
+#ifdef TWR_ABLATE
+    if (lane < w0.cnt && !(flags & 0x200)) rom_item(w0, r0, X, gst, stage, par, vbase, trash, lane, want_g, want_j && !(flags & 0x1000));
+#else
     if (lane < w0.cnt) rom_item(w0, r0, X, gst, stage, par, vbase, trash, lane, want_g, want_j);   // C
+#endif
     RomRec r2 = r1;
     if (has2) r2 = rom_load_rec(w2, lane);              // A (records first: the wait for x retires them too)
+#ifdef TWR_ABLATE
+    if (has1 && !(flags & 0x400)) rom_load_x(w1, r1, x, X);
+#else
     if (has1) rom_load_x(w1, r1, x, X);
+#endif
+#ifdef TWR_ABLATE
+    if (want_j && !(flags & 0x100))
+#else
     if (want_j)                                         // B
+#endif
+#ifdef TWR_ABLATE
+      copy_out_fixed<(kRomStage + 2 + 127) / 128, 13>(dst, stage, w0.nvals, par, lane, flags);
+#else
       copy_out_fixed<(kRomStage + 2 + 127) / 128, 13>(dst, stage, w0.nvals, par, lane);
+#endif
     if (want_g) {                                       //   3 constraint values per time node, contiguous in g
       double* go = g + w0.g_off;
 #pragma unroll
@@ -2281,6 +2037,149 @@ hipError_t launch_sample(const SampleWork* work, int n_work, const double* x, do
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- candidate scoring
+// twr_batch_score: per problem and constraint family the inf- and 1-norm of the bound violation
+// max(lower - g, g - upper, 0) over the family's rows (bounds of ConstraintSet::GetBounds, twr_structure_bounds).
+// One wave per problem; a sweep then returns 16 doubles per candidate instead of its Jacobian.
+__global__ __launch_bounds__(64) void score_kernel(const NodeWork* __restrict__ work, const double* __restrict__ g,
+                                                   double* __restrict__ scores) {
+  const NodeWork w = work[blockIdx.x];
+  const char* blob = reinterpret_cast<const char*>(w.blob);
+  const DevStruct* S = reinterpret_cast<const DevStruct*>(blob);
+  const ScoreTables* T = tbl<ScoreTables>(blob, S->o_score);
+  const double* lo = tbl<double>(blob, T->o_lower);
+  const double* up = tbl<double>(blob, T->o_upper);
+  const double* gp = g + w.g_off;
+  const int lane = threadIdx.x;
+  double fmax8[8], fsum8[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) fmax8[f] = fsum8[f] = 0.0;
+  for (int s = 0; s < T->n_sets; ++s) {
+    double vmax = 0.0, vsum = 0.0;
+    for (int r = T->sets[s].row0 + lane; r < T->sets[s].row1; r += 64) {
+      const double v = gp[r];
+      // NaN-propagating: a non-finite constraint value makes the family's scores NaN instead of hiding in a max()
+      double viol = fmax(fmax(lo[r] - v, v - up[r]), 0.0);
+      if (v != v) viol = v;
+      vmax = (viol != viol || vmax != vmax) ? (viol != viol ? viol : vmax) : fmax(vmax, viol);
+      vsum += viol;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double om = __shfl_xor(vmax, o), os = __shfl_xor(vsum, o);
+      vmax = (om != om || vmax != vmax) ? (om != om ? om : vmax) : fmax(vmax, om);
+      vsum += os;
+    }
+    const int fam = T->sets[s].family;   // wave-uniform
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+      if (f == fam) {
+        fmax8[f] = (vmax != vmax || fmax8[f] != fmax8[f]) ? (vmax != vmax ? vmax : fmax8[f]) : fmax(fmax8[f], vmax);
+        fsum8[f] += vsum;
+      }
+  }
+  if (lane == 0) {
+    double* o = scores + 16 * (size_t)blockIdx.x;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      o[2 * f] = fmax8[f];
+      o[2 * f + 1] = fsum8[f];
+    }
+  }
+}
+hipError_t launch_score(const NodeWork* work, int n_problems, const double* g, double* scores, hipStream_t stream) {
+  hipLaunchKernelGGL(score_kernel, dim3(n_problems), dim3(64), 0, stream, work, g, scores);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- contact plan
+// fpowr::ExtractFootstepPlan (fpowr/include/fpowr/footstep_plan_extractor.h:69-133) minus the nearest-plane lookup
+// (boost::geometry over ROS messages, left to the caller): the solution is sampled every dt like GetTrajectory
+// (t accumulated), a footstep state is the first sample and every sample whose contact flags differ from the
+// previous sample's (HasEndEffectorContactChanged, :55-67); its duration is the time to the next footstep state, the
+// last one lasts until time_horizon (:121-128).  One wave per problem, lane = sample, 64 samples per round, footstep
+// states compacted with a ballot.  Record: [ t | duration | contact per ee | ee-motion position (3) per ee ].
+__global__ __launch_bounds__(64) void contact_plan_kernel(const NodeWork* __restrict__ work, const double* __restrict__ x,
+                                                          double* __restrict__ out, int32_t* __restrict__ counts, double dt,
+                                                          double time_horizon, int n_samples_max, int max_steps) {
+  __shared__ double s_ph[kMaxEE][TWR_MAX_PHASES_DEV], s_md[kMaxEE][kMaxPhasePolys];
+  const NodeWork w = work[blockIdx.x];
+  const char* blob = reinterpret_cast<const char*>(w.blob);
+  const DevStruct* H = reinterpret_cast<const DevStruct*>(blob);
+  const SampleTables* ST = tbl<SampleTables>(blob, H->o_sample);
+  const double* xp = x + w.x_off;
+  const int lane = threadIdx.x, n_ee = H->n_ee;
+  for (int e = 0; e < n_ee; ++e) {
+    if (H->timings) {  // PhaseDurations::SetVariables + ConvertPhaseToPolyDurations (phase_durations.cc:77-103)
+      phase_poly_durations_wave(tbl<PhaseTables>(blob, H->o_phase), blob, xp, e, s_ph[e], s_md[e], lane);
+    } else {
+      for (int q = lane; q < ST->n_phases[e]; q += 64) s_ph[e][q] = tbl<double>(blob, ST->o_phdur[e])[q];
+      for (int q = lane; q < ST->n_mpoly[e]; q += 64) s_md[e][q] = tbl<double>(blob, ST->o_mdur[e])[q];
+    }
+  }
+  __syncthreads();
+  // GetTrajectory: while (t <= T + 1e-5) { ...; t += dt; }
+  const double T = ST->t_total;
+  const int rec = 2 + 4 * n_ee;
+  double* o = out + (size_t)blockIdx.x * (size_t)max_steps * rec;
+  int n_steps = 0;          // wave-uniform
+  double t_carry = 0.0;     // t of the last footstep state of the previous round (wave-uniform)
+  for (int s0 = 0; s0 < n_samples_max; s0 += 64) {
+    const int s_idx = s0 + lane;
+    double t = 0.0, tq = 0.0;   // this sample's and the previous sample's accumulated time (t += dt, like the reference)
+    for (int i = 0; i < s_idx; ++i) {
+      tq = t;
+      t += dt;
+    }
+    const bool live = t <= T + 1e-5;
+    unsigned mask = 0, mask_prev = 0;
+    for (int e = 0; e < n_ee; ++e) {  // PhaseDurations::IsContactPhase (phase_durations.cc:118-124)
+      double tl;
+      const int ph = locate_segment(s_ph[e], ST->n_phases[e], t, tl);
+      mask |= ((((ph & 1) == 0) == (ST->contact0[e] != 0)) ? 1u : 0u) << e;
+      const int pq = locate_segment(s_ph[e], ST->n_phases[e], tq, tl);
+      mask_prev |= ((((pq & 1) == 0) == (ST->contact0[e] != 0)) ? 1u : 0u) << e;
+    }
+    const bool step = live && (s_idx == 0 || mask != mask_prev);
+    const uint64_t ball = __ballot(step);
+    if (ball == 0) {
+      if (!__any(live)) break;
+      continue;
+    }
+    const uint64_t below = ball & ((1ull << lane) - 1ull);
+    const uint64_t above = lane == 63 ? 0ull : (ball >> (lane + 1));
+    const int my = n_steps + __popcll(below);
+    // time of the footstep state before this one: the closest step lane below, or the previous round's last
+    const double t_below = __shfl(t, below ? 63 - __clzll(below) : lane);
+    const double t_prev = below ? t_below : t_carry;
+    if (step && my < max_steps) {
+      double* r = o + (size_t)my * rec;
+      r[0] = t;
+      if (!above) r[1] = time_horizon - t;   // last footstep state so far (:125-127); a later round may close it
+      for (int e = 0; e < n_ee; ++e) {
+        r[2 + e] = (mask >> e) & 1u ? 1.0 : 0.0;
+        double tlm;
+        const int qm = locate_segment(s_md[e], ST->n_mpoly[e], t, tlm);
+        const PolyDesc pm = tbl<PolyDesc>(blob, ST->o_mdesc[e])[qm];
+        double p[3], v[3], a[3];
+        sample_spline(xp, pm, tlm, s_md[e][qm], p, v, a);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) r[2 + n_ee + 3 * e + d] = p[d];
+      }
+      if (my > 0) o[(size_t)(my - 1) * rec + 1] = t - t_prev;   // duration of the state before (:121-123)
+    }
+    t_carry = __shfl(t, 63 - __clzll(ball));
+    n_steps += __popcll(ball);
+  }
+  if (lane == 0) counts[blockIdx.x] = n_steps;
+}
+hipError_t launch_contact_plan(const NodeWork* work, int n_problems, const double* x, double* out, int32_t* counts, double dt,
+                               double time_horizon, int n_samples_max, int max_steps, hipStream_t stream) {
+  hipLaunchKernelGGL(contact_plan_kernel, dim3(n_problems), dim3(64), 0, stream, work, x, out, counts, dt, time_horizon,
+                     n_samples_max, max_steps);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- TWR_EVAL_CHECK
 // Per-problem non-finite flags (failure detection): a separate pass over the outputs of one
 // evaluation, off the hot path (it re-reads g and jac once).  status[p] |= 1 if a constraint value of problem p is
@@ -2327,8 +2226,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
                        const NodeWork* node, int n_node, const PhaseWork* pdyn, int n_pdyn, const LocWork* ploc,
                        int n_ploc, const RomPhaseWork* prom, int n_prom, const double* x, double* g, double* jac,
                        int flags, hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */) {
-  static const int dyn_bpc = env_int("TWR_DYN_BPC", 6), rom_bpc = env_int("TWR_ROM_BPC", 4);
-  static const int dyn_impl = env_int("TWR_DYN_IMPL", 2), emit_bpc = env_int("TWR_EMIT_BPC", 8);
+  static const int dyn_bpc = env_int("TWR_DYN_BPC", 8), rom_bpc = env_int("TWR_ROM_BPC", 4);
 #ifdef TWR_ABLATE
   flags |= env_int("TWR_DEBUG_FLAGS", 0) & ~0xFF;
 #endif
@@ -2338,12 +2236,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
   if (n_dyn > 0) {
     const int res = dyn_bpc * n_cu;
     dim3 grid(n_dyn < res ? n_dyn : res);
-    if (dyn_impl == 1) {
-      hipLaunchKernelGGL(dyn_kernel, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags);
-    } else {
-      const int res2 = emit_bpc * n_cu;
-      hipLaunchKernelGGL(dyn_emit_kernel, dim3(n_dyn < res2 ? n_dyn : res2), block, 0, stream, dyn, n_dyn, x, g, jac, flags);
-    }
+    hipLaunchKernelGGL(dyn_kernel, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags);
   }
   if (n_pdyn > 0) {  // optimised-timings problems
     dim3 grid(n_pdyn);

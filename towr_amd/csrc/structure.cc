@@ -653,65 +653,6 @@ void Structure::PackBlob() {
       sl.cnt = k1 - k0;
       sl.nvals = nvals_of(k0, k1);
       sl.map = put(map.data(), map.size() * sizeof(uint16_t));
-      // emit descriptors of the slice (device_tables.h): value = (+-) table[a] * table[b]
-      {
-        std::vector<uint32_t> desc;
-        desc.reserve((size_t)sl.nvals + kDynDescLead + kDynDescTail);
-        const uint32_t one = 0;   // byte offset of the constant 1.0
-        for (int i = 0; i < kDynDescLead; ++i) desc.push_back(one | (one << 16));
-        auto mk = [&](int a_idx, int b_idx, bool neg) {
-          const uint32_t a = 8u * (uint32_t)a_idx, b = 8u * (uint32_t)b_idx;
-          if (a > 0xFFFFu || b > 0x7FFFu) throw std::runtime_error("emit descriptor offset out of range");
-          desc.push_back(a | (b << 16) | (neg ? 0x80000000u : 0u));
-        };
-        auto crs_pos = [](int r, int d) { return (r == 0 && d == 2) || (r == 1 && d == 0) || (r == 2 && d == 1); };
-        for (int k = k0; k < k1; ++k) {
-          const int nbase = kDynTabConst + (k - k0) * kDynTabNode, q = dyn_base[k].poly;
-          for (int row = 0; row < 6; ++row) {
-            const int r = row % 3;
-            for (int p = row_ptr[row_dyn + 6 * k + row]; p < row_ptr[row_dyn + 6 * k + row + 1]; ++p) {
-              const int col = col_idx[p];
-              if (col >= off_base_lin && col < off_base_lin + base.var_size) {
-                const int i = col - (off_base_lin + 6 * q), j = i / 3, d = i % 3;
-                if (i < 0 || i >= 12) throw std::runtime_error("unexpected base-lin column");
-                if (row < 3) mk(nbase + kDynTabF + (3 - r - d), nbase + kDynTabWP + j, crs_pos(r, d));   // -[F]x J_pos
-                else mk(nbase + kDynTabMWA + j, 0, false);                                                   // m J_acc
-              } else if (col >= off_base_ang && col < off_base_ang + base.var_size) {
-                const int i = col - (off_base_ang + 6 * q);
-                if (i < 0 || i >= 12 || row >= 3) throw std::runtime_error("unexpected base-ang column");
-                mk(nbase + kDynTabBA + r * 12 + i, 0, false);
-              } else {
-                bool found = false;
-                for (int e = 0; e < n_ee && !found; ++e)
-                  for (int which = 0; which < 2 && !found; ++which) {
-                    const SplineLayout& sl2 = which == 0 ? motion[e] : force[e];
-                    if (col < sl2.var_offset || col >= sl2.var_offset + sl2.var_size) continue;
-                    const PolyDesc& pd = which == 0 ? mpoly[e][dyn_motion[e][k].poly] : fpoly[e][dyn_force[e][k].poly];
-                    const int slot = col - pd.xbase;
-                    int c = -1;
-                    for (int cc = 0; cc < 12; ++cc)
-                      if (pd.cand[cc] != 0xFFFF && (pd.cand[cc] & 0xF) == slot) c = cc;
-                    if (slot < 0 || c < 0) throw std::runtime_error("dynamic column outside the active polynomial");
-                    const int j = c / 3, D = c % 3, eb = nbase + kDynTabEE + kDynTabEEStride * e;
-                    if (row < 3) {
-                      if (D == r) throw std::runtime_error("cross-matrix diagonal in the pattern");
-                      // [f]x J_p resp. [r]x J_f
-                      mk(eb + (which == 0 ? 0 : 3) + (3 - r - D), eb + (which == 0 ? 6 : 10) + j, !crs_pos(r, D));
-                    } else {
-                      if (which == 0 || D != r) throw std::runtime_error("unexpected column in a linear row");
-                      mk(eb + 10 + j, 0, true);   // -J_f
-                    }
-                    found = true;
-                  }
-                if (!found) throw std::runtime_error("dynamic column of an unknown variable set");
-              }
-            }
-          }
-        }
-        for (int i = 0; i < kDynDescTail; ++i) desc.push_back(one | (one << 16));
-        if ((int)desc.size() != sl.nvals + kDynDescLead + kDynDescTail) throw std::runtime_error("emit descriptor count");
-        sl.desc = put(desc.data(), desc.size() * sizeof(uint32_t));
-      }
       dyn_slices.push_back(sl);
       for (int k = k0; k < k1; ++k) {
         const int row0 = row_dyn + 6 * k, v0 = row_ptr[row0];
@@ -911,6 +852,26 @@ void Structure::PackBlob() {
     h.grid_eps = grid->eps;
     h.grid_px = grid->pos_x;
     h.grid_py = grid->pos_y;
+  }
+  {  // candidate scoring: bounds + family of every constraint set
+    ScoreTables sc;
+    std::memset(&sc, 0, sizeof(sc));
+    if (con_sets.size() > (size_t)kMaxConSets) throw std::runtime_error("too many constraint sets");
+    sc.n_sets = (int)con_sets.size();
+    sc.n_rows = n_rows;
+    sc.o_lower = put(lower.data(), lower.size() * sizeof(double));
+    sc.o_upper = put(upper.data(), upper.size() * sizeof(double));
+    for (size_t i = 0; i < con_sets.size(); ++i) {
+      const std::string& nm = con_sets[i].name;
+      auto starts = [&](const char* p) { return nm.rfind(p, 0) == 0; };
+      const int fam = starts("terrain-") ? 0 : starts("dynamic") ? 1 : starts("splineacc-") ? 2 : starts("rangeofmotion-") ? 3
+                    : starts("force-") ? 4 : starts("swing-") ? 5 : starts("totalduration-") ? 6 : starts("baseMotion") ? 7 : -1;
+      if (fam < 0) throw std::runtime_error("constraint set of an unknown family");
+      sc.sets[i].row0 = con_sets[i].offset;
+      sc.sets[i].row1 = con_sets[i].offset + con_sets[i].size;
+      sc.sets[i].family = fam;
+    }
+    h.o_score = put(&sc, sizeof(sc));
   }
   {  // trajectory sampling tables
     SampleTables st;

@@ -79,7 +79,6 @@ struct Structure {
   struct DynSlice {
     int k0, cnt, nvals;
     uint32_t map;        // byte offset of the slice's staging map inside the blob
-    uint32_t desc;       // byte offset of the slice's emit descriptors
   };
   std::vector<DynSlice> dyn_slices;
   uint32_t off_dyn_nodes = 0, off_dyn_gather = 0, off_dyn_put = 0;
