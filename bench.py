@@ -338,7 +338,7 @@ def main():
         achieved = kbytes[dom] / (kern_ms[dom] * 1e-3) / 1e9
         path_ms = sum(kern_ms.values())
         path_achieved = alg_bytes / (path_ms * 1e-3) / 1e9
-        names = {"dynamic": "twr::dyn_kernel<4>", "rangeofmotion": "twr::rom_kernel", "nodes": "twr::node_kernel"}
+        names = {"dynamic": "twr::dyn_kernel", "rangeofmotion": "twr::rom_kernel", "nodes": "twr::node_kernel"}
         if args.workload == "c3" and args.sets == "timings":
             names.update(dynamic="twr::dyn_phase_kernel<4>", rangeofmotion="twr::rom_phase_kernel")
         out = {

@@ -74,6 +74,9 @@ def lib():
         L.orc_set_grid_map.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
         L.orc_set_grid_map.restype = C.c_int
         L.orc_terrain_probe.argtypes = [C.c_void_p, C.c_double, C.c_double, _dp]
+        L.orc_hermite_dpos_dT.argtypes = [C.c_double] * 6
+        L.orc_hermite_dpos_dT.restype = C.c_double
+        L.orc_euler_probe.argtypes = [_dp, C.c_double, C.c_double, _dp]
         L.orc_hermite_weights.argtypes = [C.c_double, C.c_double, _dp]
         L.orc_terrain_height.argtypes = [C.c_int, C.c_double, C.c_double]
         L.orc_terrain_height.restype = C.c_double
@@ -222,6 +225,21 @@ def hermite_weights(t, T):
     w = np.zeros(12)
     lib().orc_hermite_weights(t, T, _d(w))
     return w.reshape(3, 4)
+
+
+def hermite_dpos_dT(t, T, p0, v0, p1, v1):
+    return lib().orc_hermite_dpos_dT(t, T, p0, v0, p1, v1)
+
+
+def euler_probe(nodes12, T, t):
+    """EulerConverter on one base-ang polynomial; dict of M, Mdot, R, omega, omega_dot and their node derivatives."""
+    n = np.ascontiguousarray(nodes12, dtype=np.float64)
+    o = np.zeros(429)
+    lib().orc_euler_probe(_d(n), float(T), float(t), _d(o))
+    d = o[33:]
+    return dict(M=o[0:9].reshape(3, 3), Mdot=o[9:18].reshape(3, 3), R=o[18:27].reshape(3, 3), omega=o[27:30],
+                omega_dot=o[30:33], dM=d[0:108].reshape(3, 3, 12), dMdot=d[108:216].reshape(3, 3, 12),
+                dR=d[216:324].reshape(3, 3, 12), domega=d[324:360].reshape(3, 12), domega_dot=d[360:396].reshape(3, 12))
 
 
 def terrain_height(terrain, x, y):

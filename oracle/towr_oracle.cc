@@ -2089,6 +2089,62 @@ void orc_terrain_probe(const orc_problem* P, double x, double y, double out[3]) 
   out[1] = P->terrain->GetDerivativeOfHeightWrt(X, x, y);
   out[2] = P->terrain->GetDerivativeOfHeightWrt(Y, x, y);
 }
+// --- probes for tests/test_oracle_symbolic.py (closed forms re-derived from the recipes of towr/matlab/*.m)
+// CubicHermitePolynomial::GetDerivativeOfPosWrtDuration (polynomial.cc:236-257) of one scalar polynomial
+double orc_hermite_dpos_dT(double t, double T, double p0, double v0, double p1, double v1) {
+  CubicHermite c;
+  c.T = T;
+  c.n0.p = V3(p0, 0, 0); c.n0.v = V3(v0, 0, 0);
+  c.n1.p = V3(p1, 0, 0); c.n1.v = V3(v1, 0, 0);
+  c.UpdateCoeff();
+  return c.GetDerivativeOfPosWrtDuration(t)(0);
+}
+// EulerConverter on ONE polynomial of base-ang (NodesVariablesAll order: node0 {px py pz vx vy vz}, node1 {...}):
+// out = M[9] | Mdot[9] | R[9] | omega[3] | omega_dot[3]
+//     | dM[dim][c][12] (GetDerivMwrtNodes, 108) | dMdot[dim][c][12] (GetDerivMdotwrtNodes, 108) | dR[row][col][12] (108)
+//     | d omega / du [3][12] | d omega_dot / du [3][12]            = 33 + 324 + 72 = 429 doubles
+void orc_euler_probe(const double nodes[12], double T, double t, double* out) {
+  NodesVars nv = MakeNodesAll(2, "base-ang");
+  NodeSpline sp(&nv, std::vector<double>{T});
+  nv.observer = &sp;
+  nv.SetVariables(nodes);
+  EulerConverter ec;
+  ec.euler = &sp;
+  StateVal ori = sp.GetPoint(t);
+  SpMat M = EulerConverter::GetM(ori.p), Md = EulerConverter::GetMdot(ori.p, ori.v);
+  M3 R = EulerConverter::RotationDense(ori.p);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      out[3 * r + c] = M.coeff(r, c);
+      out[9 + 3 * r + c] = Md.coeff(r, c);
+      out[18 + 3 * r + c] = R(r, c);
+    }
+  V3 w = ec.GetAngularVelocityInWorld(t), wd = ec.GetAngularAccelerationInWorld(t);
+  for (int i = 0; i < 3; ++i) {
+    out[27 + i] = w(i);
+    out[30 + i] = wd(i);
+  }
+  double* o = out + 33;
+  for (int dim = 0; dim < 3; ++dim) {
+    SpMat a = ec.GetDerivMwrtNodes(t, dim), b = ec.GetDerivMdotwrtNodes(t, dim);
+    for (int c = 0; c < 3; ++c)
+      for (int u = 0; u < 12; ++u) {
+        o[(dim * 3 + c) * 12 + u] = a.coeff(c, u);
+        o[108 + (dim * 3 + c) * 12 + u] = b.coeff(c, u);
+      }
+  }
+  SpVec Rd[3][3];
+  ec.GetDerivativeOfRotationMatrixWrtNodes(t, Rd);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c)
+      for (int u = 0; u < 12; ++u) o[216 + (r * 3 + c) * 12 + u] = Rd[r][c].get(u);
+  SpMat dw = ec.GetDerivOfAngVelWrtEulerNodes(t), dwd = ec.GetDerivOfAngAccWrtEulerNodes(t);
+  for (int r = 0; r < 3; ++r)
+    for (int u = 0; u < 12; ++u) {
+      o[324 + r * 12 + u] = dw.coeff(r, u);
+      o[360 + r * 12 + u] = dwd.coeff(r, u);
+    }
+}
 double orc_terrain_height(int terrain, double x, double y) { return HeightMap(terrain).GetHeight(x, y); }
 void orc_terrain_basis(int terrain, int which, double x, double y, double out[3]) {
   V3 v = HeightMap(terrain).GetNormalizedBasis(which, x, y);

@@ -100,6 +100,10 @@ double orc_time_callbacks(orc_problem*, const double* x, int iters);
 int orc_gait(int n_ee, int combo, double t_total, int* n_phases, int* contact_at_start,
              double* out, int out_cap);
 
+// probes of the closed forms the reference took from towr/matlab/*.m (tests/test_oracle_symbolic.py)
+double orc_hermite_dpos_dT(double t, double T, double p0, double v0, double p1, double v1);
+void orc_euler_probe(const double nodes[12], double T, double t, double* out /* 429 doubles, layout in towr_oracle.cc */);
+
 // small probes used by known-answer tests
 void orc_hermite_weights(double t, double T, double w[12]);   // d{p,v,a}/d{p0,v0,p1,v1}
 double orc_terrain_height(int terrain, double x, double y);

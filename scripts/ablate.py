@@ -24,6 +24,6 @@ for name, fl in cases:
     try:
         d = json.loads(r.stdout.strip().splitlines()[-1])
         k = d["roofline"]["path"]["kernel_ms"]
-        print("%-22s flags %#6x  dyn %.3f ms  rom %.3f ms" % (name, fl, k["twr::dyn_kernel<4>"], k["twr::rom_kernel"]), flush=True)
+        print("%-22s flags %#6x  dyn %.3f ms  rom %.3f ms" % (name, fl, k["twr::dyn_kernel"], k["twr::rom_kernel"]), flush=True)
     except Exception as e:  # noqa: BLE001
         print(name, "failed:", e, r.stderr[-500:], flush=True)

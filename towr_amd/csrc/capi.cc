@@ -394,7 +394,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
         std::memset(&w, 0, sizeof(w));
         w.nodes = blob + S.off_dyn_nodes + sizeof(twr::DynNode) * (size_t)sl.k0;
         w.gather = blob + S.off_dyn_gather + sizeof(twr::DynGather) * (size_t)sl.k0 * 4;
-        w.put = blob + S.off_dyn_put + sizeof(twr::DynPut) * (size_t)sl.k0 * 4;
+        w.put = blob + S.off_dyn_put;   // (records are addressed through DynGather::put_off)
         w.map = blob + sl.map;
         w.hdr = blob;
         w.x_off = b->x_off[p];

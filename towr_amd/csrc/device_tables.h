@@ -68,7 +68,7 @@ static_assert(sizeof(DynLane) == 96, "DynLane layout");
 // gets its node values with LDS reads instead of ~30 scattered global loads, and a value that is not an
 // optimisation variable simply reads the zero slot (no selects).
 #ifndef TWR_DYN_IMAGE
-#define TWR_DYN_IMAGE 2206
+#define TWR_DYN_IMAGE 2238
 #endif
 #ifndef TWR_DYN_XS
 #define TWR_DYN_XS 222
@@ -77,9 +77,7 @@ static_assert(sizeof(DynLane) == 96, "DynLane layout");
 // 0.637 ms per 8192 C3 problems against 0.692 ms with 2654-value images at six per CU.
 constexpr int kDynImage = TWR_DYN_IMAGE;    // Jacobian values of one slice (LDS image, doubles)
 constexpr int kDynNodes = 16;      // time nodes per slice: four lanes each
-// image + parity slack, then a trash PAIR per lane (either parity).  The constraint values of the slice (6 per node,
-// written by role 3 AFTER all tile stores of the wave) are staged in the same 128 doubles.
-constexpr int kDynTrash0 = kDynImage + 2;
+constexpr int kDynG0 = kDynImage + 2;   // image + parity slack, then the constraint values of the slice (6 per node)
 constexpr int kDynXsCap = TWR_DYN_XS;     // staged doubles per slice (8-bit staging indices 2..255; 0/1 = the zero pair)
 // per time node, shared by the four lanes of the quad (32 B)
 struct DynNode {
@@ -97,11 +95,13 @@ struct DynGather {
   double tm, iTm, tf, iTf;
   uint8_t idx_m[12], idx_f[12];  // staging index of candidate c = j*3+d (0 = constant zero)
   uint32_t flags;                // bit 0: stance ee-motion polynomial (p1 shares p0's variable: w_p1 folds into w_p0)
-  uint32_t pad;
+  uint32_t put_off;              // byte offset of this lane's DynPut record from DynWork::put
 };
 static_assert(sizeof(DynGather) == 64, "DynGather layout");
-// per (time node, role): where the end-effector tiles go (128 B).  Byte offsets relative to the node's first value;
-// a candidate that is not a variable points at the lane's trash pair behind the image.
+// per (polynomial combination, role): where the end-effector tiles go (128 B).  Byte offsets relative to the node's
+// first value.  They depend only on WHICH polynomials are active (the row layout), so consecutive time nodes share a
+// record (DynGather::put_idx).  A candidate that is not a variable points at entry 8 + role of row AX -- a base-ang
+// value that the same wave writes later in program order (the tiles are stored first), so the garbage never leaves.
 struct DynPut {
   uint16_t m[12][2];   // [f]x J_p : rows (d+1)%3 and (d+2)%3 of the angular block
   uint16_t f[12][3];   // {[r]x J_f ; -J_f}: the same two angular rows, then linear row d
@@ -241,7 +241,7 @@ struct DevStruct {
 struct DynWork {          // cnt <= 16 time nodes of "dynamic"
   uint64_t nodes;         // DynNode[k0..]
   uint64_t gather;        // DynGather[k0 * 4 ..]
-  uint64_t put;           // DynPut[k0 * 4 ..]
+  uint64_t put;           // DynPut records of the structure (indexed through DynGather::put_off)
   uint64_t map;           // uint16_t[64][4]: lane l stages x[map[l][c]] at xs[2 + 64 c + l]
   uint64_t hdr;           // DevStruct (mass, gravity, inertia)
   int64_t x_off;          // problem's x

@@ -981,8 +981,7 @@ constexpr int kRomStage = 4856;   // + 2 + 64 + 192 doubles = 40912 B
 // time node on a quad of lanes), but every index is an LDS byte offset prepared on the host (device_tables.h
 // DynNode / DynGather / DynPut): the slice's part of x sits in LDS ("xs"), values that are not optimisation
 // variables read its zero slot, and a Jacobian value is stored at node base + a 16-bit offset from the record.
-constexpr int kDynG0 = kDynTrash0;         // constraint values of the slice (6 x 16), sharing the trash pairs' space
-constexpr int kDynX0 = kDynG0 + 128;       // xs: zero pair, then <= kDynXsCap staged doubles of x
+constexpr int kDynX0 = kDynG0 + 96;        // xs: zero pair, then <= kDynXsCap staged doubles of x
 constexpr int kDynLds = kDynX0 + 2 + kDynXsCap;   // 2560 doubles = 20480 B: eight workgroups per CU (the VGPR limit too)
 static_assert(kDynLds * 8 <= 20480, "dyn_kernel: eight workgroups of 20 KB per CU");
 #ifndef TWR_DYN_COPY_BATCH
@@ -1086,7 +1085,8 @@ TWR_DEV void dyn2_back(const DynWork& w, const DynNode& nd, const DynPut& pu, co
   const double sx = S.sx, cx = S.cx, sy = S.sy, cy = S.cy, sz = S.sz, cz = S.cz;
   char* nb = img + nd.nb;   // first value of this time node
   // --- ee-motion block [f]x J_p (:181-192) and ee-force block {[r]x J_f ; -J_f} (:167-179) of this lane's
-  // end-effector; a candidate that is not a variable carries the offset of the lane's trash pair
+  // end-effector, BEFORE the base blocks: a candidate that is not a variable carries the offset of a base-ang entry
+  // of this node, which the base-ang code below overwrites
   if (want_j) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1304,7 +1304,7 @@ __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ 
     } else
 #endif
     dyn2_front(nd0, ga0, xs, lane, S);                                                       // F
-    const DynPut pu = gptr<DynPut>(w0.put)[min(lane >> 2, w0.cnt - 1) * 4 + (lane & 3)];   // P
+    const DynPut pu = *gptr<DynPut>(w0.put + ga0.put_off);                                   // P
 #ifdef TWR_ABLATE
     if (pending && !(flags & 0x100)) {
 #else

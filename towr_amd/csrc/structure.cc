@@ -620,7 +620,8 @@ void Structure::PackBlob() {
     auto nvals_of = [&](int k0, int k1) { return row_ptr[row_dyn + 6 * k1] - row_ptr[row_dyn + 6 * k0]; };
     std::vector<DynNode> nodes(K);
     std::vector<DynGather> gather((size_t)K * 4);
-    std::vector<DynPut> putv((size_t)K * 4);
+    std::vector<DynPut> putv;   // one per (polynomial combination, role)
+    std::vector<int> combo_key, combo_first;   // active polynomial ids of the last combination
     dyn_slices.clear();
     for (int k0 = 0; k0 < K;) {
       int k1 = k0;
@@ -674,13 +675,25 @@ void Structure::PackBlob() {
           if (it == e2 || *it != col) throw std::runtime_error("dynamic pattern lacks an expected column");
           return (int)(it - col_idx.data()) - v0;
         };
+        // the put offsets depend on the node only through the active polynomials: one record set per combination
+        std::vector<int> key;
+        for (int e = 0; e < n_ee; ++e) {
+          key.push_back(dyn_motion[e][k].poly);
+          key.push_back(dyn_force[e][k].poly);
+        }
+        const bool new_combo = key != combo_key;
+        if (new_combo) {
+          combo_key = key;
+          putv.resize(putv.size() + 4);
+        }
+        const size_t put0 = putv.size() - 4;
         for (int role = 0; role < 4; ++role) {
           DynGather& G = gather[(size_t)k * 4 + role];
-          DynPut& P = putv[(size_t)k * 4 + role];
+          DynPut& P = putv[put0 + role];
+          DynPut Pold = P;
           std::memset(&G, 0, sizeof(G));
-          const int lane = (k - k0) * 4 + role;
-          const int trash = 8 * (kDynTrash0 + 2 * lane - node_rel);   // relative to the node, like every put offset
-          if (trash < 0 || trash > 0xFFFF) throw std::runtime_error("trash offset out of range");
+          G.put_off = (uint32_t)((put0 + role) * sizeof(DynPut));
+          const int trash = 8 * (8 + role);   // base-ang entry of row AX, rewritten after the tiles (see DynPut)
           for (int c = 0; c < 12; ++c) {
             P.m[c][0] = P.m[c][1] = (uint16_t)trash;
             P.f[c][0] = P.f[c][1] = P.f[c][2] = (uint16_t)trash;
@@ -688,7 +701,10 @@ void Structure::PackBlob() {
           for (int i = 0; i < 4; ++i) P.pad[i] = 0;
           G.tm = G.tf = 0.0;
           G.iTm = G.iTf = 1.0;   // dummy roles evaluate finite weights on zeros
-          if (role >= n_ee) continue;
+          if (role >= n_ee) {
+            if (!new_combo && std::memcmp(&Pold, &P, sizeof(P)) != 0) throw std::runtime_error("dummy put record changed");
+            continue;
+          }
           const int e = role;
           const PolyDesc& mp = mpoly[e][dyn_motion[e][k].poly];
           const PolyDesc& fp = fpoly[e][dyn_force[e][k].poly];
@@ -711,6 +727,8 @@ void Structure::PackBlob() {
               P.f[c][2] = (uint16_t)(8 * find(3 + d, col));
             }
           }
+          if (!new_combo && std::memcmp(&Pold, &P, sizeof(P)) != 0)
+            throw std::runtime_error("put offsets differ inside one polynomial combination");
         }
       }
       k0 = k1;
