@@ -20,9 +20,16 @@ model = broadcast_model(ta.model_preset("anymal", "stairs") if rank == 0 else No
 ref = ta.model_preset("anymal", "stairs")
 assert bytes(model) == bytes(ref), "model blob differs after broadcast"
 cands = sweep.enumerate_candidates(48)
-structs = [sweep.candidate_structure(model, c) for c in cands]
-weights = [s.algorithmic_bytes for s in structs]
+# SURVEY 8e: shard by a cheap weight, then every rank builds the structures of ITS shard only (threaded library call)
+weights = [int(sweep.candidate_weight(c)) for c in cands]
 a, b = my_shard(weights, rank, world)
+structs_mine = sweep.candidate_structures(model, cands[a:b], threads=2)
+assert len(structs_mine) == b - a
+structs = {a + i: s for i, s in enumerate(structs_mine)}
+if 7 not in structs:
+    structs[7] = sweep.candidate_structure(model, cands[7])   # (one common candidate for the cross-rank pattern check)
+ref7 = sweep.candidate_structure(model, cands[a])
+assert np.array_equal(ref7.col_idx, structs[a].col_idx) and ref7.nnz == structs[a].nnz   # threaded == one by one
 mine = torch.tensor([a, b, sum(weights[a:b])], dtype=torch.int64)
 allr = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
 dist.all_gather(allr, mine)
