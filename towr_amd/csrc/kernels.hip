@@ -1652,7 +1652,9 @@ __global__ __launch_bounds__(64) void dyn_phase_kernel(const PhaseWork* __restri
   const int lane = threadIdx.x, kk = lane >> 2, role = lane & 3;
   double* out = jac + pw.j_off + PT->nnz_dyn + (int64_t)pw.k0 * PT->node_vals;
   double* gout = g + pw.g_off + PT->row_dyn + 6 * pw.k0;
+#ifdef TWR_PHASE_ZERO_EARLY
   if (want_j) zero_fill(out, pw.cnt * PT->node_vals, lane);
+#endif
   if (lane < NEE)
     phase_poly_durations(tbl<PhaseTables>(blob, cptr<DevStruct>(pw.blob)->o_phase), blob, xp, lane, s_ph[lane], s_md[lane],
                          s_fd[lane], true);
@@ -1722,6 +1724,12 @@ __global__ __launch_bounds__(64) void dyn_phase_kernel(const PhaseWork* __restri
   DynX X;
   dyn_load_x(w, sh, ln, x, X);
   dyn_front<NEE, true>(w, sh, ln, X, 0, 0, lane, S);
+#ifndef TWR_PHASE_ZERO_EARLY
+  // Zero fill as LATE as possible: the values follow within a microsecond or two, while the zero lines are still dirty
+  // in the XCD's L2, so every line goes to HBM once.  (Filling at the top of the kernel, ~15 us earlier, hid the store
+  // latency behind the set-up but let the zeros be evicted first: measured 1.57 x the algorithmic write traffic.)
+  if (want_j) zero_fill(out, pw.cnt * PT->node_vals, lane);
+#endif
   // The values below overwrite zeros written by OTHER lanes of this wave: the zero stores must have been
   // acknowledged first.  A single-wave workgroup gets no s_barrier from __syncthreads(), so the dependency is
   // made explicit (on gfx9 loads and stores retire through the one in-order vmcnt counter).
