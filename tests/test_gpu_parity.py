@@ -612,3 +612,55 @@ def test_candidate_scores_and_contact_plans():
             assert np.array_equal(got[:, 2:2 + n_ee], ref[:, 2:2 + n_ee])          # contact flags
             assert np.abs(got[:, :2] - ref[:, :2]).max() <= 1e-12                    # t, duration
             assert np.abs(got[:, 2 + n_ee:] - ref[:, 2 + n_ee:]).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+
+
+def test_eval_is_graph_capturable_and_stream_ordered():
+    """twr_batch_eval is asynchronous on the caller's stream and capturable in a hipGraph (include/towr_amd.h): capture one
+    callback, replay it on new x, compare with an eager evaluation; two batches on two streams run concurrently."""
+    import torch
+
+    case = Case("anymal", "stairs", ta.gait_combo(4, 1, 2.0), constraint_sets=63)
+    S = case.S
+    B = 64
+    batch = ta.Batch([S], [0] * B, device=0)
+    dev = torch.device("cuda", 0)
+    xs = np.stack([case.x_perturbed(i, 1.5) for i in range(B)])
+    x = torch.from_numpy(xs.reshape(-1)).to(dev)
+    g = torch.zeros(int(batch.g_off[-1]), dtype=torch.float64, device=dev)
+    jac = torch.zeros(int(batch.jac_off[-1]), dtype=torch.float64, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):   # warm-up outside the capture (module load)
+        batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, side.cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    eager_g, eager_j = g.clone(), jac.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, torch.cuda.current_stream().cuda_stream)
+    g.zero_()
+    jac.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(g, eager_g) and torch.equal(jac, eager_j)
+    # new inputs through the same graph
+    xs2 = np.stack([case.x_perturbed(100 + i, 1.5) for i in range(B)])
+    x.copy_(torch.from_numpy(xs2.reshape(-1)))
+    graph.replay()
+    torch.cuda.synchronize()
+    rg, _, _, rj = case.P.eval(xs2[17])
+    assert_parity(S, g.cpu().numpy()[batch.g_off[17]:batch.g_off[18]], jac.cpu().numpy()[batch.jac_off[17]:batch.jac_off[18]],
+                  rg, rj, "graph replay", x=xs2[17])
+    # two batches, two streams, in flight together
+    batch2 = ta.Batch([S], [0] * B, device=0)
+    g2, j2 = torch.zeros_like(g), torch.zeros_like(jac)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    s1.wait_stream(torch.cuda.current_stream())
+    s2.wait_stream(torch.cuda.current_stream())
+    g.zero_(); jac.zero_()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, s1.cuda_stream)
+        batch2.eval_device(x.data_ptr(), g2.data_ptr(), j2.data_ptr(), ta.EVAL_BOTH, s2.cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(g, g2) and torch.equal(jac, j2)
