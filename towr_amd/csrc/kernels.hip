@@ -1304,7 +1304,7 @@ __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ 
     } else
 #endif
     dyn2_front(nd0, ga0, xs, lane, S);                                                       // F
-    const DynPut pu = *gptr<DynPut>(w0.put + ga0.put_off);                                   // P
+    const DynPut pu = *gptr<DynPut>(w0.put + ga0.put_off);                                   // P (earlier costs spills: slower)
 #ifdef TWR_ABLATE
     if (pending && !(flags & 0x100)) {
 #else
