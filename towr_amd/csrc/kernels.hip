@@ -928,7 +928,12 @@ TWR_DEV void copy_out_fixed(double* __restrict__ dst, const double* __restrict__
   const int total = n + par;
   const uint32_t last = (uint32_t)((total >> 1) - 1) * 16u;  // last complete pair; pairs [par, npairs) are complete
   const uint32_t first = (uint32_t)(par + lane) * 16u;
-  // kBatch = LDS reads in flight before the first store needs its data
+  // Branch-free on purpose: lanes past the end of the slice re-store its last pair (idempotent; predicating them off
+  // makes the compiler sink every LDS read into its own `if`), and the count of vector-memory instructions stays a
+  // compile-time constant (counted s_waitcnt for the prefetched loads).
+  // kBatch = LDS reads in flight before the first store needs its data.  (In dyn_kernel, which sits at the VGPR limit,
+  // the register allocator leaves the copy-out one quad of registers and the reads end up serialised with their stores
+  // anyway; moving the copy-out ahead of the front half or pipelining it by hand changed nothing measurable.)
 #pragma unroll
   for (int it0 = 0; it0 < NIT; it0 += kBatch) {
     double2 v[kBatch];
@@ -936,22 +941,15 @@ TWR_DEV void copy_out_fixed(double* __restrict__ dst, const double* __restrict__
 #pragma unroll
     for (int b = 0; b < kBatch; ++b)
       if (it0 + b < NIT) {
-        off[b] = first + 1024u * (uint32_t)(it0 + b);
+        off[b] = min(first + 1024u * (uint32_t)(it0 + b), last);
 #ifdef TWR_ABLATE
         if (abl & 0x4000) v[b] = make_double2(1.0, 2.0); else
 #endif
-        v[b] = *reinterpret_cast<const double2*>(st + min(off[b], last));
+        v[b] = *reinterpret_cast<const double2*>(st + off[b]);
       }
-    // lanes past the end of the slice store nothing, but the instruction is issued all the same: the count of
-    // vector-memory instructions stays a compile-time constant (counted s_waitcnt for the prefetched loads)
 #pragma unroll
     for (int b = 0; b < kBatch; ++b)
-      if (it0 + b < NIT) {
-#ifdef TWR_ABLATE
-        if (abl & 0x8000) { *reinterpret_cast<double2*>(al + min(off[b], last)) = v[b]; continue; }
-#endif
-        if (off[b] <= last) *reinterpret_cast<double2*>(al + off[b]) = v[b];
-      }
+      if (it0 + b < NIT) *reinterpret_cast<double2*>(al + off[b]) = v[b];
   }
   if (par && lane == 0 && n > 0) dst[0] = stage[1];
   if ((total & 1) && lane == 0 && total - 1 > par) dst[n - 1] = stage[total - 1];
@@ -987,6 +985,7 @@ static_assert(kDynLds * 8 <= 20480, "dyn_kernel: eight workgroups of 20 KB per C
 #ifndef TWR_DYN_COPY_BATCH
 #define TWR_DYN_COPY_BATCH 8
 #endif
+
 constexpr int kDynCopyBatch = TWR_DYN_COPY_BATCH;   // LDS reads in flight before the first store of the copy-out
 struct Dyn2Front {   // (the base-spline weights are recomputed in the back half: 48 registers less across the copy-out)
   double cdd[3], ed[3], edd[3];
@@ -1312,11 +1311,7 @@ __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ 
 #endif
       double* pdst = jac + wp.j_off;
       const int ppar = (int)((reinterpret_cast<uintptr_t>(pdst) >> 3) & 1);
-#ifdef TWR_ABLATE
       if (want_j) copy_out_fixed<NIT, kDynCopyBatch>(pdst, stage, wp.nvals, ppar, lane, flags);
-#else
-      if (want_j) copy_out_fixed<NIT, kDynCopyBatch>(pdst, stage, wp.nvals, ppar, lane);
-#endif
       if (want_g) {                                     // 6 constraint values per time node, contiguous in g
         double* go = g + wp.g_off;
         if (lane < 6 * wp.cnt) go[lane] = gst[lane];
