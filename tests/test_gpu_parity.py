@@ -90,6 +90,37 @@ def test_ragged_batch_of_distinct_structures():
         assert_parity(cases[s].S, gd, jd, rg, rj, "problem %d (structure %d)" % (p, s))
 
 
+def test_fused_launch_equals_separate_launches():
+    """Small batches go through one fused launch (eval_fused_kernel: rom, dyn and node roles in one grid), large or
+    profiled ones through dyn_kernel / rom_kernel / node_kernel: same code per slice, so identical bits, and both equal
+    to the oracle.  Ragged structures, odd and even offsets, NaN-prefilled outputs (every value written by both)."""
+    import torch
+    specs = [("anymal", "gap", 0, 2.0, {}), ("go1", "stairs", 3, 1.9, dict(constraint_sets=63)),
+             ("hyq", "slope", 2, 2.4, k_params(2.4, 130)), ("anymal", "block", 4, 2.8, dict(constraint_sets=255, base_z_init=0.5))]
+    cases = [Case(r, t, ta.gait_combo(4, c, T), **kw) for r, t, c, T, kw in specs]
+    order = [0, 1, 2, 3, 2, 1, 0, 3, 3]
+    batch = ta.Batch([c.S for c in cases], order, device=0)
+    xs = [cases[s].x_wild(i) for i, s in enumerate(order)]
+    x = torch.from_numpy(np.concatenate(xs)).cuda()
+    outs = []
+    for profiled in (False, True):
+        g = torch.full((int(batch.g_off[-1]),), float("nan"), dtype=torch.float64, device="cuda")
+        j = torch.full((int(batch.jac_off[-1]),), float("nan"), dtype=torch.float64, device="cuda")
+        if profiled:
+            batch.profile_begin(1)     # per-kernel events: the three separate launches
+        batch.eval_device(x.data_ptr(), g.data_ptr(), j.data_ptr(), ta.EVAL_BOTH, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        if profiled:
+            ms, n_evals = batch.profile_end()
+            assert n_evals == 1 and all(v >= 0 for v in ms.values())
+        outs.append((g.cpu().numpy(), j.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.isfinite(outs[0][0]).all() and np.isfinite(outs[0][1]).all()
+    for p, s in enumerate(order):
+        rg, _, _, rj = cases[s].P.eval(xs[p])
+        assert_parity(cases[s].S, *_split(batch, outs[0][0], outs[0][1], p), rg, rj, "problem %d" % p)
+
+
 @pytest.mark.parametrize("robot,n_ee,combo", [("monoped", 1, 2), ("monoped", 1, 4), ("biped", 2, 1), ("biped", 2, 4)])
 def test_other_leg_counts_and_gaits_starting_or_ending_in_flight(robot, n_ee, combo):
     case = Case(robot, "slope", ta.gait_combo(n_ee, combo, 2.1))

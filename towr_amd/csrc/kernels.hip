@@ -1241,16 +1241,12 @@ TWR_DEV void dyn2_back(const DynWork& w, const DynNode& nd, const DynPut& pu, co
 //      these stores, so waiting for them never waits for a store)
 //   B  back(i): Jacobian blocks -> image
 //   S  xs <- xr (x(i+1));  then issue: front record of slice i+2, xr <- gather x(i+2), mapr <- map(i+3)
-__global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ work, int n_work,
-                                                    const double* __restrict__ x, double* __restrict__ g,
-                                                    double* __restrict__ jac, int flags) {
-  __shared__ __attribute__((aligned(16))) double stage[kDynLds];
+// (`stage`: kDynLds doubles of LDS owned by this wave; the wave takes slices i, i + stride, ...)
+TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double* __restrict__ x, double* __restrict__ g,
+                      double* __restrict__ jac, int flags, double* stage, int lane, int i, int stride) {
   const bool want_g = flags & 1, want_j = flags & 2;
-  const int lane = threadIdx.x;
   double* gst = stage + kDynG0;
   char* xs = reinterpret_cast<char*>(stage + kDynX0);
-  const int stride = gridDim.x;
-  int i = blockIdx.x;
   if (i >= n_work) return;
   constexpr int NIT = (kDynImage + 2 + 127) / 128;
   if (lane < 2) stage[kDynX0 + lane] = 0.0;   // the zero pair
@@ -1350,21 +1346,23 @@ __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ 
   }
 }
 
+__global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ work, int n_work,
+                                                    const double* __restrict__ x, double* __restrict__ g,
+                                                    double* __restrict__ jac, int flags) {
+  __shared__ __attribute__((aligned(16))) double stage[kDynLds];
+  dyn_body(work, n_work, x, g, jac, flags, stage, threadIdx.x, blockIdx.x, gridDim.x);
+}
+
 #endif  // !TWR_TU_ROM
 
 // rom_kernel is compiled in its own translation unit (rom_tu.hip) with a different instruction scheduling
 // strategy: it is store bound and gains 4-5 % from clause-oriented scheduling, the VALU-bound kernels lose.
-#ifdef TWR_TU_ROM
-__global__ __launch_bounds__(64, 1) void rom_kernel(const RomWork* __restrict__ work, int n_work,
-                                                    const double* __restrict__ x, double* __restrict__ g,
-                                                    double* __restrict__ jac, int flags) {
-  __shared__ __attribute__((aligned(16))) double stage[kRomStage + 2 + 64 + 192];
+constexpr int kRomLds = kRomStage + 2 + 64 + 192;   // doubles: image, per-lane trash slots, g
+TWR_DEV void rom_body(const RomWork* __restrict__ work, int n_work, const double* __restrict__ x, double* __restrict__ g,
+                      double* __restrict__ jac, int flags, double* stage, int lane, int i, int stride) {
   const bool want_g = flags & 1, want_j = flags & 2;
-  const int lane = threadIdx.x;
   const int trash = kRomStage + 2 + lane;
   double* gst = stage + kRomStage + 2 + 64;
-  const int stride = gridDim.x;
-  int i = blockIdx.x;
   if (i >= n_work) return;
   RomWork w0 = work[i], w1 = w0, w2 = w0;
   RomRec r0 = rom_load_rec(w0, lane), r1 = r0;
@@ -1413,6 +1411,14 @@ __global__ __launch_bounds__(64, 1) void rom_kernel(const RomWork* __restrict__ 
   }
 }
 
+#ifdef TWR_TU_ROM
+__global__ __launch_bounds__(64, 1) void rom_kernel(const RomWork* __restrict__ work, int n_work,
+                                                    const double* __restrict__ x, double* __restrict__ g,
+                                                    double* __restrict__ jac, int flags) {
+  __shared__ __attribute__((aligned(16))) double stage[kRomLds];
+  rom_body(work, n_work, x, g, jac, flags, stage, threadIdx.x, blockIdx.x, gridDim.x);
+}
+
 void launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, const double* x, double* g, double* jac,
                        int flags) {
   hipLaunchKernelGGL(rom_kernel, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac, flags);
@@ -1425,19 +1431,17 @@ void launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_r
 // swing-ee-motion_e sets of one problem.  One workgroup of four waves per problem, one wave per family
 // (each with its own LDS image, no barriers), 64 spline nodes / rows at a time.
 constexpr int kStageTerrain = 64 * 3 + 2, kStageForce = 64 * 25 + 2, kStageAcc = 64 * 6 + 2, kStageSwing = 64 * 12 + 2;
-__global__ __launch_bounds__(256) void node_kernel(const NodeWork* __restrict__ work, const double* __restrict__ x,
-                                                   double* __restrict__ g, double* __restrict__ jac, int flags) {
-  __shared__ __attribute__((aligned(16))) double stage_all[kStageTerrain + kStageForce + kStageAcc + kStageSwing];
-  const NodeWork w = work[blockIdx.x];
+constexpr int kNodeStageOff[4] = {0, kStageTerrain, kStageTerrain + kStageForce, kStageTerrain + kStageForce + kStageAcc};
+// one family (wave-uniform 0..3) of one problem; `stage`: the family's LDS image (kStage<Family> doubles)
+TWR_DEV void node_body(const NodeWork& w, const double* __restrict__ x, double* __restrict__ g, double* __restrict__ jac,
+                       int flags, double* stage, int family, int lane) {
   const char* blob = reinterpret_cast<const char*>(w.blob);
   const DevStruct* S = reinterpret_cast<const DevStruct*>(blob);
   const double* xp = x + w.x_off;
   double* gp = g + w.g_off;
   double* jp = jac + w.j_off;
   const bool want_g = flags & 1, want_j = flags & 2;
-  const int lane = threadIdx.x & 63, family = threadIdx.x >> 6;  // wave-uniform
   if (family == 0) {
-    double* stage = stage_all;
     const TerrainRow* rows = tbl<TerrainRow>(blob, S->o_terrain_rows);
     const int nr = S->n_terrain_rows;
     for (int r0 = 0; r0 < nr; r0 += 64) {
@@ -1458,7 +1462,6 @@ __global__ __launch_bounds__(256) void node_kernel(const NodeWork* __restrict__ 
       if (want_j) copy_out(dst, stage, 3 * cnt, par, lane);  // single wave: LDS accesses are ordered
     }
   } else if (family == 1) {
-    double* stage = stage_all + kStageTerrain;
     const ForceNode* nodes = tbl<ForceNode>(blob, S->o_force_nodes);
     const int nn = S->n_force_nodes;
     for (int i0 = 0; i0 < nn; i0 += 64) {
@@ -1473,7 +1476,6 @@ __global__ __launch_bounds__(256) void node_kernel(const NodeWork* __restrict__ 
     // splineacc-base-lin | splineacc-base-ang (spline_acc_constraint.cc:49-81): lane = row (set, junction j,
     // dim d); its six variables are {p,v}_d of base nodes j, j+1, j+2 and the six Jacobian values depend on
     // the polynomial durations only (AccJunction), so g = sum c_i x_i.
-    double* stage = stage_all + kStageTerrain + kStageForce;
     const AccJunction* acc = tbl<AccJunction>(blob, S->o_acc);
     const int per_set = 3 * S->n_junctions, nr = 2 * per_set;
     for (int r0 = 0; r0 < nr; r0 += 64) {
@@ -1531,7 +1533,6 @@ __global__ __launch_bounds__(256) void node_kernel(const NodeWork* __restrict__ 
   } else {
     // swing-ee-motion_e (swing_constraint.cc:58-121): lane = swing node, rows {x pos, x vel, y pos, y vel},
     // columns {previous node, this node, next node}
-    double* stage = stage_all + kStageTerrain + kStageForce + kStageAcc;
     const SwingNode* sw = tbl<SwingNode>(blob, S->o_swing_nodes);
     const int nn = S->n_swing_nodes;
     const double it = S->inv_t_swing;
@@ -1577,6 +1578,40 @@ __global__ __launch_bounds__(256) void node_kernel(const NodeWork* __restrict__ 
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void node_kernel(const NodeWork* __restrict__ work, const double* __restrict__ x,
+                                                   double* __restrict__ g, double* __restrict__ jac, int flags) {
+  __shared__ __attribute__((aligned(16))) double stage_all[kStageTerrain + kStageForce + kStageAcc + kStageSwing];
+  const int family = threadIdx.x >> 6;  // wave-uniform
+  node_body(work[blockIdx.x], x, g, jac, flags, stage_all + kNodeStageOff[family], family, threadIdx.x & 63);
+}
+
+// Small and mid-size batches: the three kernels above as ONE launch, so that their pipeline fills and drains overlap
+// instead of adding up (three dependent launches cost ~14 us of a 19-us step at 32 candidates).  Workgroups of two waves
+// and 40 KB: blocks [0, g_rom) take the rom role (wave 0 only; the image is 39 KB), the next g_dyn blocks the dyn role
+// (both waves, one 20-KB half each), the rest the node role (two families per block) -- the residency per CU of each
+// role is that of its own kernel, and blocks are dispatched in this order, so a later role starts as the earlier drains.
+__global__ __launch_bounds__(128, 2) void eval_fused_kernel(const RomWork* __restrict__ rom, int n_rom, int g_rom,
+                                                            const DynWork* __restrict__ dyn, int n_dyn, int g_dyn,
+                                                            const NodeWork* __restrict__ node, const double* __restrict__ x,
+                                                            double* __restrict__ g, double* __restrict__ jac, int flags) {
+  static_assert(2 * kDynLds >= kRomLds && kDynLds >= kStageForce, "LDS of the fused kernel");
+  __shared__ __attribute__((aligned(16))) double stage[2 * kDynLds];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  int b = blockIdx.x;
+  if (b < g_rom) {
+    if (wave == 0) rom_body(rom, n_rom, x, g, jac, flags, stage, lane, b, g_rom);
+    return;
+  }
+  b -= g_rom;
+  if (b < g_dyn) {
+    dyn_body(dyn, n_dyn, x, g, jac, flags, stage + wave * kDynLds, lane, 2 * b + wave, 2 * g_dyn);
+    return;
+  }
+  b -= g_dyn;
+  const int family = 2 * (b & 1) + wave;
+  node_body(node[b >> 1], x, g, jac, flags, stage + wave * kDynLds, family, lane);
 }
 
 // ---------------------------------------------------------------- optimised timings (PhaseSpline) kernels
@@ -2235,6 +2270,14 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
 #endif
   dim3 block(64);
   if (n_ee < 1 || n_ee > 4) return hipErrorInvalidValue;
+  static const int fused_max = env_int("TWR_FUSED_MAX_ROM", 4096);   // rom slices up to which the fused launch is used
+  if (!ev && n_pdyn == 0 && n_prom == 0 && n_rom > 0 && n_dyn > 0 && n_rom <= fused_max) {
+    const int cap = rom_bpc * n_cu;
+    const int g_rom = n_rom < cap ? n_rom : cap, g_dyn = (n_dyn + 1) / 2 < cap ? (n_dyn + 1) / 2 : cap;
+    hipLaunchKernelGGL(eval_fused_kernel, dim3(g_rom + g_dyn + 2 * n_node), dim3(128), 0, stream, rom, n_rom, g_rom, dyn,
+                       n_dyn, g_dyn, node, x, g, jac, flags);
+    return hipGetLastError();
+  }
   if (ev) (void)hipEventRecord(ev[0], stream);
   if (n_dyn > 0) {
     const int res = dyn_bpc * n_cu;
