@@ -1580,7 +1580,7 @@ TWR_DEV void node_body(const NodeWork& w, const double* __restrict__ x, double* 
   }
 }
 
-__global__ __launch_bounds__(256) void node_kernel(const NodeWork* __restrict__ work, const double* __restrict__ x,
+__global__ __launch_bounds__(256, 4) void node_kernel(const NodeWork* __restrict__ work, const double* __restrict__ x,
                                                    double* __restrict__ g, double* __restrict__ jac, int flags) {
   __shared__ __attribute__((aligned(16))) double stage_all[kStageTerrain + kStageForce + kStageAcc + kStageSwing];
   const int family = threadIdx.x >> 6;  // wave-uniform
