@@ -152,9 +152,11 @@ def traffic_from_profile(workload, kernel, problems_per_gpu):
     try:
         with open(path) as f:
             t = json.load(f)
-        if (t.get("workload") == workload and t.get("problems_per_gpu") == problems_per_gpu
-                and t.get("kernel_source_sha256") == kernel_source_hash()):
-            return t.get("hbm_bytes_per_launch", {}).get(kernel)
+        if t.get("workload") == "C3" and t.get("kernel_source_sha256") == kernel_source_hash():
+            if workload == "C3" and t.get("problems_per_gpu") == problems_per_gpu:
+                return t.get("hbm_bytes_per_launch", {}).get(kernel)
+            if workload == "C3+timings" and problems_per_gpu == 2048:   # the --sets timings --batch 2048 passes
+                return t.get("timings_2048", {}).get("hbm_bytes_per_launch", {}).get(kernel)
     except (OSError, ValueError):
         pass
     return None
@@ -357,7 +359,8 @@ def main():
             "config": {"workload": workload, "problems_per_gpu": B, "bytes_per_callback": bytes_per_callback,
                        "setup_s": setup_s},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile("C3", names[dom], B) if args.workload == "c3" and args.sets == "hot" else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": (traffic_from_profile({"hot": "C3", "timings": "C3+timings"}[args.sets], names[dom], B)
+                                     if args.workload == "c3" and args.sets in ("hot", "timings") else None),
                          "kernel": names[dom], "kernel_ms": kern_ms[dom],
                          "algorithmic_bytes_per_launch": kbytes[dom],
                          # the whole callback = the three kernels back to back (SURVEY 8d figure 8*(n+m+nnz))
