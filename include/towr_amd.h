@@ -237,6 +237,14 @@ int twr_batch_profile_end(twr_batch* b, double avg_ms[3], int* n_evals);
  * d_out + p * problem_stride (doubles).  Asynchronous on hip_stream. */
 int twr_structure_sample_count(const twr_structure* s, double dt, int32_t* n_samples);
 int twr_batch_sample(twr_batch* b, const double* d_x, double dt, double* d_out, int64_t problem_stride, void* hip_stream);
+/* fpowr::ExtractInitialGuess / ExtractInitialGuesses (fpowr/include/fpowr/initial_guess_extractor.h:17-48) for a batch of
+ * solutions: every problem's x sampled at the n_times times d_times[] (device array, within [0, T]; the goal's
+ * state_sample_times).  One record of 49 doubles per time:
+ *   [ t | state (12): base-lin p, base-ang p (Euler angles), base-lin v, base-ang v (Euler rates) |
+ *     controls (36): ee-motion acceleration of ee i at 3 i, twelve zeros ("joint torques"), ee-force of ee i at 24 + 3 i ]
+ * problem p's records start at d_out + p * problem_stride (doubles, >= 49 n_times).  Asynchronous on hip_stream. */
+int twr_batch_initial_guess(twr_batch* b, const double* d_x, const double* d_times, int32_t n_times, double* d_out,
+                            int64_t problem_stride, void* hip_stream);
 
 /* Candidate scoring of a sweep (new; the reference solves one NLP per goal and lets Ipopt judge feasibility): for
  * problem p and constraint family f -- the bit index of its TWR_SET_* flag: 0 terrain, 1 dynamic, 2 splineacc, 3

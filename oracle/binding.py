@@ -67,6 +67,8 @@ def lib():
         L.orc_sample_trajectory.restype = C.c_int
         L.orc_contact_plan.argtypes = [C.c_void_p, _dp, C.c_double, C.c_double, _dp, C.c_int]
         L.orc_contact_plan.restype = C.c_int
+        L.orc_initial_guess_samples.argtypes = [C.c_void_p, _dp, _dp, C.c_int, _dp]
+        L.orc_initial_guess_samples.restype = None
         L.orc_time_callbacks.argtypes = [C.c_void_p, _dp, C.c_int]
         L.orc_time_callbacks.restype = C.c_double
         L.orc_gait.argtypes = [C.c_int, C.c_int, C.c_double, _ip, _ip, _dp, C.c_int]
@@ -203,6 +205,14 @@ class OracleProblem:
         n = lib().orc_contact_plan(self._h, _d(x), float(dt), float(time_horizon), None, 0)
         out = np.zeros((n, 2 + 4 * self.n_ee))
         lib().orc_contact_plan(self._h, _d(x), float(dt), float(time_horizon), _d(out), n)
+        return out
+
+    def initial_guess_samples(self, x, times):
+        """fpowr::ExtractInitialGuess at `times`: (n, 49) array [t | state 12 | controls 36]."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        times = np.ascontiguousarray(times, dtype=np.float64)
+        out = np.zeros((len(times), 49))
+        lib().orc_initial_guess_samples(self._h, _d(x), _d(times), len(times), _d(out))
         return out
 
     def terrain_probe(self, x, y):

@@ -1816,6 +1816,34 @@ int orc_contact_plan(orc_problem* P, const double* x, double dt, double time_hor
   return (int)steps.size();
 }
 
+// fpowr::ExtractInitialGuess (fpowr/include/fpowr/initial_guess_extractor.h:17-34), one record per requested time:
+//   [ t | state: base-lin p (3), base-ang p = Euler angles (3), base-lin v (3), base-ang v = Euler rates (3) |
+//     controls (36): ee-motion acceleration of ee i at 3 i, twelve zeros ("joint torques"), ee-force of ee i at 24 + 3 i ]
+void orc_initial_guess_samples(orc_problem* P, const double* x, const double* times, int n_times, double* out) {
+  P->SetVariables(x);
+  for (int s = 0; s < n_times; ++s) {
+    const double t = times[s];
+    double* o = out + (size_t)s * 49;
+    for (int i = 0; i < 49; ++i) o[i] = 0.0;
+    o[0] = t;
+    StateVal lin = P->sp.base_linear->GetPoint(t), ang = P->sp.base_angular->GetPoint(t);
+    for (int i = 0; i < 3; ++i) {
+      o[1 + i] = lin.p(i);
+      o[4 + i] = ang.p(i);
+      o[7 + i] = lin.v(i);
+      o[10 + i] = ang.v(i);
+    }
+    for (int ee = 0; ee < P->n_ee; ++ee) {
+      StateVal mo = P->sp.ee_motion[ee]->GetPoint(t);
+      V3 f = P->sp.ee_force[ee]->GetPoint(t).p;
+      for (int i = 0; i < 3; ++i) {
+        o[13 + 3 * ee + i] = mo.a(i);
+        o[13 + 24 + 3 * ee + i] = f(i);
+      }
+    }
+  }
+}
+
 int orc_sample_trajectory(orc_problem* P, const double* x, double dt, double* out, int max_samples) {
   P->SetVariables(x);
   EulerConverter base_angular;

@@ -86,6 +86,10 @@ void orc_bounds(orc_problem*, double* lower, double* upper);
 // number of samples (pass out = NULL to query it); record layout in towr_oracle.cc.
 int orc_sample_trajectory(orc_problem*, const double* x, double dt, double* out, int max_samples);
 
+// fpowr::ExtractInitialGuess (initial_guess_extractor.h:17-34) at the given times: 49 doubles per time
+// [t | state 12 | controls 36], layout in towr_oracle.cc
+void orc_initial_guess_samples(orc_problem*, const double* x, const double* times, int n_times, double* out);
+
 // fpowr::ExtractFootstepPlan (footstep_plan_extractor.h:69-133) minus the nearest-plane lookup: footstep states
 // [t | duration | contact per ee | ee position per ee]; returns their number (out = NULL to query it).
 int orc_contact_plan(orc_problem*, const double* x, double dt, double time_horizon, double* out, int max_steps);

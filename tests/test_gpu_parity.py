@@ -372,6 +372,42 @@ def test_trajectory_sampling():
     assert neg_trace > 0
 
 
+def test_initial_guess_samples():
+    """twr_batch_initial_guess vs the oracle's restatement of fpowr::ExtractInitialGuess (initial_guess_extractor.h:
+    17-34): base position / Euler angles / their rates, foot accelerations, twelve zeros, foot forces at arbitrary
+    sample times (unsorted, incl. 0, T and polynomial junctions), for 4-, 2- and 1-legged robots, fixed and optimised
+    timings; more than 64 times (two workgroups per problem)."""
+    import torch
+
+    for robot, n_ee, kw in (("anymal", 4, {}), ("anymal", 4, dict(constraint_sets=127)), ("biped", 2, {}), ("monoped", 1, {})):
+        T = 2.0
+        cases = [Case(robot, "stairs" if n_ee == 4 else "flat", ta.gait_combo(n_ee, 1 if n_ee > 1 else 2, T), **kw),
+                 Case(robot, "flat", ta.gait_combo(n_ee, 0, T), duration_base_poly=0.13, **kw)]
+        order = [0, 1, 0]
+        batch = ta.Batch([k.S for k in cases], order, device=0)
+        xs = [cases[s].x_wild(40 + i) for i, s in enumerate(order)]
+        rng = np.random.default_rng(5)
+        times = np.concatenate([[0.0, T, 0.1, 0.2, 0.13, 1.0], rng.uniform(0.0, T, 70)])
+        stride = 49 * len(times) + 3
+        x = torch.from_numpy(np.concatenate(xs)).cuda()
+        tt = torch.from_numpy(times).cuda()
+        out = torch.full((len(order) * stride,), float("nan"), dtype=torch.float64, device="cuda")
+        batch.initial_guess_device(x.data_ptr(), tt.data_ptr(), len(times), out.data_ptr(), stride,
+                                   torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        oh = out.cpu().numpy()
+        for p, s in enumerate(order):
+            ref = cases[s].P.initial_guess_samples(xs[p], times)
+            got = oh[p * stride:p * stride + 49 * len(times)].reshape(len(times), 49)
+            assert np.array_equal(got[:, 0], times)
+            assert np.array_equal(got[:, 25:37], np.zeros((len(times), 12)))          # the "joint torques"
+            assert np.array_equal(got[:, 13 + 3 * n_ee:25], np.zeros((len(times), 12 - 3 * n_ee)))   # absent feet
+            assert np.isnan(oh[p * stride + 49 * len(times):(p + 1) * stride]).all()   # nothing written past the records
+            scale = np.maximum(np.abs(ref).max(axis=0, keepdims=True), 1.0)
+            err = np.abs(got - ref) / scale
+            assert err.max() < 1e-10, "%s problem %d: field %d off by %.3e" % (robot, p, int(err.max(axis=0).argmax()), err.max())
+
+
 def test_foot_starting_in_swing():
     """ee_in_contact_at_start = false: first polynomial of ee-motion is a swing one, force starts at zero."""
     sched = ta.schedule([[0.3, 0.5, 0.3, 0.4], [0.6, 0.3, 0.6]], [0, 1])

@@ -460,6 +460,30 @@ def test_grid_map_terrain_known_answers():
     assert P2.terrain_probe(0.25, 0.0)[0] == float(f32(0.5 * (0.75 * (1 + 2) + 0.25 * (4 + 8))))
 
 
+def test_initial_guess_samples_known_answer():
+    """fpowr::ExtractInitialGuess (initial_guess_extractor.h:17-34).  At a base-spline node time the state is that
+    node's variables: hopper, base polynomials of 0.1 s, variable layout [p0 v0 | p1 v1 | ...] per base set
+    (nodes_variables_all.cc:45-61): t = 0.3 is node 3.  The controls hold the foot acceleration at 0..2, zeros at
+    3..23 (one foot; twelve "joint torques"), the foot force at 24..26, zeros after; and they agree with GetTrajectory."""
+    P = ob.OracleProblem("monoped", "flat", [[0.4, 0.2, 0.4, 0.2, 0.4, 0.2, 0.2]], [1])
+    x = P.initial_guess([0, 0, 0.5], [0, 0, 0], [1, 0, 0.5], [0, 0, 0], [[0, 0, 0]])
+    rng = np.random.default_rng(3)
+    x = x + 0.05 * rng.standard_normal(x.size)
+    rec = P.initial_guess_samples(x, [0.3, 0.0, 1.234])
+    assert rec.shape == (3, 49) and list(rec[:, 0]) == [0.3, 0.0, 1.234]
+    n_lin = 6 * 21    # 20 base polynomials of 0.1 s -> 21 nodes x (p, v) x 3 (parameters.cc:82-98)
+    for row, node in ((0, 3), (1, 0)):
+        lin, ang = x[6 * node:6 * node + 6], x[n_lin + 6 * node:n_lin + 6 * node + 6]
+        assert np.allclose(rec[row, 1:4], lin[:3], rtol=0, atol=1e-13) and np.allclose(rec[row, 7:10], lin[3:], rtol=0, atol=1e-12)
+        assert np.allclose(rec[row, 4:7], ang[:3], rtol=0, atol=1e-13) and np.allclose(rec[row, 10:13], ang[3:], rtol=0, atol=1e-12)
+    assert np.array_equal(rec[:, 16:37], np.zeros((3, 21))) and np.array_equal(rec[:, 40:], np.zeros((3, 9)))
+    traj = P.sample_trajectory(x, 0.1)     # [t | lin p v a | quaternion | omega | omega_dot | contact, ee p v a, force]
+    assert abs(traj[3, 0] - 0.3) < 1e-12
+    assert np.allclose(rec[0, 13:16], traj[3, 20 + 7:20 + 10], rtol=1e-12, atol=1e-12)
+    assert np.allclose(rec[0, 37:40], traj[3, 20 + 10:20 + 13], rtol=1e-12, atol=1e-12)
+    assert np.allclose(rec[0, 1:4], traj[3, 1:4], rtol=1e-12, atol=1e-12)
+
+
 def test_contact_plan_known_answer():
     """fpowr::ExtractFootstepPlan (footstep_plan_extractor.h:69-133): footstep states where the contact flags change.
     Hopper phases {0.4,0.2,0.4,0.2,0.4,0.2,0.2} starting in contact, sampled every 0.01 s: states start at the first

@@ -131,6 +131,7 @@ def lib():
         L.twr_batch_eval_host.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int]
         L.twr_structure_sample_count.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int32)]
         L.twr_batch_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int64, C.c_void_p]
+        L.twr_batch_initial_guess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
         L.twr_batch_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.twr_structure_contact_steps_max.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.twr_batch_contact_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_int32, C.c_void_p,
@@ -400,6 +401,12 @@ class Batch:
         """twr_batch_sample: d_out[p * problem_stride + sample * (20 + 13 n_ee) + field] (device pointers)."""
         _check(lib().twr_batch_sample(self._h, C.c_void_p(d_x), float(dt), C.c_void_p(d_out), int(problem_stride),
                                       C.c_void_p(stream)))
+
+    def initial_guess_device(self, d_x, d_times, n_times, d_out, problem_stride, stream=0):
+        """twr_batch_initial_guess (fpowr ExtractInitialGuess): d_out[p * problem_stride + 49 s + field], sample s at
+        d_times[s]; record [t | state 12 | controls 36] (device pointers)."""
+        _check(lib().twr_batch_initial_guess(self._h, C.c_void_p(d_x), C.c_void_p(d_times), int(n_times), C.c_void_p(d_out),
+                                             int(problem_stride), C.c_void_p(stream)))
 
     def score_device(self, d_g, d_scores, stream=0):
         """twr_batch_score: d_scores[16 p + 2 f + {0: inf-norm, 1: 1-norm}] of the bound violation per family f."""

@@ -25,7 +25,8 @@ hipError_t launch_check(int n_problems, const int64_t* g_off, const int64_t* j_o
 hipError_t launch_score(const NodeWork* work, int n_problems, const double* g, double* scores, hipStream_t stream);
 hipError_t launch_contact_plan(const NodeWork* work, int n_problems, const double* x, double* out, int32_t* counts, double dt,
                                double time_horizon, int n_samples_max, int max_steps, hipStream_t stream);
-hipError_t launch_sample(const SampleWork* work, int n_work, const double* x, double* out, double dt, hipStream_t stream);
+hipError_t launch_sample(const SampleWork* work, int n_work, const double* x, double* out, double dt, const double* times,
+                         hipStream_t stream);
 int rom_stage_capacity();
 }  // namespace twr
 
@@ -51,6 +52,9 @@ struct twr_batch {
   int n_swork = 0;
   double swork_dt = 0.0;
   int64_t swork_stride = -1;
+  twr::SampleWork* d_gwork = nullptr;        // work list of the last twr_batch_initial_guess call (cached per count / stride)
+  int n_gwork = 0, gwork_times = -1;
+  int64_t gwork_stride = -1;
   twr::DynWork* d_dyn = nullptr;
   twr::RomWork* d_rom = nullptr;
   twr::NodeWork* d_node = nullptr;
@@ -542,6 +546,7 @@ void twr_batch_destroy(twr_batch* b) {
   if (b->d_joff) (void)hipFree(b->d_joff);
   if (b->d_status) (void)hipFree(b->d_status);
   if (b->d_swork) (void)hipFree(b->d_swork);
+  if (b->d_gwork) (void)hipFree(b->d_gwork);
   for (hipEvent_t e : b->prof_events) (void)hipEventDestroy(e);
   if (b->d_x) (void)hipFree(b->d_x);
   if (b->d_g) (void)hipFree(b->d_g);
@@ -703,7 +708,43 @@ int twr_batch_sample(twr_batch* b, const double* d_x, double dt, double* d_out, 
       b->swork_dt = dt;
       b->swork_stride = problem_stride;
     }
-    hipError_t e = twr::launch_sample(b->d_swork, b->n_swork, d_x, d_out, dt, static_cast<hipStream_t>(hip_stream));
+    hipError_t e = twr::launch_sample(b->d_swork, b->n_swork, d_x, d_out, dt, nullptr, static_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return TWR_OK;
+  } catch (const std::exception& e) {
+    return fail(TWR_ERR_HIP, e.what());
+  }
+}
+
+int twr_batch_initial_guess(twr_batch* b, const double* d_x, const double* d_times, int32_t n_times, double* d_out,
+                            int64_t problem_stride, void* hip_stream) {
+  if (!b || !d_x || !d_times || !d_out || n_times < 1) return fail(TWR_ERR_INVALID, "bad arguments");
+  if ((int64_t)n_times * 49 > problem_stride) return fail(TWR_ERR_INVALID, "problem_stride too small for the records");
+  try {
+    TWR_HIP(hipSetDevice(b->device));
+    if (!b->d_gwork || b->gwork_times != n_times || b->gwork_stride != problem_stride) {
+      std::vector<twr::SampleWork> work;
+      for (int p = 0; p < b->n_problems; ++p) {
+        if (!b->sample_ok[p]) throw std::runtime_error("too many polynomials per spline for trajectory sampling");
+        for (int s0 = 0; s0 < n_times; s0 += 64) {
+          twr::SampleWork w;
+          w.blob = b->blob_of_problem[p];
+          w.x_off = b->x_off[p];
+          w.out_off = (int64_t)p * problem_stride;
+          w.s0 = s0;
+          w.cnt = std::min(64, n_times - s0);
+          work.push_back(w);
+        }
+      }
+      if (b->d_gwork) TWR_HIP(hipFree(b->d_gwork));
+      b->d_gwork = nullptr;
+      TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_gwork), work.size() * sizeof(twr::SampleWork)));
+      TWR_HIP(hipMemcpy(b->d_gwork, work.data(), work.size() * sizeof(twr::SampleWork), hipMemcpyHostToDevice));
+      b->n_gwork = (int)work.size();
+      b->gwork_times = n_times;
+      b->gwork_stride = problem_stride;
+    }
+    hipError_t e = twr::launch_sample(b->d_gwork, b->n_gwork, d_x, d_out, 0.0, d_times, static_cast<hipStream_t>(hip_stream));
     if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return TWR_OK;
   } catch (const std::exception& e) {

@@ -1961,8 +1961,12 @@ TWR_DEV void sample_spline(const double* __restrict__ xp, const PolyDesc& pd, do
     a[d] = wa[0] * nv[0][d] + wa[1] * nv[1][d] + wa[2] * nv[2][d] + wa[3] * nv[3][d];
   }
 }
+// With `times` set the kernel is fpowr::ExtractInitialGuess (fpowr/include/fpowr/initial_guess_extractor.h:17-34)
+// instead: sample s of every problem is taken at times[s] and the record is [ t | state: base-lin p, base-ang p (Euler
+// angles), base-lin v, base-ang v (Euler rates) | controls (36): ee-motion acceleration of ee i at 3 i, twelve zeros
+// ("joint torques"), ee-force of ee i at 24 + 3 i ] = 49 doubles.
 __global__ __launch_bounds__(64) void sample_kernel(const SampleWork* __restrict__ work, const double* __restrict__ x,
-                                                    double* __restrict__ out, double dt) {
+                                                    double* __restrict__ out, double dt, const double* __restrict__ times) {
   __shared__ double s_bd[2 * kMaxPhasePolys], s_ph[kMaxEE][TWR_MAX_PHASES_DEV], s_md[kMaxEE][kMaxPhasePolys],
       s_fd[kMaxEE][kMaxPhasePolys];
   const SampleWork sw = work[blockIdx.x];
@@ -1988,8 +1992,9 @@ __global__ __launch_bounds__(64) void sample_kernel(const SampleWork* __restrict
   if (lane >= sw.cnt) return;
   const int s_idx = sw.s0 + lane;
   double t = 0.0;
-  for (int i = 0; i < s_idx; ++i) t += dt;   // the reference's accumulated sample time
-  const int rec = 20 + 13 * n_ee;
+  if (times) t = times[s_idx];
+  else for (int i = 0; i < s_idx; ++i) t += dt;   // the reference's accumulated sample time
+  const int rec = times ? 49 : 20 + 13 * n_ee;
   double* o = out + sw.out_off + (int64_t)s_idx * rec;
   o[0] = t;
   // base-lin / base-ang (NodesVariablesAll: [p0 v0 p1 v1] x 3 of polynomial q at 6 q)
@@ -2008,6 +2013,28 @@ __global__ __launch_bounds__(64) void sample_kernel(const SampleWork* __restrict
     e3[d] = wp[0] * xa[d] + wp[1] * xa[3 + d] + wp[2] * xa[6 + d] + wp[3] * xa[9 + d];
     ed[d] = wv[0] * xa[d] + wv[1] * xa[3 + d] + wv[2] * xa[6 + d] + wv[3] * xa[9 + d];
     edd[d] = wa[0] * xa[d] + wa[1] * xa[3 + d] + wa[2] * xa[6 + d] + wa[3] * xa[9 + d];
+  }
+  if (times) {   // ExtractInitialGuess record
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const double lv = o[4 + d];
+      o[4 + d] = e3[d];
+      o[7 + d] = lv;
+      o[10 + d] = ed[d];
+    }
+    for (int q = 13; q < 49; ++q) o[q] = 0.0;
+    for (int e = 0; e < n_ee; ++e) {
+      double tlm, tlf, p[3], v[3], a[3];
+      const int qm = locate_segment(s_md[e], ST->n_mpoly[e], t, tlm);
+      const int qf = locate_segment(s_fd[e], ST->n_fpoly[e], t, tlf);
+      sample_spline(xp, tbl<PolyDesc>(blob, ST->o_mdesc[e])[qm], tlm, s_md[e][qm], p, v, a);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) o[13 + 3 * e + d] = a[d];
+      sample_spline(xp, tbl<PolyDesc>(blob, ST->o_fdesc[e])[qf], tlf, s_fd[e][qf], p, v, a);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) o[37 + 3 * e + d] = p[d];
+    }
+    return;
   }
   Rot ro;
   rotation(e3, ro);
@@ -2070,8 +2097,9 @@ __global__ __launch_bounds__(64) void sample_kernel(const SampleWork* __restrict
     for (int d = 0; d < 3; ++d) oe[10 + d] = p[d];
   }
 }
-hipError_t launch_sample(const SampleWork* work, int n_work, const double* x, double* out, double dt, hipStream_t stream) {
-  if (n_work > 0) hipLaunchKernelGGL(sample_kernel, dim3(n_work), dim3(64), 0, stream, work, x, out, dt);
+hipError_t launch_sample(const SampleWork* work, int n_work, const double* x, double* out, double dt, const double* times,
+                         hipStream_t stream) {
+  if (n_work > 0) hipLaunchKernelGGL(sample_kernel, dim3(n_work), dim3(64), 0, stream, work, x, out, dt, times);
   return hipGetLastError();
 }
 
