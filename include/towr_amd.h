@@ -256,7 +256,7 @@ int twr_batch_initial_guess(twr_batch* b, const double* d_x, const double* d_tim
  * twr_batch_eval with TWR_EVAL_VALUES.  Asynchronous on hip_stream. */
 int twr_batch_score(twr_batch* b, const double* d_g, double* d_scores /* 16 * n_problems */, void* hip_stream);
 /* fpowr::ExtractFootstepPlan (fpowr/include/fpowr/footstep_plan_extractor.h:69-133) for every problem of the batch,
- * minus the nearest-plane lookup (boost::geometry over ROS messages -- the caller's): the solution x sampled every dt
+ * up to the nearest-plane lookup (twr_batch_contact_planes below): the solution x sampled every dt
  * (GetTrajectory, :19-53), a footstep state at the first sample and wherever HasEndEffectorContactChanged (:55-67)
  * against the previous sample; duration = time to the next footstep state, the last one lasts until time_horizon.
  * Problem p's records start at d_out + p * max_steps * (2 + 4 n_ee):
@@ -265,6 +265,28 @@ int twr_batch_score(twr_batch* b, const double* d_g, double* d_scores /* 16 * n_
 int twr_structure_contact_steps_max(const twr_structure* s, int32_t* max_steps);
 int twr_batch_contact_plan(twr_batch* b, const double* d_x, double dt, double time_horizon, double* d_out, int32_t max_steps,
                            int32_t* d_counts, void* hip_stream);
+
+/* fpowr::NearestPlaneLookup (fpowr/include/fpowr/nearest_plane_lookup.h:51-85), the last step of ExtractFootstepPlan
+ * (footstep_plan_extractor.h:72-73,111-118): the planar regions of the goal's terrain message as polygons in world x, y
+ * (PlanarRegionsToPolygons, :20-49: boundary point (x, y, 0) rotated by the region's orientation, shifted by its
+ * position) and, for every footstep state of twr_batch_contact_plan and every end-effector in contact, the index of the
+ * first polygon with the smallest boost::geometry::distance to the foot's x, y (0 inside or on the boundary, else the
+ * distance to the nearest boundary segment; the boundary points are walked as given, no closing edge is added -- what
+ * boost does with the reference's uncorrected polygons); -1 for a foot in the air, for footstep states past d_counts[p]
+ * and when there are no regions.
+ *   regions:        n_regions x 7 doubles  [position x y z | orientation x y z w]   (plane_parameters)
+ *   boundary_xy:    the outer_boundary points of all regions, x y each, region r = points [boundary_start[r],
+ *                   boundary_start[r+1])
+ *   d_plane_index:  n_problems x max_steps x n_ee int32, written by twr_batch_contact_planes from the d_out / d_counts
+ *                   of twr_batch_contact_plan (same max_steps).  Asynchronous on hip_stream. */
+typedef struct twr_planes twr_planes;
+int twr_planes_create(const double* regions, const double* boundary_xy, const int32_t* boundary_start, int32_t n_regions,
+                      int device, twr_planes** out);
+void twr_planes_destroy(twr_planes* planes);
+/* the polygons in world coordinates (x y per boundary point, in the order given), for inspection */
+int twr_planes_world_xy(const twr_planes* planes, double* world_xy);
+int twr_batch_contact_planes(twr_batch* b, const twr_planes* planes, const double* d_plan, const int32_t* d_counts,
+                             int32_t max_steps, int32_t* d_plane_index, void* hip_stream);
 
 /* Convenience for single-problem / adapter use: host buffers, synchronous (H2D, eval, D2H). */
 int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_jac, int flags);

@@ -68,6 +68,10 @@ def lib():
         L.orc_contact_plan.argtypes = [C.c_void_p, _dp, C.c_double, C.c_double, _dp, C.c_int]
         L.orc_contact_plan.restype = C.c_int
         L.orc_initial_guess_samples.argtypes = [C.c_void_p, _dp, _dp, C.c_int, _dp]
+        L.orc_planes_world_xy.argtypes = [_dp, _dp, _ip, C.c_int, _dp]
+        L.orc_planes_world_xy.restype = None
+        L.orc_nearest_plane.argtypes = [_dp, _ip, C.c_int, C.c_double, C.c_double]
+        L.orc_nearest_plane.restype = C.c_int
         L.orc_initial_guess_samples.restype = None
         L.orc_time_callbacks.argtypes = [C.c_void_p, _dp, C.c_int]
         L.orc_time_callbacks.restype = C.c_double
@@ -266,3 +270,21 @@ def terrain_dbasis(terrain, which, dim, x, y):
     o = np.zeros(3)
     lib().orc_terrain_dbasis(TERRAINS[terrain], which, dim, x, y, _d(o))
     return o
+
+
+def planes_world_xy(regions, local_xy, start):
+    """fpowr::PlanarRegionsToPolygons: regions (n, 7) [position xyz, orientation xyzw], boundary points local_xy (m, 2),
+    start (n + 1) -> world xy (m, 2)."""
+    regions = np.ascontiguousarray(regions, dtype=np.float64)
+    local_xy = np.ascontiguousarray(local_xy, dtype=np.float64)
+    start = np.ascontiguousarray(start, dtype=np.int32)
+    out = np.zeros_like(local_xy)
+    lib().orc_planes_world_xy(_d(regions), _d(local_xy), start.ctypes.data_as(C.POINTER(C.c_int)), len(regions), _d(out))
+    return out
+
+
+def nearest_plane(world_xy, start, px, py):
+    """fpowr::NearestPlaneLookup::GetNearestPlaneIndex."""
+    world_xy = np.ascontiguousarray(world_xy, dtype=np.float64)
+    start = np.ascontiguousarray(start, dtype=np.int32)
+    return lib().orc_nearest_plane(_d(world_xy), start.ctypes.data_as(C.POINTER(C.c_int)), len(start) - 1, float(px), float(py))

@@ -1816,6 +1816,99 @@ int orc_contact_plan(orc_problem* P, const double* x, double dt, double time_hor
   return (int)steps.size();
 }
 
+// ---- fpowr::NearestPlaneLookup (fpowr/include/fpowr/nearest_plane_lookup.h).  Third-party pieces that are absent
+// from /root/reference and restated from their published sources: tf::Matrix3x3(tf::Quaternion) (ROS tf / Bullet
+// LinearMath Matrix3x3::setRotation) and boost::geometry::distance(point, polygon) (Boost 1.71 of the Ubuntu 20.04
+// image: strategy/cartesian/point_in_poly_winding.hpp, strategies/cartesian/distance_projected_point.hpp,
+// algorithms/detail/distance/point_to_geometry.hpp).  The reference appends the boundary points to a default
+// bg::model::polygon (clockwise, CLOSED) without bg::correct: boost then walks the consecutive points exactly as given
+// -- no closing edge is added -- and so does this restatement.  Deviation: boost compares coordinates / the side
+// determinant with a few-ulp tolerance (math::equals), here exactly; it only matters for a point within rounding of a
+// polygon boundary, where both give a distance of (almost) zero.
+// PlanarRegionsToPolygons (:20-49): boundary point (x, y, 0) of a region rotated by its orientation, shifted by its
+// position; the polygon keeps the world x, y.
+void orc_planes_world_xy(const double* regions /* n x [position xyz, orientation xyzw] */, const double* local_xy,
+                         const int* start /* n + 1 */, int n, double* out_xy) {
+  for (int r = 0; r < n; ++r) {
+    const double* P = regions + 7 * r;
+    const double x = P[3], y = P[4], z = P[5], w = P[6];
+    const double d = x * x + y * y + z * z + w * w, s = 2.0 / d;   // Matrix3x3::setRotation
+    const double xs = x * s, ys = y * s, zs = z * s, wz = w * zs, xx = x * xs, xy = x * ys, yy = y * ys, zz = z * zs;
+    const double R00 = 1.0 - (yy + zz), R01 = xy - wz, R10 = xy + wz, R11 = 1.0 - (xx + zz);
+    for (int i = start[r]; i < start[r + 1]; ++i) {
+      const double lx = local_xy[2 * i], ly = local_xy[2 * i + 1];
+      out_xy[2 * i] = (R00 * lx + R01 * ly + 0.0) + P[0];       // tf: m_el[0].dot(v) with v.z = 0, then + position
+      out_xy[2 * i + 1] = (R10 * lx + R11 * ly + 0.0) + P[1];
+    }
+  }
+}
+namespace {
+// boost winding strategy over the ring's consecutive points: 1 inside, 0 on the boundary, -1 outside
+int RingSide(const double* xy, int n, double px, double py) {
+  if (n < 4) return -1;   // core_detail::closure::minimum_ring_size<closed>
+  int count = 0;
+  for (int i = 0; i + 1 < n; ++i) {
+    const double s1x = xy[2 * i], s1y = xy[2 * i + 1], s2x = xy[2 * i + 2], s2y = xy[2 * i + 3];
+    const bool eq1 = s1x == px, eq2 = s2x == px;
+    int c;
+    if (eq1 && eq2) {   // vertical segment through px: touch if py lies on it
+      if ((s1y <= py && s2y >= py) || (s2y <= py && s1y >= py)) return 0;
+      c = 0;
+    } else {
+      c = eq1 ? (s2x > px ? 1 : -1) : eq2 ? (s1x > px ? -1 : 1) : (s1x < px && s2x > px) ? 2 : (s2x < px && s1x > px) ? -2 : 0;
+    }
+    if (c != 0) {
+      int side;
+      if (c == 1 || c == -1) {
+        const double sey = eq1 ? s1y : s2y;
+        side = py == sey ? 0 : (py < sey ? -c : c);
+      } else {
+        const double det = (s2x - s1x) * (py - s1y) - (s2y - s1y) * (px - s1x);   // side_by_triangle: > 0 left
+        side = det > 0 ? 1 : (det < 0 ? -1 : 0);
+      }
+      if (side == 0) return 0;
+      if (side * c > 0) count += c;
+    }
+  }
+  return count == 0 ? -1 : 1;
+}
+double RingDistance(const double* xy, int n, double px, double py) {   // point_to_range + projected_point
+  if (n == 0) return 0.0;
+  auto comparable = [&](double ax, double ay, double bx, double by) {
+    const double vx = bx - ax, vy = by - ay, wx = px - ax, wy = py - ay;
+    const double c1 = wx * vx + wy * vy;
+    if (c1 <= 0) return wx * wx + wy * wy;
+    const double c2 = vx * vx + vy * vy;
+    if (c2 <= c1) return (px - bx) * (px - bx) + (py - by) * (py - by);
+    const double b = c1 / c2, qx = ax + b * vx, qy = ay + b * vy;
+    return (px - qx) * (px - qx) + (py - qy) * (py - qy);
+  };
+  if (n == 1) return std::sqrt(comparable(xy[0], xy[1], xy[0], xy[1]));
+  double best = comparable(xy[0], xy[1], xy[2], xy[3]);
+  for (int i = 0; i + 1 < n; ++i) {
+    const double c = comparable(xy[2 * i], xy[2 * i + 1], xy[2 * i + 2], xy[2 * i + 3]);
+    if (c == 0.0) return 0.0;
+    if (c < best) best = c;
+  }
+  return std::sqrt(best);
+}
+}  // namespace
+// NearestPlaneLookup::GetNearestPlaneIndex (:62-84): first polygon with the smallest bg::distance, -1 without polygons
+int orc_nearest_plane(const double* world_xy, const int* start, int n_polys, double px, double py) {
+  double min_distance = std::numeric_limits<double>::max();
+  int nearest = -1;
+  for (int i = 0; i < n_polys; ++i) {
+    const double* xy = world_xy + 2 * start[i];
+    const int n = start[i + 1] - start[i];
+    const double distance = RingSide(xy, n, px, py) >= 0 ? 0.0 : RingDistance(xy, n, px, py);
+    if (distance < min_distance) {
+      min_distance = distance;
+      nearest = i;
+    }
+  }
+  return nearest;
+}
+
 // fpowr::ExtractInitialGuess (fpowr/include/fpowr/initial_guess_extractor.h:17-34), one record per requested time:
 //   [ t | state: base-lin p (3), base-ang p = Euler angles (3), base-lin v (3), base-ang v = Euler rates (3) |
 //     controls (36): ee-motion acceleration of ee i at 3 i, twelve zeros ("joint torques"), ee-force of ee i at 24 + 3 i ]

@@ -86,6 +86,11 @@ void orc_bounds(orc_problem*, double* lower, double* upper);
 // number of samples (pass out = NULL to query it); record layout in towr_oracle.cc.
 int orc_sample_trajectory(orc_problem*, const double* x, double dt, double* out, int max_samples);
 
+// fpowr::PlanarRegionsToPolygons / NearestPlaneLookup::GetNearestPlaneIndex (nearest_plane_lookup.h:20-85); tf and
+// boost::geometry restated from their published algorithms (notes in towr_oracle.cc)
+void orc_planes_world_xy(const double* regions, const double* local_xy, const int* start, int n, double* out_xy);
+int orc_nearest_plane(const double* world_xy, const int* start, int n_polys, double px, double py);
+
 // fpowr::ExtractInitialGuess (initial_guess_extractor.h:17-34) at the given times: 49 doubles per time
 // [t | state 12 | controls 36], layout in towr_oracle.cc
 void orc_initial_guess_samples(orc_problem*, const double* x, const double* times, int n_times, double* out);

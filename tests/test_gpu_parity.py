@@ -679,6 +679,40 @@ def test_candidate_scores_and_contact_plans():
             assert np.array_equal(got[:, 2:2 + n_ee], ref[:, 2:2 + n_ee])          # contact flags
             assert np.abs(got[:, :2] - ref[:, :2]).max() <= 1e-12                    # t, duration
             assert np.abs(got[:, 2 + n_ee:] - ref[:, 2 + n_ee:]).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+        # nearest planar region of every foot in contact (fpowr NearestPlaneLookup): rotated, overlapping, open and
+        # closed polygons along the path of the robot
+        from oracle import binding as ob
+        rng = np.random.default_rng(11)
+        regions, boundaries = [], []
+        for r in range(14):
+            yaw, k = rng.uniform(-np.pi, np.pi), int(rng.integers(3, 9))
+            ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+            pts = np.stack([np.cos(ang), np.sin(ang)], axis=1) * rng.uniform(0.15, 0.6, (k, 1))
+            if r % 2 == 0:
+                pts = np.concatenate([pts, pts[:1]])          # closed ring (first point repeated); the others stay open
+            regions.append([rng.uniform(-0.5, 2.5), rng.uniform(-0.6, 0.6), rng.uniform(0, 0.3), 0, 0, np.sin(yaw / 2), np.cos(yaw / 2)])
+            boundaries.append(pts)
+        planes = ta.Planes(regions, boundaries, device=0)
+        start = planes.start
+        wxy = ob.planes_world_xy(regions, np.concatenate(boundaries), start)
+        assert np.allclose(planes.world_xy, wxy, rtol=0, atol=1e-15)
+        idx = torch.full((len(order), max_steps, n_ee), -7, dtype=torch.int32, device=dev)
+        batch.contact_planes_device(planes, out.data_ptr(), counts.data_ptr(), max_steps, idx.data_ptr(), st)
+        torch.cuda.synchronize()
+        ih = idx.cpu().numpy()
+        seen = set()
+        for p, s in enumerate(order):
+            if p == 4:
+                continue
+            for k in range(max_steps):
+                for e in range(n_ee):
+                    if k < ch[p] and oh[p, k, 2 + e] != 0.0:
+                        want = ob.nearest_plane(planes.world_xy, start, oh[p, k, 2 + n_ee + 3 * e], oh[p, k, 2 + n_ee + 3 * e + 1])
+                        seen.add(want)
+                    else:
+                        want = -1
+                    assert ih[p, k, e] == want, (p, k, e, ih[p, k, e], want)
+        assert len(seen - {-1}) >= 3
 
 
 def test_eval_is_graph_capturable_and_stream_ordered():

@@ -460,6 +460,43 @@ def test_grid_map_terrain_known_answers():
     assert P2.terrain_probe(0.25, 0.0)[0] == float(f32(0.5 * (0.75 * (1 + 2) + 0.25 * (4 + 8))))
 
 
+def test_nearest_plane_known_answers():
+    """fpowr PlanarRegionsToPolygons / NearestPlaneLookup (nearest_plane_lookup.h:20-85) with boost::geometry's
+    distance(point, polygon) restated: 0 inside and on the boundary, distance to the nearest boundary segment outside,
+    the first polygon wins a tie, -1 without polygons; the boundary points are walked as given (an unclosed ring has no
+    closing edge: a point next to the missing edge is 'outside' and measured to the edges that exist)."""
+    sq = np.array([[0, 0], [0, 1], [1, 1], [1, 0], [0, 0]], float)          # closed, clockwise
+    xy = np.concatenate([sq, sq + [3, 0], (sq + [1.5, 2.0])[::-1]])         # third one counter-clockwise
+    start = [0, 5, 10, 15]
+    near = lambda x, y: ob.nearest_plane(xy, start, x, y)
+    assert near(0.5, 0.5) == 0 and near(3.2, 0.9) == 1 and near(2.0, 2.5) == 2       # inside (either orientation)
+    assert near(1.0, 0.5) == 0 and near(3.0, 0.0) == 1                                # on an edge / a corner
+    assert near(1.9, 0.5) == 0 and near(2.1, 0.5) == 1 and near(2.0, 0.5) == 0        # outside; the tie goes to the first
+    assert near(2.0, 1.4) == 2                                                        # 0.6 below polygon 2, ~1.08 from 0 and 1
+    assert near(-7.0, -7.0) == 0 and near(40.0, 3.0) == 1
+    assert ob.nearest_plane(np.zeros((0, 2)), [0], 0.3, 0.3) == -1
+    # corner distance: point (1.3, 1.4) is sqrt(0.09 + 0.16) = 0.5 from corner (1, 1) of polygon 0, 0.6 below polygon 2
+    assert near(1.3, 1.4) == 0 and near(1.6, 1.45) == 2
+    # unclosed ring (last point not repeated): the edge (1,0)-(0,0) does not exist
+    opn = np.array([[0, 0], [0, 1], [1, 1], [1, 0]], float)
+    far = sq + [0.0, -3.0]
+    xy2, st2 = np.concatenate([opn, far]), [0, 4, 9]
+    assert ob.nearest_plane(xy2, st2, 0.5, 0.9) == 0
+    # (0.5, -1.4): 1.4 + from the existing edges of the open ring (corners (0,0) / (1,0): sqrt(0.25 + 1.96) = 1.487),
+    # 0.6 above the closed square below -> the square; a closing edge would have made it 1.4 vs 0.6 as well
+    assert ob.nearest_plane(xy2, st2, 0.5, -1.4) == 1
+    # fewer than 4 points: never 'inside' (minimum ring size), distance to its segments
+    tri = np.array([[0, 0], [2, 0], [1, 2]], float)
+    assert ob.nearest_plane(np.concatenate([sq + [5, 5], tri]), [0, 5, 8], 1.0, 0.5) == 1
+    # PlanarRegionsToPolygons: yaw 90 degrees maps local (1, 0) to world (0, 1); roll 180 degrees flips y; + position
+    q_yaw = [0, 0, np.sin(np.pi / 4), np.cos(np.pi / 4)]
+    w = ob.planes_world_xy([[1, 2, 3] + q_yaw, [0, 0, 0, 1, 0, 0, 0]], [[1, 0], [0, 1], [0.25, 0.5]], [0, 2, 3])
+    assert np.allclose(w, [[1, 3], [0, 2], [0.25, -0.5]], rtol=0, atol=1e-15)
+    # a non-unit quaternion is normalised by 2 / |q|^2 (tf Matrix3x3::setRotation)
+    w2 = ob.planes_world_xy([[0, 0, 0, 0, 0, 3 * np.sin(0.3), 3 * np.cos(0.3)]], [[1, 0]], [0, 1])
+    assert np.allclose(w2, [[np.cos(0.6), np.sin(0.6)]], rtol=0, atol=1e-15)
+
+
 def test_initial_guess_samples_known_answer():
     """fpowr::ExtractInitialGuess (initial_guess_extractor.h:17-34).  At a base-spline node time the state is that
     node's variables: hopper, base polynomials of 0.1 s, variable layout [p0 v0 | p1 v1 | ...] per base set

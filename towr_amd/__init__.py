@@ -134,6 +134,11 @@ def lib():
         L.twr_batch_initial_guess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
         L.twr_batch_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.twr_structure_contact_steps_max.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        L.twr_planes_create.argtypes = [_dp, _dp, C.POINTER(C.c_int32), C.c_int32, C.c_int, C.POINTER(C.c_void_p)]
+        L.twr_planes_destroy.argtypes = [C.c_void_p]
+        L.twr_planes_destroy.restype = None
+        L.twr_planes_world_xy.argtypes = [C.c_void_p, _dp]
+        L.twr_batch_contact_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.twr_batch_contact_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_int32, C.c_void_p,
                                              C.c_void_p]
         L.twr_batch_host_buffers.argtypes = [C.c_void_p, C.POINTER(_dp), C.POINTER(_dp), C.POINTER(_dp)]
@@ -220,6 +225,30 @@ class GridMap(TerrainGrid):
                                                  C.byref(self._h)))
         self.elevation, self.resolution, self.position = a, float(resolution), (float(position[0]), float(position[1]))
         self.heights = None
+
+
+class Planes:
+    """The planar regions of a terrain message as world polygons on a device (fpowr PlanarRegionsToPolygons /
+    NearestPlaneLookup): regions (n, 7) [position xyz | orientation xyzw], boundaries = one (k, 2) array of local
+    outer-boundary points per region."""
+
+    def __init__(self, regions, boundaries, device=0):
+        regions = np.ascontiguousarray(regions, dtype=np.float64).reshape(-1, 7)
+        assert len(regions) == len(boundaries)
+        pts = [np.asarray(b, dtype=np.float64).reshape(-1, 2) for b in boundaries]
+        self.start = np.concatenate([[0], np.cumsum([len(b) for b in pts])]).astype(np.int32)
+        xy = np.ascontiguousarray(np.concatenate(pts) if pts else np.zeros((0, 2)))
+        self._h = C.c_void_p()
+        _check(lib().twr_planes_create(_d(regions), _d(xy), self.start.ctypes.data_as(C.POINTER(C.c_int32)), len(regions),
+                                       int(device), C.byref(self._h)))
+        self.world_xy = np.zeros_like(xy)
+        if len(xy):
+            _check(lib().twr_planes_world_xy(self._h, _d(self.world_xy)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().twr_planes_destroy(self._h)
+            self._h = None
 
 
 class Structure:
@@ -416,6 +445,12 @@ class Batch:
         """twr_batch_contact_plan (fpowr ExtractFootstepPlan without the plane lookup)."""
         _check(lib().twr_batch_contact_plan(self._h, C.c_void_p(d_x), float(dt), float(time_horizon), C.c_void_p(d_out),
                                             int(max_steps), C.c_void_p(d_counts), C.c_void_p(stream)))
+
+    def contact_planes_device(self, planes, d_plan, d_counts, max_steps, d_plane_index, stream=0):
+        """twr_batch_contact_planes: nearest planar region of every foot in contact of every footstep state of
+        contact_plan_device(); d_plane_index int32[n_problems, max_steps, n_ee], -1 = in the air / no such state."""
+        _check(lib().twr_batch_contact_planes(self._h, planes._h, C.c_void_p(d_plan), C.c_void_p(d_counts), int(max_steps),
+                                              C.c_void_p(d_plane_index), C.c_void_p(stream)))
 
     def host_buffers(self):
         """Page-locked x / g / jac arrays owned by the batch (numpy views); eval_host_pinned() uses them."""

@@ -25,6 +25,8 @@ hipError_t launch_check(int n_problems, const int64_t* g_off, const int64_t* j_o
 hipError_t launch_score(const NodeWork* work, int n_problems, const double* g, double* scores, hipStream_t stream);
 hipError_t launch_contact_plan(const NodeWork* work, int n_problems, const double* x, double* out, int32_t* counts, double dt,
                                double time_horizon, int n_samples_max, int max_steps, hipStream_t stream);
+hipError_t launch_planes(const double* plan, const int32_t* counts, const double* poly_xy, const int32_t* poly_start, int n_polys,
+                         int n_problems, int max_steps, int n_ee, int32_t* plane_index, hipStream_t stream);
 hipError_t launch_sample(const SampleWork* work, int n_work, const double* x, double* out, double dt, const double* times,
                          hipStream_t stream);
 int rom_stage_capacity();
@@ -35,6 +37,14 @@ struct twr_structure {
 };
 struct twr_terrain_grid {
   std::shared_ptr<twr::TerrainGrid> g;
+};
+
+struct twr_planes {
+  int device = 0;
+  std::vector<int32_t> start;      // polygon r = points [start[r], start[r+1])
+  std::vector<double> world_xy;    // PlanarRegionsToPolygons output
+  double* d_xy = nullptr;
+  int32_t* d_start = nullptr;
 };
 
 struct twr_batch {
@@ -750,6 +760,70 @@ int twr_batch_initial_guess(twr_batch* b, const double* d_x, const double* d_tim
   } catch (const std::exception& e) {
     return fail(TWR_ERR_HIP, e.what());
   }
+}
+
+int twr_planes_create(const double* regions, const double* boundary_xy, const int32_t* boundary_start, int32_t n_regions,
+                      int device, twr_planes** out) {
+  if (!out || n_regions < 0 || (n_regions > 0 && (!regions || !boundary_start))) return fail(TWR_ERR_INVALID, "bad arguments");
+  try {
+    auto pl = std::make_unique<twr_planes>();
+    pl->device = device;
+    pl->start.assign(1, 0);
+    for (int r = 0; r < n_regions; ++r) {
+      if (boundary_start[r + 1] < boundary_start[r] || boundary_start[0] != 0) throw std::runtime_error("boundary_start must ascend from 0");
+      pl->start.push_back(boundary_start[r + 1]);
+    }
+    const int n_pts = pl->start.back();
+    if (n_pts > 0 && !boundary_xy) throw std::runtime_error("boundary_xy is null");
+    pl->world_xy.resize(2 * (size_t)n_pts);
+    for (int r = 0; r < n_regions; ++r) {   // PlanarRegionsToPolygons: tf::Matrix3x3(q) * (x, y, 0) + position
+      const double* P = regions + 7 * r;
+      const double x = P[3], y = P[4], z = P[5], w = P[6];
+      const double d = x * x + y * y + z * z + w * w;
+      if (!(d > 0)) throw std::runtime_error("zero orientation quaternion");
+      const double s2 = 2.0 / d, xs = x * s2, ys = y * s2, zs = z * s2, wz = w * zs, xx = x * xs, xy = x * ys, yy = y * ys, zz = z * zs;
+      const double R00 = 1.0 - (yy + zz), R01 = xy - wz, R10 = xy + wz, R11 = 1.0 - (xx + zz);
+      for (int i = pl->start[r]; i < pl->start[r + 1]; ++i) {
+        const double lx = boundary_xy[2 * i], ly = boundary_xy[2 * i + 1];
+        pl->world_xy[2 * i] = (R00 * lx + R01 * ly + 0.0) + P[0];
+        pl->world_xy[2 * i + 1] = (R10 * lx + R11 * ly + 0.0) + P[1];
+      }
+    }
+    TWR_HIP(hipSetDevice(device));
+    TWR_HIP(hipMalloc(reinterpret_cast<void**>(&pl->d_xy), std::max<size_t>(16, pl->world_xy.size() * sizeof(double))));
+    TWR_HIP(hipMalloc(reinterpret_cast<void**>(&pl->d_start), pl->start.size() * sizeof(int32_t)));
+    if (n_pts > 0) TWR_HIP(hipMemcpy(pl->d_xy, pl->world_xy.data(), pl->world_xy.size() * sizeof(double), hipMemcpyHostToDevice));
+    TWR_HIP(hipMemcpy(pl->d_start, pl->start.data(), pl->start.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    *out = pl.release();
+    return TWR_OK;
+  } catch (const std::exception& e) {
+    return fail(TWR_ERR_INVALID, e.what());
+  }
+}
+
+void twr_planes_destroy(twr_planes* planes) {
+  if (!planes) return;
+  if (planes->d_xy) (void)hipFree(planes->d_xy);
+  if (planes->d_start) (void)hipFree(planes->d_start);
+  delete planes;
+}
+
+int twr_planes_world_xy(const twr_planes* planes, double* world_xy) {
+  if (!planes || !world_xy) return fail(TWR_ERR_INVALID, "null argument");
+  std::memcpy(world_xy, planes->world_xy.data(), planes->world_xy.size() * sizeof(double));
+  return TWR_OK;
+}
+
+int twr_batch_contact_planes(twr_batch* b, const twr_planes* planes, const double* d_plan, const int32_t* d_counts,
+                             int32_t max_steps, int32_t* d_plane_index, void* hip_stream) {
+  if (!b || !planes || !d_plan || !d_counts || !d_plane_index || max_steps < 1) return fail(TWR_ERR_INVALID, "bad arguments");
+  if (planes->device != b->device) return fail(TWR_ERR_INVALID, "planes and batch live on different devices");
+  if (hipSetDevice(b->device) != hipSuccess) return fail(TWR_ERR_HIP, "hipSetDevice failed");
+  (void)hipGetLastError();
+  hipError_t e = twr::launch_planes(d_plan, d_counts, planes->d_xy, planes->d_start, (int)planes->start.size() - 1, b->n_problems,
+                                    max_steps, b->n_ee, d_plane_index, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  return TWR_OK;
 }
 
 int twr_batch_score(twr_batch* b, const double* d_g, double* d_scores, void* hip_stream) {

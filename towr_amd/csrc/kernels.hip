@@ -2246,6 +2246,92 @@ hipError_t launch_contact_plan(const NodeWork* work, int n_problems, const doubl
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- nearest plane of a footstep
+// fpowr::NearestPlaneLookup::GetNearestPlaneIndex (nearest_plane_lookup.h:62-84) for every (problem, footstep state,
+// end-effector) of a contact plan: boost::geometry::distance(point, polygon) restated from Boost 1.71 (winding
+// strategy for covered_by, projected-point distance to the ring's consecutive points, no closing edge added; exact
+// coordinate comparisons where boost allows a few ulp).  One thread per foot, polygons read from global memory.
+TWR_DEV int ring_side(const double* __restrict__ xy, int n, double px, double py) {   // 1 inside, 0 boundary, -1 outside
+  if (n < 4) return -1;
+  int count = 0;
+  for (int i = 0; i + 1 < n; ++i) {
+    const double s1x = xy[2 * i], s1y = xy[2 * i + 1], s2x = xy[2 * i + 2], s2y = xy[2 * i + 3];
+    const bool eq1 = s1x == px, eq2 = s2x == px;
+    int c = 0;
+    if (eq1 && eq2) {
+      if ((s1y <= py && s2y >= py) || (s2y <= py && s1y >= py)) return 0;
+    } else {
+      c = eq1 ? (s2x > px ? 1 : -1) : eq2 ? (s1x > px ? -1 : 1) : (s1x < px && s2x > px) ? 2 : (s2x < px && s1x > px) ? -2 : 0;
+    }
+    if (c != 0) {
+      int side;
+      if (c == 1 || c == -1) {
+        const double sey = eq1 ? s1y : s2y;
+        side = py == sey ? 0 : (py < sey ? -c : c);
+      } else {
+        // (no FMA contraction: the sign of a tiny determinant must not depend on it)
+        const double det = __dsub_rn(__dmul_rn(s2x - s1x, py - s1y), __dmul_rn(s2y - s1y, px - s1x));
+        side = det > 0 ? 1 : (det < 0 ? -1 : 0);
+      }
+      if (side == 0) return 0;
+      if (side * c > 0) count += c;
+    }
+  }
+  return count == 0 ? -1 : 1;
+}
+TWR_DEV double ring_distance(const double* __restrict__ xy, int n, double px, double py) {
+  if (n == 0) return 0.0;
+  auto comparable = [&](double ax, double ay, double bx, double by) {
+    const double vx = bx - ax, vy = by - ay, wx = px - ax, wy = py - ay;
+    const double c1 = __dadd_rn(__dmul_rn(wx, vx), __dmul_rn(wy, vy));
+    if (c1 <= 0) return __dadd_rn(__dmul_rn(wx, wx), __dmul_rn(wy, wy));
+    const double c2 = __dadd_rn(__dmul_rn(vx, vx), __dmul_rn(vy, vy));
+    if (c2 <= c1) return __dadd_rn(__dmul_rn(px - bx, px - bx), __dmul_rn(py - by, py - by));
+    const double b = c1 / c2, qx = __dadd_rn(ax, __dmul_rn(b, vx)), qy = __dadd_rn(ay, __dmul_rn(b, vy));
+    return __dadd_rn(__dmul_rn(px - qx, px - qx), __dmul_rn(py - qy, py - qy));
+  };
+  if (n == 1) return sqrt(comparable(xy[0], xy[1], xy[0], xy[1]));
+  double best = comparable(xy[0], xy[1], xy[2], xy[3]);
+  for (int i = 0; i + 1 < n; ++i) {
+    const double c = comparable(xy[2 * i], xy[2 * i + 1], xy[2 * i + 2], xy[2 * i + 3]);
+    if (c == 0.0) return 0.0;
+    if (c < best) best = c;
+  }
+  return sqrt(best);
+}
+__global__ __launch_bounds__(256) void plane_kernel(const double* __restrict__ plan, const int32_t* __restrict__ counts,
+                                                    const double* __restrict__ poly_xy, const int32_t* __restrict__ poly_start,
+                                                    int n_polys, int n_problems, int max_steps, int n_ee,
+                                                    int32_t* __restrict__ plane_index) {
+  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (int64_t)n_problems * max_steps * n_ee) return;
+  const int e = (int)(id % n_ee), s = (int)((id / n_ee) % max_steps), p = (int)(id / ((int64_t)n_ee * max_steps));
+  const double* rec = plan + ((int64_t)p * max_steps + s) * (2 + 4 * n_ee);
+  int nearest = -1;
+  if (s < counts[p] && rec[2 + e] != 0.0) {
+    const double px = rec[2 + n_ee + 3 * e], py = rec[2 + n_ee + 3 * e + 1];
+    double min_distance = 1.7976931348623157e308;
+    for (int i = 0; i < n_polys; ++i) {
+      const double* xy = poly_xy + 2 * poly_start[i];
+      const int n = poly_start[i + 1] - poly_start[i];
+      const double distance = ring_side(xy, n, px, py) >= 0 ? 0.0 : ring_distance(xy, n, px, py);
+      if (distance < min_distance) {
+        min_distance = distance;
+        nearest = i;
+      }
+    }
+  }
+  plane_index[id] = nearest;
+}
+hipError_t launch_planes(const double* plan, const int32_t* counts, const double* poly_xy, const int32_t* poly_start, int n_polys,
+                         int n_problems, int max_steps, int n_ee, int32_t* plane_index, hipStream_t stream) {
+  const int64_t n = (int64_t)n_problems * max_steps * n_ee;
+  if (n > 0)
+    hipLaunchKernelGGL(plane_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, plan, counts, poly_xy, poly_start,
+                       n_polys, n_problems, max_steps, n_ee, plane_index);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- TWR_EVAL_CHECK
 // Per-problem non-finite flags (failure detection): a separate pass over the outputs of one
 // evaluation, off the hot path (it re-reads g and jac once).  status[p] |= 1 if a constraint value of problem p is
