@@ -95,7 +95,7 @@ int orc_nearest_plane(const double* world_xy, const int* start, int n_polys, dou
 // [t | state 12 | controls 36], layout in towr_oracle.cc
 void orc_initial_guess_samples(orc_problem*, const double* x, const double* times, int n_times, double* out);
 
-// fpowr::ExtractFootstepPlan (footstep_plan_extractor.h:69-133) minus the nearest-plane lookup: footstep states
+// fpowr::ExtractFootstepPlan (footstep_plan_extractor.h:69-133) up to the nearest-plane lookup (orc_nearest_plane): footstep states
 // [t | duration | contact per ee | ee position per ee]; returns their number (out = NULL to query it).
 int orc_contact_plan(orc_problem*, const double* x, double dt, double time_horizon, double* out, int max_steps);
 
