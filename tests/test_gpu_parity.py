@@ -713,6 +713,10 @@ def test_candidate_scores_and_contact_plans():
                         want = -1
                     assert ih[p, k, e] == want, (p, k, e, ih[p, k, e], want)
         assert len(seen - {-1}) >= 3
+        none = ta.Planes(np.zeros((0, 7)), [], device=0)          # a terrain message without regions: -1 everywhere
+        batch.contact_planes_device(none, out.data_ptr(), counts.data_ptr(), max_steps, idx.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert (idx.cpu().numpy() == -1).all()
 
 
 def test_eval_is_graph_capturable_and_stream_ordered():

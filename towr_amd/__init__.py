@@ -246,7 +246,7 @@ class Planes:
             _check(lib().twr_planes_world_xy(self._h, _d(self.world_xy)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib().twr_planes_destroy(self._h)
             self._h = None
 
