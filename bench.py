@@ -205,6 +205,36 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     elapsed, setup_max, build_max = float(stats[0]), float(stats[1]), float(stats[2])
     bytes_total = float(tot[3])
+    # Planner-style step (optional exchange): constraint values only, scored on the device, one all-gather of
+    # the 16 scores per candidate, arg-min on every rank -- what a sweep that wants ONE decision does per iterate.
+    from towr_amd.dist import best_candidate, gather_scores
+    sizes = [bounds[r + 1] - bounds[r] for r in range(world)]
+    scores = torch.empty((len(mine), 16), dtype=torch.float64, device=dev)
+
+    def planner_step():
+        batch.eval_device(x.data_ptr(), g.data_ptr(), 0, ta.EVAL_VALUES, stream)
+        batch.score_device(g.data_ptr(), scores.data_ptr(), stream)
+        table = scores
+        if world > 1:
+            table = gather_scores(scores if backend == "nccl" else scores.cpu(), sizes)
+        return best_candidate(table)
+
+    for _ in range(3):
+        best = planner_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    p_steps = max(20, steps // 4)
+    t3 = time.perf_counter()
+    for _ in range(p_steps):
+        best = planner_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    p_elapsed = torch.tensor([time.perf_counter() - t3], dtype=torch.float64, device=dev if backend == "nccl" else None)
+    if world > 1:
+        dist.all_reduce(p_elapsed, op=dist.ReduceOp.MAX)
+    p_elapsed = float(p_elapsed[0])
     return {"workload": "C5 sweep: %d enumerated ANYmal candidates (combo x T x swing scale) on Stairs, K=200, ragged"
                         % n_total,
             "candidates": n_total, "scaling": "strong", "steps": steps,
@@ -212,7 +242,11 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
             "path_GBps": bytes_total * steps / elapsed / 1e9,
             "shards": [bounds[r + 1] - bounds[r] for r in range(world)],
             "setup_s": setup_max, "structure_build_s": build_max, "build_threads_per_rank": threads,
-            "rccl_ranks": dist.get_world_size() if world > 1 else 1}
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "planner": {"what": "values only -> twr_batch_score -> all-gather of 16 scores per candidate -> arg-min "
+                                "(host-synchronous: one decision per step)",
+                        "steps": p_steps, "value": n_total * p_steps / p_elapsed, "unit": "candidates scored/s",
+                        "ms_per_step": p_elapsed / p_steps * 1e3, "best_candidate": int(best[0])}}
 
 
 def main():

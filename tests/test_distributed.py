@@ -13,7 +13,7 @@ sys.path.insert(0, os.environ["TWR_ROOT"])
 import numpy as np, torch, torch.distributed as dist
 import towr_amd as ta
 from towr_amd import sweep
-from towr_amd.dist import broadcast_model, my_shard
+from towr_amd.dist import broadcast_model, my_shard, gather_scores, best_candidate
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 model = broadcast_model(ta.model_preset("anymal", "stairs") if rank == 0 else None)
@@ -44,6 +44,17 @@ h = hashlib.sha256(structs[7].col_idx.tobytes() + structs[7].row_ptr.tobytes()).
 hs = [None] * world
 dist.all_gather_object(hs, h)
 assert all(x == hs[0] for x in hs)
+# planner-style exchange: every rank scores its shard, one all-gather gives everyone the table in candidate order
+sizes = [t[1] - t[0] for t in allr]
+local = torch.stack([torch.full((16,), float(c), dtype=torch.float64) for c in range(a, b)])
+local[:, 2] = torch.tensor([abs(c - 29) + 0.25 for c in range(a, b)], dtype=torch.float64)   # "dynamic" inf-norm: best is 29
+if a <= 5 < b:
+    local[5 - a, 2] = float("nan")                                                          # a failed candidate never wins
+table = gather_scores(local, sizes)
+assert table.shape == (len(cands), 16)
+assert torch.equal(table[:, 0], torch.arange(len(cands), dtype=torch.float64))
+best, score = best_candidate(table, families=(1,))
+assert best == 29 and score == 0.25
 oks = [None] * world
 dist.all_gather_object(oks, (rank, int(a), int(b)))
 dist.barrier()

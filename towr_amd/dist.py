@@ -1,6 +1,8 @@
 """Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on
-ROCm, "gloo" in CPU tests).  The path shards by independent candidates, so the only collective is
-ONE broadcast of the POD model blob; afterwards every rank works on its own contiguous shard."""
+ROCm, "gloo" in CPU tests).  The path shards by independent candidates, so the only collective on the evaluation
+path is ONE broadcast of the POD model blob; afterwards every rank works on its own contiguous shard.  A planner-style
+sweep that wants one decision from all shards adds an all-gather of the per-candidate scores (16 doubles per
+candidate, twr_batch_score) -- SURVEY section 8e."""
 import ctypes
 
 import numpy as np
@@ -27,3 +29,31 @@ def broadcast_model(model, src=0, device=None):
 def my_shard(weights, rank, world):
     b = shard_bounds(weights, world)
     return b[rank], b[rank + 1]
+
+
+def gather_scores(local, shard_sizes):
+    """All-gather of the per-candidate score rows: `local` is this rank's (n_local, k) tensor (twr_batch_score gives
+    k = 16), shard_sizes the candidates per rank in rank order; every rank returns the (sum(shard_sizes), k) table in
+    candidate order.  One collective of equal blocks (shards padded to the largest)."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    assert len(shard_sizes) == world and local.shape[0] == shard_sizes[rank]
+    k, n_max = local.shape[1], max(shard_sizes)
+    block = torch.zeros((n_max, k), dtype=local.dtype, device=local.device)
+    block[:local.shape[0]] = local
+    blocks = [torch.empty_like(block) for _ in range(world)]
+    dist.all_gather(blocks, block)
+    return torch.cat([blocks[r][:shard_sizes[r]] for r in range(world)], dim=0)
+
+
+def best_candidate(table, families=(0, 1, 3, 4)):
+    """Index and score of the candidate with the smallest summed inf-norm violation over the given constraint
+    families (bit indices of TWR_SET_*: 0 terrain, 1 dynamic, 3 rangeofmotion, 4 force); NaN scores lose."""
+    import torch
+
+    total = sum(table[:, 2 * f] for f in families)
+    total = torch.where(torch.isnan(total), torch.full_like(total, float("inf")), total)
+    idx = int(torch.argmin(total))
+    return idx, float(total[idx])
