@@ -663,16 +663,23 @@ int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_
       TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_j), nj * sizeof(double)));
     }
     // one stream-ordered chain and a single synchronisation (with page-locked buffers the copies are DMA)
-    TWR_HIP(hipMemcpyAsync(b->d_x, h_x, nx * sizeof(double), hipMemcpyHostToDevice, nullptr));
     static const bool zero_copy = [] { const char* e = getenv("TWR_HOST_ZERO_COPY"); return !e || atoi(e) != 0; }();
-    if (zero_copy && b->p_g && h_g == b->p_g && h_jac == b->p_j && nj * sizeof(double) <= (size_t)(32u << 20)) {
+    static const bool zero_copy_x = [] { const char* e = getenv("TWR_HOST_ZERO_COPY_X"); return !e || atoi(e) != 0; }();
+    const bool zc = zero_copy && b->p_g && h_g == b->p_g && h_jac == b->p_j && nj * sizeof(double) <= (size_t)(32u << 20);
+    const double* dx = b->d_x;
+    if (zc && zero_copy_x && h_x == b->p_x) {   // x too: the kernels gather it straight from the page-locked buffer
+      TWR_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(const_cast<double**>(&dx)), b->p_x, 0));
+    } else {
+      TWR_HIP(hipMemcpyAsync(b->d_x, h_x, nx * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    }
+    if (zc) {
       // The batch's own page-locked buffers, small batch (the single-problem callback of the ifopt adapter): the
       // kernels store g and the Jacobian values straight into host memory over PCIe -- coalesced 16-byte stores,
       // each value written once -- instead of HBM plus two device-to-host copies.
       double *dg = nullptr, *dj = nullptr;
       TWR_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dg), b->p_g, 0));
       TWR_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dj), b->p_j, 0));
-      int rc0 = twr_batch_eval(b, b->d_x, dg, dj, flags, nullptr);
+      int rc0 = twr_batch_eval(b, dx, dg, dj, flags, nullptr);
       if (rc0 != TWR_OK) return rc0;
       TWR_HIP(hipStreamSynchronize(nullptr));
       return TWR_OK;
