@@ -2387,7 +2387,20 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
   static const int fused_max = env_int("TWR_FUSED_MAX_ROM", 4096);   // rom slices up to which the fused launch is used
   if (!ev && n_pdyn == 0 && n_prom == 0 && n_rom > 0 && n_dyn > 0 && n_rom <= fused_max) {
     const int cap = rom_bpc * n_cu;
-    const int g_rom = n_rom < cap ? n_rom : cap, g_dyn = (n_dyn + 1) / 2 < cap ? (n_dyn + 1) / 2 : cap;
+    int g_rom = n_rom < cap ? n_rom : cap, g_dyn = (n_dyn + 1) / 2 < cap ? (n_dyn + 1) / 2 : cap;
+    // When the two persistent roles do not fit the CUs together, the blocks of the later role only start as the earlier
+    // ones retire, i.e. the roles run one after the other.  For up to 2560 rom slices (160 quadruped candidates of
+    // K = 200) it pays to give each role half of the residency instead, so that the latency-bound dyn waves and the
+    // store-bound rom waves overlap from the start (64 / 128 / 160 candidates: 18.7 / 30.1 / 35.2 -> 17.5 / 27.8 /
+    // 31.6 us per step; from 200 candidates on the extra rounds cost more than the overlap gains).
+    // TWR_FUSED_SPLIT = eighths of the residency given to rom (experiments; 8 = never split).
+    static const int split_env = env_int("TWR_FUSED_SPLIT", 0);
+    const int split = split_env > 0 ? split_env : (n_rom <= 2560 ? 4 : 8);
+    if (split < 8 && g_rom + g_dyn > cap) {
+      const int r = cap * split / 8, d = cap - r;
+      if (g_rom > r) g_rom = r;
+      if (g_dyn > d) g_dyn = d;
+    }
     hipLaunchKernelGGL(eval_fused_kernel, dim3(g_rom + g_dyn + 2 * n_node), dim3(128), 0, stream, rom, n_rom, g_rom, dyn,
                        n_dyn, g_dyn, node, x, g, jac, flags);
     return hipGetLastError();
