@@ -243,6 +243,8 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
             "shards": [bounds[r + 1] - bounds[r] for r in range(world)],
             "setup_s": setup_max, "structure_build_s": build_max, "build_threads_per_rank": threads,
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            # a shard that re-writes < ~220 MB per step keeps its output in the 256-MB Infinity Cache
+            "output_MB_per_rank": float(batch.algorithmic_bytes) / 1e6,
             "planner": {"what": "values only -> twr_batch_score -> all-gather of 16 scores per candidate -> arg-min "
                                 "(host-synchronous: one decision per step)",
                         "steps": p_steps, "value": n_total * p_steps / p_elapsed, "unit": "candidates scored/s",
