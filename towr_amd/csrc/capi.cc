@@ -17,9 +17,9 @@
 
 namespace twr {
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
-                       const NodeWork* node, int n_node, const PhaseWork* pdyn, int n_pdyn, const LocWork* ploc,
-                       int n_ploc, const RomPhaseWork* prom, int n_prom, const double* x, double* g, double* jac,
-                       int flags, hipStream_t stream, hipEvent_t* ev);
+                       const NodeWork* node, int n_node, const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap,
+                       const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, const double* x, double* g,
+                       double* jac, int flags, hipStream_t stream, hipEvent_t* ev);
 hipError_t launch_check(int n_problems, const int64_t* g_off, const int64_t* j_off, const double* g, const double* jac,
                         int32_t* status, int flags, hipStream_t stream);
 hipError_t launch_score(const NodeWork* work, int n_problems, const double* g, double* scores, hipStream_t stream);
@@ -69,12 +69,13 @@ struct twr_batch {
   twr::RomWork* d_rom = nullptr;
   twr::NodeWork* d_node = nullptr;
   // optimised-timings problems have their own work lists
-  twr::PhaseWork* d_pdyn = nullptr;
+  twr::PDynWork* d_pdyn = nullptr;
+  int pdyn_img_cap = 0;                      // doubles of the dyn_phase_kernel's LDS image (largest group of the batch)
   twr::LocWork* d_ploc = nullptr;
   twr::RomPhaseWork* d_prom = nullptr;
   int64_t *d_goff = nullptr, *d_joff = nullptr;  // device copies of g_off / j_off (TWR_EVAL_CHECK)
   int32_t* d_status = nullptr;                    // per-problem non-finite flags of the last checked evaluation
-  void* d_precs = nullptr;  // scratch: x-dependent RomRec records of the optimised-timings problems
+  void* d_precs = nullptr;  // scratch: x-dependent DynLoc / RomRec records of the optimised-timings problems
   int n_pdyn = 0, n_ploc = 0, n_prom = 0;
   // lazily sized scratch for twr_batch_eval_host
   double *d_x = nullptr, *d_g = nullptr, *d_j = nullptr;
@@ -369,7 +370,12 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     std::vector<twr::DynWork> dyn;
     std::vector<twr::RomWork> rom;
     std::vector<twr::NodeWork> node;
-    std::vector<twr::PhaseWork> pdyn;
+    std::vector<twr::PDynWork> pdyn;
+    std::vector<int> pdyn_first;   // first dynamic run of every optimised-timings problem (+ end)
+    // dyn_phase_kernel streams a run out in groups of time nodes whose expanded rows fit its LDS image: TWR_PDYN_LDS_KB
+    // per workgroup (image + 96 constraint values), TWR_PDYN_NODES time nodes per run (experiments)
+    auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e && atoi(e) > 0 ? atoi(e) : dflt; };
+    const int pdyn_cap = env_int("TWR_PDYN_LDS_KB", 40) * 128 - 98, pdyn_nodes = std::min(16, env_int("TWR_PDYN_NODES", 16));
     std::vector<twr::LocWork> ploc;
     std::vector<twr::RomPhaseWork> prom;
     size_t prec_bytes = 0;  // offsets into the scratch buffer are stored first and rebased after hipMalloc
@@ -435,45 +441,65 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
         }
       }
       if (S.timings) {
-        twr::PhaseWork pw;
-        std::memset(&pw, 0, sizeof(pw));
-        pw.blob = blob;
-        pw.x_off = b->x_off[p];
-        pw.g_off = b->g_off[p];
-        pw.j_off = b->j_off[p];
-        if (S.FindSet("dynamic"))
-          for (int k0 = 0; k0 < (int)S.grid_dyn.size(); k0 += 16) {
+        const bool have_dyn = S.FindSet("dynamic") != nullptr;
+        const int Kd = (int)S.grid_dyn.size();
+        const size_t loc_bytes = have_dyn ? sizeof(twr::DynLoc) * 4 * (size_t)Kd : 0;
+        const size_t loc_off = prec_bytes;   // DynLoc[4 * Kd] of this problem, then its RomRec arrays
+        prec_bytes += loc_bytes;
+        if (have_dyn) {
+          const twr::SetInfo* dset = S.FindSet("dynamic");
+          const int nv = S.phase_tables.node_vals;
+          const int group = std::max(1, std::min(pdyn_nodes, pdyn_cap / nv));
+          const int run = std::max(group, pdyn_nodes / group * group);   // a multiple of the group
+          b->pdyn_img_cap = std::max(b->pdyn_img_cap, group * nv);
+          pdyn_first.push_back((int)pdyn.size());
+          for (int k0 = 0; k0 < Kd; k0 += run) {
+            twr::PDynWork pw;
+            std::memset(&pw, 0, sizeof(pw));
+            pw.blob = blob;
+            pw.loc = loc_off + sizeof(twr::DynLoc) * 4 * (size_t)k0;
+            pw.x_off = b->x_off[p];
+            pw.g_off = b->g_off[p] + dset->offset + 6 * k0;
+            pw.j_off = b->j_off[p] + dset->nnz_offset + (int64_t)k0 * nv;
             pw.k0 = k0;
-            pw.cnt = std::min(16, (int)S.grid_dyn.size() - k0);
-            pw.ee = 0;
+            pw.cnt = std::min(run, Kd - k0);
+            pw.node_vals = nv;
+            pw.group = group;
             pdyn.push_back(pw);
           }
-        for (int e = 0; e < S.n_ee; ++e)
-          if (const twr::SetInfo* rs = S.FindSet("rangeofmotion-" + std::to_string(e))) {
-            const int K = (int)S.grid_rom.size(), nv = S.phase_tables.rom_node_vals[e];
-            twr::LocWork lw;
-            lw.blob = blob;
-            lw.recs = prec_bytes;
-            lw.x_off = b->x_off[p];
-            lw.ee = e;
-            lw.pad = 0;
-            ploc.push_back(lw);
-            for (int k0 = 0; k0 < K; k0 += 16) {
-              twr::RomPhaseWork rw;
-              rw.recs = prec_bytes + sizeof(twr::RomRec) * (size_t)k0;
-              rw.x_off = b->x_off[p];
-              rw.g_off = b->g_off[p] + rs->offset + 3 * k0;
-              rw.j_off = b->j_off[p] + rs->nnz_offset + (int64_t)k0 * nv;
-              rw.off_lin = S.off_base_lin;
-              rw.off_ang = S.off_base_ang;
-              rw.cnt = std::min(16, K - k0);
-              rw.msize = S.phase_tables.msize[e];
-              rw.ns = S.schedule.n_phases[e] - 1;
-              rw.node_vals = nv;
-              prom.push_back(rw);
-            }
-            prec_bytes += sizeof(twr::RomRec) * (size_t)K;
+        }
+        bool any_rom = false;
+        for (int e = 0; e < S.n_ee; ++e) {
+          const twr::SetInfo* rs = S.FindSet("rangeofmotion-" + std::to_string(e));
+          if (!rs && !have_dyn) continue;
+          twr::LocWork lw;
+          std::memset(&lw, 0, sizeof(lw));
+          lw.blob = blob;
+          lw.recs = rs ? prec_bytes + 1 : 0;             // (+1: "present" marker until the buffer address is known)
+          lw.dyn_loc = have_dyn ? loc_off + 1 : 0;
+          lw.x_off = b->x_off[p];
+          lw.ee = e;
+          ploc.push_back(lw);
+          if (!rs) continue;
+          any_rom = true;
+          const int K = (int)S.grid_rom.size(), nv = S.phase_tables.rom_node_vals[e];
+          for (int k0 = 0; k0 < K; k0 += 16) {
+            twr::RomPhaseWork rw;
+            rw.recs = prec_bytes + sizeof(twr::RomRec) * (size_t)k0;
+            rw.x_off = b->x_off[p];
+            rw.g_off = b->g_off[p] + rs->offset + 3 * k0;
+            rw.j_off = b->j_off[p] + rs->nnz_offset + (int64_t)k0 * nv;
+            rw.off_lin = S.off_base_lin;
+            rw.off_ang = S.off_base_ang;
+            rw.cnt = std::min(16, K - k0);
+            rw.msize = S.phase_tables.msize[e];
+            rw.ns = S.schedule.n_phases[e] - 1;
+            rw.node_vals = nv;
+            prom.push_back(rw);
           }
+          prec_bytes += sizeof(twr::RomRec) * (size_t)K;
+        }
+        (void)any_rom;
       }
       twr::NodeWork nw;
       nw.blob = blob;
@@ -523,14 +549,37 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     b->n_pdyn = (int)pdyn.size();
     b->n_ploc = (int)ploc.size();
     b->n_prom = (int)prom.size();
-    if (!pdyn.empty()) upload(pdyn.data(), pdyn.size() * sizeof(twr::PhaseWork), reinterpret_cast<void**>(&b->d_pdyn));
-    if (!prom.empty()) {
+    if (!ploc.empty()) {
       TWR_HIP(hipMalloc(&b->d_precs, prec_bytes));
       const uint64_t base = reinterpret_cast<uint64_t>(b->d_precs);
-      for (auto& lw : ploc) lw.recs += base;
+      for (auto& lw : ploc) {
+        if (lw.recs) lw.recs += base - 1;
+        if (lw.dyn_loc) lw.dyn_loc += base - 1;
+      }
       for (auto& rw : prom) rw.recs += base;
+      for (auto& pw : pdyn) pw.loc += base;
       upload(ploc.data(), ploc.size() * sizeof(twr::LocWork), reinterpret_cast<void**>(&b->d_ploc));
-      upload(prom.data(), prom.size() * sizeof(twr::RomPhaseWork), reinterpret_cast<void**>(&b->d_prom));
+    }
+    if (!prom.empty()) upload(prom.data(), prom.size() * sizeof(twr::RomPhaseWork), reinterpret_cast<void**>(&b->d_prom));
+    if (!pdyn.empty()) {
+      pdyn_first.push_back((int)pdyn.size());
+      // same XCD-aware order as the fixed-timing lists (all runs of one problem on one XCD)
+      auto src = pdyn;
+      size_t out_i = 0;
+      const int np_all = (int)pdyn_first.size() - 1;
+      for (int p0 = 0; p0 < np_all; p0 += 8) {
+        const int np = std::min(8, np_all - p0);
+        for (int s2 = 0;; ++s2) {
+          bool any = false;
+          for (int k = 0; k < np; ++k)
+            if (pdyn_first[p0 + k] + s2 < pdyn_first[p0 + k + 1]) {
+              pdyn[out_i++] = src[pdyn_first[p0 + k] + s2];
+              any = true;
+            }
+          if (!any) break;
+        }
+      }
+      upload(pdyn.data(), pdyn.size() * sizeof(twr::PDynWork), reinterpret_cast<void**>(&b->d_pdyn));
     }
     *out = b.release();
     return TWR_OK;
@@ -591,8 +640,8 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
   if (b->prof_count < b->prof_capacity) ev = b->prof_events.data() + 4 * b->prof_count++;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->d_rom, b->n_rom, b->d_node, b->n_node,
-                                  b->d_pdyn, b->n_pdyn, b->d_ploc, b->n_ploc, b->d_prom, b->n_prom, d_x, d_g, d_jac,
-                                  flags & TWR_EVAL_BOTH, stream, ev);
+                                  b->d_pdyn, b->n_pdyn, b->pdyn_img_cap, b->d_ploc, b->n_ploc, b->d_prom, b->n_prom, d_x,
+                                  d_g, d_jac, flags & TWR_EVAL_BOTH, stream, ev);
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   if (flags & TWR_EVAL_CHECK) {
     e = twr::launch_check(b->n_problems, b->d_goff, b->d_joff, d_g, d_jac, b->d_status, flags & TWR_EVAL_BOTH, stream);

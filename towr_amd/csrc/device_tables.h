@@ -53,14 +53,6 @@ struct DynShared {
 };
 static_assert(sizeof(DynShared) == 32, "DynShared layout");
 
-// dynamic, per (time node, ee) (96 B)
-struct DynLane {
-  double tm, iTm, tf, iTf;
-  int32_t xbase_m, xbase_f;
-  uint32_t meta_m, meta_f;
-  uint16_t cand_m[12], cand_f[12];
-};
-static_assert(sizeof(DynLane) == 96, "DynLane layout");
 
 // ---- dynamic, fixed timings (dyn_kernel): everything index-like is resolved on the host, down to LDS byte offsets.
 // A slice (work item) is a run of <= 16 time nodes.  The wave first stages the slice's part of x in LDS ("xs":
@@ -143,6 +135,39 @@ struct PhasePoly {
 };
 static_assert(sizeof(PhasePoly) == 64, "PhasePoly layout");
 
+// dynamic with optimised timings: where the values of ONE polynomial's candidates go inside a time node's expanded
+// rows.  The rows hold all variables of every ee set, so the row layout is a constant of the structure and the byte
+// offset (relative to the node's first value) of a candidate depends on its end-effector and polynomial only: one
+// record per (ee, polynomial), read off the CSR pattern like DynPut.  A candidate that is not a variable points at
+// entry 8 + ee of row AX (a base-ang value the same wave writes afterwards).
+struct PhasePutM {
+  uint16_t off[12][2];   // [f]x J_p : rows (d+1)%3 and (d+2)%3 of the angular block
+  uint16_t pad[8];
+};
+static_assert(sizeof(PhasePutM) == 64, "PhasePutM layout");
+struct PhasePutF {
+  uint16_t off[12][3];   // {[r]x J_f ; -J_f}: the same two angular rows, then linear row d
+  uint16_t pad[12];
+};
+static_assert(sizeof(PhasePutF) == 96, "PhasePutF layout");
+struct PhaseEe {         // per end-effector: its duration columns inside a time node of "dynamic" (byte offsets)
+  int32_t ns;            // optimised durations (phases - 1)
+  int32_t dur_ang[3], dur_lin[3];
+  int32_t pad;
+};
+static_assert(sizeof(PhaseEe) == 32, "PhaseEe layout");
+// dynamic with optimised timings, per (time node, ee): the x-dependent segment lookup, written by the pre-pass
+// (phase_locate_kernel) into a scratch buffer and read by dyn_phase_kernel (64 B)
+struct DynLoc {
+  double tm, Tm, tf, Tf;         // local time in / duration of the active ee-motion and ee-force polynomials
+  int32_t xbase_m, xbase_f;      // first x index of their variables
+  uint32_t slots_m[2], slots_f[2];  // 12 x 4 bit: slot of candidate c, 0xF = absent
+  uint8_t qm, qf;                // the polynomials (PhasePutM / PhasePutF index)
+  uint8_t cur, flags;            // current phase; bit 0: it is the last one (not a variable), bit 1: stance ee-motion polynomial
+  uint8_t nin_m, pin_m, nin_f, pin_f;  // polynomials in the phase / before this one in the phase
+};
+static_assert(sizeof(DynLoc) == 64, "DynLoc layout");
+
 // Tables of the optimised-timings variant (TWR_SET_TOTAL_TIME), appended to DevStruct.
 struct PhaseTables {
   int32_t off_sched[kMaxEE];   // x offset of ee-schedule<e>
@@ -161,6 +186,8 @@ struct PhaseTables {
   uint32_t o_dyn_shared, o_rom_recs[kMaxEE];  // host records (their base-spline part stays x-independent)
   int32_t pad_;
   double t_total[kMaxEE];      // PhaseDurations::t_total_
+  uint32_t o_mput[kMaxEE], o_fput[kMaxEE];  // PhasePutM[n_mpoly] / PhasePutF[n_fpoly]
+  PhaseEe ee[kMaxEE];
 };
 constexpr int kMaxPhasePolys = 64;  // polynomials per ee spline with optimised timings (LDS table size)
 
@@ -266,12 +293,17 @@ struct NodeWork {         // all terrain-* and force-* sets of one problem
 };
 static_assert(sizeof(NodeWork) == 32, "NodeWork layout");
 
-struct PhaseWork {        // optimised timings: cnt <= 16 time nodes of dynamic / rangeofmotion-<ee> from k0
+struct PDynWork {         // optimised timings: cnt <= 16 time nodes of "dynamic" from k0
   uint64_t blob;
-  int64_t x_off, g_off, j_off;  // the problem's x / g / jac
-  int32_t k0, cnt, ee, pad;
+  uint64_t loc;           // DynLoc[4 * k0 ..] of this problem (scratch, written by the pre-pass)
+  int64_t x_off;          // problem's x
+  int64_t g_off, j_off;   // first constraint value (row 6 k0 of the set) / first Jacobian value of the run
+  int32_t k0, cnt;
+  int32_t node_vals;      // expanded values per time node
+  int32_t group;          // time nodes per LDS image (the run is streamed out group by group)
+  int64_t pad;
 };
-static_assert(sizeof(PhaseWork) == 48, "PhaseWork layout");
+static_assert(sizeof(PDynWork) == 64, "PDynWork layout");
 
 // Optimised timings, rangeofmotion-<ee>: a light pre-pass (rom_locate_kernel) turns the x-dependent segment
 // lookup into RomRec records in a scratch buffer, so that the persistent kernel sees the same two-step
@@ -279,11 +311,13 @@ static_assert(sizeof(PhaseWork) == 48, "PhaseWork layout");
 //   pad[0] = base_all | current phase << 16 | in_last_phase << 24,  pad[1] = n_in_phase | poly_in_phase << 8
 struct LocWork {          // one (problem, ee)
   uint64_t blob;
-  uint64_t recs;          // RomRec[k_rom] (output)
+  uint64_t recs;          // RomRec[k_rom] (output), 0: no rangeofmotion sets
+  uint64_t dyn_loc;       // DynLoc[4 * k_dyn] of the problem (output; this ee writes entries 4 k + ee), 0: no dynamic set
   int64_t x_off;
   int32_t ee, pad;
+  int64_t pad2;
 };
-static_assert(sizeof(LocWork) == 32, "LocWork layout");
+static_assert(sizeof(LocWork) == 48, "LocWork layout");
 struct RomPhaseWork {     // cnt <= 32 time nodes of one (problem, ee)
   uint64_t recs;          // RomRec[k0..] written by the pre-pass
   int64_t x_off, g_off, j_off;  // problem's x; first constraint value / first Jacobian value of the run

@@ -22,6 +22,7 @@
 // arithmetic is re-associated (Hermite basis form, factored base-ang tile) and agrees
 // with the reference formulas to rounding, tests/ pin that at <= 1e-9.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -304,303 +305,8 @@ TWR_DEV void duration_columns(const double nv[4][3], double t, double T, double 
 // The base-ang block is evaluated in factored form: with u = (p0,v0,p1,v1) of Euler dim d,
 //   d g_ang / d u_j = A_d wP[j] + B_d wV[j] + C_d wA[j],
 //   A_d = d g_ang/d e_d, B_d = d g_ang/d edot_d, C_d = d g_ang/d eddot_d  (3-vectors).
-struct DynX {  // the lane's slice of x: ONE node value (role: p0, v0, p1, v1) of base-lin / base-ang, ee candidates
-  double bl[3], ba[3], m[12], f[12];
-};
-// (the optimised-timings kernel builds its per-lane records on the fly and drives the quad math below through this
-// local descriptor; the fixed-timing kernel has its own, fully pre-resolved path: dyn2_front / dyn2_back)
-struct DynWorkP {
-  uint64_t hdr;            // DevStruct (mass, gravity, inertia)
-  int64_t x_off;           // problem's x
-  int32_t off_lin, off_ang;  // x offsets of base-lin / base-ang inside the problem
-  int32_t cnt;             // time nodes of the run
-};
-TWR_DEV void dyn_load_x(const DynWorkP& w, const DynShared& sh, const DynLane& ln, const double* __restrict__ x, DynX& X) {
-  const double* xp = x + w.x_off;
-  // The base nodes of the active polynomial are [p0 v0 p1 v1] x 3 (NodesVariablesAll order).  The four lanes
-  // of the quad would all load the same 24 doubles: each one loads the node value of its role only and the
-  // spline points are completed with quad sums in dyn_front.
-  const int role = threadIdx.x & 3;
-  const double* xl = xp + w.off_lin + sh.q6 + 3 * role;
-  const double* xa = xp + w.off_ang + sh.q6 + 3 * role;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    X.bl[i] = xl[i];
-    X.ba[i] = xa[i];
-  }
-  gather12c(xp, ln.xbase_m, ln.cand_m, X.m);
-  gather12c(xp, ln.xbase_f, ln.cand_f, X.f);
-}
-
-// Front half of the quad: consumes the x values (so their registers die before the previous slice
-// is copied out), everything that needs a DPP exchange, and the row layout.
-struct DynFront {
-  double wP[4], wV[4], wA[4];
-  double cdd[3], ed[3], edd[3];
-  double wm[4], wf[4], f[3], rv[3], F[3], tau[3];
-  double sx, cx, sy, cy, sz, cz;
-  int rs[3], rl[3], ms[3], fs[3], ls[3];
-};
-// PHASE (optimised timings): the row layout is given (rows hold all variables of every ee set, S.rs .. S.ls
-// are filled by the caller), otherwise it follows from the slot counts of the active polynomials.
-template <int NEE, bool PHASE = false>
-TWR_DEV void dyn_front(const DynWorkP& w, const DynShared& sh, const DynLane& ln, const DynX& X, int par, int vbase,
-                       int lane, DynFront& S) {
-  const int role = lane & 3;
-  const bool has_ee = role < NEE;
-  const int soff = par + sh.voff - vbase;
-  double (&wP)[4] = S.wP, (&wV)[4] = S.wV, (&wA)[4] = S.wA;
-  hermite_all(sh.tb, sh.iTb, wP, wV, wA);
-  double c[3], e[3];
-  double (&cdd)[3] = S.cdd, (&ed)[3] = S.ed, (&edd)[3] = S.edd;
-  {  // this lane's node value times its weights, summed over the quad (Spline::GetPoint in basis form)
-    const double myP = sel3(role, wP[0], wP[1], wP[2]), myV = sel3(role, wV[0], wV[1], wV[2]), myA = sel3(role, wA[0], wA[1], wA[2]);
-    const double qP = role == 3 ? wP[3] : myP, qV = role == 3 ? wV[3] : myV, qA = role == 3 ? wA[3] : myA;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      c[d] = quad_sum(qP * X.bl[d]);
-      cdd[d] = quad_sum(qA * X.bl[d]);
-      e[d] = quad_sum(qP * X.ba[d]);
-      ed[d] = quad_sum(qV * X.ba[d]);
-      edd[d] = quad_sum(qA * X.ba[d]);
-    }
-  }
-  // --- this lane's end-effector: weights and spline points
-  double p[3];
-  double (&wm)[4] = S.wm, (&wf)[4] = S.wf, (&f)[3] = S.f, (&rv)[3] = S.rv;
-  ee_pointc(ln.cand_m, meta_shared(ln.meta_m), ln.tm, ln.iTm, X.m, wm, p);
-  ee_pointc(ln.cand_f, false, ln.tf, ln.iTf, X.f, wf, f);
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    rv[d] = c[d] - p[d];
-    if (!has_ee) f[d] = 0.0;
-  }
-  // force and torque sums over the end-effectors (single_rigid_body_dynamics.cc:81-88)
-  double t3[3];
-  cross3(f, rv, t3);
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    S.F[d] = quad_sum(f[d]);
-    S.tau[d] = quad_sum(t3[d]);
-  }
-  if constexpr (!PHASE) {
-  // slot counts of every end-effector of the quad -> row layout of this time node in the CSR slice
-  const uint32_t my_mm = has_ee ? ln.meta_m : 0u, my_fm = has_ee ? ln.meta_f : 0u;
-  uint32_t mmeta[4], fmeta[4];
-  mmeta[0] = quad_perm_u32<0x00>(my_mm); fmeta[0] = quad_perm_u32<0x00>(my_fm);
-  mmeta[1] = quad_perm_u32<0x55>(my_mm); fmeta[1] = quad_perm_u32<0x55>(my_fm);
-  mmeta[2] = quad_perm_u32<0xAA>(my_mm); fmeta[2] = quad_perm_u32<0xAA>(my_fm);
-  mmeta[3] = quad_perm_u32<0xFF>(my_mm); fmeta[3] = quad_perm_u32<0xFF>(my_fm);
-  int nma[3] = {0, 0, 0}, nfa[3] = {0, 0, 0}, nfl[3] = {0, 0, 0};   // totals over the end-effectors
-  int pma[3] = {0, 0, 0}, pfa[3] = {0, 0, 0}, pfl[3] = {0, 0, 0};   // prefix for this lane's end-effector
-#pragma unroll
-  for (int e2 = 0; e2 < NEE; ++e2)
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int a = meta_nslots(mmeta[e2]) - meta_cnt(mmeta[e2], r);
-      const int b = meta_nslots(fmeta[e2]) - meta_cnt(fmeta[e2], r);
-      const int l = meta_cnt(fmeta[e2], r);
-      nma[r] += a; nfa[r] += b; nfl[r] += l;
-      if (e2 < role) { pma[r] += a; pfa[r] += b; pfl[r] += l; }
-    }
-  int (&rs)[3] = S.rs, (&rl)[3] = S.rl;
-  rs[0] = soff;
-  rs[1] = rs[0] + 20 + nma[0] + nfa[0];
-  rs[2] = rs[1] + 20 + nma[1] + nfa[1];
-  rl[0] = rs[2] + 20 + nma[2] + nfa[2];
-  rl[1] = rl[0] + 4 + nfl[0];
-  rl[2] = rl[1] + 4 + nfl[1];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    S.ms[r] = rs[r] + 20 + pma[r];
-    S.fs[r] = rs[r] + 20 + nma[r] + pfa[r];
-    S.ls[r] = rl[r] + 4 + pfl[r];
-  }
-  }
-  // --- rotation: lanes 0..2 of the quad evaluate one sincos each and broadcast it
-  double my_s, my_c;
-  sincos_fast(sel3(role, e[0], e[1], e[2]), &my_s, &my_c);
-  S.sx = quad_perm<0x00>(my_s); S.cx = quad_perm<0x00>(my_c);
-  S.sy = quad_perm<0x55>(my_s); S.cy = quad_perm<0x55>(my_c);
-  S.sz = quad_perm<0xAA>(my_s); S.cz = quad_perm<0xAA>(my_c);
-}
-
-// Back half: the Jacobian blocks and the constraint values, written into the LDS image.
-// DIRECT: `stage` is global memory (expanded rows of the optimised-timings variant): candidates that are
-// not variables are skipped by a predicated store instead of being sent to an LDS trash slot.
-template <bool DIRECT>
-TWR_DEV void put_if(double* __restrict__ stage, bool valid, int idx, int trash, double v) {
-  if constexpr (DIRECT) {
-    if (valid) stage[idx] = v;
-  } else {
-    stage[valid ? idx : trash] = v;
-  }
-}
-template <int NEE, bool DIRECT = false>
-TWR_DEV void dyn_back(const DynWorkP& w, const DynLane& ln, const DynFront& S, double* __restrict__ gst,
-                      double* __restrict__ stage, int trash, int lane, bool want_g, bool want_j) {
-  const int kk = lane >> 2, role = lane & 3;
-  if (kk >= w.cnt) return;
-  const bool has_ee = role < NEE;
-  const double (&wP)[4] = S.wP, (&wV)[4] = S.wV, (&wA)[4] = S.wA;
-  const double (&cdd)[3] = S.cdd, (&ed)[3] = S.ed, (&edd)[3] = S.edd;
-  const double (&wm)[4] = S.wm, (&wf)[4] = S.wf, (&f)[3] = S.f, (&rv)[3] = S.rv, (&F)[3] = S.F, (&tau)[3] = S.tau;
-  const double sx = S.sx, cx = S.cx, sy = S.sy, cy = S.cy, sz = S.sz, cz = S.cz;
-  const int (&rs)[3] = S.rs, (&rl)[3] = S.rl;
-
-  // --- ee-motion block [f]x J_p (:181-192) and ee-force block {[r]x J_f ; -J_f} (:167-179) of this
-  // lane's end-effector, written first so that their inputs die before the base-ang algebra.
-  // Candidates that are not variables write to the lane's trash slot.
-  if (want_j) {
-    const int (&ms)[3] = S.ms, (&fs)[3] = S.fs, (&ls)[3] = S.ls;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#define TWR_EE_TILE(D, R1, R2)                                                              \
-  {                                                                                         \
-    const uint32_t cm = ln.cand_m[j * 3 + D];                                               \
-    const bool vm = has_ee && (cm & 0xF) != 0xF;                                            \
-    put_if<DIRECT>(stage, vm, ms[R1] + (int)((cm >> 4) & 0xF), trash, crs<R1, D>(f) * wm[j]);   \
-    put_if<DIRECT>(stage, vm, ms[R2] + (int)((cm >> 8) & 0xF), trash, crs<R2, D>(f) * wm[j]);   \
-    const uint32_t cf = ln.cand_f[j * 3 + D];                                               \
-    const bool vf = has_ee && (cf & 0xF) != 0xF;                                            \
-    put_if<DIRECT>(stage, vf, fs[R1] + (int)((cf >> 4) & 0xF), trash, crs<R1, D>(rv) * wf[j]);  \
-    put_if<DIRECT>(stage, vf, fs[R2] + (int)((cf >> 8) & 0xF), trash, crs<R2, D>(rv) * wf[j]);  \
-    put_if<DIRECT>(stage, vf, ls[D] + (int)((cf >> 12) & 0xF), trash, -wf[j]);                  \
-  }
-      TWR_EE_TILE(0, 1, 2)
-      TWR_EE_TILE(1, 2, 0)
-      TWR_EE_TILE(2, 0, 1)
-#undef TWR_EE_TILE
-    }
-  }
-
-  // --- angular quantities (euler_converter.cc:58-83,133-166,207-221)
-  double R[3][3];
-  R[0][0] = cy * cz; R[0][1] = cz * sx * sy - cx * sz; R[0][2] = sx * sz + cx * cz * sy;
-  R[1][0] = cy * sz; R[1][1] = cx * cz + sx * sy * sz; R[1][2] = cx * sy * sz - cz * sx;
-  R[2][0] = -sy;     R[2][1] = cy * sx;                R[2][2] = cx * cy;
-  const double xd = ed[0], yd = ed[1], zd = ed[2];
-  const double Mx[3] = {cy * cz, cy * sz, -sy}, My[3] = {-sz, cz, 0.0};
-  const double Mdx[3] = {-cz * sy * yd - cy * sz * zd, cy * cz * zd - sy * sz * yd, -cy * yd};
-  const double Mdy[3] = {-cz * zd, -sz * zd, 0.0};
-  double om[3], omd[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    om[i] = Mx[i] * xd + My[i] * yd;
-    omd[i] = Mdx[i] * xd + Mdy[i] * yd + Mx[i] * edd[0] + My[i] * edd[1];
-  }
-  om[2] += zd;
-  omd[2] += edd[2];
-  const TWR_CONST DevStruct* H = cptr<DevStruct>(w.hdr);  // uniform per work item: scalar loads
-  // I_w = R I_b R^T (single_rigid_body_dynamics.cc:91), symmetric: (00,01,02,11,12,22)
-  double Iw6[6];
-  {
-    double Ib[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) Ib[i] = H->Ib[i];
-    double T[3][3];  // R I_b
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      T[i][0] = R[i][0] * Ib[0] + R[i][1] * Ib[1] + R[i][2] * Ib[2];
-      T[i][1] = R[i][0] * Ib[1] + R[i][1] * Ib[3] + R[i][2] * Ib[4];
-      T[i][2] = R[i][0] * Ib[2] + R[i][1] * Ib[4] + R[i][2] * Ib[5];
-    }
-    Iw6[0] = T[0][0] * R[0][0] + T[0][1] * R[0][1] + T[0][2] * R[0][2];
-    Iw6[1] = T[0][0] * R[1][0] + T[0][1] * R[1][1] + T[0][2] * R[1][2];
-    Iw6[2] = T[0][0] * R[2][0] + T[0][1] * R[2][1] + T[0][2] * R[2][2];
-    Iw6[3] = T[1][0] * R[1][0] + T[1][1] * R[1][1] + T[1][2] * R[1][2];
-    Iw6[4] = T[1][0] * R[2][0] + T[1][1] * R[2][1] + T[1][2] * R[2][2];
-    Iw6[5] = T[2][0] * R[2][0] + T[2][1] * R[2][1] + T[2][2] * R[2][2];
-  }
-  double Iw_wd[3], Iw_w[3];
-  symmul(Iw6, omd, Iw_wd);
-  symmul(Iw6, om, Iw_w);
-  const double m = H->mass;
-
-  if (role == 3) {
-    if (want_g) {  // GetDynamicViolation, single_rigid_body_dynamics.cc:76-101
-      double wxIw[3];
-      cross3(om, Iw_w, wxIw);
-      double* go = gst + 6 * kk;  // staged in LDS, written out coalesced with the Jacobian slice
-#pragma unroll
-      for (int i = 0; i < 3; ++i) go[i] = Iw_wd[i] + wxIw[i] - tau[i];
-      go[3] = m * cdd[0] - F[0];
-      go[4] = m * cdd[1] - F[1];
-      go[5] = m * cdd[2] - F[2] + m * H->gravity;
-    }
-    if (want_j) {  // base-lin block: ang rows -sum_i [f_i]x J_pos, lin rows m J_acc (:103-121)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        stage[rs[0] + 2 * j + 0] = -crs<0, 1>(F) * wP[j];
-        stage[rs[0] + 2 * j + 1] = -crs<0, 2>(F) * wP[j];
-        stage[rs[1] + 2 * j + 0] = -crs<1, 0>(F) * wP[j];
-        stage[rs[1] + 2 * j + 1] = -crs<1, 2>(F) * wP[j];
-        stage[rs[2] + 2 * j + 0] = -crs<2, 0>(F) * wP[j];
-        stage[rs[2] + 2 * j + 1] = -crs<2, 1>(F) * wP[j];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) stage[rl[d] + j] = m * wA[j];
-      }
-    }
-  } else if (want_j) {
-    // --- base-ang block (:123-165), Euler dimension d = role, factored.
-    // The columns of M are the rotation axes of the ZYX sequence, so dR/d e_d = [M_d]x R
-    // (the cell-wise derivatives of euler_converter.cc:241-268 in closed form) and
-    //   d(I_w v)/d e_d = R_d I_b R^T v + R I_b R_d^T v = M_d x (I_w v) + I_w (v x M_d)
-    // (jac11+jac12 resp. jac21+jac22 of the reference) without ever forming R_d.
-    const double dMx_dy[3] = {-sy * cz, -sy * sz, -cy};
-    const double dMx_dz[3] = {-cy * sz, cy * cz, 0.0};
-    const double dMy_dz[3] = {-cz, -sz, 0.0};
-    const double dMdx_dy[3] = {-cz * cy * yd + sy * sz * zd, -sy * cz * zd - cy * sz * yd, sy * yd};
-    const double dMdx_dz[3] = {sz * sy * yd - cy * cz * zd, -cy * sz * zd - sy * cz * yd, 0.0};
-    const double dMdy_dz[3] = {sz * zd, -cz * zd, 0.0};
-    double Md[3], dwd_ed[3], dw[3], dwd[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      Md[i] = sel3(role, Mx[i], My[i], i == 2 ? 1.0 : 0.0);  // column d of M (euler_converter.cc:133-148)
-      // d omega_dot / d edot_d
-      dwd_ed[i] = sel3(role, Mdx[i], Mdy[i] + xd * dMx_dy[i], xd * dMx_dz[i] + yd * dMy_dz[i]);
-      // d omega / d e_d , d omega_dot / d e_d   (roll: none)   (euler_converter.cc:168-198,270-304)
-      dw[i] = sel3(role, 0.0, xd * dMx_dy[i], xd * dMx_dz[i] + yd * dMy_dz[i]);
-      dwd[i] = sel3(role, 0.0, xd * dMdx_dy[i] + edd[0] * dMx_dy[i],
-                    xd * dMdx_dz[i] + yd * dMdy_dz[i] + edd[0] * dMx_dz[i] + edd[1] * dMy_dz[i]);
-    }
-    auto dIw = [&](const double v[3], const double Iwv[3], double o[3]) {
-      double t1[3], t2[3], t3b[3];
-      cross3(Md, Iwv, t1);
-      cross3(v, Md, t2);
-      symmul(Iw6, t2, t3b);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) o[i] = t1[i] + t3b[i];
-    };
-    double A[3], B[3], C[3];
-    symmul(Iw6, Md, C);
-    {  // B_d = I_w d(omega_dot)/d(edot_d) + M_d x (I_w omega) + omega x (I_w M_d)
-      double t1[3], t2[3], t3b[3];
-      symmul(Iw6, dwd_ed, t1);
-      cross3(Md, Iw_w, t2);
-      cross3(om, C, t3b);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) B[i] = t1[i] + t2[i] + t3b[i];
-    }
-    {  // A_d = dI_w(omega_dot) + I_w d(omega_dot) + d(omega) x I_w omega + omega x (dI_w(omega) + I_w d(omega))
-      double t1[3], t2[3], t3b[3], t4[3], t5[3], t6[3], t7[3];
-      dIw(omd, Iw_wd, t1);
-      symmul(Iw6, dwd, t2);
-      cross3(dw, Iw_w, t3b);
-      dIw(om, Iw_w, t4);
-      symmul(Iw6, dw, t5);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) t6[i] = t4[i] + t5[i];
-      cross3(om, t6, t7);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) A[i] = t1[i] + t2[i] + t3b[i] + t7[i];
-    }
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) stage[rs[r] + 8 + 3 * j + role] = A[r] * wP[j] + B[r] * wV[j] + C[r] * wA[j];
-  }
-}
+// Two kernels share this mapping: dyn_kernel (fixed timings: dyn2_front / dyn2_back, every index resolved on the
+// host) and dyn_phase_kernel (optimised timings: pdyn_math / pdyn_puts behind the phase_locate_kernel pre-pass).
 
 // ---------------------------------------------------------------- range-of-motion item
 // RangeOfMotionConstraint::{UpdateConstraintAtInstance, UpdateJacobianAtInstance}
@@ -1670,143 +1376,463 @@ TWR_DEV void phase_poly_durations_wave(const PhaseTables* PT, const char* blob, 
   __syncthreads();
 }
 
-template <int NEE>
-__global__ __launch_bounds__(64) void dyn_phase_kernel(const PhaseWork* __restrict__ work, const double* __restrict__ x,
-                                                       double* __restrict__ g, double* __restrict__ jac, int flags) {
-  __shared__ double s_ph[NEE][TWR_MAX_PHASES_DEV], s_md[NEE][kMaxPhasePolys], s_fd[NEE][kMaxPhasePolys];
-  const PhaseWork pw = work[blockIdx.x];
-  const char* blob = reinterpret_cast<const char*>(pw.blob);
-  const TWR_CONST PhaseTables* PT = cptr<PhaseTables>(pw.blob + cptr<DevStruct>(pw.blob)->o_phase);  // scalar loads
-  const double* xp = x + pw.x_off;
-  const bool want_g = flags & 1, want_j = flags & 2;
-  const int lane = threadIdx.x, kk = lane >> 2, role = lane & 3;
-  double* out = jac + pw.j_off + PT->nnz_dyn + (int64_t)pw.k0 * PT->node_vals;
-  double* gout = g + pw.g_off + PT->row_dyn + 6 * pw.k0;
-#ifdef TWR_PHASE_ZERO_EARLY
-  if (want_j) zero_fill(out, pw.cnt * PT->node_vals, lane);
-#endif
-  if (lane < NEE)
-    phase_poly_durations(tbl<PhaseTables>(blob, cptr<DevStruct>(pw.blob)->o_phase), blob, xp, lane, s_ph[lane], s_md[lane],
-                         s_fd[lane], true);
-  __syncthreads();
-  const int e = min(role, NEE - 1);
-  const bool has_ee = role < NEE;
-  const int k = pw.k0 + min(kk, pw.cnt - 1);
-  const double t = tbl<double>(blob, PT->o_tdyn)[k];
-  // active polynomials of this lane's end-effector and the current phase
-  double tlm, tlf, tlp;
-  const int qm = locate_segment(s_md[e], PT->n_mpoly[e], t, tlm);
-  const int qf = locate_segment(s_fd[e], PT->n_fpoly[e], t, tlf);
-  const int cur = locate_segment(s_ph[e], PT->n_phases[e], t, tlp);
-  const PhasePoly pm = tbl<PhasePoly>(blob, PT->o_mpoly[e])[qm];
-  const PhasePoly pf = tbl<PhasePoly>(blob, PT->o_fpoly[e])[qf];
-  const double Tm = s_md[e][qm], Tf = s_fd[e][qf];
-  DynShared sh = tbl<DynShared>(blob, PT->o_dyn_shared)[k];
-  DynLane ln;
-  ln.tm = tlm; ln.iTm = 1.0 / Tm;
-  ln.tf = tlf; ln.iTf = 1.0 / Tf;
-  ln.xbase_m = pm.xbase; ln.xbase_f = pf.xbase;
-  ln.meta_m = pm.meta;   ln.meta_f = pf.meta;
+// ---- dynamic with optimised timings (dyn_phase_kernel)
+// Persistent single-wave workgroups, software pipelined like rom_kernel; a work item is a run of <= 16 time nodes, four
+// lanes per node.  What depends on x in the index work -- the active polynomials, local times and current phase of
+// every (time node, ee) -- comes from the pre-pass (phase_locate_kernel -> DynLoc records); everything else is a constant
+// of the structure because the rows hold ALL variables of every ee set: the byte offset of every Jacobian value inside
+// its time node is read off the CSR pattern on the host (PhasePutM / PhasePutF per polynomial, PhaseEe for the duration
+// columns).  A run is far larger than LDS (C3: 1280 values = 10 KB per node, ~75 % explicit zeros), so it goes out in
+// GROUPS of `group` nodes: the wave clears an LDS image of the group's expanded rows, the quads of those nodes store
+// their values at their final positions (the math of the whole run was done once, before the first group), and the
+// wave streams the image to HBM with 16-byte coalesced stores: every byte of the Jacobian is written exactly once.
+struct PDynRec {       // per lane: what depends on the work item only
+  DynShared sh;
+  DynLoc lc;
+};
+struct PDynIn {        // per lane: what depends on the record (second stage of the pipeline)
+  double bl[3], ba[3], m[12], f[12];   // ONE node value (role: p0, v0, p1, v1) of base-lin / base-ang; ee candidates
+  PhasePutM pm;
+  PhasePutF pf;
+  PhaseEe pe;
+};
+struct PDynOut {       // per lane: what the put phase needs
+  double wP[4], wV[4], wA[4];
+  double A[3], B[3], C[3];             // roles 0..2: base-ang factors of Euler dimension `role`
+  double F[3], mass;                   // role 3: base-lin block
+  double wm[4], wf[4], f[3], rv[3];
+  double ap[3], ac[3], lp[3], lc[3];   // duration columns: angular rows (previous phases / current phase), linear rows
+  int n_dur, cur;                      // duration columns that are non-zero for this lane: p < n_dur; p == cur takes `ac/lc`
+};
+TWR_DEV uint64_t pack_slots(const uint32_t s[2]) { return ((uint64_t)s[1] << 32) | s[0]; }
+TWR_DEV PDynRec pdyn_load_rec(const PDynWork& w, const TWR_CONST PhaseTables* PT, int n_ee, int lane) {
+  PDynRec r;
+  const int kk = min(lane >> 2, w.cnt - 1), e = min(lane & 3, n_ee - 1);   // (roles >= n_ee read ee n_ee-1 and are neutralised)
+  r.sh = gptr<DynShared>(w.blob + PT->o_dyn_shared)[w.k0 + kk];
+  r.lc = gptr<DynLoc>(w.loc)[kk * 4 + e];
+  return r;
+}
+TWR_DEV void pdyn_load_in(const PDynWork& w, const TWR_CONST PhaseTables* PT, int n_ee, const PDynRec& r,
+                          const double* __restrict__ x, int lane, PDynIn& in) {
+  const double* xp = x + w.x_off;
+  const int role = lane & 3, e = min(role, n_ee - 1);
+  const double* xl = xp + PT->off_lin + r.sh.q6 + 3 * role;
+  const double* xa = xp + PT->off_ang + r.sh.q6 + 3 * role;
 #pragma unroll
-  for (int c = 0; c < 12; ++c) {
-    ln.cand_m[c] = pm.cand[c];
-    ln.cand_f[c] = pf.cand[c];
+  for (int i = 0; i < 3; ++i) {
+    in.bl[i] = xl[i];
+    in.ba[i] = xa[i];
   }
-  DynWorkP w;
-  w.hdr = pw.blob;
-  w.x_off = pw.x_off;
-  w.off_lin = PT->off_lin; w.off_ang = PT->off_ang;
-  w.cnt = pw.cnt;
-  // expanded row layout of this time node (relative to the first value of node k0)
-  DynFront S;
-  {
-    const int soff = min(kk, pw.cnt - 1) * PT->node_vals;
-    S.rs[0] = soff;
-    S.rs[1] = S.rs[0] + PT->len_ang[0];
-    S.rs[2] = S.rs[1] + PT->len_ang[1];
-    S.rl[0] = S.rs[2] + PT->len_ang[2];
-    S.rl[1] = S.rl[0] + PT->len_lin[0];
-    S.rl[2] = S.rl[1] + PT->len_lin[1];
-  }
-  int sa[3], sl[3];  // first duration column of this end-effector in the ang / lin rows
-  {
-    int pre_s = 0;
+  gather12(xp, r.lc.xbase_m, pack_slots(r.lc.slots_m), in.m);
+  gather12(xp, r.lc.xbase_f, pack_slots(r.lc.slots_f), in.f);
+  in.pm = gptr<PhasePutM>(w.blob + PT->o_mput[e])[r.lc.qm];
+  in.pf = gptr<PhasePutF>(w.blob + PT->o_fput[e])[r.lc.qf];
+  in.pe = gptr<PhaseEe>(w.blob + cptr<DevStruct>(w.blob)->o_phase + (uint32_t)offsetof(PhaseTables, ee))[e];
+}
+// The math of one run: splines, quad exchanges, SRBD violation, the factors of every Jacobian block.
+TWR_DEV void pdyn_math(const PDynWork& w, int n_ee, const PDynRec& r, const PDynIn& in, double* __restrict__ gst, int lane,
+                       bool want_g, PDynOut& T) {
+  const int kk = lane >> 2, role = lane & 3;
+  const bool has_ee = role < n_ee;
+  hermite_all(r.sh.tb, r.sh.iTb, T.wP, T.wV, T.wA);
+  double c[3], e[3], cdd[3], ed[3], edd[3];
+  {  // this lane's node value times its weights, summed over the quad (Spline::GetPoint in basis form)
+    const double qP = role == 3 ? T.wP[3] : sel3(role, T.wP[0], T.wP[1], T.wP[2]);
+    const double qV = role == 3 ? T.wV[3] : sel3(role, T.wV[0], T.wV[1], T.wV[2]);
+    const double qA = role == 3 ? T.wA[3] : sel3(role, T.wA[0], T.wA[1], T.wA[2]);
 #pragma unroll
-    for (int e2 = 0; e2 < NEE; ++e2) {
-      const int n = PT->n_phases[e2] - 1;
-      if (e2 < role) pre_s += n;
+    for (int d = 0; d < 3; ++d) {
+      c[d] = quad_sum(qP * in.bl[d]);
+      cdd[d] = quad_sum(qA * in.bl[d]);
+      e[d] = quad_sum(qP * in.ba[d]);
+      ed[d] = quad_sum(qV * in.ba[d]);
+      edd[d] = quad_sum(qA * in.ba[d]);
     }
+  }
+  // --- this lane's end-effector: weights and spline points
+  const uint64_t sm = pack_slots(r.lc.slots_m), sf = pack_slots(r.lc.slots_f);
+  const bool shared = (r.lc.flags >> 1) & 1;
+  double p[3];
+  ee_point(sm, shared, r.lc.tm, 1.0 / r.lc.Tm, in.m, T.wm, p);
+  ee_point(sf, false, r.lc.tf, 1.0 / r.lc.Tf, in.f, T.wf, T.f);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    T.rv[d] = c[d] - p[d];
+    if (!has_ee) T.f[d] = 0.0;
+  }
+  // force and torque sums over the end-effectors (single_rigid_body_dynamics.cc:81-88)
+  double t3[3], tau[3];
+  cross3(T.f, T.rv, t3);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    T.F[d] = quad_sum(T.f[d]);
+    tau[d] = quad_sum(t3[d]);
+  }
+  // --- duration columns: {[r]x J_f + [f]x J_p ; -J_f} with J = GetJacobianOfPosWrtDurations of the ee-force /
+  // ee-motion PhaseSpline (dynamic_constraint.cc:107-113, single_rigid_body_dynamics.cc:167-192)
+  {
+    double nv[4][3], fprev[3], fcur[3], xprev[3], xcur[3], t1[3], t2[3];
+    const bool in_last = r.lc.flags & 1;
+    node_values(sf, false, in.f, nv);
+    duration_columns(nv, r.lc.tf, r.lc.Tf, 1.0 / (double)r.lc.nin_f, (double)r.lc.pin_f, in_last, fprev, fcur);
+    node_values(sm, shared, in.m, nv);
+    duration_columns(nv, r.lc.tm, r.lc.Tm, 1.0 / (double)r.lc.nin_m, (double)r.lc.pin_m, in_last, xprev, xcur);
+    cross3(T.rv, fprev, t1);
+    cross3(T.f, xprev, t2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      T.ap[i] = t1[i] + t2[i];
+      T.lp[i] = -fprev[i];
+    }
+    cross3(T.rv, fcur, t1);
+    cross3(T.f, xcur, t2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      T.ac[i] = t1[i] + t2[i];
+      T.lc[i] = -fcur[i];
+    }
+    T.cur = r.lc.cur;
+    T.n_dur = has_ee ? min((int)r.lc.cur + 1, in.pe.ns) : 0;   // columns after the current phase stay zero
+  }
+  // --- rotation: lanes 0..2 of the quad evaluate one sincos each and broadcast it
+  double my_s, my_c;
+  sincos_fast(sel3(role, e[0], e[1], e[2]), &my_s, &my_c);
+  const double sx = quad_perm<0x00>(my_s), cx = quad_perm<0x00>(my_c);
+  const double sy = quad_perm<0x55>(my_s), cy = quad_perm<0x55>(my_c);
+  const double sz = quad_perm<0xAA>(my_s), cz = quad_perm<0xAA>(my_c);
+  // --- angular quantities (euler_converter.cc:58-83,133-166,207-221)
+  double R[3][3];
+  R[0][0] = cy * cz; R[0][1] = cz * sx * sy - cx * sz; R[0][2] = sx * sz + cx * cz * sy;
+  R[1][0] = cy * sz; R[1][1] = cx * cz + sx * sy * sz; R[1][2] = cx * sy * sz - cz * sx;
+  R[2][0] = -sy;     R[2][1] = cy * sx;                R[2][2] = cx * cy;
+  const double xd = ed[0], yd = ed[1], zd = ed[2];
+  const double Mx[3] = {cy * cz, cy * sz, -sy}, My[3] = {-sz, cz, 0.0};
+  const double Mdx[3] = {-cz * sy * yd - cy * sz * zd, cy * cz * zd - sy * sz * yd, -cy * yd};
+  const double Mdy[3] = {-cz * zd, -sz * zd, 0.0};
+  double om[3], omd[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    om[i] = Mx[i] * xd + My[i] * yd;
+    omd[i] = Mdx[i] * xd + Mdy[i] * yd + Mx[i] * edd[0] + My[i] * edd[1];
+  }
+  om[2] += zd;
+  omd[2] += edd[2];
+  const TWR_CONST DevStruct* H = cptr<DevStruct>(w.blob);  // uniform per work item: scalar loads
+  double Iw6[6];  // I_w = R I_b R^T (single_rigid_body_dynamics.cc:91), symmetric: (00,01,02,11,12,22)
+  {
+    double Ib[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Ib[i] = H->Ib[i];
+    double Tm[3][3];  // R I_b
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      Tm[i][0] = R[i][0] * Ib[0] + R[i][1] * Ib[1] + R[i][2] * Ib[2];
+      Tm[i][1] = R[i][0] * Ib[1] + R[i][1] * Ib[3] + R[i][2] * Ib[4];
+      Tm[i][2] = R[i][0] * Ib[2] + R[i][1] * Ib[4] + R[i][2] * Ib[5];
+    }
+    Iw6[0] = Tm[0][0] * R[0][0] + Tm[0][1] * R[0][1] + Tm[0][2] * R[0][2];
+    Iw6[1] = Tm[0][0] * R[1][0] + Tm[0][1] * R[1][1] + Tm[0][2] * R[1][2];
+    Iw6[2] = Tm[0][0] * R[2][0] + Tm[0][1] * R[2][1] + Tm[0][2] * R[2][2];
+    Iw6[3] = Tm[1][0] * R[1][0] + Tm[1][1] * R[1][1] + Tm[1][2] * R[1][2];
+    Iw6[4] = Tm[1][0] * R[2][0] + Tm[1][1] * R[2][1] + Tm[1][2] * R[2][2];
+    Iw6[5] = Tm[2][0] * R[2][0] + Tm[2][1] * R[2][1] + Tm[2][2] * R[2][2];
+  }
+  double Iw_wd[3], Iw_w[3];
+  symmul(Iw6, omd, Iw_wd);
+  symmul(Iw6, om, Iw_w);
+  const double m = H->mass;
+  T.mass = m;
+  if (role == 3) {
+    if (want_g && kk < w.cnt) {  // GetDynamicViolation, single_rigid_body_dynamics.cc:76-101
+      double wxIw[3];
+      cross3(om, Iw_w, wxIw);
+      double* go = gst + 6 * kk;  // staged in LDS, written out coalesced
+#pragma unroll
+      for (int i = 0; i < 3; ++i) go[i] = Iw_wd[i] + wxIw[i] - tau[i];
+      go[3] = m * cdd[0] - T.F[0];
+      go[4] = m * cdd[1] - T.F[1];
+      go[5] = m * cdd[2] - T.F[2] + m * H->gravity;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) T.A[i] = T.B[i] = T.C[i] = 0.0;
+  } else {
+    // --- base-ang block (:123-165), Euler dimension d = role, factored.
+    // The columns of M are the rotation axes of the ZYX sequence, so dR/d e_d = [M_d]x R
+    // (the cell-wise derivatives of euler_converter.cc:241-268 in closed form) and
+    //   d(I_w v)/d e_d = R_d I_b R^T v + R I_b R_d^T v = M_d x (I_w v) + I_w (v x M_d)
+    // (jac11+jac12 resp. jac21+jac22 of the reference) without ever forming R_d.
+    const double dMx_dy[3] = {-sy * cz, -sy * sz, -cy};
+    const double dMx_dz[3] = {-cy * sz, cy * cz, 0.0};
+    const double dMy_dz[3] = {-cz, -sz, 0.0};
+    const double dMdx_dy[3] = {-cz * cy * yd + sy * sz * zd, -sy * cz * zd - cy * sz * yd, sy * yd};
+    const double dMdx_dz[3] = {sz * sy * yd - cy * cz * zd, -cy * sz * zd - sy * cz * yd, 0.0};
+    const double dMdy_dz[3] = {sz * zd, -cz * zd, 0.0};
+    double Md[3], dwd_ed[3], dw[3], dwd[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      Md[i] = sel3(role, Mx[i], My[i], i == 2 ? 1.0 : 0.0);  // column d of M (euler_converter.cc:133-148)
+      // d omega_dot / d edot_d
+      dwd_ed[i] = sel3(role, Mdx[i], Mdy[i] + xd * dMx_dy[i], xd * dMx_dz[i] + yd * dMy_dz[i]);
+      // d omega / d e_d , d omega_dot / d e_d   (roll: none)   (euler_converter.cc:168-198,270-304)
+      dw[i] = sel3(role, 0.0, xd * dMx_dy[i], xd * dMx_dz[i] + yd * dMy_dz[i]);
+      dwd[i] = sel3(role, 0.0, xd * dMdx_dy[i] + edd[0] * dMx_dy[i],
+                    xd * dMdx_dz[i] + yd * dMdy_dz[i] + edd[0] * dMx_dz[i] + edd[1] * dMy_dz[i]);
+    }
+    auto dIw = [&](const double v[3], const double Iwv[3], double o[3]) {
+      double t1[3], t2[3], t3b[3];
+      cross3(Md, Iwv, t1);
+      cross3(v, Md, t2);
+      symmul(Iw6, t2, t3b);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) o[i] = t1[i] + t3b[i];
+    };
+    symmul(Iw6, Md, T.C);
+    {  // B_d = I_w d(omega_dot)/d(edot_d) + M_d x (I_w omega) + omega x (I_w M_d)
+      double t1[3], t2[3], t3b[3];
+      symmul(Iw6, dwd_ed, t1);
+      cross3(Md, Iw_w, t2);
+      cross3(om, T.C, t3b);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) T.B[i] = t1[i] + t2[i] + t3b[i];
+    }
+    {  // A_d = dI_w(omega_dot) + I_w d(omega_dot) + d(omega) x I_w omega + omega x (dI_w(omega) + I_w d(omega))
+      double t1[3], t2[3], t3b[3], t4[3], t5[3], t6[3], t7[3];
+      dIw(omd, Iw_wd, t1);
+      symmul(Iw6, dwd, t2);
+      cross3(dw, Iw_w, t3b);
+      dIw(om, Iw_w, t4);
+      symmul(Iw6, dw, t5);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) t6[i] = t4[i] + t5[i];
+      cross3(om, t6, t7);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) T.A[i] = t1[i] + t2[i] + t3b[i] + t7[i];
+    }
+  }
+}
+// The Jacobian values of this lane's time node into the group's LDS image (`nb`: byte address of the node's first
+// value).  ee tiles first: a candidate that is not a variable carries the offset of a base-ang entry of row AX, which
+// the base-ang stores below overwrite (same wave, program order).
+TWR_DEV void pdyn_puts(const TWR_CONST PhaseTables* PT, const PDynIn& in, const PDynOut& T, char* __restrict__ nb, int lane) {
+  const int role = lane & 3;
+  const double (&wm)[4] = T.wm, (&wf)[4] = T.wf, (&f)[3] = T.f, (&rv)[3] = T.rv, (&F)[3] = T.F;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#define TWR_EE_TILE3(D, R1, R2)                                        \
+  {                                                                    \
+    lds_put(nb, in.pm.off[j * 3 + D][0], crs<R1, D>(f) * wm[j]);      \
+    lds_put(nb, in.pm.off[j * 3 + D][1], crs<R2, D>(f) * wm[j]);      \
+    lds_put(nb, in.pf.off[j * 3 + D][0], crs<R1, D>(rv) * wf[j]);     \
+    lds_put(nb, in.pf.off[j * 3 + D][1], crs<R2, D>(rv) * wf[j]);     \
+    lds_put(nb, in.pf.off[j * 3 + D][2], -wf[j]);                     \
+  }
+    TWR_EE_TILE3(0, 1, 2)
+    TWR_EE_TILE3(1, 2, 0)
+    TWR_EE_TILE3(2, 0, 1)
+#undef TWR_EE_TILE3
+  }
+  // duration columns of this lane's end-effector: `prev` for the phases before the current one, `cur` for it
+  for (int p = 0; p < T.n_dur; ++p) {
+    const bool is_cur = p == T.cur;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      int pre_m = 0, tot_m = 0, pre_f = 0, tot_f = 0, pre_l = 0, tot_l = 0;
-#pragma unroll
-      for (int e2 = 0; e2 < NEE; ++e2) {
-        tot_m += PT->mne[e2][r]; tot_f += PT->fne[e2][r]; tot_l += PT->feq[e2][r];
-        if (e2 < role) { pre_m += PT->mne[e2][r]; pre_f += PT->fne[e2][r]; pre_l += PT->feq[e2][r]; }
-      }
-      S.ms[r] = S.rs[r] + 20 + pre_m + pm.base_ne[r];
-      S.fs[r] = S.rs[r] + 20 + tot_m + pre_f + pf.base_ne[r];
-      S.ls[r] = S.rl[r] + 4 + pre_l + pf.base_eq[r];
-      sa[r] = S.rs[r] + 20 + tot_m + tot_f + pre_s;
-      sl[r] = S.rl[r] + 4 + tot_l + pre_s;
+      lds_put(nb, (uint32_t)(in.pe.dur_ang[r] + 8 * p), is_cur ? T.ac[r] : T.ap[r]);
+      lds_put(nb, (uint32_t)(in.pe.dur_lin[r] + 8 * p), is_cur ? T.lc[r] : T.lp[r]);
     }
   }
-  DynX X;
-  dyn_load_x(w, sh, ln, x, X);
-  dyn_front<NEE, true>(w, sh, ln, X, 0, 0, lane, S);
-#ifndef TWR_PHASE_ZERO_EARLY
-  // Zero fill as LATE as possible: the values follow within a microsecond or two, while the zero lines are still dirty
-  // in the XCD's L2, so every line goes to HBM once.  (Filling at the top of the kernel, ~15 us earlier, hid the store
-  // latency behind the set-up but let the zeros be evicted first: measured 1.57 x the algorithmic write traffic.)
-  if (want_j) zero_fill(out, pw.cnt * PT->node_vals, lane);
-#endif
-  // The values below overwrite zeros written by OTHER lanes of this wave: the zero stores must have been
-  // acknowledged first.  A single-wave workgroup gets no s_barrier from __syncthreads(), so the dependency is
-  // made explicit (on gfx9 loads and stores retire through the one in-order vmcnt counter).
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (want_j && has_ee && kk < pw.cnt) {
-    // duration columns: {[r]x J_f + [f]x J_p ; -J_f} with J = GetJacobianOfPosWrtDurations of the ee-force /
-    // ee-motion PhaseSpline (dynamic_constraint.cc:107-113, single_rigid_body_dynamics.cc:167-192)
-    double nv[4][3], fprev[3], fcur[3], xprev[3], xcur[3];
-    const bool in_last = cur == PT->n_phases[e] - 1;
-    node_values(slots_of(ln.cand_f), false, X.f, nv);
-    duration_columns(nv, tlf, Tf, 1.0 / pf.n_in_phase, (double)pf.poly_in_phase, in_last, fprev, fcur);
-    node_values(slots_of(ln.cand_m), meta_shared(ln.meta_m), X.m, nv);
-    duration_columns(nv, tlm, Tm, 1.0 / pm.n_in_phase, (double)pm.poly_in_phase, in_last, xprev, xcur);
-    double ap[3], ac[3], t1[3], t2[3];
-    cross3(S.rv, fprev, t1);
-    cross3(S.f, xprev, t2);
+  const uint32_t rs1 = 8u * (uint32_t)PT->len_ang[0], rs2 = rs1 + 8u * (uint32_t)PT->len_ang[1];
+  char* row[3] = {nb, nb + rs1, nb + rs2};
+  if (role == 3) {   // base-lin block: ang rows -sum_i [f_i]x J_pos, lin rows m J_acc (:103-121)
+    const uint32_t rl0 = rs2 + 8u * (uint32_t)PT->len_ang[2], rl1 = rl0 + 8u * (uint32_t)PT->len_lin[0],
+                   rl2 = rl1 + 8u * (uint32_t)PT->len_lin[1];
+    char* lin[3] = {nb + rl0, nb + rl1, nb + rl2};
 #pragma unroll
-    for (int i = 0; i < 3; ++i) ap[i] = t1[i] + t2[i];
-    cross3(S.rv, fcur, t1);
-    cross3(S.f, xcur, t2);
+    for (int j = 0; j < 4; ++j) {
+      lds_put(row[0], 8 * (2 * j + 0), -crs<0, 1>(F) * T.wP[j]);
+      lds_put(row[0], 8 * (2 * j + 1), -crs<0, 2>(F) * T.wP[j]);
+      lds_put(row[1], 8 * (2 * j + 0), -crs<1, 0>(F) * T.wP[j]);
+      lds_put(row[1], 8 * (2 * j + 1), -crs<1, 2>(F) * T.wP[j]);
+      lds_put(row[2], 8 * (2 * j + 0), -crs<2, 0>(F) * T.wP[j]);
+      lds_put(row[2], 8 * (2 * j + 1), -crs<2, 1>(F) * T.wP[j]);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) ac[i] = t1[i] + t2[i];
-    const int ns = PT->n_phases[e] - 1;
-    for (int p = 0; p < ns; ++p)
+      for (int d = 0; d < 3; ++d) lds_put(lin[d], 8 * j, T.mass * T.wA[j]);
+    }
+  } else {           // base-ang block, Euler dimension `role`
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        out[sa[r] + p] = p < cur ? ap[r] : (p == cur ? ac[r] : 0.0);
-        out[sl[r] + p] = p < cur ? -fprev[r] : (p == cur ? -fcur[r] : 0.0);
-      }
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        lds_put(row[r], 8 * (8 + 3 * j + role), T.A[r] * T.wP[j] + T.B[r] * T.wV[j] + T.C[r] * T.wA[j]);
   }
-  dyn_back<NEE, true>(w, ln, S, gout, out, 0, lane, want_g, want_j);
+}
+// zero [0, n) doubles of an LDS image (n rounded up to a pair), 16 bytes per lane and instruction
+TWR_DEV void lds_clear(double* __restrict__ img, int n, int lane) {
+  const double2 z = {0.0, 0.0};
+  const int npairs = (n + 1) >> 1;
+  for (int t = lane; t < npairs; t += 64) reinterpret_cast<double2*>(img)[t] = z;
+}
+// image -> HBM like copy_out_fixed, for a run-time length: batches of eight 16-byte LDS reads, then their stores;
+// iterations past the end re-store the last complete pair (idempotent).  The kernel runs one wave per SIMD, so the
+// accumulation registers are free: the batch is staged in AGPRs (DS and vector-memory instructions take them as data
+// operands), which leaves the arch VGPRs to the math state of the run -- left to the register allocator the eight reads
+// end up serialised through one VGPR quad, or spilled.  Written as asm for that reason; the waits are explicit
+// (the compiler's own s_waitcnt counts stay conservative: unknown younger operations only make them stricter).
+typedef float twr_v4f __attribute__((ext_vector_type(4)));
+TWR_DEV void stream_out(double* __restrict__ dst, const double* __restrict__ stage, int n, int par, int lane) {
+  char* al = reinterpret_cast<char*>(dst - par);  // 16-byte aligned
+  const int total = n + par;
+  const uint32_t last = (uint32_t)((total >> 1) - 1) * 16u;
+  const uint32_t first = (uint32_t)(par + lane) * 16u;
+  const int nit = ((total >> 1) - par + 63) >> 6;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)stage;   // LDS byte address
+  constexpr int kB = 8;
+  for (int it0 = 0; it0 < nit; it0 += kB) {
+    uint32_t off[kB];
+    twr_v4f v[kB];
+#pragma unroll
+    for (int b = 0; b < kB; ++b) {
+      off[b] = min(first + 1024u * (uint32_t)(it0 + b), last);
+      asm volatile("ds_read_b128 %0, %1" : "=a"(v[b]) : "v"(lds0 + off[b]) : "memory");
+    }
+#pragma unroll
+    for (int b = 0; b < kB; ++b) {
+      switch (kB - 1 - b) {   // the b-th read has landed once at most kB-1-b younger ones are outstanding
+        case 7: asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+      }
+      asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(off[b]), "a"(v[b]), "s"(al) : "memory");
+    }
+  }
+  if (par && lane == 0 && n > 0) dst[0] = stage[1];
+  if ((total & 1) && lane == 0 && total - 1 > par) dst[n - 1] = stage[total - 1];
 }
 
-// rangeofmotion-<ee> with optimised timings.
-// Pre-pass: one workgroup per (problem, ee) resolves the x-dependent part of every time node -- phase and
-// polynomial durations, active polynomial, local time, current phase -- into RomRec records.
-__global__ __launch_bounds__(64) void rom_locate_kernel(const LocWork* __restrict__ work, const double* __restrict__ x) {
-  __shared__ double s_ph[TWR_MAX_PHASES_DEV], s_md[kMaxPhasePolys];
+// LDS: image of one group (img_cap + 2 doubles) | constraint values of the run (96)
+__global__ __launch_bounds__(64, 1) void dyn_phase_kernel(const PDynWork* __restrict__ work, int n_work,
+                                                          const double* __restrict__ x, double* __restrict__ g,
+                                                          double* __restrict__ jac, int flags, int img_cap) {
+  extern __shared__ __attribute__((aligned(16))) double pdyn_lds[];
+  double* img = pdyn_lds;
+  double* gst = pdyn_lds + ((img_cap + 3) & ~1);
+  const bool want_g = flags & 1, want_j = flags & 2;
+  const int lane = threadIdx.x, kk = lane >> 2;
+  const int stride = gridDim.x;
+  int i = blockIdx.x;
+  if (i >= n_work) return;
+  PDynWork w0 = work[i], w1 = w0, w2 = w0;
+  // (all problems of a batch share n_ee; the tables of the slice's own structure are reached through its blob)
+  const int n_ee = cptr<DevStruct>(w0.blob)->n_ee;
+  auto tables = [](const PDynWork& w) { return cptr<PhaseTables>(w.blob + cptr<DevStruct>(w.blob)->o_phase); };
+  PDynRec r0 = pdyn_load_rec(w0, tables(w0), n_ee, lane), r1 = r0;
+  if (i + stride < n_work) {
+    w1 = work[i + stride];
+    r1 = pdyn_load_rec(w1, tables(w1), n_ee, lane);
+  }
+  PDynIn in;
+  pdyn_load_in(w0, tables(w0), n_ee, r0, x, lane, in);
+  for (; i < n_work; i += stride) {
+    const bool has1 = i + stride < n_work, has2 = i + 2 * stride < n_work;
+    if (has2) w2 = work[i + 2 * stride];
+    const TWR_CONST PhaseTables* PT = tables(w0);
+    PDynOut T;
+    pdyn_math(w0, n_ee, r0, in, gst, lane, want_g, T);
+    // the put offsets of roles without an end-effector all point at the trash entry
+    PhasePutM pm = in.pm;
+    PhasePutF pf = in.pf;
+    if ((lane & 3) >= n_ee) {
+      const uint16_t trash = (uint16_t)(8 * (8 + (lane & 3)));
+#pragma unroll
+      for (int c = 0; c < 12; ++c) {
+        pm.off[c][0] = pm.off[c][1] = trash;
+        pf.off[c][0] = pf.off[c][1] = pf.off[c][2] = trash;
+      }
+    }
+    PDynIn put;   // (only the offsets of `in` survive into the put phase)
+    put.pm = pm;
+    put.pf = pf;
+    put.pe = in.pe;
+    PDynRec r2 = r1;
+    if (has2) r2 = pdyn_load_rec(w2, tables(w2), n_ee, lane);   // records first: the wait for x retires them too
+    if (has1) pdyn_load_in(w1, tables(w1), n_ee, r1, x, lane, in);
+    if (want_j) {
+      const int node_vals = w0.node_vals, G = w0.group;
+      for (int n0 = 0; n0 < w0.cnt; n0 += G) {
+        const int gcnt = min(G, w0.cnt - n0), nv = gcnt * node_vals;
+        double* dst = jac + w0.j_off + (int64_t)n0 * node_vals;
+        const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+        lds_clear(img, nv + par, lane);
+        // (the factors are opaque per group: otherwise the compiler hoists all ~110 products of a node out of this loop
+        // and spills them)
+        asm volatile("" : "+v"(T.wm[0]), "+v"(T.wm[1]), "+v"(T.wm[2]), "+v"(T.wm[3]), "+v"(T.wf[0]), "+v"(T.wf[1]),
+                     "+v"(T.wf[2]), "+v"(T.wf[3]), "+v"(T.wP[0]), "+v"(T.wP[1]), "+v"(T.wP[2]), "+v"(T.wP[3]));
+        asm volatile("" : "+v"(T.wV[0]), "+v"(T.wV[1]), "+v"(T.wV[2]), "+v"(T.wV[3]), "+v"(T.wA[0]), "+v"(T.wA[1]),
+                     "+v"(T.wA[2]), "+v"(T.wA[3]));
+        if (kk >= n0 && kk < n0 + gcnt)
+          pdyn_puts(PT, put, T, reinterpret_cast<char*>(img + par) + (size_t)(kk - n0) * node_vals * 8, lane);
+        stream_out(dst, img, nv, par, lane);
+      }
+    }
+    if (want_g) {   // 6 constraint values per time node, contiguous in g
+      double* go = g + w0.g_off;
+      if (lane < 6 * w0.cnt) go[lane] = gst[lane];
+      if (lane + 64 < 6 * w0.cnt) go[lane + 64] = gst[lane + 64];
+    }
+    w0 = w1; r0 = r1;
+    w1 = w2; r1 = r2;
+  }
+}
+
+// Optimised timings, pre-pass: one workgroup per (problem, ee) resolves the x-dependent part of every time node of
+// the dynamic and the rangeofmotion-<ee> grids -- phase and polynomial durations, active polynomials, local times,
+// current phase (PhaseDurations::SetVariables, ConvertPhaseToPolyDurations, Spline::GetSegmentID / GetLocalTime) -- into
+// DynLoc / RomRec records in the batch's scratch buffer.
+__global__ __launch_bounds__(64) void phase_locate_kernel(const LocWork* __restrict__ work, const double* __restrict__ x) {
+  __shared__ double s_ph[TWR_MAX_PHASES_DEV], s_md[kMaxPhasePolys], s_fd[kMaxPhasePolys];
   const LocWork lw = work[blockIdx.x];
   const char* blob = reinterpret_cast<const char*>(lw.blob);
   const DevStruct* H = reinterpret_cast<const DevStruct*>(blob);
   const PhaseTables* PT = tbl<PhaseTables>(blob, H->o_phase);
   const int lane = threadIdx.x, e = lw.ee;
   phase_poly_durations_wave(PT, blob, x + lw.x_off, e, s_ph, s_md, lane);
+  const PhasePoly* mp = tbl<PhasePoly>(blob, PT->o_mpoly[e]);
+  const int last_phase = PT->n_phases[e] - 1;
+  if (lw.dyn_loc) {
+    const PhasePoly* fp = tbl<PhasePoly>(blob, PT->o_fpoly[e]);
+    for (int q = lane; q < PT->n_fpoly[e]; q += 64) s_fd[q] = s_ph[fp[q].phase] / fp[q].n_in_phase;
+    __syncthreads();
+    const double* tg = tbl<double>(blob, PT->o_tdyn);
+    DynLoc* out = reinterpret_cast<DynLoc*>(lw.dyn_loc);
+    for (int k = lane; k < PT->k_dyn; k += 64) {
+      const double t = tg[k];
+      double tlm, tlf, tlp;
+      const int qm = locate_segment(s_md, PT->n_mpoly[e], t, tlm);
+      const int qf = locate_segment(s_fd, PT->n_fpoly[e], t, tlf);
+      const int cur = locate_segment(s_ph, PT->n_phases[e], t, tlp);
+      const PhasePoly pm = mp[qm], pf = fp[qf];
+      DynLoc o;
+      o.tm = tlm; o.Tm = s_md[qm];
+      o.tf = tlf; o.Tf = s_fd[qf];
+      o.xbase_m = pm.xbase; o.xbase_f = pf.xbase;
+      const uint64_t sm = slots_of(pm.cand), sf = slots_of(pf.cand);
+      o.slots_m[0] = (uint32_t)sm; o.slots_m[1] = (uint32_t)(sm >> 32);
+      o.slots_f[0] = (uint32_t)sf; o.slots_f[1] = (uint32_t)(sf >> 32);
+      o.qm = (uint8_t)qm; o.qf = (uint8_t)qf;
+      o.cur = (uint8_t)cur;
+      o.flags = (uint8_t)((cur == last_phase ? 1 : 0) | (meta_shared(pm.meta) ? 2 : 0));
+      o.nin_m = (uint8_t)pm.n_in_phase; o.pin_m = (uint8_t)pm.poly_in_phase;
+      o.nin_f = (uint8_t)pf.n_in_phase; o.pin_f = (uint8_t)pf.poly_in_phase;
+      out[(size_t)k * 4 + e] = o;
+    }
+  }
+  if (!lw.recs) return;
   const double* tg = tbl<double>(blob, PT->o_trom);
   const RomRec* base = tbl<RomRec>(blob, PT->o_rom_recs[e]);  // base-spline part (tb, iTb, q6) is x-independent
-  const PhasePoly* mp = tbl<PhasePoly>(blob, PT->o_mpoly[e]);
   RomRec* out = reinterpret_cast<RomRec*>(lw.recs);
   for (int k = lane; k < PT->k_rom; k += 64) {
     const double t = tg[k];
@@ -1823,7 +1849,7 @@ __global__ __launch_bounds__(64) void rom_locate_kernel(const LocWork* __restric
     r.slots[0] = (uint32_t)slots;
     r.slots[1] = (uint32_t)(slots >> 32);
     r.voff = 0;
-    r.pad[0] = (uint32_t)pm.base_all | ((uint32_t)cur << 16) | ((cur == PT->n_phases[e] - 1 ? 1u : 0u) << 24);
+    r.pad[0] = (uint32_t)pm.base_all | ((uint32_t)cur << 16) | ((cur == last_phase ? 1u : 0u) << 24);
     r.pad[1] = (uint32_t)pm.n_in_phase | ((uint32_t)pm.poly_in_phase << 8);
     out[k] = r;
   }
@@ -2375,9 +2401,9 @@ static int env_int(const char* name, int dflt) {
   return v > 0 ? v : dflt;
 }
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
-                       const NodeWork* node, int n_node, const PhaseWork* pdyn, int n_pdyn, const LocWork* ploc,
-                       int n_ploc, const RomPhaseWork* prom, int n_prom, const double* x, double* g, double* jac,
-                       int flags, hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */) {
+                       const NodeWork* node, int n_node, const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap,
+                       const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, const double* x, double* g,
+                       double* jac, int flags, hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */) {
   static const int dyn_bpc = env_int("TWR_DYN_BPC", 8), rom_bpc = env_int("TWR_ROM_BPC", 4);
 #ifdef TWR_ABLATE
   flags |= env_int("TWR_DEBUG_FLAGS", 0) & ~0xFF;
@@ -2411,18 +2437,26 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
     dim3 grid(n_dyn < res ? n_dyn : res);
     hipLaunchKernelGGL(dyn_kernel, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags);
   }
-  if (n_pdyn > 0) {  // optimised-timings problems
-    dim3 grid(n_pdyn);
-    switch (n_ee) {
-      case 1: hipLaunchKernelGGL(dyn_phase_kernel<1>, grid, block, 0, stream, pdyn, x, g, jac, flags); break;
-      case 2: hipLaunchKernelGGL(dyn_phase_kernel<2>, grid, block, 0, stream, pdyn, x, g, jac, flags); break;
-      case 3: hipLaunchKernelGGL(dyn_phase_kernel<3>, grid, block, 0, stream, pdyn, x, g, jac, flags); break;
-      case 4: hipLaunchKernelGGL(dyn_phase_kernel<4>, grid, block, 0, stream, pdyn, x, g, jac, flags); break;
+  // optimised-timings problems: the pre-pass (segment lookup -> records), then the persistent kernels
+  if (n_ploc > 0) hipLaunchKernelGGL(phase_locate_kernel, dim3(n_ploc), block, 0, stream, ploc, x);
+  if (n_pdyn > 0) {
+    // LDS per workgroup: the group image + the run's constraint values; residency follows from it
+    const size_t lds = sizeof(double) * (size_t)(((pdyn_img_cap + 3) & ~1) + 96);
+    static const int pdyn_bpc_env = env_int("TWR_PDYN_BPC", 0);
+    int bpc = (int)((size_t)(160 * 1024) / lds);
+    if (bpc > 8) bpc = 8;
+    if (bpc < 1) bpc = 1;
+    if (pdyn_bpc_env > 0) bpc = pdyn_bpc_env;
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dyn_phase_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
     }
+    const int res = bpc * n_cu;
+    hipLaunchKernelGGL(dyn_phase_kernel, dim3(n_pdyn < res ? n_pdyn : res), block, lds, stream, pdyn, n_pdyn, x, g, jac, flags,
+                       pdyn_img_cap);
   }
   if (ev) (void)hipEventRecord(ev[1], stream);
-  if (n_prom > 0) {  // pre-pass (segment lookup -> records), then the persistent kernel
-    hipLaunchKernelGGL(rom_locate_kernel, dim3(n_ploc), block, 0, stream, ploc, x);
+  if (n_prom > 0) {
     const int res = 8 * n_cu;
     hipLaunchKernelGGL(rom_phase_kernel, dim3(n_prom < res ? n_prom : res), block, 0, stream, prom, n_prom, x, g, jac, flags);
   }

@@ -852,6 +852,54 @@ void Structure::PackBlob() {
       pt.row_total = si->offset;
       pt.nnz_total = si->nnz_offset;
     }
+    // dynamic: byte offset of every ee value inside a time node's expanded rows, read off the CSR pattern of time
+    // node 0 (the rows hold all variables of every ee set, so the ee part of the layout is the same at every node)
+    if (dyn_set) {
+      if (pt.node_vals > 8191) throw std::runtime_error("optimised timings: a time node of the dynamic set has more than 8191 Jacobian values");
+      const int v0 = row_ptr[row_dyn];
+      auto find = [&](int row, int col) -> int {
+        const int32_t* b = col_idx.data() + row_ptr[row_dyn + row];
+        const int32_t* e2 = col_idx.data() + row_ptr[row_dyn + row + 1];
+        const int32_t* it = std::lower_bound(b, e2, col);
+        if (it == e2 || *it != col) throw std::runtime_error("dynamic pattern lacks an expected column");
+        return (int)(it - col_idx.data()) - v0;
+      };
+      for (int e = 0; e < n_ee; ++e) {
+        const uint16_t trash = (uint16_t)(8 * (8 + e));   // base-ang entry of row AX, rewritten after the tiles
+        std::vector<PhasePutM> pm(mpoly[e].size());
+        std::vector<PhasePutF> pf(fpoly[e].size());
+        for (size_t q = 0; q < mpoly[e].size(); ++q) {
+          std::memset(&pm[q], 0, sizeof(PhasePutM));
+          for (int c = 0; c < 12; ++c) {
+            const int d = c % 3, r1 = (d + 1) % 3, r2 = (d + 2) % 3;
+            pm[q].off[c][0] = pm[q].off[c][1] = trash;
+            if (mpoly[e][q].cand[c] == 0xFFFF) continue;
+            const int col = mpoly[e][q].xbase + (mpoly[e][q].cand[c] & 0xF);
+            pm[q].off[c][0] = (uint16_t)(8 * find(r1, col));
+            pm[q].off[c][1] = (uint16_t)(8 * find(r2, col));
+          }
+        }
+        for (size_t q = 0; q < fpoly[e].size(); ++q) {
+          std::memset(&pf[q], 0, sizeof(PhasePutF));
+          for (int c = 0; c < 12; ++c) {
+            const int d = c % 3, r1 = (d + 1) % 3, r2 = (d + 2) % 3;
+            pf[q].off[c][0] = pf[q].off[c][1] = pf[q].off[c][2] = trash;
+            if (fpoly[e][q].cand[c] == 0xFFFF) continue;
+            const int col = fpoly[e][q].xbase + (fpoly[e][q].cand[c] & 0xF);
+            pf[q].off[c][0] = (uint16_t)(8 * find(r1, col));
+            pf[q].off[c][1] = (uint16_t)(8 * find(r2, col));
+            pf[q].off[c][2] = (uint16_t)(8 * find(3 + d, col));
+          }
+        }
+        pt.o_mput[e] = put(pm.data(), pm.size() * sizeof(PhasePutM));
+        pt.o_fput[e] = put(pf.data(), pf.size() * sizeof(PhasePutF));
+        pt.ee[e].ns = schedule.n_phases[e] - 1;
+        for (int r = 0; r < 3; ++r) {
+          pt.ee[e].dur_ang[r] = 8 * find(r, off_schedule[e]);
+          pt.ee[e].dur_lin[r] = 8 * find(3 + r, off_schedule[e]);
+        }
+      }
+    }
     // the pattern builder and these closed forms must agree
     if (dyn_set && dyn_set->nnz != pt.node_vals * (int)grid_dyn.size()) throw std::runtime_error("dynamic row lengths inconsistent");
     for (int e = 0; e < n_ee && have_rom; ++e)
