@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstddef>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -372,10 +373,8 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     std::vector<twr::NodeWork> node;
     std::vector<twr::PDynWork> pdyn;
     std::vector<int> pdyn_first;   // first dynamic run of every optimised-timings problem (+ end)
-    // dyn_phase_kernel streams a run out in groups of time nodes whose expanded rows fit its LDS image: TWR_PDYN_LDS_KB
-    // per workgroup (image + 96 constraint values), TWR_PDYN_NODES time nodes per run (experiments)
-    auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e && atoi(e) > 0 ? atoi(e) : dflt; };
-    const int pdyn_cap = env_int("TWR_PDYN_LDS_KB", 40) * 128 - 98, pdyn_nodes = std::min(16, env_int("TWR_PDYN_NODES", 16));
+    // dyn_phase_kernel: a pass = the time nodes whose expanded rows fit the LDS image (four at sixteen lanes each,
+    // fewer when a node has more than 5120 values: the image then takes the whole 160 KB of a CU)
     std::vector<twr::LocWork> ploc;
     std::vector<twr::RomPhaseWork> prom;
     size_t prec_bytes = 0;  // offsets into the scratch buffer are stored first and rebased after hipMalloc
@@ -449,22 +448,31 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
         if (have_dyn) {
           const twr::SetInfo* dset = S.FindSet("dynamic");
           const int nv = S.phase_tables.node_vals;
-          const int group = std::max(1, std::min(pdyn_nodes, pdyn_cap / nv));
-          const int run = std::max(group, pdyn_nodes / group * group);   // a multiple of the group
-          b->pdyn_img_cap = std::max(b->pdyn_img_cap, group * nv);
+          const int run = std::max(1, std::min(4, (160 * 128) / nv));
+          b->pdyn_img_cap = std::max(b->pdyn_img_cap, run * nv);
           pdyn_first.push_back((int)pdyn.size());
           for (int k0 = 0; k0 < Kd; k0 += run) {
             twr::PDynWork pw;
             std::memset(&pw, 0, sizeof(pw));
-            pw.blob = blob;
+            const twr::PhaseTables& pt = S.phase_tables;
+            const uint64_t pt_addr = blob + reinterpret_cast<const twr::DevStruct*>(S.blob.data())->o_phase;
+            pw.hdr = blob;
             pw.loc = loc_off + sizeof(twr::DynLoc) * 4 * (size_t)k0;
+            pw.shared = blob + pt.o_dyn_shared + sizeof(twr::DynShared) * (size_t)k0;
+            pw.mput = blob + pt.o_mput;
+            pw.fput = blob + pt.o_fput;
+            pw.ee = pt_addr + offsetof(twr::PhaseTables, ee);
             pw.x_off = b->x_off[p];
             pw.g_off = b->g_off[p] + dset->offset + 6 * k0;
             pw.j_off = b->j_off[p] + dset->nnz_offset + (int64_t)k0 * nv;
-            pw.k0 = k0;
             pw.cnt = std::min(run, Kd - k0);
             pw.node_vals = nv;
-            pw.group = group;
+            pw.off_lin = S.off_base_lin;
+            pw.off_ang = S.off_base_ang;
+            pw.n_ee = S.n_ee;
+            pw.n_mput = pt.n_mput;
+            pw.n_fput = pt.n_fput;
+            for (int q = 0; q < 5; ++q) pw.row_off[q] = pt.dyn_row_off[q];
             pdyn.push_back(pw);
           }
         }

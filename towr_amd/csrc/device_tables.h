@@ -141,13 +141,11 @@ static_assert(sizeof(PhasePoly) == 64, "PhasePoly layout");
 // record per (ee, polynomial), read off the CSR pattern like DynPut.  A candidate that is not a variable points at
 // entry 8 + ee of row AX (a base-ang value the same wave writes afterwards).
 struct PhasePutM {
-  uint16_t off[12][2];   // [f]x J_p : rows (d+1)%3 and (d+2)%3 of the angular block
-  uint16_t pad[8];
+  uint16_t off[4][8];    // [j][2 D + r]  [f]x J_p of candidate (j, D): rows (D+1)%3 and (D+2)%3 of the angular block
 };
 static_assert(sizeof(PhasePutM) == 64, "PhasePutM layout");
 struct PhasePutF {
-  uint16_t off[12][3];   // {[r]x J_f ; -J_f}: the same two angular rows, then linear row d
-  uint16_t pad[12];
+  uint16_t off[4][12];   // [j][3 D + r]  {[r]x J_f ; -J_f}: the same two angular rows, then linear row D
 };
 static_assert(sizeof(PhasePutF) == 96, "PhasePutF layout");
 struct PhaseEe {         // per end-effector: its duration columns inside a time node of "dynamic" (byte offsets)
@@ -162,9 +160,9 @@ struct DynLoc {
   double tm, Tm, tf, Tf;         // local time in / duration of the active ee-motion and ee-force polynomials
   int32_t xbase_m, xbase_f;      // first x index of their variables
   uint32_t slots_m[2], slots_f[2];  // 12 x 4 bit: slot of candidate c, 0xF = absent
-  uint8_t qm, qf;                // the polynomials (PhasePutM / PhasePutF index)
+  uint16_t im, jf;               // the polynomials: index into the structure's PhasePutM / PhasePutF arrays (all ee)
   uint8_t cur, flags;            // current phase; bit 0: it is the last one (not a variable), bit 1: stance ee-motion polynomial
-  uint8_t nin_m, pin_m, nin_f, pin_f;  // polynomials in the phase / before this one in the phase
+  uint8_t np_m, np_f;            // polynomials in the phase | polynomials before this one in the phase << 4
 };
 static_assert(sizeof(DynLoc) == 64, "DynLoc layout");
 
@@ -186,8 +184,13 @@ struct PhaseTables {
   uint32_t o_dyn_shared, o_rom_recs[kMaxEE];  // host records (their base-spline part stays x-independent)
   int32_t pad_;
   double t_total[kMaxEE];      // PhaseDurations::t_total_
-  uint32_t o_mput[kMaxEE], o_fput[kMaxEE];  // PhasePutM[n_mpoly] / PhasePutF[n_fpoly]
+  uint32_t o_mput, o_fput;     // PhasePutM / PhasePutF records of all ee, ee after ee, then 4 dummy records (ee index
+                               // e without an end-effector: every offset = its trash entry)
+  int32_t n_mput, n_fput;      // real records
+  int32_t mput_base[kMaxEE], fput_base[kMaxEE];  // index of the ee's first record
   PhaseEe ee[kMaxEE];
+  uint32_t dyn_row_off[5];     // byte offsets of rows AY, AZ, LX, LY, LZ inside a time node of "dynamic" (AX = 0)
+  int32_t pad2_[3];
 };
 constexpr int kMaxPhasePolys = 64;  // polynomials per ee spline with optimised timings (LDS table size)
 
@@ -293,17 +296,22 @@ struct NodeWork {         // all terrain-* and force-* sets of one problem
 };
 static_assert(sizeof(NodeWork) == 32, "NodeWork layout");
 
-struct PDynWork {         // optimised timings: cnt <= 16 time nodes of "dynamic" from k0
-  uint64_t blob;
-  uint64_t loc;           // DynLoc[4 * k0 ..] of this problem (scratch, written by the pre-pass)
+struct PDynWork {         // optimised timings: one pass = cnt <= 4 time nodes of "dynamic".  Everything the kernel
+                          // needs is an absolute address or a value here: no dependent table lookups per pass.
+  uint64_t hdr;           // DevStruct (mass, gravity, inertia)
+  uint64_t loc;           // DynLoc[4 k0 ..] of this problem (scratch, written by the pre-pass)
+  uint64_t shared;        // DynShared[k0 ..]
+  uint64_t mput, fput;    // PhasePutM / PhasePutF arrays of the structure
+  uint64_t ee;            // PhaseEe[4]
   int64_t x_off;          // problem's x
-  int64_t g_off, j_off;   // first constraint value (row 6 k0 of the set) / first Jacobian value of the run
-  int32_t k0, cnt;
-  int32_t node_vals;      // expanded values per time node
-  int32_t group;          // time nodes per LDS image (the run is streamed out group by group)
-  int64_t pad;
+  int64_t g_off, j_off;   // first constraint value (row 6 k0 of the set) / first Jacobian value of the pass
+  int32_t cnt, node_vals; // time nodes; expanded values per time node
+  int32_t off_lin, off_ang, n_ee;
+  uint32_t row_off[5];    // PhaseTables::dyn_row_off
+  int32_t n_mput, n_fput; // records of real polynomials; four dummy records (one per ee index) follow them
+  int32_t pad[2];
 };
-static_assert(sizeof(PDynWork) == 64, "PDynWork layout");
+static_assert(sizeof(PDynWork) == 128, "PDynWork layout");
 
 // Optimised timings, rangeofmotion-<ee>: a light pre-pass (rom_locate_kernel) turns the x-dependent segment
 // lookup into RomRec records in a scratch buffer, so that the persistent kernel sees the same two-step

@@ -1377,126 +1377,246 @@ TWR_DEV void phase_poly_durations_wave(const PhaseTables* PT, const char* blob, 
 }
 
 // ---- dynamic with optimised timings (dyn_phase_kernel)
-// Persistent single-wave workgroups, software pipelined like rom_kernel; a work item is a run of <= 16 time nodes, four
-// lanes per node.  What depends on x in the index work -- the active polynomials, local times and current phase of
-// every (time node, ee) -- comes from the pre-pass (phase_locate_kernel -> DynLoc records); everything else is a constant
-// of the structure because the rows hold ALL variables of every ee set: the byte offset of every Jacobian value inside
-// its time node is read off the CSR pattern on the host (PhasePutM / PhasePutF per polynomial, PhaseEe for the duration
-// columns).  A run is far larger than LDS (C3: 1280 values = 10 KB per node, ~75 % explicit zeros), so it goes out in
-// GROUPS of `group` nodes: the wave clears an LDS image of the group's expanded rows, the quads of those nodes store
-// their values at their final positions (the math of the whole run was done once, before the first group), and the
-// wave streams the image to HBM with 16-byte coalesced stores: every byte of the Jacobian is written exactly once.
-struct PDynRec {       // per lane: what depends on the work item only
-  DynShared sh;
-  DynLoc lc;
+// Persistent single-wave workgroups, software pipelined like rom_kernel.  The rows of "dynamic" now hold ALL variables
+// of every ee set (C3: 1280 values = 10 KB per time node, ~75 % explicit zeros), so a work item is a "pass" of only FOUR
+// consecutive time nodes (40 KB of Jacobian values) and a time node gets SIXTEEN lanes:
+//   lane = 16 n + 4 e + j:   n = time node of the pass, e = end-effector, j = node value (p0, v0, p1, v1)
+// Lane (n, e, j) loads the three dimensions of node value j of the base splines and of ee e's active polynomials and owns
+// their Jacobian columns.  Spline points are sums over j (DPP quad sums), force / torque totals are sums over e (DPP row
+// rotations by 4 and 8 lanes); the SRBD algebra is evaluated by every lane (the same instructions for all of them);
+// lanes e < 3 produce Euler dimension e of the base-ang block, lanes e = 3 the base-lin block, the duration columns of
+// ee e are spread over its four lanes.  What depends on x in the index work -- active polynomials, local times, current
+// phase of every (time node, ee) -- comes from the pre-pass (phase_locate_kernel -> DynLoc); everything else is a
+// constant of the structure: the byte offset of every value inside its time node is read off the CSR pattern on the
+// host (PhasePutM / PhasePutF per polynomial, PhaseEe for the duration columns).  Per pass the wave clears the LDS image
+// of the four expanded nodes, every lane stores its ~25 values at their final positions, and the wave streams the image
+// to HBM with 16-byte coalesced stores: every byte of the Jacobian is written exactly once.
+struct PDynRec {       // per lane: what depends on the work item only -- DynShared {tb, iTb, q6} and the DynLoc record,
+                       // kept as whole dwords (unpacked with shifts where used)
+  double tb, iTb;      // base spline: local time in the active polynomial, 1 / duration
+  int32_t q6;
+  double tm, Tm, tf, Tf;
+  int32_t xbase_m, xbase_f;
+  uint32_t slots_m[2], slots_f[2];
+  uint32_t imjf;       // im | jf << 16
+  uint32_t misc;       // cur | flags << 8 | np_m << 16 | np_f << 24
 };
+TWR_DEV double pdyn_f64(float lo, float hi) { return __hiloint2double((int)__float_as_uint(hi), (int)__float_as_uint(lo)); }
 struct PDynIn {        // per lane: what depends on the record (second stage of the pipeline)
-  double bl[3], ba[3], m[12], f[12];   // ONE node value (role: p0, v0, p1, v1) of base-lin / base-ang; ee candidates
-  PhasePutM pm;
-  PhasePutF pf;
-  PhaseEe pe;
+  double bl[3], ba[3], m[3], f[3];   // node value j (3 dimensions) of base-lin / base-ang and of ee e's polynomials
 };
-struct PDynOut {       // per lane: what the put phase needs
-  double wP[4], wV[4], wA[4];
-  double A[3], B[3], C[3];             // roles 0..2: base-ang factors of Euler dimension `role`
-  double F[3], mass;                   // role 3: base-lin block
-  double wm[4], wf[4], f[3], rv[3];
-  double ap[3], ac[3], lp[3], lc[3];   // duration columns: angular rows (previous phases / current phase), linear rows
-  int n_dur, cur;                      // duration columns that are non-zero for this lane: p < n_dur; p == cur takes `ac/lc`
+struct PDynPut {       // per lane: where its values go (loaded at the top of the pass, used at its end), whole dwords
+  uint32_t pm[4], pf[6];             // 16-bit put offsets of candidates (j, D): index 2 D + r resp. 3 D + r
+  int32_t ns, dur_ang[3], dur_lin[3];
+  TWR_DEV uint32_t m(int q) const { return (pm[q >> 1] >> (16 * (q & 1))) & 0xFFFFu; }
+  TWR_DEV uint32_t f(int q) const { return (pf[q >> 1] >> (16 * (q & 1))) & 0xFFFFu; }
 };
-TWR_DEV uint64_t pack_slots(const uint32_t s[2]) { return ((uint64_t)s[1] << 32) | s[0]; }
-TWR_DEV PDynRec pdyn_load_rec(const PDynWork& w, const TWR_CONST PhaseTables* PT, int n_ee, int lane) {
-  PDynRec r;
-  const int kk = min(lane >> 2, w.cnt - 1), e = min(lane & 3, n_ee - 1);   // (roles >= n_ee read ee n_ee-1 and are neutralised)
-  r.sh = gptr<DynShared>(w.blob + PT->o_dyn_shared)[w.k0 + kk];
-  r.lc = gptr<DynLoc>(w.loc)[kk * 4 + e];
-  return r;
+TWR_DEV double sel4(int i, const double v[4]) { return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3])); }
+// sum over the four quads of a 16-lane row (lanes l, l-4, l-8, l-12 mod 16): DPP row_ror
+TWR_DEV double row_perm_ror4(double v) { return quad_perm<0x124>(v); }
+TWR_DEV double row_perm_ror8(double v) { return quad_perm<0x128>(v); }
+TWR_DEV double row4_sum(double v) {
+  v += row_perm_ror4(v);
+  v += row_perm_ror8(v);
+  return v;
 }
-TWR_DEV void pdyn_load_in(const PDynWork& w, const TWR_CONST PhaseTables* PT, int n_ee, const PDynRec& r,
-                          const double* __restrict__ x, int lane, PDynIn& in) {
-  const double* xp = x + w.x_off;
-  const int role = lane & 3, e = min(role, n_ee - 1);
-  const double* xl = xp + PT->off_lin + r.sh.q6 + 3 * role;
-  const double* xa = xp + PT->off_ang + r.sh.q6 + 3 * role;
+// --- asynchronous loads.  The software pipeline of dyn_phase_kernel is scheduled by hand: its vector loads are issued
+// as asm into AGPRs (free at one wave per SIMD) and waited for with explicit counted s_waitcnt, always inside the
+// iteration that issued them.  Left to the compiler the prefetched values are shuffled between register files right
+// after the loads are issued (which waits for them on the spot), and every wait behind the copy-out drains its stores.
+// The compiler sees none of these loads; a value is used only through the wait that follows its load (`+a` operands),
+// and the compiler's own waits (scalar loads, LDS) are unaffected.
+typedef float twr_v4f __attribute__((ext_vector_type(4)));
+TWR_DEV void aload(double& d, const void* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=a"(d) : "v"(p) : "memory"); }
+TWR_DEV void aload(twr_v4f& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(d) : "v"(p) : "memory"); }
+TWR_DEV void aload(uint32_t& d, const void* p) { asm volatile("global_load_dword %0, %1, off" : "=a"(d) : "v"(p) : "memory"); }
+// s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt / lgkmcnt fields left at "no wait")
+constexpr int vmcnt_imm(int n) { return (n & 0xF) | (0x7 << 4) | (0xF << 8) | ((n >> 4) << 14); }
+struct ARec {          // record of a pass: DynShared {tb, iTb}, q6, DynLoc                 (6 loads)
+  twr_v4f sh;
+  uint32_t q6;
+  twr_v4f lc[4];
+};
+struct AIn {           // x values of a pass                                               (12 loads)
+  double v[12];
+};
+struct APut {          // put offsets of a pass: PhasePutM row j, PhasePutF row j, PhaseEe  (6 loads)
+  twr_v4f pm;
+  double pf[3];
+  twr_v4f pe[2];
+};
+TWR_DEV void pdyn_issue_rec(uint64_t shared, uint64_t loc, int cnt, int n_ee, int lane, ARec& a) {
+  const int n = min(lane >> 4, cnt - 1), e = min((lane >> 2) & 3, n_ee - 1);   // (ee >= n_ee read ee n_ee-1 and are neutralised)
+  const char* sh = reinterpret_cast<const char*>(shared) + sizeof(DynShared) * (size_t)n;
+  const char* lc = reinterpret_cast<const char*>(loc) + sizeof(DynLoc) * (size_t)(n * 4 + e);
+  aload(a.sh, sh);
+  aload(a.q6, sh + offsetof(DynShared, q6));
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    in.bl[i] = xl[i];
-    in.ba[i] = xa[i];
-  }
-  gather12(xp, r.lc.xbase_m, pack_slots(r.lc.slots_m), in.m);
-  gather12(xp, r.lc.xbase_f, pack_slots(r.lc.slots_f), in.f);
-  in.pm = gptr<PhasePutM>(w.blob + PT->o_mput[e])[r.lc.qm];
-  in.pf = gptr<PhasePutF>(w.blob + PT->o_fput[e])[r.lc.qf];
-  in.pe = gptr<PhaseEe>(w.blob + cptr<DevStruct>(w.blob)->o_phase + (uint32_t)offsetof(PhaseTables, ee))[e];
+  for (int q = 0; q < 4; ++q) aload(a.lc[q], lc + 16 * q);
 }
-// The math of one run: splines, quad exchanges, SRBD violation, the factors of every Jacobian block.
-TWR_DEV void pdyn_math(const PDynWork& w, int n_ee, const PDynRec& r, const PDynIn& in, double* __restrict__ gst, int lane,
-                       bool want_g, PDynOut& T) {
-  const int kk = lane >> 2, role = lane & 3;
-  const bool has_ee = role < n_ee;
-  hermite_all(r.sh.tb, r.sh.iTb, T.wP, T.wV, T.wA);
+template <int N>
+TWR_DEV void pdyn_wait_rec(ARec& a, PDynRec& r) {
+  asm volatile("s_waitcnt %6" : "+a"(a.sh), "+a"(a.q6), "+a"(a.lc[0]), "+a"(a.lc[1]), "+a"(a.lc[2]), "+a"(a.lc[3]) : "n"(vmcnt_imm(N)));
+  static_assert(offsetof(DynLoc, xbase_m) == 32 && offsetof(DynLoc, slots_m) == 40 && offsetof(DynLoc, slots_f) == 48 &&
+                offsetof(DynLoc, im) == 56 && offsetof(DynLoc, cur) == 60, "DynLoc dwords");
+  r.tb = pdyn_f64(a.sh.x, a.sh.y);
+  r.iTb = pdyn_f64(a.sh.z, a.sh.w);
+  r.q6 = (int32_t)a.q6;
+  r.tm = pdyn_f64(a.lc[0].x, a.lc[0].y);
+  r.Tm = pdyn_f64(a.lc[0].z, a.lc[0].w);
+  r.tf = pdyn_f64(a.lc[1].x, a.lc[1].y);
+  r.Tf = pdyn_f64(a.lc[1].z, a.lc[1].w);
+  r.xbase_m = (int32_t)__float_as_uint(a.lc[2].x);
+  r.xbase_f = (int32_t)__float_as_uint(a.lc[2].y);
+  r.slots_m[0] = __float_as_uint(a.lc[2].z);
+  r.slots_m[1] = __float_as_uint(a.lc[2].w);
+  r.slots_f[0] = __float_as_uint(a.lc[3].x);
+  r.slots_f[1] = __float_as_uint(a.lc[3].y);
+  r.imjf = __float_as_uint(a.lc[3].z);
+  r.misc = __float_as_uint(a.lc[3].w);
+}
+TWR_DEV void pdyn_issue_in(const PDynWork& w, const PDynRec& r, const double* __restrict__ x, int lane, AIn& a) {
+  const double* xp = x + w.x_off;
+  const int j = lane & 3;
+  const double* xl = xp + w.off_lin + r.q6 + 3 * j;
+  const double* xa = xp + w.off_ang + r.q6 + 3 * j;
+  const uint32_t sm = (uint32_t)((((uint64_t)r.slots_m[1] << 32) | r.slots_m[0]) >> (12 * j)) & 0xFFFu;
+  const uint32_t sf = (uint32_t)((((uint64_t)r.slots_f[1] << 32) | r.slots_f[0]) >> (12 * j)) & 0xFFFu;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    aload(a.v[d], xl + d);
+    aload(a.v[3 + d], xa + d);
+    const uint32_t am = (sm >> (4 * d)) & 0xFu, af = (sf >> (4 * d)) & 0xFu;   // absent candidates read slot 0, weight 0
+    aload(a.v[6 + d], xp + r.xbase_m + (am != 0xFu ? am : 0u));
+    aload(a.v[9 + d], xp + r.xbase_f + (af != 0xFu ? af : 0u));
+  }
+}
+template <int N>
+TWR_DEV void pdyn_wait_in(AIn& a, PDynIn& in) {
+  asm volatile("s_waitcnt %12" : "+a"(a.v[0]), "+a"(a.v[1]), "+a"(a.v[2]), "+a"(a.v[3]), "+a"(a.v[4]), "+a"(a.v[5]), "+a"(a.v[6]),
+               "+a"(a.v[7]), "+a"(a.v[8]), "+a"(a.v[9]), "+a"(a.v[10]), "+a"(a.v[11]) : "n"(vmcnt_imm(N)));
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    in.bl[d] = a.v[d];
+    in.ba[d] = a.v[3 + d];
+    in.m[d] = a.v[6 + d];
+    in.f[d] = a.v[9 + d];
+  }
+}
+TWR_DEV void pdyn_issue_put(const PDynWork& w, const PDynRec& r, int lane, APut& a) {
+  const int ee = (lane >> 2) & 3, j = lane & 3;
+  // an end-effector the robot does not have takes the structure's dummy records (every offset = its trash entry, no
+  // duration columns): the select is on the index, nothing is done to the loaded values
+  const bool has_ee = ee < w.n_ee;
+  const uint32_t im = has_ee ? (r.imjf & 0xFFFFu) : (uint32_t)(w.n_mput + ee), jf = has_ee ? (r.imjf >> 16) : (uint32_t)(w.n_fput + ee);
+  const char* pm = reinterpret_cast<const char*>(w.mput) + sizeof(PhasePutM) * (size_t)im + 16 * j;
+  const char* pf = reinterpret_cast<const char*>(w.fput) + sizeof(PhasePutF) * (size_t)jf + 24 * j;
+  const char* pe = reinterpret_cast<const char*>(w.ee) + sizeof(PhaseEe) * (size_t)ee;
+  aload(a.pm, pm);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) aload(a.pf[q], pf + 8 * q);
+  aload(a.pe[0], pe);
+  aload(a.pe[1], pe + 16);
+}
+template <int N>
+TWR_DEV void pdyn_wait_put(APut& a, PDynPut& pu) {
+  asm volatile("s_waitcnt %6" : "+a"(a.pm), "+a"(a.pf[0]), "+a"(a.pf[1]), "+a"(a.pf[2]), "+a"(a.pe[0]), "+a"(a.pe[1]) : "n"(vmcnt_imm(N)));
+  pu.pm[0] = __float_as_uint(a.pm.x); pu.pm[1] = __float_as_uint(a.pm.y); pu.pm[2] = __float_as_uint(a.pm.z); pu.pm[3] = __float_as_uint(a.pm.w);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    pu.pf[2 * q] = (uint32_t)__double2loint(a.pf[q]);
+    pu.pf[2 * q + 1] = (uint32_t)__double2hiint(a.pf[q]);
+  }
+  pu.ns = (int32_t)__float_as_uint(a.pe[0].x);
+  pu.dur_ang[0] = (int32_t)__float_as_uint(a.pe[0].y); pu.dur_ang[1] = (int32_t)__float_as_uint(a.pe[0].z); pu.dur_ang[2] = (int32_t)__float_as_uint(a.pe[0].w);
+  pu.dur_lin[0] = (int32_t)__float_as_uint(a.pe[1].x); pu.dur_lin[1] = (int32_t)__float_as_uint(a.pe[1].y); pu.dur_lin[2] = (int32_t)__float_as_uint(a.pe[1].z);
+}
+// One pass, first half: the math of lane (n, e, j); its share of the constraint values goes straight to global memory.
+struct PDynVals {      // what the put half needs
+  double wPj, wVj, wAj, wmj, wfj, f[3], rv[3];
+  double F[3], mass;                     // e = 3: base-lin block
+  double A[3], B[3], C[3];               // e < 3: base-ang factors of Euler dimension e
+  double ap[3], ac[3], fprev[3], fcur[3];   // duration columns: angular rows (previous phases / current phase), forces
+};
+TWR_DEV void pdyn_math(const PDynWork& w, const PDynRec& r, const PDynIn& in, double* __restrict__ g, int lane, bool want_g,
+                       PDynVals& V) {
+  const int n = lane >> 4, ee = (lane >> 2) & 3, j = lane & 3;
+  const bool live = n < w.cnt, has_ee = ee < w.n_ee;
+  double (&f)[3] = V.f, (&rv)[3] = V.rv, (&F)[3] = V.F, (&fprev)[3] = V.fprev, (&fcur)[3] = V.fcur;
+  double &wPj = V.wPj, &wVj = V.wVj, &wAj = V.wAj, &wmj = V.wmj, &wfj = V.wfj;
+  {
+    double wP[4], wV[4], wA[4];
+    hermite_all(r.tb, r.iTb, wP, wV, wA);
+    wPj = sel4(j, wP); wVj = sel4(j, wV); wAj = sel4(j, wA);
+  }
+  // base spline points (Spline::GetPoint in basis form): this lane's node value times its weight, summed over j
   double c[3], e[3], cdd[3], ed[3], edd[3];
-  {  // this lane's node value times its weights, summed over the quad (Spline::GetPoint in basis form)
-    const double qP = role == 3 ? T.wP[3] : sel3(role, T.wP[0], T.wP[1], T.wP[2]);
-    const double qV = role == 3 ? T.wV[3] : sel3(role, T.wV[0], T.wV[1], T.wV[2]);
-    const double qA = role == 3 ? T.wA[3] : sel3(role, T.wA[0], T.wA[1], T.wA[2]);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    c[d] = quad_sum(wPj * in.bl[d]);
+    cdd[d] = quad_sum(wAj * in.bl[d]);
+    e[d] = quad_sum(wPj * in.ba[d]);
+    ed[d] = quad_sum(wVj * in.ba[d]);
+    edd[d] = quad_sum(wAj * in.ba[d]);
+  }
+  // --- end-effector e: positions, forces, and the duration columns (PhaseSpline::GetJacobianOfPosWrtDurations,
+  // phase_spline.cc:67-93, phase_durations.cc:126-154, polynomial.cc:236-257: dx/dT_poly is linear in the node values,
+  // so it is a sum over j like the point itself)
+  const uint32_t sm = (uint32_t)((((uint64_t)r.slots_m[1] << 32) | r.slots_m[0]) >> (12 * j)) & 0xFFFu;
+  const uint32_t sf = (uint32_t)((((uint64_t)r.slots_f[1] << 32) | r.slots_f[0]) >> (12 * j)) & 0xFFFu;
+  const bool shared = (r.misc >> 9) & 1, in_last = (r.misc >> 8) & 1;
+  double xprev[3], xcur[3];
+  auto ee_spline = [&](double t, double T, uint32_t slots, const double v[3], bool fold, double inner, double prevp, double& wj,
+                       double pt[3], double prev[3], double cur[3]) {
+    const double iT = 1.0 / T, iT2 = iT * iT, t2 = t * t, t3 = t2 * t;
+    double wp[4], wv[4], wa[4], ct[4];
+    hermite_all(t, iT, wp, wv, wa);
+    // d pos / d T_poly = ct . (x0, v0, x1, v1)   (polynomial.cc:236-257, collected by node value)
+    ct[0] = 6.0 * t2 * iT2 * iT - 6.0 * t3 * iT2 * iT2;
+    ct[1] = 2.0 * t2 * iT2 - 2.0 * t3 * iT2 * iT;
+    ct[2] = -ct[0];
+    ct[3] = t2 * iT2 - 2.0 * t3 * iT2 * iT;
+    if (fold) {   // stance ee-motion polynomial: p1 is the same variable as p0
+      wp[0] += wp[2];
+      wv[0] += wv[2];
+      ct[0] += ct[2];
+    }
+    wj = sel4(j, wp);
+    const double wvj = sel4(j, wv), ctj = sel4(j, ct);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      c[d] = quad_sum(qP * in.bl[d]);
-      cdd[d] = quad_sum(qA * in.bl[d]);
-      e[d] = quad_sum(qP * in.ba[d]);
-      ed[d] = quad_sum(qV * in.ba[d]);
-      edd[d] = quad_sum(qA * in.ba[d]);
+      const double nv = ((slots >> (4 * d)) & 0xFu) != 0xFu ? v[d] : 0.0;
+      pt[d] = quad_sum(wj * nv);
+      const double vel = quad_sum(wvj * nv), dxdT = quad_sum(ctj * nv);
+      const double dph = inner * (dxdT - prevp * vel);
+      cur[d] = dph;
+      prev[d] = -vel - (in_last ? dph : 0.0);
     }
-  }
-  // --- this lane's end-effector: weights and spline points
-  const uint64_t sm = pack_slots(r.lc.slots_m), sf = pack_slots(r.lc.slots_f);
-  const bool shared = (r.lc.flags >> 1) & 1;
-  double p[3];
-  ee_point(sm, shared, r.lc.tm, 1.0 / r.lc.Tm, in.m, T.wm, p);
-  ee_point(sf, false, r.lc.tf, 1.0 / r.lc.Tf, in.f, T.wf, T.f);
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    T.rv[d] = c[d] - p[d];
-    if (!has_ee) T.f[d] = 0.0;
-  }
-  // force and torque sums over the end-effectors (single_rigid_body_dynamics.cc:81-88)
-  double t3[3], tau[3];
-  cross3(T.f, T.rv, t3);
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    T.F[d] = quad_sum(T.f[d]);
-    tau[d] = quad_sum(t3[d]);
-  }
-  // --- duration columns: {[r]x J_f + [f]x J_p ; -J_f} with J = GetJacobianOfPosWrtDurations of the ee-force /
-  // ee-motion PhaseSpline (dynamic_constraint.cc:107-113, single_rigid_body_dynamics.cc:167-192)
+  };
   {
-    double nv[4][3], fprev[3], fcur[3], xprev[3], xcur[3], t1[3], t2[3];
-    const bool in_last = r.lc.flags & 1;
-    node_values(sf, false, in.f, nv);
-    duration_columns(nv, r.lc.tf, r.lc.Tf, 1.0 / (double)r.lc.nin_f, (double)r.lc.pin_f, in_last, fprev, fcur);
-    node_values(sm, shared, in.m, nv);
-    duration_columns(nv, r.lc.tm, r.lc.Tm, 1.0 / (double)r.lc.nin_m, (double)r.lc.pin_m, in_last, xprev, xcur);
-    cross3(T.rv, fprev, t1);
-    cross3(T.f, xprev, t2);
+    double p[3];
+    ee_spline(r.tm, r.Tm, sm, in.m, shared, 1.0 / (double)((r.misc >> 16) & 0xF), (double)((r.misc >> 20) & 0xF), wmj, p, xprev, xcur);
+    ee_spline(r.tf, r.Tf, sf, in.f, false, 1.0 / (double)((r.misc >> 24) & 0xF), (double)(r.misc >> 28), wfj, f, fprev, fcur);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      T.ap[i] = t1[i] + t2[i];
-      T.lp[i] = -fprev[i];
+    for (int d = 0; d < 3; ++d) {
+      rv[d] = c[d] - p[d];
+      if (!has_ee) f[d] = 0.0;
     }
-    cross3(T.rv, fcur, t1);
-    cross3(T.f, xcur, t2);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      T.ac[i] = t1[i] + t2[i];
-      T.lc[i] = -fcur[i];
-    }
-    T.cur = r.lc.cur;
-    T.n_dur = has_ee ? min((int)r.lc.cur + 1, in.pe.ns) : 0;   // columns after the current phase stay zero
   }
-  // --- rotation: lanes 0..2 of the quad evaluate one sincos each and broadcast it
+  // force and torque sums over the end-effectors (single_rigid_body_dynamics.cc:81-88): over the four quads of the row
+  double tau[3];
+  {
+    double t3[3];
+    cross3(f, rv, t3);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      F[d] = row4_sum(f[d]);
+      tau[d] = row4_sum(t3[d]);
+    }
+  }
+  // --- rotation: lanes j = 0..2 of a quad evaluate one sincos each and broadcast it
   double my_s, my_c;
-  sincos_fast(sel3(role, e[0], e[1], e[2]), &my_s, &my_c);
+  sincos_fast(sel3(j, e[0], e[1], e[2]), &my_s, &my_c);
   const double sx = quad_perm<0x00>(my_s), cx = quad_perm<0x00>(my_c);
   const double sy = quad_perm<0x55>(my_s), cy = quad_perm<0x55>(my_c);
   const double sz = quad_perm<0xAA>(my_s), cz = quad_perm<0xAA>(my_c);
@@ -1517,7 +1637,7 @@ TWR_DEV void pdyn_math(const PDynWork& w, int n_ee, const PDynRec& r, const PDyn
   }
   om[2] += zd;
   omd[2] += edd[2];
-  const TWR_CONST DevStruct* H = cptr<DevStruct>(w.blob);  // uniform per work item: scalar loads
+  const TWR_CONST DevStruct* H = cptr<DevStruct>(w.hdr);  // uniform per work item: scalar loads
   double Iw6[6];  // I_w = R I_b R^T (single_rigid_body_dynamics.cc:91), symmetric: (00,01,02,11,12,22)
   {
     double Ib[6];
@@ -1541,26 +1661,34 @@ TWR_DEV void pdyn_math(const PDynWork& w, int n_ee, const PDynRec& r, const PDyn
   symmul(Iw6, omd, Iw_wd);
   symmul(Iw6, om, Iw_w);
   const double m = H->mass;
-  T.mass = m;
-  if (role == 3) {
-    if (want_g && kk < w.cnt) {  // GetDynamicViolation, single_rigid_body_dynamics.cc:76-101
-      double wxIw[3];
-      cross3(om, Iw_w, wxIw);
-      double* go = gst + 6 * kk;  // staged in LDS, written out coalesced
+  if (want_g && live && ee < 2 && j < 3) {  // GetDynamicViolation, single_rigid_body_dynamics.cc:76-101: one value per lane
+    double wxIw[3];
+    cross3(om, Iw_w, wxIw);
+    const double ga = sel3(j, Iw_wd[0] + wxIw[0] - tau[0], Iw_wd[1] + wxIw[1] - tau[1], Iw_wd[2] + wxIw[2] - tau[2]);
+    const double gl = sel3(j, m * cdd[0] - F[0], m * cdd[1] - F[1], m * cdd[2] - F[2] + m * H->gravity);
+    g[w.g_off + 6 * n + 3 * ee + j] = ee == 0 ? ga : gl;
+  }
+  V.mass = m;
+  {  // duration columns {[r]x J_f + [f]x J_p ; -J_f} of ee e (dynamic_constraint.cc:107-113)
+    double t1[3], t2[3];
+    cross3(rv, fprev, t1);
+    cross3(f, xprev, t2);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) go[i] = Iw_wd[i] + wxIw[i] - tau[i];
-      go[3] = m * cdd[0] - T.F[0];
-      go[4] = m * cdd[1] - T.F[1];
-      go[5] = m * cdd[2] - T.F[2] + m * H->gravity;
-    }
+    for (int i = 0; i < 3; ++i) V.ap[i] = t1[i] + t2[i];
+    cross3(rv, fcur, t1);
+    cross3(f, xcur, t2);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) T.A[i] = T.B[i] = T.C[i] = 0.0;
-  } else {
-    // --- base-ang block (:123-165), Euler dimension d = role, factored.
+    for (int i = 0; i < 3; ++i) V.ac[i] = t1[i] + t2[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) V.A[i] = V.B[i] = V.C[i] = 0.0;
+  if (ee < 3) {
+    // --- base-ang block (:123-165), Euler dimension d = e, node value j, factored.
     // The columns of M are the rotation axes of the ZYX sequence, so dR/d e_d = [M_d]x R
     // (the cell-wise derivatives of euler_converter.cc:241-268 in closed form) and
     //   d(I_w v)/d e_d = R_d I_b R^T v + R I_b R_d^T v = M_d x (I_w v) + I_w (v x M_d)
     // (jac11+jac12 resp. jac21+jac22 of the reference) without ever forming R_d.
+    const int role = ee;
     const double dMx_dy[3] = {-sy * cz, -sy * sz, -cy};
     const double dMx_dz[3] = {-cy * sz, cy * cz, 0.0};
     const double dMy_dz[3] = {-cz, -sz, 0.0};
@@ -1586,14 +1714,15 @@ TWR_DEV void pdyn_math(const PDynWork& w, int n_ee, const PDynRec& r, const PDyn
 #pragma unroll
       for (int i = 0; i < 3; ++i) o[i] = t1[i] + t3b[i];
     };
-    symmul(Iw6, Md, T.C);
+    double (&A)[3] = V.A, (&B)[3] = V.B, (&C)[3] = V.C;
+    symmul(Iw6, Md, C);
     {  // B_d = I_w d(omega_dot)/d(edot_d) + M_d x (I_w omega) + omega x (I_w M_d)
       double t1[3], t2[3], t3b[3];
       symmul(Iw6, dwd_ed, t1);
       cross3(Md, Iw_w, t2);
-      cross3(om, T.C, t3b);
+      cross3(om, C, t3b);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) T.B[i] = t1[i] + t2[i] + t3b[i];
+      for (int i = 0; i < 3; ++i) B[i] = t1[i] + t2[i] + t3b[i];
     }
     {  // A_d = dI_w(omega_dot) + I_w d(omega_dot) + d(omega) x I_w omega + omega x (dI_w(omega) + I_w d(omega))
       double t1[3], t2[3], t3b[3], t4[3], t5[3], t6[3], t7[3];
@@ -1606,185 +1735,179 @@ TWR_DEV void pdyn_math(const PDynWork& w, int n_ee, const PDynRec& r, const PDyn
       for (int i = 0; i < 3; ++i) t6[i] = t4[i] + t5[i];
       cross3(om, t6, t7);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) T.A[i] = t1[i] + t2[i] + t3b[i] + t7[i];
+      for (int i = 0; i < 3; ++i) A[i] = t1[i] + t2[i] + t3b[i] + t7[i];
     }
   }
 }
-// The Jacobian values of this lane's time node into the group's LDS image (`nb`: byte address of the node's first
-// value).  ee tiles first: a candidate that is not a variable carries the offset of a base-ang entry of row AX, which
-// the base-ang stores below overwrite (same wave, program order).
-TWR_DEV void pdyn_puts(const TWR_CONST PhaseTables* PT, const PDynIn& in, const PDynOut& T, char* __restrict__ nb, int lane) {
-  const int role = lane & 3;
-  const double (&wm)[4] = T.wm, (&wf)[4] = T.wf, (&f)[3] = T.f, (&rv)[3] = T.rv, (&F)[3] = T.F;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-#define TWR_EE_TILE3(D, R1, R2)                                        \
-  {                                                                    \
-    lds_put(nb, in.pm.off[j * 3 + D][0], crs<R1, D>(f) * wm[j]);      \
-    lds_put(nb, in.pm.off[j * 3 + D][1], crs<R2, D>(f) * wm[j]);      \
-    lds_put(nb, in.pf.off[j * 3 + D][0], crs<R1, D>(rv) * wf[j]);     \
-    lds_put(nb, in.pf.off[j * 3 + D][1], crs<R2, D>(rv) * wf[j]);     \
-    lds_put(nb, in.pf.off[j * 3 + D][2], -wf[j]);                     \
+// One pass, second half: the Jacobian values of lane (n, e, j) into the LDS image (`img`: byte address of the image's
+// first value).
+TWR_DEV void pdyn_puts(const PDynWork& w, const PDynRec& r, const PDynPut& pu, const PDynVals& V, char* __restrict__ img, int lane) {
+  const int n = lane >> 4, ee = (lane >> 2) & 3, j = lane & 3;
+  if (n >= w.cnt) return;
+  const double (&f)[3] = V.f, (&rv)[3] = V.rv, (&F)[3] = V.F;
+  const double wPj = V.wPj, wVj = V.wVj, wAj = V.wAj, wmj = V.wmj, wfj = V.wfj, m = V.mass;
+  char* nb = img + (size_t)n * (size_t)w.node_vals * 8;   // first value of this time node
+  // --- ee-motion block [f]x J_p (:181-192) and ee-force block {[r]x J_f ; -J_f} (:167-179), candidates (j, D), BEFORE
+  // the base blocks: a candidate that is not a variable carries the offset of a base-ang entry of row AX, which the
+  // base-ang stores below overwrite (same wave, program order)
+#define TWR_EE_TILE3(D, R1, R2)                           \
+  {                                                       \
+    lds_put(nb, pu.m(2 * D + 0), crs<R1, D>(f) * wmj);    \
+    lds_put(nb, pu.m(2 * D + 1), crs<R2, D>(f) * wmj);    \
+    lds_put(nb, pu.f(3 * D + 0), crs<R1, D>(rv) * wfj);   \
+    lds_put(nb, pu.f(3 * D + 1), crs<R2, D>(rv) * wfj);   \
+    lds_put(nb, pu.f(3 * D + 2), -wfj);                   \
   }
-    TWR_EE_TILE3(0, 1, 2)
-    TWR_EE_TILE3(1, 2, 0)
-    TWR_EE_TILE3(2, 0, 1)
+  TWR_EE_TILE3(0, 1, 2)
+  TWR_EE_TILE3(1, 2, 0)
+  TWR_EE_TILE3(2, 0, 1)
 #undef TWR_EE_TILE3
-  }
-  // duration columns of this lane's end-effector: `prev` for the phases before the current one, `cur` for it
-  for (int p = 0; p < T.n_dur; ++p) {
-    const bool is_cur = p == T.cur;
+  {  // duration columns of ee e, phases p = j, j + 4, ...: `prev` for the phases before the current one, `cur` for it,
+     // zero (the cleared image) after it
+    const int cur = (int)(r.misc & 0xFF), n_dur = min(cur + 1, pu.ns);
+    for (int p = j; p < n_dur; p += 4) {
+      const bool is_cur = p == cur;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      lds_put(nb, (uint32_t)(in.pe.dur_ang[r] + 8 * p), is_cur ? T.ac[r] : T.ap[r]);
-      lds_put(nb, (uint32_t)(in.pe.dur_lin[r] + 8 * p), is_cur ? T.lc[r] : T.lp[r]);
+      for (int q = 0; q < 3; ++q) {
+        lds_put(nb, (uint32_t)(pu.dur_ang[q] + 8 * p), is_cur ? V.ac[q] : V.ap[q]);
+        lds_put(nb, (uint32_t)(pu.dur_lin[q] + 8 * p), is_cur ? -V.fcur[q] : -V.fprev[q]);
+      }
     }
   }
-  const uint32_t rs1 = 8u * (uint32_t)PT->len_ang[0], rs2 = rs1 + 8u * (uint32_t)PT->len_ang[1];
-  char* row[3] = {nb, nb + rs1, nb + rs2};
-  if (role == 3) {   // base-lin block: ang rows -sum_i [f_i]x J_pos, lin rows m J_acc (:103-121)
-    const uint32_t rl0 = rs2 + 8u * (uint32_t)PT->len_ang[2], rl1 = rl0 + 8u * (uint32_t)PT->len_lin[0],
-                   rl2 = rl1 + 8u * (uint32_t)PT->len_lin[1];
-    char* lin[3] = {nb + rl0, nb + rl1, nb + rl2};
+  char* row[3] = {nb, nb + w.row_off[0], nb + w.row_off[1]};
+  if (ee == 3) {   // base-lin block, node value j: ang rows -sum_i [f_i]x J_pos, lin rows m J_acc (:103-121)
+    const uint32_t rl0 = w.row_off[2], rl1 = w.row_off[3], rl2 = w.row_off[4];
+    lds_put(row[0], 8 * (2 * j + 0), -crs<0, 1>(F) * wPj);
+    lds_put(row[0], 8 * (2 * j + 1), -crs<0, 2>(F) * wPj);
+    lds_put(row[1], 8 * (2 * j + 0), -crs<1, 0>(F) * wPj);
+    lds_put(row[1], 8 * (2 * j + 1), -crs<1, 2>(F) * wPj);
+    lds_put(row[2], 8 * (2 * j + 0), -crs<2, 0>(F) * wPj);
+    lds_put(row[2], 8 * (2 * j + 1), -crs<2, 1>(F) * wPj);
+    lds_put(nb + rl0, 8 * j, m * wAj);
+    lds_put(nb + rl1, 8 * j, m * wAj);
+    lds_put(nb + rl2, 8 * j, m * wAj);
+  } else {         // base-ang block, Euler dimension e, node value j
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      lds_put(row[0], 8 * (2 * j + 0), -crs<0, 1>(F) * T.wP[j]);
-      lds_put(row[0], 8 * (2 * j + 1), -crs<0, 2>(F) * T.wP[j]);
-      lds_put(row[1], 8 * (2 * j + 0), -crs<1, 0>(F) * T.wP[j]);
-      lds_put(row[1], 8 * (2 * j + 1), -crs<1, 2>(F) * T.wP[j]);
-      lds_put(row[2], 8 * (2 * j + 0), -crs<2, 0>(F) * T.wP[j]);
-      lds_put(row[2], 8 * (2 * j + 1), -crs<2, 1>(F) * T.wP[j]);
-#pragma unroll
-      for (int d = 0; d < 3; ++d) lds_put(lin[d], 8 * j, T.mass * T.wA[j]);
-    }
-  } else {           // base-ang block, Euler dimension `role`
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        lds_put(row[r], 8 * (8 + 3 * j + role), T.A[r] * T.wP[j] + T.B[r] * T.wV[j] + T.C[r] * T.wA[j]);
+    for (int q = 0; q < 3; ++q) lds_put(row[q], 8 * (8 + 3 * j + ee), V.A[q] * wPj + V.B[q] * wVj + V.C[q] * wAj);
   }
 }
-// zero [0, n) doubles of an LDS image (n rounded up to a pair), 16 bytes per lane and instruction
+// zero [0, n) doubles of an LDS image (n rounded up to a pair): eight 16-byte stores per lane and round, lanes past the
+// end re-clear the last pair
 TWR_DEV void lds_clear(double* __restrict__ img, int n, int lane) {
   const double2 z = {0.0, 0.0};
-  const int npairs = (n + 1) >> 1;
-  for (int t = lane; t < npairs; t += 64) reinterpret_cast<double2*>(img)[t] = z;
+  const int npairs = (n + 1) >> 1, nit = (npairs + 63) >> 6;
+  for (int it0 = 0; it0 < nit; it0 += 8) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) reinterpret_cast<double2*>(img)[min(lane + 64 * (it0 + b), npairs - 1)] = z;
+  }
 }
-// image -> HBM like copy_out_fixed, for a run-time length: batches of eight 16-byte LDS reads, then their stores;
-// iterations past the end re-store the last complete pair (idempotent).  The kernel runs one wave per SIMD, so the
-// accumulation registers are free: the batch is staged in AGPRs (DS and vector-memory instructions take them as data
-// operands), which leaves the arch VGPRs to the math state of the run -- left to the register allocator the eight reads
-// end up serialised through one VGPR quad, or spilled.  Written as asm for that reason; the waits are explicit
-// (the compiler's own s_waitcnt counts stay conservative: unknown younger operations only make them stricter).
-typedef float twr_v4f __attribute__((ext_vector_type(4)));
+// image -> HBM for a run-time length: batches of eight 16-byte LDS reads, then their eight stores; iterations past the
+// end re-store the last complete pair (idempotent).  The image is NOT shifted by the parity of the destination (it fills
+// the workgroup's LDS to the last byte): a 16-byte aligned global pair is read from an 8-byte aligned LDS address with
+// ds_read2_b64.  The batch is staged in AGPRs (DS and vector-memory instructions take them as data operands; the kernel
+// runs few waves per SIMD, so they are free), which leaves the arch VGPRs to the math -- left to the register
+// allocator the eight reads end up serialised through one VGPR quad.  Written as asm for that reason; the waits are
+// explicit (the compiler's own s_waitcnt counts stay conservative: unknown younger operations only make them stricter).
+// NIT > 0: compile-time number of store instructions (the wait for the loads issued before them can then be counted);
+// NIT = 0: run-time length (images larger than 40 KB).  At most two more stores follow (odd head / tail).
+template <int NIT>
 TWR_DEV void stream_out(double* __restrict__ dst, const double* __restrict__ stage, int n, int par, int lane) {
-  char* al = reinterpret_cast<char*>(dst - par);  // 16-byte aligned
+  char* al = reinterpret_cast<char*>(dst - par);  // 16-byte aligned; global pair t = image values 2t - par, 2t + 1 - par
   const int total = n + par;
   const uint32_t last = (uint32_t)((total >> 1) - 1) * 16u;
   const uint32_t first = (uint32_t)(par + lane) * 16u;
-  const int nit = ((total >> 1) - par + 63) >> 6;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)stage;   // LDS byte address
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)stage - 8u * (uint32_t)par;
   constexpr int kB = 8;
-  for (int it0 = 0; it0 < nit; it0 += kB) {
+  auto batch = [&](int it0) {
     uint32_t off[kB];
     twr_v4f v[kB];
 #pragma unroll
     for (int b = 0; b < kB; ++b) {
       off[b] = min(first + 1024u * (uint32_t)(it0 + b), last);
-      asm volatile("ds_read_b128 %0, %1" : "=a"(v[b]) : "v"(lds0 + off[b]) : "memory");
+      asm volatile("ds_read2_b64 %0, %1 offset1:1" : "=a"(v[b]) : "v"(lds0 + off[b]) : "memory");
     }
 #pragma unroll
     for (int b = 0; b < kB; ++b) {
       switch (kB - 1 - b) {   // the b-th read has landed once at most kB-1-b younger ones are outstanding
-        case 7: asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt lgkmcnt(7)" : "+a"(v[b])); break;
+        case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+a"(v[b])); break;
+        case 5: asm volatile("s_waitcnt lgkmcnt(5)" : "+a"(v[b])); break;
+        case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+a"(v[b])); break;
+        case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+a"(v[b])); break;
+        case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+a"(v[b])); break;
+        case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+a"(v[b])); break;
+        default: asm volatile("s_waitcnt lgkmcnt(0)" : "+a"(v[b])); break;
       }
       asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(off[b]), "a"(v[b]), "s"(al) : "memory");
     }
+  };
+  if constexpr (NIT > 0) {
+    static_assert(NIT % kB == 0, "whole batches");
+#pragma unroll
+    for (int it0 = 0; it0 < NIT; it0 += kB) batch(it0);
+  } else {
+    const int nit = ((total >> 1) - par + 63) >> 6;
+    for (int it0 = 0; it0 < nit; it0 += kB) batch(it0);
   }
-  if (par && lane == 0 && n > 0) dst[0] = stage[1];
-  if ((total & 1) && lane == 0 && total - 1 > par) dst[n - 1] = stage[total - 1];
+  if (par && lane == 0 && n > 0) dst[0] = stage[0];
+  if ((total & 1) && lane == 0 && total - 1 > par) dst[n - 1] = stage[n - 1];
 }
 
-// LDS: image of one group (img_cap + 2 doubles) | constraint values of the run (96)
+// LDS: the image of one pass (dynamic size).  State at the top of iteration i: the record and the x values of pass i have
+// landed.  Vector-memory operations of one iteration, in issue order (loads by hand, see aload):
+//   P  put offsets of pass i (6 loads)        R  record of pass i+1 (6 loads)
+//   .. clear the image, math of pass i ..     G  constraint values (1 store, WANT_G)
+//   wait P (younger: R, G)  .. puts ..        wait R (younger: G)
+//   X  x values of pass i+1 (12 loads)        S  copy-out of pass i (NIT stores + at most 2)
+//   wait X (younger: S)
+template <int NIT, bool WANT_G, bool WANT_J>   // NIT: store instructions of the copy-out (40: images of up to 40 KB, C3 sizes; 0: run-time)
 __global__ __launch_bounds__(64, 1) void dyn_phase_kernel(const PDynWork* __restrict__ work, int n_work,
                                                           const double* __restrict__ x, double* __restrict__ g,
-                                                          double* __restrict__ jac, int flags, int img_cap) {
+                                                          double* __restrict__ jac) {
   extern __shared__ __attribute__((aligned(16))) double pdyn_lds[];
-  double* img = pdyn_lds;
-  double* gst = pdyn_lds + ((img_cap + 3) & ~1);
-  const bool want_g = flags & 1, want_j = flags & 2;
-  const int lane = threadIdx.x, kk = lane >> 2;
+  const int lane = threadIdx.x;
   const int stride = gridDim.x;
   int i = blockIdx.x;
   if (i >= n_work) return;
-  PDynWork w0 = work[i], w1 = w0, w2 = w0;
-  // (all problems of a batch share n_ee; the tables of the slice's own structure are reached through its blob)
-  const int n_ee = cptr<DevStruct>(w0.blob)->n_ee;
-  auto tables = [](const PDynWork& w) { return cptr<PhaseTables>(w.blob + cptr<DevStruct>(w.blob)->o_phase); };
-  PDynRec r0 = pdyn_load_rec(w0, tables(w0), n_ee, lane), r1 = r0;
-  if (i + stride < n_work) {
-    w1 = work[i + stride];
-    r1 = pdyn_load_rec(w1, tables(w1), n_ee, lane);
-  }
+  PDynWork w0 = work[i], w1 = w0;
+  const int n_ee = w0.n_ee;   // (all problems of a batch share n_ee)
+  PDynRec r0;
   PDynIn in;
-  pdyn_load_in(w0, tables(w0), n_ee, r0, x, lane, in);
+  {
+    ARec ar;
+    AIn ai;
+    pdyn_issue_rec(w0.shared, w0.loc, w0.cnt, n_ee, lane, ar);
+    pdyn_wait_rec<0>(ar, r0);
+    pdyn_issue_in(w0, r0, x, lane, ai);
+    pdyn_wait_in<0>(ai, in);
+  }
   for (; i < n_work; i += stride) {
-    const bool has1 = i + stride < n_work, has2 = i + 2 * stride < n_work;
-    if (has2) w2 = work[i + 2 * stride];
-    const TWR_CONST PhaseTables* PT = tables(w0);
-    PDynOut T;
-    pdyn_math(w0, n_ee, r0, in, gst, lane, want_g, T);
-    // the put offsets of roles without an end-effector all point at the trash entry
-    PhasePutM pm = in.pm;
-    PhasePutF pf = in.pf;
-    if ((lane & 3) >= n_ee) {
-      const uint16_t trash = (uint16_t)(8 * (8 + (lane & 3)));
-#pragma unroll
-      for (int c = 0; c < 12; ++c) {
-        pm.off[c][0] = pm.off[c][1] = trash;
-        pf.off[c][0] = pf.off[c][1] = pf.off[c][2] = trash;
-      }
+    const bool has1 = i + stride < n_work;   // (the last pass of a workgroup prefetches itself once more: harmless)
+    if (has1) w1 = work[i + stride];
+    APut ap;
+    ARec ar;
+    AIn ai;
+    if (WANT_J) pdyn_issue_put(w0, r0, lane, ap);                                   // P
+    pdyn_issue_rec(w1.shared, w1.loc, w1.cnt, n_ee, lane, ar);                      // R
+    const int nv = w0.cnt * w0.node_vals;
+    if (WANT_J) lds_clear(pdyn_lds, nv, lane);
+    PDynVals V;
+    pdyn_math(w0, r0, in, g, lane, WANT_G, V);                                      // (G inside)
+    if (WANT_J) {
+      PDynPut pu;
+      pdyn_wait_put<6 + (WANT_G ? 1 : 0)>(ap, pu);
+      pdyn_puts(w0, r0, pu, V, reinterpret_cast<char*>(pdyn_lds), lane);
     }
-    PDynIn put;   // (only the offsets of `in` survive into the put phase)
-    put.pm = pm;
-    put.pf = pf;
-    put.pe = in.pe;
-    PDynRec r2 = r1;
-    if (has2) r2 = pdyn_load_rec(w2, tables(w2), n_ee, lane);   // records first: the wait for x retires them too
-    if (has1) pdyn_load_in(w1, tables(w1), n_ee, r1, x, lane, in);
-    if (want_j) {
-      const int node_vals = w0.node_vals, G = w0.group;
-      for (int n0 = 0; n0 < w0.cnt; n0 += G) {
-        const int gcnt = min(G, w0.cnt - n0), nv = gcnt * node_vals;
-        double* dst = jac + w0.j_off + (int64_t)n0 * node_vals;
-        const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-        lds_clear(img, nv + par, lane);
-        // (the factors are opaque per group: otherwise the compiler hoists all ~110 products of a node out of this loop
-        // and spills them)
-        asm volatile("" : "+v"(T.wm[0]), "+v"(T.wm[1]), "+v"(T.wm[2]), "+v"(T.wm[3]), "+v"(T.wf[0]), "+v"(T.wf[1]),
-                     "+v"(T.wf[2]), "+v"(T.wf[3]), "+v"(T.wP[0]), "+v"(T.wP[1]), "+v"(T.wP[2]), "+v"(T.wP[3]));
-        asm volatile("" : "+v"(T.wV[0]), "+v"(T.wV[1]), "+v"(T.wV[2]), "+v"(T.wV[3]), "+v"(T.wA[0]), "+v"(T.wA[1]),
-                     "+v"(T.wA[2]), "+v"(T.wA[3]));
-        if (kk >= n0 && kk < n0 + gcnt)
-          pdyn_puts(PT, put, T, reinterpret_cast<char*>(img + par) + (size_t)(kk - n0) * node_vals * 8, lane);
-        stream_out(dst, img, nv, par, lane);
-      }
+    PDynRec r1;
+    pdyn_wait_rec<(WANT_G ? 1 : 0)>(ar, r1);
+    pdyn_issue_in(w1, r1, x, lane, ai);                                             // X
+    if (WANT_J) {                                                                   // S
+      double* dst = jac + w0.j_off;
+      stream_out<NIT>(dst, pdyn_lds, nv, (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1), lane);
     }
-    if (want_g) {   // 6 constraint values per time node, contiguous in g
-      double* go = g + w0.g_off;
-      if (lane < 6 * w0.cnt) go[lane] = gst[lane];
-      if (lane + 64 < 6 * w0.cnt) go[lane + 64] = gst[lane + 64];
-    }
-    w0 = w1; r0 = r1;
-    w1 = w2; r1 = r2;
+    pdyn_wait_in<(WANT_J ? (NIT < 63 ? NIT : 63) : 0)>(ai, in);   // (NIT = 0: drains the copy-out)
+    w0 = w1;
+    r0 = r1;
   }
 }
 
@@ -1822,11 +1945,11 @@ __global__ __launch_bounds__(64) void phase_locate_kernel(const LocWork* __restr
       const uint64_t sm = slots_of(pm.cand), sf = slots_of(pf.cand);
       o.slots_m[0] = (uint32_t)sm; o.slots_m[1] = (uint32_t)(sm >> 32);
       o.slots_f[0] = (uint32_t)sf; o.slots_f[1] = (uint32_t)(sf >> 32);
-      o.qm = (uint8_t)qm; o.qf = (uint8_t)qf;
+      o.im = (uint16_t)(PT->mput_base[e] + qm); o.jf = (uint16_t)(PT->fput_base[e] + qf);
       o.cur = (uint8_t)cur;
       o.flags = (uint8_t)((cur == last_phase ? 1 : 0) | (meta_shared(pm.meta) ? 2 : 0));
-      o.nin_m = (uint8_t)pm.n_in_phase; o.pin_m = (uint8_t)pm.poly_in_phase;
-      o.nin_f = (uint8_t)pf.n_in_phase; o.pin_f = (uint8_t)pf.poly_in_phase;
+      o.np_m = (uint8_t)(pm.n_in_phase | (pm.poly_in_phase << 4));
+      o.np_f = (uint8_t)(pf.n_in_phase | (pf.poly_in_phase << 4));
       out[(size_t)k * 4 + e] = o;
     }
   }
@@ -2440,20 +2563,34 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
   // optimised-timings problems: the pre-pass (segment lookup -> records), then the persistent kernels
   if (n_ploc > 0) hipLaunchKernelGGL(phase_locate_kernel, dim3(n_ploc), block, 0, stream, ploc, x);
   if (n_pdyn > 0) {
-    // LDS per workgroup: the group image + the run's constraint values; residency follows from it
-    const size_t lds = sizeof(double) * (size_t)(((pdyn_img_cap + 3) & ~1) + 96);
+    // LDS per workgroup: the image of one pass; residency follows from it
+    const size_t lds = sizeof(double) * (size_t)((pdyn_img_cap + 1) & ~1);
     static const int pdyn_bpc_env = env_int("TWR_PDYN_BPC", 0);
     int bpc = (int)((size_t)(160 * 1024) / lds);
-    if (bpc > 8) bpc = 8;
+    if (bpc > 4) bpc = 4;   // one wave per SIMD (the kernel uses the AGPR half of the register file as well)
     if (bpc < 1) bpc = 1;
     if (pdyn_bpc_env > 0) bpc = pdyn_bpc_env;
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dyn_phase_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-    }
     const int res = bpc * n_cu;
-    hipLaunchKernelGGL(dyn_phase_kernel, dim3(n_pdyn < res ? n_pdyn : res), block, lds, stream, pdyn, n_pdyn, x, g, jac, flags,
-                       pdyn_img_cap);
+    dim3 grid(n_pdyn < res ? n_pdyn : res);
+    const bool wg = flags & 1, wj = flags & 2;
+#define TWR_PDYN_LAUNCH(NIT, WG, WJ) hipLaunchKernelGGL((dyn_phase_kernel<NIT, WG, WJ>), grid, block, lds, stream, pdyn, n_pdyn, x, g, jac)
+    if (pdyn_img_cap <= 40 * 128) {
+      if (wg && wj) TWR_PDYN_LAUNCH(40, true, true);
+      else if (wj) TWR_PDYN_LAUNCH(40, false, true);
+      else TWR_PDYN_LAUNCH(40, true, false);
+    } else {
+      if (lds > 64 * 1024) {
+        const void* fn = wg && wj ? reinterpret_cast<const void*>(dyn_phase_kernel<0, true, true>)
+                                  : (wj ? reinterpret_cast<const void*>(dyn_phase_kernel<0, false, true>)
+                                        : reinterpret_cast<const void*>(dyn_phase_kernel<0, true, false>));
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+      }
+      if (wg && wj) TWR_PDYN_LAUNCH(0, true, true);
+      else if (wj) TWR_PDYN_LAUNCH(0, false, true);
+      else TWR_PDYN_LAUNCH(0, true, false);
+    }
+#undef TWR_PDYN_LAUNCH
   }
   if (ev) (void)hipEventRecord(ev[1], stream);
   if (n_prom > 0) {

@@ -864,6 +864,8 @@ void Structure::PackBlob() {
         if (it == e2 || *it != col) throw std::runtime_error("dynamic pattern lacks an expected column");
         return (int)(it - col_idx.data()) - v0;
       };
+      std::vector<PhasePutM> pm_all;
+      std::vector<PhasePutF> pf_all;
       for (int e = 0; e < n_ee; ++e) {
         const uint16_t trash = (uint16_t)(8 * (8 + e));   // base-ang entry of row AX, rewritten after the tiles
         std::vector<PhasePutM> pm(mpoly[e].size());
@@ -871,34 +873,55 @@ void Structure::PackBlob() {
         for (size_t q = 0; q < mpoly[e].size(); ++q) {
           std::memset(&pm[q], 0, sizeof(PhasePutM));
           for (int c = 0; c < 12; ++c) {
-            const int d = c % 3, r1 = (d + 1) % 3, r2 = (d + 2) % 3;
-            pm[q].off[c][0] = pm[q].off[c][1] = trash;
+            const int j = c / 3, d = c % 3, r1 = (d + 1) % 3, r2 = (d + 2) % 3;
+            pm[q].off[j][2 * d] = pm[q].off[j][2 * d + 1] = trash;
             if (mpoly[e][q].cand[c] == 0xFFFF) continue;
             const int col = mpoly[e][q].xbase + (mpoly[e][q].cand[c] & 0xF);
-            pm[q].off[c][0] = (uint16_t)(8 * find(r1, col));
-            pm[q].off[c][1] = (uint16_t)(8 * find(r2, col));
+            pm[q].off[j][2 * d] = (uint16_t)(8 * find(r1, col));
+            pm[q].off[j][2 * d + 1] = (uint16_t)(8 * find(r2, col));
           }
+          for (int j = 0; j < 4; ++j) pm[q].off[j][6] = pm[q].off[j][7] = trash;
         }
         for (size_t q = 0; q < fpoly[e].size(); ++q) {
           std::memset(&pf[q], 0, sizeof(PhasePutF));
           for (int c = 0; c < 12; ++c) {
-            const int d = c % 3, r1 = (d + 1) % 3, r2 = (d + 2) % 3;
-            pf[q].off[c][0] = pf[q].off[c][1] = pf[q].off[c][2] = trash;
+            const int j = c / 3, d = c % 3, r1 = (d + 1) % 3, r2 = (d + 2) % 3;
+            pf[q].off[j][3 * d] = pf[q].off[j][3 * d + 1] = pf[q].off[j][3 * d + 2] = trash;
             if (fpoly[e][q].cand[c] == 0xFFFF) continue;
             const int col = fpoly[e][q].xbase + (fpoly[e][q].cand[c] & 0xF);
-            pf[q].off[c][0] = (uint16_t)(8 * find(r1, col));
-            pf[q].off[c][1] = (uint16_t)(8 * find(r2, col));
-            pf[q].off[c][2] = (uint16_t)(8 * find(3 + d, col));
+            pf[q].off[j][3 * d] = (uint16_t)(8 * find(r1, col));
+            pf[q].off[j][3 * d + 1] = (uint16_t)(8 * find(r2, col));
+            pf[q].off[j][3 * d + 2] = (uint16_t)(8 * find(3 + d, col));
           }
+          for (int j = 0; j < 4; ++j) pf[q].off[j][9] = pf[q].off[j][10] = pf[q].off[j][11] = trash;
         }
-        pt.o_mput[e] = put(pm.data(), pm.size() * sizeof(PhasePutM));
-        pt.o_fput[e] = put(pf.data(), pf.size() * sizeof(PhasePutF));
+        pt.mput_base[e] = (int)pm_all.size();
+        pt.fput_base[e] = (int)pf_all.size();
+        pm_all.insert(pm_all.end(), pm.begin(), pm.end());
+        pf_all.insert(pf_all.end(), pf.begin(), pf.end());
         pt.ee[e].ns = schedule.n_phases[e] - 1;
         for (int r = 0; r < 3; ++r) {
           pt.ee[e].dur_ang[r] = 8 * find(r, off_schedule[e]);
           pt.ee[e].dur_lin[r] = 8 * find(3 + r, off_schedule[e]);
         }
       }
+      pt.n_mput = (int)pm_all.size();
+      pt.n_fput = (int)pf_all.size();
+      for (int e = 0; e < kMaxEE; ++e) {   // dummy records
+        PhasePutM dm;
+        PhasePutF df;
+        for (int j = 0; j < 4; ++j) {
+          for (int q = 0; q < 8; ++q) dm.off[j][q] = (uint16_t)(8 * (8 + e));
+          for (int q = 0; q < 12; ++q) df.off[j][q] = (uint16_t)(8 * (8 + e));
+        }
+        pm_all.push_back(dm);
+        pf_all.push_back(df);
+      }
+      pt.o_mput = put(pm_all.data(), pm_all.size() * sizeof(PhasePutM));
+      pt.o_fput = put(pf_all.data(), pf_all.size() * sizeof(PhasePutF));
+      for (int r = 1; r < 6; ++r) pt.dyn_row_off[r - 1] = 8u * (uint32_t)(row_ptr[row_dyn + r] - v0);
+      if (params.polys_per_swing > 15 || params.polys_per_stance_force > 15)
+        throw std::runtime_error("optimised timings: at most 15 polynomials per phase");
     }
     // the pattern builder and these closed forms must agree
     if (dyn_set && dyn_set->nnz != pt.node_vals * (int)grid_dyn.size()) throw std::runtime_error("dynamic row lengths inconsistent");
