@@ -23,7 +23,7 @@ assert L.twr_debug_pdyn_stamps(out.ctypes.data_as(C.c_void_p), out.size) == 0
 a = out.reshape(-1, 8).astype(np.float64)
 a = a[a[:, 7] > 0]
 per = a[:, :7] / a[:, 7:8]
-names = ["top", "clear", "wait vmcnt(0)", "pass (math+puts)", "issue prefetch", "stream", "-"]
+names = ["top: wait x, issue P R", "clear", "math", "wait P", "puts", "wait R, issue X", "stream"]
 tot = per.sum(axis=1).mean()
 print("workgroups %d, runs per workgroup %.1f, memtime ticks per run %.0f" % (len(a), a[:, 7].mean(), tot))
 for n, v in zip(names, per.mean(axis=0)):

@@ -19,8 +19,8 @@
 namespace twr {
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
                        const NodeWork* node, int n_node, const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap,
-                       const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, const double* x, double* g,
-                       double* jac, int flags, hipStream_t stream, hipEvent_t* ev);
+                       const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
+                       double* g, double* jac, int flags, hipStream_t stream, hipEvent_t* ev);
 hipError_t launch_check(int n_problems, const int64_t* g_off, const int64_t* j_off, const double* g, const double* jac,
                         int32_t* status, int flags, hipStream_t stream);
 hipError_t launch_score(const NodeWork* work, int n_problems, const double* g, double* scores, hipStream_t stream);
@@ -71,7 +71,8 @@ struct twr_batch {
   twr::NodeWork* d_node = nullptr;
   // optimised-timings problems have their own work lists
   twr::PDynWork* d_pdyn = nullptr;
-  int pdyn_img_cap = 0;                      // doubles of the dyn_phase_kernel's LDS image (largest group of the batch)
+  int pdyn_img_cap = 0, prom_img_cap = 0;    // ... and of the rom_phase_kernel's (largest pass of the batch)
+  int pdyn_img_cap_unused_ = 0;                      // doubles of the dyn_phase_kernel's LDS image (largest group of the batch)
   twr::LocWork* d_ploc = nullptr;
   twr::RomPhaseWork* d_prom = nullptr;
   int64_t *d_goff = nullptr, *d_joff = nullptr;  // device copies of g_off / j_off (TWR_EVAL_CHECK)
@@ -491,7 +492,9 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
           if (!rs) continue;
           any_rom = true;
           const int K = (int)S.grid_rom.size(), nv = S.phase_tables.rom_node_vals[e];
-          for (int k0 = 0; k0 < K; k0 += 16) {
+          const int run = std::max(1, std::min(16, (160 * 128) / nv));   // time nodes per pass (four lanes each)
+          b->prom_img_cap = std::max(b->prom_img_cap, run * nv);
+          for (int k0 = 0; k0 < K; k0 += run) {
             twr::RomPhaseWork rw;
             rw.recs = prec_bytes + sizeof(twr::RomRec) * (size_t)k0;
             rw.x_off = b->x_off[p];
@@ -499,7 +502,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
             rw.j_off = b->j_off[p] + rs->nnz_offset + (int64_t)k0 * nv;
             rw.off_lin = S.off_base_lin;
             rw.off_ang = S.off_base_ang;
-            rw.cnt = std::min(16, K - k0);
+            rw.cnt = std::min(run, K - k0);
             rw.msize = S.phase_tables.msize[e];
             rw.ns = S.schedule.n_phases[e] - 1;
             rw.node_vals = nv;
@@ -648,8 +651,8 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
   if (b->prof_count < b->prof_capacity) ev = b->prof_events.data() + 4 * b->prof_count++;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->d_rom, b->n_rom, b->d_node, b->n_node,
-                                  b->d_pdyn, b->n_pdyn, b->pdyn_img_cap, b->d_ploc, b->n_ploc, b->d_prom, b->n_prom, d_x,
-                                  d_g, d_jac, flags & TWR_EVAL_BOTH, stream, ev);
+                                  b->d_pdyn, b->n_pdyn, b->pdyn_img_cap, b->d_ploc, b->n_ploc, b->d_prom, b->n_prom,
+                                  b->prom_img_cap, d_x, d_g, d_jac, flags & TWR_EVAL_BOTH, stream, ev);
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   if (flags & TWR_EVAL_CHECK) {
     e = twr::launch_check(b->n_problems, b->d_goff, b->d_joff, d_g, d_jac, b->d_status, flags & TWR_EVAL_BOTH, stream);

@@ -1978,117 +1978,234 @@ __global__ __launch_bounds__(64) void phase_locate_kernel(const LocWork* __restr
   }
 }
 
-// Persistent, software pipelined like rom_kernel: lane = time node (<= 32 per slice).  The lanes fill a
-// compact LDS image (the fixed-timing layout at a fixed stride per node), then the wave streams out every
-// expanded row [base-lin 12 | base-ang 12 (8) | all ee-motion_e variables | all durations] as coalesced runs,
-// taking the active polynomial's values from the image and writing explicit zeros everywhere else; the
-// record of slice i+2 and the x values of slice i+1 are in flight meanwhile.
-constexpr int kRomPStride = 108;  // compact values of one time node: 3 rows x (24 + <= 12 slots)
-constexpr int kRomPNodes = 16;    // time nodes per slice: 15 KB of LDS, eight workgroups per CU (VGPR bound)
-TWR_DEV RomRec romp_load_rec(const RomPhaseWork& w, int lane) {
-  return gptr<RomRec>(w.recs)[min(lane, w.cnt - 1)];
+// rangeofmotion-<ee> with optimised timings (rom_phase_kernel): the same recipe as dyn_phase_kernel.  A pass is a run of
+// up to SIXTEEN consecutive time nodes of one (problem, ee) -- their expanded rows [base-lin 12 | base-ang 12 (8) | all
+// ee-motion_e variables | all durations] are one contiguous slice of the value array (C3: 182 values per node, 23 KB
+// per pass) -- and a time node gets FOUR lanes:
+//   lane = 4 n + j:   n = time node of the pass, j = node value (p0, v0, p1, v1)
+// Lane (n, j) loads the three dimensions of node value j of the base splines and of the active ee-motion polynomial
+// (9 values instead of 36) and owns their Jacobian columns; spline points are DPP quad sums, the rotation algebra is
+// evaluated by all four lanes.  The wave clears the LDS image of the pass, every lane stores its ~26 values (+ its share
+// of the duration columns) at their final positions, and the image goes to HBM with 16-byte coalesced stores.
+// The x-dependent lookup comes from the pre-pass (RomRec); the pipeline is scheduled by hand like dyn_phase_kernel's.
+struct ARomIn {        // x values of a pass (9 loads)
+  double v[9];
+};
+struct RomPRec {       // the RomRec written by the pre-pass, whole dwords
+  double tb, iTb, tm, iTm;
+  int32_t q6, xbase;
+  uint32_t slots[2], pad0, pad1;   // pad0 = base_all | current phase << 16 | in_last_phase << 24, pad1 = n_in_phase | poly_in_phase << 8
+  uint32_t meta;
+};
+struct ARomRec {
+  twr_v4f q[4];
+};
+TWR_DEV void romp_issue_rec(uint64_t recs, int cnt, int lane, ARomRec& a) {
+  const char* p = reinterpret_cast<const char*>(recs) + sizeof(RomRec) * (size_t)min(lane >> 2, cnt - 1);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) aload(a.q[q], p + 16 * q);
 }
-TWR_DEV RomWork romp_as_work(const RomPhaseWork& w) {
-  RomWork o;
-  o.recs = w.recs;
-  o.x_off = w.x_off; o.g_off = w.g_off; o.j_off = w.j_off;
-  o.off_lin = w.off_lin; o.off_ang = w.off_ang;
-  o.cnt = w.cnt; o.nvals = 0;
-  return o;
+template <int N>
+TWR_DEV void romp_wait_rec(ARomRec& a, RomPRec& r) {
+  asm volatile("s_waitcnt %4" : "+a"(a.q[0]), "+a"(a.q[1]), "+a"(a.q[2]), "+a"(a.q[3]) : "n"(vmcnt_imm(N)));
+  static_assert(offsetof(RomRec, q6) == 32 && offsetof(RomRec, meta) == 44 && offsetof(RomRec, slots) == 48 && offsetof(RomRec, pad) == 56,
+                "RomRec dwords");
+  r.tb = pdyn_f64(a.q[0].x, a.q[0].y);
+  r.iTb = pdyn_f64(a.q[0].z, a.q[0].w);
+  r.tm = pdyn_f64(a.q[1].x, a.q[1].y);
+  r.iTm = pdyn_f64(a.q[1].z, a.q[1].w);
+  r.q6 = (int32_t)__float_as_uint(a.q[2].x);
+  r.xbase = (int32_t)__float_as_uint(a.q[2].y);
+  r.meta = __float_as_uint(a.q[2].w);
+  r.slots[0] = __float_as_uint(a.q[3].x);
+  r.slots[1] = __float_as_uint(a.q[3].y);
+  r.pad0 = __float_as_uint(a.q[3].z);
+  r.pad1 = __float_as_uint(a.q[3].w);
 }
-__global__ __launch_bounds__(64, 2) void rom_phase_kernel(const RomPhaseWork* __restrict__ work, int n_work,
+TWR_DEV void romp_issue_in(const RomPhaseWork& w, const RomPRec& r, const double* __restrict__ x, int lane, ARomIn& a) {
+  const double* xp = x + w.x_off;
+  const int j = lane & 3;
+  const double* xl = xp + w.off_lin + r.q6 + 3 * j;
+  const double* xa = xp + w.off_ang + r.q6 + 3 * j;
+  const uint32_t sm = (uint32_t)((((uint64_t)r.slots[1] << 32) | r.slots[0]) >> (12 * j)) & 0xFFFu;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    aload(a.v[d], xl + d);
+    aload(a.v[3 + d], xa + d);
+    const uint32_t am = (sm >> (4 * d)) & 0xFu;   // an absent candidate reads slot 0, weight 0
+    aload(a.v[6 + d], xp + r.xbase + (am != 0xFu ? am : 0u));
+  }
+}
+template <int N>
+TWR_DEV void romp_wait_in(ARomIn& a, double in[9]) {
+  asm volatile("s_waitcnt %9" : "+a"(a.v[0]), "+a"(a.v[1]), "+a"(a.v[2]), "+a"(a.v[3]), "+a"(a.v[4]), "+a"(a.v[5]), "+a"(a.v[6]),
+               "+a"(a.v[7]), "+a"(a.v[8]) : "n"(vmcnt_imm(N)));
+#pragma unroll
+  for (int q = 0; q < 9; ++q) in[q] = a.v[q];
+}
+// RangeOfMotionConstraint::{UpdateConstraintAtInstance, UpdateJacobianAtInstance} (range_of_motion_constraint.cc:58-109)
+// with the PhaseSpline Jacobians (phase_spline.cc:44-93) for lane (n, j); `img`: byte address of the image.
+TWR_DEV void romp_pass(const RomPhaseWork& w, const RomPRec& r, const double in[9], char* __restrict__ img, double* __restrict__ g,
+                       int lane, bool want_g, bool want_j) {
+  const int n = lane >> 2, j = lane & 3;
+  const bool live = n < w.cnt;
+  double wPj;
+  {
+    double wP[4];
+    hermite_pos(r.tb, r.iTb, wP);
+    wPj = sel4(j, wP);
+  }
+  double c[3], e[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    c[d] = quad_sum(wPj * in[d]);
+    e[d] = quad_sum(wPj * in[3 + d]);
+  }
+  // ee-motion point and the duration columns of PhaseSpline::GetJacobianOfPosWrtDurations (phase_spline.cc:67-93,
+  // phase_durations.cc:126-154, polynomial.cc:236-257; dx/dT_poly collected by node value: a sum over j)
+  const uint32_t sm = (uint32_t)((((uint64_t)r.slots[1] << 32) | r.slots[0]) >> (12 * j)) & 0xFFFu;
+  const bool shared = meta_shared(r.meta), in_last = (r.pad0 >> 24) & 1;
+  double wmj, v[3], prev[3], cur[3];
+  {
+    const double t = r.tm, iT = r.iTm, iT2 = iT * iT, t2 = t * t, t3 = t2 * t;
+    const double inner = 1.0 / (double)(r.pad1 & 0xFF), prevp = (double)((r.pad1 >> 8) & 0xFF);
+    double wp[4], wv[4], wa[4], ct[4];
+    hermite_all(t, iT, wp, wv, wa);
+    ct[0] = 6.0 * t2 * iT2 * iT - 6.0 * t3 * iT2 * iT2;
+    ct[1] = 2.0 * t2 * iT2 - 2.0 * t3 * iT2 * iT;
+    ct[2] = -ct[0];
+    ct[3] = t2 * iT2 - 2.0 * t3 * iT2 * iT;
+    if (shared) {   // stance ee-motion polynomial: p1 is the same variable as p0
+      wp[0] += wp[2];
+      wv[0] += wv[2];
+      ct[0] += ct[2];
+    }
+    wmj = sel4(j, wp);
+    const double wvj = sel4(j, wv), ctj = sel4(j, ct);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const double nv = ((sm >> (4 * d)) & 0xFu) != 0xFu ? in[6 + d] : 0.0;
+      v[d] = quad_sum(wmj * nv) - c[d];
+      const double vel = quad_sum(wvj * nv), dxdT = quad_sum(ctj * nv);
+      const double dph = inner * (dxdT - prevp * vel);
+      cur[d] = dph;
+      prev[d] = -vel - (in_last ? dph : 0.0);
+    }
+  }
+  // rotation: lanes j = 0..2 of the quad evaluate one sincos each and broadcast it (euler_converter.cc:207-221)
+  Rot ro;
+  {
+    double my_s, my_c;
+    sincos_fast(sel3(j, e[0], e[1], e[2]), &my_s, &my_c);
+    const double sx = quad_perm<0x00>(my_s), cx = quad_perm<0x00>(my_c);
+    const double sy = quad_perm<0x55>(my_s), cy = quad_perm<0x55>(my_c);
+    const double sz = quad_perm<0xAA>(my_s), cz = quad_perm<0xAA>(my_c);
+    ro.sx = sx; ro.cx = cx; ro.sy = sy; ro.cy = cy; ro.sz = sz; ro.cz = cz;
+    ro.R[0][0] = cy * cz; ro.R[0][1] = cz * sx * sy - cx * sz; ro.R[0][2] = sx * sz + cx * cz * sy;
+    ro.R[1][0] = cy * sz; ro.R[1][1] = cx * cz + sx * sy * sz; ro.R[1][2] = cx * sy * sz - cz * sx;
+    ro.R[2][0] = -sy;     ro.R[2][1] = cy * sx;                ro.R[2][2] = cx * cy;
+  }
+  if (want_g && live && j < 3) {   // b_R_w (p - c): one value per lane
+    double gv[3];
+    matTvec(ro.R, v, gv);
+    g[w.g_off + 3 * n + j] = sel3(j, gv[0], gv[1], gv[2]);
+  }
+  if (!want_j || !live) return;
+  // DerivOfRotVecMult(t, v, inverse=true) = d(R^T v)/d e_d = R^T (v x M_d)  (euler_converter.cc:223-239, see rom_item)
+  double ux[3], uy[3], uz[3];
+  {
+    const double Mx[3] = {ro.cy * ro.cz, ro.cy * ro.sz, -ro.sy}, My[3] = {-ro.sz, ro.cz, 0.0};
+    double tx[3], ty[3];
+    cross3(v, Mx, tx);
+    cross3(v, My, ty);
+    const double tz[3] = {v[1], -v[0], 0.0};  // v x e_z
+    matTvec(ro.R, tx, ux);
+    matTvec(ro.R, ty, uy);
+    matTvec(ro.R, tz, uz);
+  }
+  const int base_all = r.pad0 & 0xFFFF, cur_ph = (r.pad0 >> 16) & 0xFF;
+  const uint32_t len0 = 20u + (uint32_t)(w.msize + w.ns), len1 = len0 + 4u;
+  char* nb = img + (size_t)n * (size_t)w.node_vals * 8;
+  char* row[3] = {nb, nb + 8u * len0, nb + 8u * (len0 + len1)};
+  const uint32_t mo[3] = {20u, 24u, 24u};
+  // R^T J_p of candidates (j, D), BEFORE the base blocks: a candidate that is not a variable goes to the first value of
+  // row 0, which the base-lin stores below overwrite (same wave, program order)
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const uint32_t sl = (sm >> (4 * d)) & 0xFu;
+    const bool valid = sl != 0xFu;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      lds_put(valid ? row[q] + 8u * (mo[q] + (uint32_t)base_all + sl) : nb, 0, ro.R[d][q] * wmj);
+  }
+  {  // duration columns b_R_w * GetJacobianOfPosWrtDurations (range_of_motion_constraint.cc:106-108), phases p = j, j + 4, ..:
+     // `prev` for the phases before the current one, `cur` for it, zero (the cleared image) after it
+    double rp[3], rc[3];
+    matTvec(ro.R, prev, rp);
+    matTvec(ro.R, cur, rc);
+    const int n_dur = min(cur_ph + 1, w.ns);
+    for (int p = j; p < n_dur; p += 4) {
+      const bool is_cur = p == cur_ph;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) lds_put(row[q], 8u * (mo[q] + (uint32_t)w.msize + (uint32_t)p), is_cur ? rc[q] : rp[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) lds_put(row[q], 8 * (3 * j + d), -ro.R[d][q] * wPj);  // -R^T J_c
+    if (q == 0) {  // row 0 of R^T v does not depend on roll
+      lds_put(row[0], 8 * (12 + 2 * j + 0), wPj * uy[0]);
+      lds_put(row[0], 8 * (12 + 2 * j + 1), wPj * uz[0]);
+    } else {
+      lds_put(row[q], 8 * (12 + 3 * j + 0), wPj * ux[q]);
+      lds_put(row[q], 8 * (12 + 3 * j + 1), wPj * uy[q]);
+      lds_put(row[q], 8 * (12 + 3 * j + 2), wPj * uz[q]);
+    }
+  }
+}
+// Vector-memory operations of one iteration, in issue order:  R record of pass i+1 (4 loads)  .. clear, math ..
+//   G constraint values (1 store, WANT_G)  .. puts ..  wait R (younger: G)  X x values of pass i+1 (9 loads)
+//   S copy-out of pass i (NIT stores + at most 2)   wait X (younger: S)
+template <int NIT, bool WANT_G, bool WANT_J>
+__global__ __launch_bounds__(64, 1) void rom_phase_kernel(const RomPhaseWork* __restrict__ work, int n_work,
                                                           const double* __restrict__ x, double* __restrict__ g,
-                                                          double* __restrict__ jac, int flags) {
-  // compact image | trash slots | duration columns (6 per node): one array, so one LDS read per output value
-  __shared__ __attribute__((aligned(16))) double img[kRomPNodes * kRomPStride + 64 + kRomPNodes * 6];
-  __shared__ int s_meta[kRomPNodes];  // nslots | base_all << 8 | current phase << 24
-  double* s_sched = img + kRomPNodes * kRomPStride + 64;
-  const bool want_g = flags & 1, want_j = flags & 2;
+                                                          double* __restrict__ jac) {
+  extern __shared__ __attribute__((aligned(16))) double romp_lds[];
   const int lane = threadIdx.x;
-  const int trash = kRomPNodes * kRomPStride + lane;
   const int stride = gridDim.x;
   int i = blockIdx.x;
   if (i >= n_work) return;
-  RomPhaseWork w0 = work[i], w1 = w0, w2 = w0;
-  RomRec r0 = romp_load_rec(w0, lane), r1 = r0;
-  RomX X;
-  if (i + stride < n_work) {
-    w1 = work[i + stride];
-    r1 = romp_load_rec(w1, lane);
+  RomPhaseWork w0 = work[i], w1 = w0;
+  RomPRec r0;
+  double in[9];
+  {
+    ARomRec ar;
+    ARomIn ai;
+    romp_issue_rec(w0.recs, w0.cnt, lane, ar);
+    romp_wait_rec<0>(ar, r0);
+    romp_issue_in(w0, r0, x, lane, ai);
+    romp_wait_in<0>(ai, in);
   }
-  rom_load_x(romp_as_work(w0), r0, x, X);
   for (; i < n_work; i += stride) {
-    const bool has1 = i + stride < n_work, has2 = i + 2 * stride < n_work;
-    if (has2) w2 = work[i + 2 * stride];
-    const int kl = min(lane, w0.cnt - 1);
-    r0.voff = kl * kRomPStride;
-    if (lane < w0.cnt) {
-      const int base_all = r0.pad[0] & 0xFFFF, cur = (r0.pad[0] >> 16) & 0xFF;
-      RomPhase ph;
-      ph.in_last = (r0.pad[0] >> 24) & 1;
-      ph.inner = 1.0 / (double)(r0.pad[1] & 0xFF);
-      ph.prevp = (double)((r0.pad[1] >> 8) & 0xFF);
-      ph.T = 1.0 / r0.iTm;
-      ph.sched = s_sched + 6 * lane;
-      s_meta[lane] = meta_nslots(r0.meta) | (base_all << 8) | (cur << 24);
-      rom_item<true>(romp_as_work(w0), r0, X, g + w0.g_off, img, 0, 0, trash, lane, want_g, want_j, &ph);
+    const bool has1 = i + stride < n_work;   // (the last pass of a workgroup prefetches itself once more: harmless)
+    if (has1) w1 = work[i + stride];
+    ARomRec ar;
+    ARomIn ai;
+    romp_issue_rec(w1.recs, w1.cnt, lane, ar);                                       // R
+    const int nv = w0.cnt * w0.node_vals;
+    if (WANT_J) lds_clear(romp_lds, nv, lane);
+    romp_pass(w0, r0, in, reinterpret_cast<char*>(romp_lds), g, lane, WANT_G, WANT_J);   // (G inside)
+    RomPRec r1;
+    romp_wait_rec<(WANT_G ? 1 : 0)>(ar, r1);
+    romp_issue_in(w1, r1, x, lane, ai);                                              // X
+    if (WANT_J) {                                                                    // S
+      double* dst = jac + w0.j_off;
+      stream_out<NIT>(dst, romp_lds, nv, (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1), lane);
     }
-    RomRec r2 = r1;
-    if (has2) r2 = romp_load_rec(w2, lane);
-    if (has1) rom_load_x(romp_as_work(w1), r1, x, X);
-    if (want_j) {
-      const int msize = w0.msize, ns = w0.ns, node_vals = w0.node_vals;
-      const int len0 = 20 + msize + ns, len1 = 24 + msize + ns;
-      double* out = jac + w0.j_off;
-      // Expanded values of one node, 64 per chunk.  What depends on the position inside the node only (row,
-      // column, which block) is computed once per slice and chunk; per node just the polynomial's offset.
-      for (int i0 = 0; i0 < node_vals; i0 += 256) {
-        int ii[4], cb[4], pp[4], ibase[4], rb[4], srow[4];
-        bool in_base[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          ii[c] = min(i0 + 64 * c + lane, node_vals - 1);   // clamped: the tail re-stores the last value
-          const int row = (ii[c] >= len0) + (ii[c] >= len0 + len1);
-          const int col = ii[c] - (row == 0 ? 0 : (row == 1 ? len0 : len0 + len1));
-          const int nb = row == 0 ? 20 : 24;
-          cb[c] = col - nb;                           // column inside the ee-motion block (if >= 0)
-          pp[c] = cb[c] - msize;                      // duration column (if >= 0)
-          in_base[c] = col < nb;
-          // compact row start = {0, 20, 44}[row] + row * nslots; base block at +col, polynomial at +nb+j
-          ibase[c] = (row == 0 ? 0 : (row == 1 ? 20 : 44)) + (in_base[c] ? col : nb);
-          rb[c] = row;
-          srow[c] = kRomPNodes * kRomPStride + 64 + row;   // s_sched follows img: one address space
-        }
-        int meta_next = s_meta[0];
-        for (int node = 0; node < w0.cnt; ++node) {
-          const int meta = meta_next;
-          meta_next = s_meta[min(node + 1, w0.cnt - 1)];   // next node's descriptor while this one is expanded
-          const int nm = meta & 0xFF, ba = (meta >> 8) & 0xFFFF, ncur = meta >> 24;
-          const int nbase = node * kRomPStride, sbase = 6 * node;
-          double* dst = out + (int64_t)node * node_vals;
-          int addr[4];
-          bool keep[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int j = cb[c] - ba;
-            const bool in_poly = (unsigned)j < (unsigned)nm;
-            const bool from_img = in_base[c] || in_poly;
-            const bool from_sched = pp[c] >= 0 && pp[c] <= ncur;
-            const int a_img = nbase + ibase[c] + rb[c] * nm + (in_poly ? j : 0);
-            const int a_sch = sbase + srow[c] + (pp[c] == ncur ? 3 : 0);
-            addr[c] = from_img ? a_img : a_sch;
-            keep[c] = from_img || from_sched;
-          }
-          double v[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = img[addr[c]];   // four LDS reads in flight
-#pragma unroll
-          for (int c = 0; c < 4; ++c) dst[ii[c]] = keep[c] ? v[c] : 0.0;
-        }
-      }
-    }
-    w0 = w1; r0 = r1;
-    w1 = w2; r1 = r2;
+    romp_wait_in<(WANT_J ? (NIT < 63 ? NIT : 63) : 0)>(ai, in);   // (NIT = 0: drains the copy-out)
+    w0 = w1;
+    r0 = r1;
   }
 }
 
@@ -2525,8 +2642,8 @@ static int env_int(const char* name, int dflt) {
 }
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
                        const NodeWork* node, int n_node, const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap,
-                       const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, const double* x, double* g,
-                       double* jac, int flags, hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */) {
+                       const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
+                       double* g, double* jac, int flags, hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */) {
   static const int dyn_bpc = env_int("TWR_DYN_BPC", 8), rom_bpc = env_int("TWR_ROM_BPC", 4);
 #ifdef TWR_ABLATE
   flags |= env_int("TWR_DEBUG_FLAGS", 0) & ~0xFF;
@@ -2594,8 +2711,36 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
   }
   if (ev) (void)hipEventRecord(ev[1], stream);
   if (n_prom > 0) {
-    const int res = 8 * n_cu;
-    hipLaunchKernelGGL(rom_phase_kernel, dim3(n_prom < res ? n_prom : res), block, 0, stream, prom, n_prom, x, g, jac, flags);
+    const size_t lds = sizeof(double) * (size_t)((prom_img_cap + 1) & ~1);
+    static const int prom_bpc_env = env_int("TWR_PROM_BPC", 0);
+    int bpc = (int)((size_t)(160 * 1024) / lds);
+    if (bpc > 8) bpc = 8;
+    if (bpc < 1) bpc = 1;
+    if (prom_bpc_env > 0) bpc = prom_bpc_env;
+    const int res = bpc * n_cu;
+    dim3 grid(n_prom < res ? n_prom : res);
+    const bool wg = flags & 1, wj = flags & 2;
+#define TWR_PROM_LAUNCH(NIT, WG, WJ) hipLaunchKernelGGL((rom_phase_kernel<NIT, WG, WJ>), grid, block, lds, stream, prom, n_prom, x, g, jac)
+#define TWR_PROM_FLAGS(NIT)                           \
+  {                                                   \
+    if (wg && wj) TWR_PROM_LAUNCH(NIT, true, true);   \
+    else if (wj) TWR_PROM_LAUNCH(NIT, false, true);   \
+    else TWR_PROM_LAUNCH(NIT, true, false);           \
+  }
+    if (prom_img_cap <= 24 * 128) TWR_PROM_FLAGS(24)
+    else if (prom_img_cap <= 40 * 128) TWR_PROM_FLAGS(40)
+    else {
+      if (lds > 64 * 1024) {
+        const void* fn = wg && wj ? reinterpret_cast<const void*>(rom_phase_kernel<0, true, true>)
+                                  : (wj ? reinterpret_cast<const void*>(rom_phase_kernel<0, false, true>)
+                                        : reinterpret_cast<const void*>(rom_phase_kernel<0, true, false>));
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+      }
+      TWR_PROM_FLAGS(0)
+    }
+#undef TWR_PROM_FLAGS
+#undef TWR_PROM_LAUNCH
   }
   if (n_rom > 0) {
     const int res = rom_bpc * n_cu;
