@@ -71,18 +71,30 @@ def _cpu_model():
 
 
 def host_cores():
-    """Host threads this process may actually keep busy: the affinity mask, cut down by a cgroup CPU quota when
-    one is set, and by the GPU pool's per-GPU CPU share (16 host threads per GPU; a 256-thread pool on such a box
-    is time-sliced onto that share).  TWR_HOST_CORES overrides."""
+    """Host threads this process may keep busy and where the number comes from: the scheduler affinity mask, cut down by
+    a cgroup CPU quota when one is set (v2 cpu.max, v1 cpu.cfs_quota_us); TWR_HOST_CORES overrides both."""
+    env = os.environ.get("TWR_HOST_CORES")
+    if env:
+        return max(1, int(env)), "env"
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    source = "affinity"
+    quota = None
     try:
         with open("/sys/fs/cgroup/cpu.max") as f:
-            quota, period = f.read().split()
-        if quota != "max":
-            n = min(n, max(1, int(float(quota) / float(period))))
+            q, period = f.read().split()
+        if q != "max":
+            quota = float(q) / float(period)
     except (OSError, ValueError):
-        pass
-    return max(1, min(n, int(os.environ.get("TWR_HOST_CORES", "16"))))
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, period = int(f.read()), int(fp.read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        n, source = max(1, int(quota)), "cgroup"
+    return max(1, n), source
 
 
 def cpu_baseline(sched, params, x, terrain, budget_s=3.0):
@@ -111,25 +123,32 @@ def cpu_baseline(sched, params, x, terrain, budget_s=3.0):
     iters = max(5, int(budget_s / max(t1, 1e-6)))
     rates = sorted(iters / P.time_callbacks(x, iters) for _ in range(5))
     single = statistics.median(rates)
-    cores = host_cores()
+    cores, source = host_cores()
     probs = [make() for _ in range(cores)]
-    secs = [0.0] * cores
-
-    def run(i):
-        secs[i] = probs[i].time_callbacks(x, iters)   # ctypes drops the GIL for the duration of the call
-
+    counts = [0] * cores
+    chunk = max(1, int(0.25 / max(t1, 1e-6)))   # ~0.25 s of callbacks between looks at the clock
+    wall_budget = 4.0
     t0 = time.perf_counter()
+
+    def run(i):   # ctypes drops the GIL for the duration of a call; every instance runs until the common deadline
+        while time.perf_counter() - t0 < wall_budget:
+            probs[i].time_callbacks(x, chunk)
+            counts[i] += chunk
+
     th = [threading.Thread(target=run, args=(i,)) for i in range(cores)]
     for t in th:
         t.start()
     for t in th:
         t.join()
     wall = time.perf_counter() - t0
+    all_rate = sum(counts) / wall
     return {"value": single, "unit": "callbacks/s", "cores": 1, "kind": "port",
             "sample": "median of 5 x %d callbacks (%.1f s each) of the same ANYmal K=200 problem, single-thread C++ "
                       "oracle, g++ -O3 -march=native; min %.1f max %.1f" % (iters, iters / single, rates[0], rates[-1]),
-            "all_cores": {"value": cores * iters / wall, "unit": "callbacks/s", "cores": cores,
-                          "sample": "%d instances x %d callbacks at once (%.1f s)" % (cores, iters, wall)},
+            "all_cores": {"value": all_rate, "unit": "callbacks/s", "cores": cores, "cores_source": source,
+                          "parallel_efficiency": all_rate / (cores * single),
+                          "sample": "%d instances at once for %.1f s, %d callbacks in all (%d .. %d per instance)"
+                                    % (cores, wall, sum(counts), min(counts), max(counts))},
             "nproc": os.cpu_count(), "cpu_model": _cpu_model()}
 
 
@@ -156,7 +175,10 @@ def traffic_from_profile(workload, kernel, problems_per_gpu):
             if workload == "C3" and t.get("problems_per_gpu") == problems_per_gpu:
                 return t.get("hbm_bytes_per_launch", {}).get(kernel)
             if workload == "C3+timings" and problems_per_gpu == 2048:   # the --sets timings --batch 2048 passes
-                return t.get("timings_2048", {}).get("hbm_bytes_per_launch", {}).get(kernel)
+                per = t.get("timings_2048", {}).get("hbm_bytes_per_launch", {})
+                if kernel is None:
+                    return per
+                return sum(v for k, v in per.items() if k.startswith(kernel)) or None
     except (OSError, ValueError):
         pass
     return None
@@ -174,7 +196,7 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
     cands = sweep.enumerate_candidates(n_total)
     bounds = sweep.shard_bounds([sweep.candidate_weight(c) for c in cands], world)
     lo, hi = bounds[rank], bounds[rank + 1]
-    threads = host_cores()   # per rank: the pool gives every GPU its own CPU share
+    threads = min(host_cores()[0], 64)   # per rank
     t0 = time.perf_counter()
     mine = sweep.candidate_structures(m5, cands[lo:hi], threads=threads)
     t1 = time.perf_counter()
@@ -200,11 +222,20 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
     stats = torch.tensor([elapsed, setup_s, t1 - t0, float(batch.algorithmic_bytes)], dtype=torch.float64,
                          device=dev if backend == "nccl" else None)
     tot = stats.clone()
+    stats0 = stats.clone()
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     elapsed, setup_max, build_max = float(stats[0]), float(stats[1]), float(stats[2])
     bytes_total = float(tot[3])
+    # per-rank step time and set-up time (imbalance must be visible, not only the maximum)
+    mine_t = torch.tensor([float(stats0[0]) / steps * 1e3, float(stats0[1])], dtype=torch.float64,
+                          device=dev if backend == "nccl" else None)
+    per_rank = [mine_t.clone() for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, mine_t)
+    per_rank_ms = [float(t_[0]) for t_ in per_rank]
+    per_rank_setup = [float(t_[1]) for t_ in per_rank]
     # Planner-style step (optional exchange): constraint values only, scored on the device, one all-gather of
     # the 16 scores per candidate, arg-min on every rank -- what a sweep that wants ONE decision does per iterate.
     from towr_amd.dist import best_candidate, gather_scores
@@ -242,13 +273,73 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
             "path_GBps": bytes_total * steps / elapsed / 1e9,
             "shards": [bounds[r + 1] - bounds[r] for r in range(world)],
             "setup_s": setup_max, "structure_build_s": build_max, "build_threads_per_rank": threads,
-            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "world_size": world, "backend": backend if world > 1 else "none (single process)",
+            "rccl_ranks": world if (world > 1 and backend == "nccl") else (1 if world == 1 else 0),
+            "device_count": torch.cuda.device_count(),
+            "ms_per_step_per_rank": {"min": min(per_rank_ms), "max": max(per_rank_ms), "all": per_rank_ms},
+            "setup_s_per_rank": per_rank_setup,
             # a shard that re-writes < ~220 MB per step keeps its output in the 256-MB Infinity Cache (DESIGN 6.1)
             "output_MB_per_rank": float(batch.algorithmic_bytes) / 1e6,
             "planner": {"what": "values only -> twr_batch_score -> all-gather of 16 scores per candidate -> arg-min "
                                 "(host-synchronous: one decision per step)",
                         "steps": p_steps, "value": n_total * p_steps / p_elapsed, "unit": "candidates scored/s",
                         "ms_per_step": p_elapsed / p_steps * 1e3, "best_candidate": int(best[0])}}
+
+
+def timings_c3(ta, torch, dist, model, world, rank, dev, dev_index, backend, stream, steps=20, B=2048):
+    """The optimised-timings mode of the same C3 problem (Parameters::OptimizePhaseDurations: ee-schedule variables,
+    x-dependent active polynomials, rows that hold every variable of every ee set): 2048 problems per GPU, per-kernel HIP
+    events, roofline of the dominant kernel and of the whole path (SURVEY 8f #2)."""
+    m = ta.Model.from_buffer_copy(bytes(model))
+    m.terrain_id = ta.TERRAINS["flat"]
+    sched, params, S = build_case(ta, m, constraint_sets=127)
+    batch = ta.Batch([S], [0] * B, device=dev_index)
+    base = perturbed_inputs(S, m, min(B, 256), first_seed=rank * 100000)
+    x = torch.from_numpy(np.tile(base, ((B + base.shape[0] - 1) // base.shape[0], 1))[:B].reshape(-1)).to(dev)
+    g = torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device=dev)
+    jac = torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev)
+    for _ in range(3):
+        batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)
+    batch.profile_begin(steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms, n_prof = batch.profile_end()
+    assert n_prof == steps
+    assert bool(torch.isfinite(g).all()) and bool(torch.isfinite(jac).all())
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else None)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    names = {"dynamic": "twr::phase_locate_kernel + twr::dyn_phase_kernel", "rangeofmotion": "twr::rom_phase_kernel",
+             "nodes": "twr::node_kernel"}
+    kbytes = batch.kernel_bytes()
+    dom = max(kern_ms, key=kern_ms.get)
+    path_ms = sum(kern_ms.values())
+    traffic = traffic_from_profile("C3+timings", None, B)
+    dom_traffic = None
+    if traffic:   # the dynamic interval holds the pre-pass and the kernel: both are charged
+        keys = {"dynamic": ["twr::dyn_phase_kernel", "twr::phase_locate_kernel"], "rangeofmotion": ["twr::rom_phase_kernel"],
+                "nodes": ["twr::node_kernel"]}[dom]
+        vals = [v for k, v in traffic.items() if any(k.startswith(q) for q in keys)]
+        dom_traffic = sum(vals) if vals else None
+    return {"workload": "C3 with optimised phase durations: n=%d m=%d nnz=%d, %d problems/GPU" % (S.n, S.m, S.nnz, B),
+            "problems_per_gpu": B, "steps": steps, "value": B * world * steps / elapsed, "unit": "callbacks/s",
+            "ms_per_step": elapsed / steps * 1e3, "bytes_per_callback": S.algorithmic_bytes,
+            "roofline": {"bound": "hbm", "achieved": kbytes[dom] / (kern_ms[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": kbytes[dom] / (kern_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": dom_traffic,
+                         "kernel": names[dom], "kernel_ms": kern_ms[dom], "algorithmic_bytes_per_launch": kbytes[dom],
+                         "path": {"achieved": batch.algorithmic_bytes / (path_ms * 1e-3) / 1e9,
+                                  "frac": batch.algorithmic_bytes / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "kernel_ms": {names[k]: v for k, v in kern_ms.items()},
+                                  "algorithmic_bytes_per_step": batch.algorithmic_bytes}}}
 
 
 def main():
@@ -266,6 +357,7 @@ def main():
                          "optimised phase durations (ee-schedule variables, all-variables rows); c3 only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scale-c5", action="store_true", help="skip the strong-scaling C5 leg of the default run")
+    ap.add_argument("--no-timings-c3", action="store_true", help="skip the optimised-timings leg of the default run")
     args = ap.parse_args()
 
     import torch
@@ -359,12 +451,18 @@ def main():
     kern_ms, n_prof = batch.profile_end()
     assert n_prof == args.steps
 
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else None)
+        every = [t.clone() for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank_ms = [float(e_[0]) / args.steps * 1e3 for e_ in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # sanity: the outputs are finite (no work skipped / no garbage)
+    if os.environ.get("TWR_DEBUG_FLAGS") and "ablate" not in os.path.basename(ta.LIB_PATH):
+        raise SystemExit("TWR_DEBUG_FLAGS is only meaningful with a diagnostic library (TWR_AMD_LIB=.../libtowr_amd_ablate*.so)")
     if not os.environ.get("TWR_DEBUG_FLAGS"):   # (diagnostic ablation builds write garbage on purpose)
         assert bool(torch.isfinite(g).all()) and bool(torch.isfinite(jac).all())
 
@@ -378,12 +476,14 @@ def main():
         path_achieved = alg_bytes / (path_ms * 1e-3) / 1e9
         names = {"dynamic": "twr::dyn_kernel", "rangeofmotion": "twr::rom_kernel", "nodes": "twr::node_kernel"}
         if args.workload == "c3" and args.sets == "timings":
-            names.update(dynamic="twr::dyn_phase_kernel<4>", rangeofmotion="twr::rom_phase_kernel")
+            names.update(dynamic="twr::dyn_phase_kernel", rangeofmotion="twr::rom_phase_kernel")
         out = {
             "metric": "constraint+Jacobian evals/sec (full NLP callback), 4-EE SRBD",
             "value": callbacks / elapsed,
             "unit": "callbacks/s",
             "n_gpus": world,
+            "backend": backend if world > 1 else "none (single process)", "device_count": torch.cuda.device_count(),
+            "ms_per_step_per_rank": per_rank_ms,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -407,11 +507,17 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sched, params, x_host[:S.n], terrain)
     # north_star's strong-scaling claim rides on the same command: 1024 sweep candidates over all ranks
-    c5 = None
-    if args.workload == "c3" and args.sets == "hot" and not args.no_scale_c5:
+    c5 = t3 = None
+    default_run = args.workload == "c3" and args.sets == "hot"
+    if default_run and not (args.no_scale_c5 and args.no_timings_c3):
         del x, g, jac, batch
+    if default_run and not args.no_timings_c3:
+        t3 = timings_c3(ta, torch, dist, model, world, rank, dev, dev_index, backend, stream)
+    if default_run and not args.no_scale_c5:
         c5 = scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, stream)
     if rank == 0:
+        if t3 is not None:
+            out["timings_c3"] = t3
         if c5 is not None:
             out["scale_c5"] = c5
         print(json.dumps(out), flush=True)

@@ -215,8 +215,10 @@ int twr_batch_layout(const twr_batch* b, int64_t* x_off, int64_t* g_off, int64_t
  *   ifopt::Problem::EvalNonzerosOfJacobian(x,val) -> jac   (TWR_EVAL_JACOBIAN)
  * i.e. Composite::SetVariables + {Terrain,Dynamic,RangeOfMotion,Force}Constraint::
  * {GetValues, FillJacobianBlock}.  Asynchronous on `hip_stream` (hipStream_t, may be
- * NULL for the default stream); no host synchronisation, capturable in a hipGraph.  The batch's device is made
- * current and a pending sticky HIP error of the caller is cleared.  At most ONE evaluation of a given batch may
+ * NULL for the default stream); no host synchronisation, capturable in a hipGraph.  If the calling thread's current
+ * device is not the batch's, the call switches to it for the launches and RESTORES the caller's device before it
+ * returns; it neither reads nor clears the thread's sticky HIP error (every launch returns its own status, which is
+ * what a TWR_ERR_HIP result reports).  At most ONE evaluation of a given batch may
  * be in flight at a time (batches with optimised timings keep per-batch scratch records; the profiling
  * counters are per batch too): serialise evaluations of one batch on one stream, use one batch per stream. */
 int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, int flags, void* hip_stream);
@@ -261,7 +263,10 @@ int twr_batch_score(twr_batch* b, const double* d_g, double* d_scores /* 16 * n_
  * against the previous sample; duration = time to the next footstep state, the last one lasts until time_horizon.
  * Problem p's records start at d_out + p * max_steps * (2 + 4 n_ee):
  *   [ t_global | duration | contact flag per ee | ee-motion position (3) per ee ]
- * and d_counts[p] is their number (never more than twr_structure_contact_steps_max).  Asynchronous on hip_stream. */
+ * and d_counts[p] is the number of footstep states FOUND -- never more than twr_structure_contact_steps_max, but it
+ * may exceed a smaller max_steps the caller chose: then only the first min(d_counts[p], max_steps) records are
+ * valid (each with its duration; the last of them lasts until the first state that was dropped).  Asynchronous on
+ * hip_stream. */
 int twr_structure_contact_steps_max(const twr_structure* s, int32_t* max_steps);
 int twr_batch_contact_plan(twr_batch* b, const double* d_x, double dt, double time_horizon, double* d_out, int32_t max_steps,
                            int32_t* d_counts, void* hip_stream);

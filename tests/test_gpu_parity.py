@@ -220,6 +220,8 @@ def _many_phases(n_ee, n_phases, seed):
     ("two_nodes_dt_gt_T", lambda: Case("biped", "slope", ta.gait_combo(2, 0, 1.1), dt_dynamic=5.0, dt_rom=7.0)),
     ("max_phases_32", lambda: Case("anymal", "stairs", _many_phases(4, 31, 1), constraint_sets=63)),
     ("max_phases_32_timings", lambda: Case("biped", "gap", _many_phases(2, 31, 2), constraint_sets=127)),
+    # largest expanded rows of the ABI: 4224 values per dynamic time node, a four-node pass takes 135 KB of LDS
+    ("max_phases_32_timings_quad", lambda: Case("anymal", "stairs", _many_phases(4, 31, 3), constraint_sets=127)),
     ("long_horizon_K1000", lambda: Case("hyq", "block", ta.gait_combo(4, 1, 6.0), **k_params(6.0, 1000))),
     ("many_polys", lambda: Case("go1", "chimney_lr", ta.gait_combo(4, 2, 2.0), polys_per_swing=4, polys_per_stance_force=5)),
     ("fine_base_spline", lambda: Case("monoped", "gap", hopper_schedule(), duration_base_poly=0.013, constraint_sets=63)),
@@ -281,6 +283,36 @@ def test_page_locked_host_buffers():
     assert np.array_equal(pg, g) and np.array_equal(pj, j)
     px2, _, _ = batch.host_buffers()
     assert px2.ctypes.data == px.ctypes.data   # allocated once, owned by the batch
+
+
+def test_page_locked_host_buffers_optimised_timings_and_flags():
+    """The zero-copy branch of twr_batch_eval_host (kernels store g / jac straight into the batch's page-locked
+    buffers and gather x from them) for the kernels test_page_locked_host_buffers does not reach: a ragged batch that
+    mixes fixed and optimised timings with every constraint set, and the VALUES-only / JACOBIAN-only flag variants
+    (untouched outputs must stay untouched); x copied from pageable memory while g / jac are zero-copy."""
+    cases = [Case("anymal", "gap", ta.gait_combo(4, 1, 2.0), constraint_sets=127),
+             Case("anymal", "stairs", ta.gait_combo(4, 2, 1.7), constraint_sets=63),
+             Case("anymal", "flat", ta.gait_combo(4, 0, 2.2), constraint_sets=255, base_z_init=0.5)]
+    order = [0, 1, 2, 0, 1]
+    batch = ta.Batch([c.S for c in cases], order, device=0)
+    xs = np.concatenate([cases[s].x_wild(70 + p) for p, s in enumerate(order)])
+    g, j = batch.eval_host(xs)                      # pageable buffers: device outputs + copies
+    for p, s in enumerate(order):
+        rg, _, _, rj = cases[s].P.eval(xs[batch.x_off[p]:batch.x_off[p + 1]])
+        assert_parity(cases[s].S, *_split(batch, g, j, p), rg, rj, "problem %d" % p, x=xs[batch.x_off[p]:batch.x_off[p + 1]])
+    px, pg, pj = batch.host_buffers()
+    px[:] = xs
+    for flags, want_g, want_j in ((ta.EVAL_BOTH, True, True), (ta.EVAL_VALUES, True, False), (ta.EVAL_JACOBIAN, False, True)):
+        pg[:] = np.nan
+        pj[:] = np.nan
+        batch.eval_host_pinned(flags)
+        assert np.array_equal(pg, g) if want_g else np.isnan(pg).all(), flags
+        assert np.array_equal(pj, j) if want_j else np.isnan(pj).all(), flags
+    # x from pageable memory, outputs zero-copy
+    pg[:] = np.nan
+    pj[:] = np.nan
+    ta._check(ta.lib().twr_batch_eval_host(batch._h, ta._d(xs), ta._d(pg), ta._d(pj), ta.EVAL_BOTH))
+    assert np.array_equal(pg, g) and np.array_equal(pj, j)
 
 
 def test_random_structures_in_one_ragged_batch():
@@ -523,11 +555,21 @@ def _run_sweep(robot, terrain, count, sample_idx):
     assert bool(torch.isfinite(g).all()), "constraint values left unwritten / non-finite"
     assert bool(torch.isfinite(jac).all()), "Jacobian values left unwritten / non-finite"
     gh, jh = g.cpu().numpy(), jac.cpu().numpy()
-    for p in sample_idx:
+
+    def check(p):
         S = structs[p]
-        rg, rp, ci, rj = _oracle_for(robot, terrain, S).eval(xs[p])
+        rg, rp, ci, rj = _oracle_for(robot, terrain, S).eval(xs[p])   # (one oracle instance per candidate: not re-entrant)
         assert np.array_equal(rp, S.row_ptr) and np.array_equal(ci, S.col_idx), "pattern of candidate %d" % p
         assert_parity(S, *_split(batch, gh, jh, p), rg, rj, "%s/%s candidate %d %s" % (robot, terrain, p, cands[p]))
+
+    if len(sample_idx) > 64:   # the whole sweep: oracle instances on a thread pool (ctypes drops the GIL in the calls)
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
+            list(pool.map(check, sample_idx))
+    else:
+        for p in sample_idx:
+            check(p)
     return cands
 
 
@@ -546,10 +588,11 @@ def _c5_samples():
 @pytest.mark.parametrize("robot", ["anymal", "go1"])
 def test_sweep_c5_1024_stairs(robot):
     """BASELINE config 5: the 1024-candidate gait / phase-duration sweep on Stairs in ONE ragged batch
-    (gait_generator.cc:54-105, quadruped_gait_generator.cc:76-87; Go1 constants go1_model.h:19-52)."""
+    (gait_generator.cc:54-105, quadruped_gait_generator.cc:76-87; Go1 constants go1_model.h:19-52); all 1024
+    candidates are compared with the oracle."""
     idx = _c5_samples()
     assert len(idx) >= 16
-    cands = _run_sweep(robot, "stairs", 1024, idx)
+    cands = _run_sweep(robot, "stairs", 1024, list(range(1024)))   # every candidate against the oracle
     assert {c[0] for c in (cands[i] for i in idx)} == {0, 1, 2, 3, 4}
 
 
@@ -679,6 +722,20 @@ def test_candidate_scores_and_contact_plans():
             assert np.array_equal(got[:, 2:2 + n_ee], ref[:, 2:2 + n_ee])          # contact flags
             assert np.abs(got[:, :2] - ref[:, :2]).max() <= 1e-12                    # t, duration
             assert np.abs(got[:, 2 + n_ee:] - ref[:, 2 + n_ee:]).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+        # a caller-chosen max_steps smaller than the number of footstep states: counts report what was found, the first
+        # max_steps records are the same as before -- durations included (the last kept record ends at the first dropped state)
+        few = 3
+        out3 = torch.full((len(order), few, rec), float("nan"), dtype=torch.float64, device=dev)
+        counts3 = torch.zeros(len(order), dtype=torch.int32, device=dev)
+        batch.contact_plan_device(x.data_ptr(), dt, horizon, out3.data_ptr(), few, counts3.data_ptr(), st)
+        torch.cuda.synchronize()
+        o3, c3 = out3.cpu().numpy(), counts3.cpu().numpy()
+        for p in range(len(order)):
+            if p == 4:
+                continue
+            assert c3[p] == ch[p]
+            k = min(few, ch[p])
+            assert np.array_equal(o3[p, :k], oh[p, :k]), (p, o3[p, :k, :2], oh[p, :k, :2])
         # nearest planar region of every foot in contact (fpowr NearestPlaneLookup): rotated, overlapping, open and
         # closed polygons along the path of the robot
         from oracle import binding as ob

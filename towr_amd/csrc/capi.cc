@@ -46,6 +46,15 @@ struct twr_planes {
   std::vector<double> world_xy;    // PlanarRegionsToPolygons output
   double* d_xy = nullptr;
   int32_t* d_start = nullptr;
+  ~twr_planes() {                  // (also runs on the error paths of twr_planes_create)
+    if (!d_xy && !d_start) return;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != device) (void)hipSetDevice(device);
+    if (d_xy) (void)hipFree(d_xy);
+    if (d_start) (void)hipFree(d_start);
+    if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+  }
 };
 
 struct twr_batch {
@@ -492,7 +501,8 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
           if (!rs) continue;
           any_rom = true;
           const int K = (int)S.grid_rom.size(), nv = S.phase_tables.rom_node_vals[e];
-          const int run = std::max(1, std::min(16, (160 * 128) / nv));   // time nodes per pass (four lanes each)
+          static const int prom_nodes = [] { const char* e = getenv("TWR_PROM_NODES"); return e && atoi(e) > 0 ? std::min(16, atoi(e)) : 16; }();
+          const int run = std::max(1, std::min(prom_nodes, (160 * 128) / nv));   // time nodes per pass (four lanes each)
           b->prom_img_cap = std::max(b->prom_img_cap, run * nv);
           for (int k0 = 0; k0 < K; k0 += run) {
             twr::RomPhaseWork rw;
@@ -643,10 +653,17 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
   if ((flags & TWR_EVAL_BOTH) == 0) return fail(TWR_ERR_INVALID, "flags select nothing");
   if (((flags & TWR_EVAL_VALUES) && !d_g) || ((flags & TWR_EVAL_JACOBIAN) && !d_jac))
     return fail(TWR_ERR_INVALID, "missing output buffer");
-  // one process may drive several devices: make the batch's device current (as every other entry point does),
-  // and drop a sticky error the host application may have left behind so that it is not reported as ours
-  if (hipSetDevice(b->device) != hipSuccess) return fail(TWR_ERR_HIP, "hipSetDevice failed");
-  (void)hipGetLastError();
+  // One process may drive several devices: the launch needs the batch's device current.  The calling thread's current
+  // device is restored afterwards and its error state is left alone (the launch's own status is what is returned).
+  int cur_dev = -1;
+  if (hipGetDevice(&cur_dev) != hipSuccess) cur_dev = -1;
+  const bool switch_dev = cur_dev != b->device;
+  if (switch_dev && hipSetDevice(b->device) != hipSuccess) return fail(TWR_ERR_HIP, "hipSetDevice failed");
+  struct Restore {
+    int dev;
+    bool on;
+    ~Restore() { if (on && dev >= 0) (void)hipSetDevice(dev); }
+  } restore{cur_dev, switch_dev};
   hipEvent_t* ev = nullptr;
   if (b->prof_count < b->prof_capacity) ev = b->prof_events.data() + 4 * b->prof_count++;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
@@ -845,12 +862,15 @@ int twr_batch_initial_guess(twr_batch* b, const double* d_x, const double* d_tim
 int twr_planes_create(const double* regions, const double* boundary_xy, const int32_t* boundary_start, int32_t n_regions,
                       int device, twr_planes** out) {
   if (!out || n_regions < 0 || (n_regions > 0 && (!regions || !boundary_start))) return fail(TWR_ERR_INVALID, "bad arguments");
-  try {
-    auto pl = std::make_unique<twr_planes>();
+  std::unique_ptr<twr_planes> pl;
+  try {   // argument errors
+    pl = std::make_unique<twr_planes>();
     pl->device = device;
     pl->start.assign(1, 0);
     for (int r = 0; r < n_regions; ++r) {
       if (boundary_start[r + 1] < boundary_start[r] || boundary_start[0] != 0) throw std::runtime_error("boundary_start must ascend from 0");
+      // (boost::geometry::distance throws on an empty geometry; a region without boundary points cannot be the nearest)
+      if (boundary_start[r + 1] == boundary_start[r]) throw std::runtime_error("planar region " + std::to_string(r) + " has no boundary points");
       pl->start.push_back(boundary_start[r + 1]);
     }
     const int n_pts = pl->start.back();
@@ -869,24 +889,30 @@ int twr_planes_create(const double* regions, const double* boundary_xy, const in
         pl->world_xy[2 * i + 1] = (R10 * lx + R11 * ly + 0.0) + P[1];
       }
     }
+  } catch (const std::exception& e) {
+    return fail(TWR_ERR_INVALID, e.what());
+  }
+  try {   // device errors (the handle's destructor releases what was allocated)
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) return fail(TWR_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n_dev) return fail(TWR_ERR_INVALID, "device ordinal out of range");
+    int cur = -1;
+    (void)hipGetDevice(&cur);
     TWR_HIP(hipSetDevice(device));
+    const int n_pts = pl->start.back();
     TWR_HIP(hipMalloc(reinterpret_cast<void**>(&pl->d_xy), std::max<size_t>(16, pl->world_xy.size() * sizeof(double))));
     TWR_HIP(hipMalloc(reinterpret_cast<void**>(&pl->d_start), pl->start.size() * sizeof(int32_t)));
     if (n_pts > 0) TWR_HIP(hipMemcpy(pl->d_xy, pl->world_xy.data(), pl->world_xy.size() * sizeof(double), hipMemcpyHostToDevice));
     TWR_HIP(hipMemcpy(pl->d_start, pl->start.data(), pl->start.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
     *out = pl.release();
     return TWR_OK;
   } catch (const std::exception& e) {
-    return fail(TWR_ERR_INVALID, e.what());
+    return fail(TWR_ERR_HIP, e.what());
   }
 }
 
-void twr_planes_destroy(twr_planes* planes) {
-  if (!planes) return;
-  if (planes->d_xy) (void)hipFree(planes->d_xy);
-  if (planes->d_start) (void)hipFree(planes->d_start);
-  delete planes;
-}
+void twr_planes_destroy(twr_planes* planes) { delete planes; }
 
 int twr_planes_world_xy(const twr_planes* planes, double* world_xy) {
   if (!planes || !world_xy) return fail(TWR_ERR_INVALID, "null argument");
@@ -899,7 +925,6 @@ int twr_batch_contact_planes(twr_batch* b, const twr_planes* planes, const doubl
   if (!b || !planes || !d_plan || !d_counts || !d_plane_index || max_steps < 1) return fail(TWR_ERR_INVALID, "bad arguments");
   if (planes->device != b->device) return fail(TWR_ERR_INVALID, "planes and batch live on different devices");
   if (hipSetDevice(b->device) != hipSuccess) return fail(TWR_ERR_HIP, "hipSetDevice failed");
-  (void)hipGetLastError();
   hipError_t e = twr::launch_planes(d_plan, d_counts, planes->d_xy, planes->d_start, (int)planes->start.size() - 1, b->n_problems,
                                     max_steps, b->n_ee, d_plane_index, static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -909,7 +934,6 @@ int twr_batch_contact_planes(twr_batch* b, const twr_planes* planes, const doubl
 int twr_batch_score(twr_batch* b, const double* d_g, double* d_scores, void* hip_stream) {
   if (!b || !d_g || !d_scores) return fail(TWR_ERR_INVALID, "null argument");
   if (hipSetDevice(b->device) != hipSuccess) return fail(TWR_ERR_HIP, "hipSetDevice failed");
-  (void)hipGetLastError();
   hipError_t e = twr::launch_score(b->d_node, b->n_problems, d_g, d_scores, static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   return TWR_OK;
@@ -928,7 +952,6 @@ int twr_batch_contact_plan(twr_batch* b, const double* d_x, double dt, double ti
   if (!b || !d_x || !d_out || !d_counts || max_steps < 1 || !(dt > 0)) return fail(TWR_ERR_INVALID, "bad arguments");
   try {
     TWR_HIP(hipSetDevice(b->device));
-    (void)hipGetLastError();
     int n_max = 0;
     for (int p = 0; p < b->n_problems; ++p) {
       if (!b->sample_ok[p]) throw std::runtime_error("too many polynomials per spline for trajectory sampling");

@@ -7,8 +7,9 @@
 //   rom_kernel   rangeofmotion-ee  : lanes = consecutive time nodes k               (3 rows each)
 //   node_kernel  terrain-* / force-* / splineacc-base-* / swing-* (+ totalduration-*) of one problem:
 //                four waves, one per family, lanes = spline nodes / rows
-//   dyn_phase_kernel / rom_phase_kernel: the same math for problems with optimised phase durations
-//                (x-dependent active polynomials, rows that hold all variables of every ee set)
+//   phase_locate_kernel + dyn_phase_kernel / rom_phase_kernel: the same math for problems with optimised phase
+//                durations (x-dependent active polynomials, rows that hold all variables of every ee set): 16 resp. 4
+//                lanes per time node, expanded rows assembled in LDS
 // Every lane computes its rows in registers (FP64, no MFMA: the work is 3x3 algebra),
 // scatters the values into an LDS image of the slice at the CSR position they have in
 // global memory, and the wave then streams the image out with 16-byte coalesced stores.
@@ -25,6 +26,9 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
+
+#include <tuple>
+#include <utility>
 
 #include "device_tables.h"
 
@@ -60,6 +64,21 @@ TWR_DEV const TWR_CONST T* cptr(uint64_t addr) {
   return reinterpret_cast<const TWR_CONST T*>(addr);
 }
 
+// Kernel launch that RETURNS its status (hipLaunchKernel) instead of leaving it in the thread's sticky error slot: the
+// library neither reads nor clears an error the host application may have pending.
+template <typename T, size_t... I>
+static inline hipError_t twr_launch_impl(const void* k, dim3 g, dim3 b, size_t lds, hipStream_t s, T& vals, std::index_sequence<I...>) {
+  void* ptrs[] = {static_cast<void*>(&std::get<I>(vals))...};
+  return hipLaunchKernel(k, g, b, ptrs, lds, s);
+}
+template <typename... P, typename... A>
+static inline hipError_t twr_launch(void (*kern)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, A... args) {
+  static_assert(sizeof...(P) == sizeof...(A), "kernel argument count");
+  std::tuple<P...> vals{static_cast<P>(args)...};
+  return twr_launch_impl(reinterpret_cast<const void*>(kern), grid, block, lds, stream, vals, std::index_sequence_for<P...>{});
+}
+static inline hipError_t twr_first(hipError_t a, hipError_t b) { return a != hipSuccess ? a : b; }
+
 // ---------------------------------------------------------------- cubic Hermite weights
 // d{pos,vel,acc}/d{p0,v0,p1,v1} of CubicHermitePolynomial (src/polynomial.cc:140-234); iT = 1/T comes
 // from the tables (one IEEE division on the host instead of one per lane and spline).
@@ -90,7 +109,6 @@ TWR_DEV void hermite_all(double t, double iT, double wp[4], double wv[4], double
 
 // ---------------------------------------------------------------- candidate descriptors
 TWR_DEV int meta_nslots(uint32_t meta) { return meta & 0xF; }
-TWR_DEV int meta_cnt(uint32_t meta, int d) { return (meta >> (4 * (d + 1))) & 0xF; }
 TWR_DEV bool meta_shared(uint32_t meta) { return (meta >> 16) & 1; }
 // all 12 candidate loads are issued unconditionally (absent candidates read slot 0 and later get
 // weight 0): one memory round trip, no branches (Spline::GetPoint needs at most these 12 values)
@@ -122,19 +140,6 @@ TWR_DEV void gather12c(const double* __restrict__ xp, int xbase, const uint16_t 
     const int sl = cand[c] & 0xF;
     v[c] = xp[xbase + (sl != 0xF ? sl : 0)];
   }
-}
-TWR_DEV void ee_pointc(const uint16_t cand[12], bool shared, double tl, double iT, const double v[12], double w[4],
-                       double out[3]) {
-  hermite_pos(tl, iT, w);
-  if (shared) w[0] += w[2];
-  out[0] = out[1] = out[2] = 0.0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const bool valid = (cand[j * 3 + d] & 0xF) != 0xF;
-      out[d] = fma(valid ? w[j] : 0.0, v[j * 3 + d], out[d]);
-    }
 }
 TWR_DEV uint64_t slots_of(const uint16_t cand[12]) {
   uint64_t s = 0;
@@ -227,10 +232,6 @@ TWR_DEV double quad_perm(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
-template <int CTRL>
-TWR_DEV uint32_t quad_perm_u32(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
-}
 TWR_DEV double quad_sum(double v) {
   v += quad_perm<0xB1>(v);  // lane ^ 1
   v += quad_perm<0x4E>(v);  // lane ^ 2
@@ -271,28 +272,6 @@ TWR_DEV void node_values(uint64_t slots, bool shared, const double v[12], double
     for (int d = 0; d < 3; ++d) nv[2][d] = nv[0][d];
   }
 }
-// The two distinct columns of PhaseSpline::GetJacobianOfPosWrtDurations (src/phase_spline.cc:67-93,
-// src/phase_durations.cc:126-154): `prev` for every phase before the current one, `cur` for the
-// current phase (unused in the last phase, which is not a variable).
-//   dx/dT_phase = 1/n_polys * (dpos/dT_poly - polys_before_in_phase * vel)   (polynomial.cc:236-257)
-TWR_DEV void duration_columns(const double nv[4][3], double t, double T, double inner, double prevp, bool in_last,
-                              double prev[3], double cur[3]) {
-  const double t2 = t * t, t3 = t2 * t;
-  const double T2 = T * T, T3 = T2 * T, T4 = T3 * T;
-  double wp[4], wv[4], wa[4];
-  hermite_all(t, 1.0 / T, wp, wv, wa);
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const double x0 = nv[0][d], v0 = nv[1][d], x1 = nv[2][d], v1 = nv[3][d];
-    const double vel = wv[0] * x0 + wv[1] * v0 + wv[2] * x1 + wv[3] * v1;
-    const double dxdT = (t3 * (v0 + v1)) / T3 - (t2 * (2 * v0 + v1)) / T2 - (3 * t3 * (2 * x0 - 2 * x1 + T * v0 + T * v1)) / T4 +
-                        (2 * t2 * (3 * x0 - 3 * x1 + 2 * T * v0 + T * v1)) / T3;
-    const double dph = inner * (dxdT - prevp * vel);
-    cur[d] = dph;
-    prev[d] = -vel - (in_last ? dph : 0.0);
-  }
-}
-
 // ---------------------------------------------------------------- dynamic (SRBD) quad
 // DynamicConstraint::{UpdateModel, UpdateConstraintAtInstance, UpdateJacobianAtInstance}
 // (dynamic_constraint.cc:59-137) with SingleRigidBodyDynamics::{GetDynamicViolation,
@@ -329,14 +308,8 @@ TWR_DEV void rom_load_x(const RomWork& w, const RomRec& r, const double* __restr
   }
   gather12(xp, r.xbase, rom_slots(r), X.m);
 }
-struct RomPhase {           // optimised timings: what the duration columns of one (time node, ee) need
-  bool in_last;             // current phase is the last one (not a variable)
-  double inner, prevp, T;   // 1/n_polys of the phase, polynomials before this one in the phase, its duration
-  double* sched;            // LDS: [0..2] column of the phases before the current one, [3..5] of the current one
-};
-template <bool PHASE = false>
 TWR_DEV void rom_item(const RomWork& w, const RomRec& r, const RomX& X, double* __restrict__ gst, double* __restrict__ stage,
-                      int par, int vbase, int trash, int lane, bool want_g, bool want_j, const RomPhase* ph = nullptr) {
+                      int par, int vbase, int trash, int lane, bool want_g, bool want_j) {
   const int soff = par + r.voff - vbase;
   double wP[4];
   hermite_pos(r.tb, r.iTb, wP);
@@ -395,18 +368,6 @@ TWR_DEV void rom_item(const RomWork& w, const RomRec& r, const RomX& X, double* 
         const int sl = (int)((slots >> (4 * (j * 3 + d))) & 0xF);
         stage[sl != 0xF ? rs[row] + mo[row] + sl : trash] = ro.R[d][row] * wm[j];
       }
-    }
-  }
-  if constexpr (PHASE) {  // b_R_w * GetJacobianOfPosWrtDurations (range_of_motion_constraint.cc:106-108)
-    double nv[4][3], prev[3], cur[3], rp[3], rc[3];
-    node_values(slots, meta_shared(r.meta), X.m, nv);
-    duration_columns(nv, r.tm, ph->T, ph->inner, ph->prevp, ph->in_last, prev, cur);
-    matTvec(ro.R, prev, rp);
-    matTvec(ro.R, cur, rc);
-#pragma unroll
-    for (int row = 0; row < 3; ++row) {
-      ph->sched[row] = rp[row];
-      ph->sched[3 + row] = rc[row];
     }
   }
 }
@@ -681,10 +642,10 @@ constexpr int kRomStage = 4856;   // + 2 + 64 + 192 doubles = 40912 B
 //   back(i+1):  Jacobian blocks of slice i+1 -> image        (single call site of each half)
 #ifndef TWR_TU_ROM
 // ---------------------------------------------------------------- dynamic, fixed timings (dyn_kernel)
-// Same math as dyn_front / dyn_back above (DynamicConstraint + SingleRigidBodyDynamics + EulerConverter for one
-// time node on a quad of lanes), but every index is an LDS byte offset prepared on the host (device_tables.h
-// DynNode / DynGather / DynPut): the slice's part of x sits in LDS ("xs"), values that are not optimisation
-// variables read its zero slot, and a Jacobian value is stored at node base + a 16-bit offset from the record.
+// DynamicConstraint + SingleRigidBodyDynamics + EulerConverter for one time node on a quad of lanes (see above); every
+// index is an LDS byte offset prepared on the host (device_tables.h DynNode / DynGather / DynPut): the slice's part of x
+// sits in LDS ("xs"), values that are not optimisation variables read its zero slot, and a Jacobian value is stored at
+// node base + a 16-bit offset from the record.
 constexpr int kDynX0 = kDynG0 + 96;        // xs: zero pair, then <= kDynXsCap staged doubles of x
 constexpr int kDynLds = kDynX0 + 2 + kDynXsCap;   // 2560 doubles = 20480 B: eight workgroups per CU (the VGPR limit too)
 static_assert(kDynLds * 8 <= 20480, "dyn_kernel: eight workgroups of 20 KB per CU");
@@ -884,7 +845,7 @@ TWR_DEV void dyn2_back(const DynWork& w, const DynNode& nd, const DynPut& pu, co
       }
     }
   } else if (want_j) {
-    // --- base-ang block (:123-165), Euler dimension d = role, factored (see dyn_back)
+    // --- base-ang block (:123-165), Euler dimension d = role, factored (derivation: see pdyn_math)
     const double dMx_dy[3] = {-sy * cz, -sy * sz, -cy};
     const double dMx_dz[3] = {-cy * sz, cy * cz, 0.0};
     const double dMy_dz[3] = {-cz, -sz, 0.0};
@@ -1125,13 +1086,13 @@ __global__ __launch_bounds__(64, 1) void rom_kernel(const RomWork* __restrict__ 
   rom_body(work, n_work, x, g, jac, flags, stage, threadIdx.x, blockIdx.x, gridDim.x);
 }
 
-void launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, const double* x, double* g, double* jac,
-                       int flags) {
-  hipLaunchKernelGGL(rom_kernel, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac, flags);
+hipError_t launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, const double* x, double* g, double* jac,
+                             int flags) {
+  return twr_launch(rom_kernel, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac, flags);
 }
 #else   // !TWR_TU_ROM
-void launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, const double* x, double* g, double* jac,
-                       int flags);
+hipError_t launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, const double* x, double* g, double* jac,
+                             int flags);
 
 // all terrain-ee-motion_e (terrain_constraint.cc:57-108), force-ee-force_e, splineacc-base-* and
 // swing-ee-motion_e sets of one problem.  One workgroup of four waves per problem, one wave per family
@@ -1323,43 +1284,15 @@ __global__ __launch_bounds__(128, 2) void eval_fused_kernel(const RomWork* __res
 // ---------------------------------------------------------------- optimised timings (PhaseSpline) kernels
 // With Parameters::OptimizePhaseDurations the active polynomial of every ee spline depends on x and every
 // Jacobian row of an ee spline holds all variables of its set (phase_spline.cc:44-51), most of them
-// explicit zeros.  A workgroup (one wave) owns a run of 16 time nodes, i.e. one contiguous slice of the
-// value array; it locates the active polynomials from the durations in x and evaluates the same quad / lane
-// math as the fixed-timing kernels, plus the duration columns (dynamic_constraint.cc:107-113,
-// range_of_motion_constraint.cc:106-108).  dyn_phase_kernel first streams zeros over its slice with
-// coalesced 16-byte stores and, once they have been acknowledged, stores the non-zero values directly at
-// their CSR positions; rom_phase_kernel stages a compact image in LDS and streams out whole expanded rows.
-TWR_DEV void zero_fill(double* __restrict__ dst, int n, int lane) {
-  const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-  if (n <= 0) return;
-  if (par && lane == 0) dst[0] = 0.0;
-  double* al = dst + par;  // 16-byte aligned
-  const int m = n - par, npairs = m >> 1;
-  const double2 z = {0.0, 0.0};
-  for (int t = lane; t < npairs; t += 64) reinterpret_cast<double2*>(al)[t] = z;
-  if ((m & 1) && lane == 0) al[m - 1] = 0.0;
-}
-TWR_DEV void phase_poly_durations(const PhaseTables* PT, const char* blob, const double* __restrict__ xp, int e,
-                                  double* ph, double* md, double* fd, bool want_force) {
-  // PhaseDurations::SetVariables (phase_durations.cc:77-103) + ConvertPhaseToPolyDurations
-  // (nodes_variables_phase_based.cc:73-84)
-  const int ns = PT->n_phases[e] - 1;
-  double sum = 0.0;
-  for (int i = 0; i < ns; ++i) {
-    const double d = xp[PT->off_sched[e] + i];
-    ph[i] = d;
-    sum += d;
-  }
-  ph[ns] = PT->t_total[e] - sum;
-  const PhasePoly* mp = tbl<PhasePoly>(blob, PT->o_mpoly[e]);
-  for (int q = 0; q < PT->n_mpoly[e]; ++q) md[q] = ph[mp[q].phase] / mp[q].n_in_phase;
-  if (want_force) {
-    const PhasePoly* fp = tbl<PhasePoly>(blob, PT->o_fpoly[e]);
-    for (int q = 0; q < PT->n_fpoly[e]; ++q) fd[q] = ph[fp[q].phase] / fp[q].n_in_phase;
-  }
-}
-
-// The same, spread over the lanes of a wave (one ee): loads in parallel, only the duration sum is serial.
+// explicit zeros; the duration columns come on top (dynamic_constraint.cc:107-113,
+// range_of_motion_constraint.cc:106-108).  Three kernels: phase_locate_kernel resolves what depends on x in the index
+// work (durations -> active polynomials, local times, current phase) into per-(time node, ee) records;
+// dyn_phase_kernel and rom_phase_kernel then evaluate the same math as the fixed-timing kernels with more lanes per
+// time node, assemble the EXPANDED rows of a few time nodes in LDS (clear, store every value at its final position)
+// and stream them out, so every byte of the Jacobian -- zeros included -- is written to HBM exactly once.
+// PhaseDurations::SetVariables (phase_durations.cc:77-103) + ConvertPhaseToPolyDurations
+// (nodes_variables_phase_based.cc:73-84) of one ee, spread over the lanes of a wave: loads in parallel, only the
+// duration sum is serial.
 TWR_DEV void phase_poly_durations_wave(const PhaseTables* PT, const char* blob, const double* __restrict__ xp, int e,
                                        double* ph, double* md, int lane) {
   const int ns = PT->n_phases[e] - 1;
@@ -2365,8 +2298,8 @@ __global__ __launch_bounds__(64) void sample_kernel(const SampleWork* __restrict
 }
 hipError_t launch_sample(const SampleWork* work, int n_work, const double* x, double* out, double dt, const double* times,
                          hipStream_t stream) {
-  if (n_work > 0) hipLaunchKernelGGL(sample_kernel, dim3(n_work), dim3(64), 0, stream, work, x, out, dt, times);
-  return hipGetLastError();
+  if (n_work <= 0) return hipSuccess;
+  return twr_launch(sample_kernel, dim3(n_work), dim3(64), 0, stream, work, x, out, dt, times);
 }
 
 // ---------------------------------------------------------------- candidate scoring
@@ -2420,8 +2353,7 @@ __global__ __launch_bounds__(64) void score_kernel(const NodeWork* __restrict__ 
   }
 }
 hipError_t launch_score(const NodeWork* work, int n_problems, const double* g, double* scores, hipStream_t stream) {
-  hipLaunchKernelGGL(score_kernel, dim3(n_problems), dim3(64), 0, stream, work, g, scores);
-  return hipGetLastError();
+  return twr_launch(score_kernel, dim3(n_problems), dim3(64), 0, stream, work, g, scores);
 }
 
 // ---------------------------------------------------------------- contact plan
@@ -2498,8 +2430,10 @@ __global__ __launch_bounds__(64) void contact_plan_kernel(const NodeWork* __rest
 #pragma unroll
         for (int d = 0; d < 3; ++d) r[2 + n_ee + 3 * e + d] = p[d];
       }
-      if (my > 0) o[(size_t)(my - 1) * rec + 1] = t - t_prev;   // duration of the state before (:121-123)
     }
+    // duration of the state before (:121-123) -- also when THIS state no longer fits the output (my == max_steps): the
+    // last record that was kept still gets its duration
+    if (step && my > 0 && my - 1 < max_steps) o[(size_t)(my - 1) * rec + 1] = t - t_prev;
     t_carry = __shfl(t, 63 - __clzll(ball));
     n_steps += __popcll(ball);
   }
@@ -2507,9 +2441,8 @@ __global__ __launch_bounds__(64) void contact_plan_kernel(const NodeWork* __rest
 }
 hipError_t launch_contact_plan(const NodeWork* work, int n_problems, const double* x, double* out, int32_t* counts, double dt,
                                double time_horizon, int n_samples_max, int max_steps, hipStream_t stream) {
-  hipLaunchKernelGGL(contact_plan_kernel, dim3(n_problems), dim3(64), 0, stream, work, x, out, counts, dt, time_horizon,
-                     n_samples_max, max_steps);
-  return hipGetLastError();
+  return twr_launch(contact_plan_kernel, dim3(n_problems), dim3(64), 0, stream, work, x, out, counts, dt, time_horizon,
+                    n_samples_max, max_steps);
 }
 
 // ---------------------------------------------------------------- nearest plane of a footstep
@@ -2592,10 +2525,9 @@ __global__ __launch_bounds__(256) void plane_kernel(const double* __restrict__ p
 hipError_t launch_planes(const double* plan, const int32_t* counts, const double* poly_xy, const int32_t* poly_start, int n_polys,
                          int n_problems, int max_steps, int n_ee, int32_t* plane_index, hipStream_t stream) {
   const int64_t n = (int64_t)n_problems * max_steps * n_ee;
-  if (n > 0)
-    hipLaunchKernelGGL(plane_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, plan, counts, poly_xy, poly_start,
-                       n_polys, n_problems, max_steps, n_ee, plane_index);
-  return hipGetLastError();
+  if (n <= 0) return hipSuccess;
+  return twr_launch(plane_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, plan, counts, poly_xy, poly_start, n_polys,
+                    n_problems, max_steps, n_ee, plane_index);
 }
 
 // ---------------------------------------------------------------- TWR_EVAL_CHECK
@@ -2625,8 +2557,7 @@ hipError_t launch_check(int n_problems, const int64_t* g_off, const int64_t* j_o
                         int32_t* status, int flags, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(status, 0, sizeof(int32_t) * (size_t)n_problems, stream);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(check_kernel, dim3(n_problems * kCheckParts), dim3(256), 0, stream, g_off, j_off, g, jac, status, flags);
-  return hipGetLastError();
+  return twr_launch(check_kernel, dim3(n_problems * kCheckParts), dim3(256), 0, stream, g_off, j_off, g, jac, status, flags);
 }
 
 // host-side launcher (called from capi.cc): three launches on one stream.  The dyn/rom grids are
@@ -2649,6 +2580,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
   flags |= env_int("TWR_DEBUG_FLAGS", 0) & ~0xFF;
 #endif
   dim3 block(64);
+  hipError_t st = hipSuccess;
   if (n_ee < 1 || n_ee > 4) return hipErrorInvalidValue;
   static const int fused_max = env_int("TWR_FUSED_MAX_ROM", 4096);   // rom slices up to which the fused launch is used
   if (!ev && n_pdyn == 0 && n_prom == 0 && n_rom > 0 && n_dyn > 0 && n_rom <= fused_max) {
@@ -2667,18 +2599,17 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
       if (g_rom > r) g_rom = r;
       if (g_dyn > d) g_dyn = d;
     }
-    hipLaunchKernelGGL(eval_fused_kernel, dim3(g_rom + g_dyn + 2 * n_node), dim3(128), 0, stream, rom, n_rom, g_rom, dyn,
-                       n_dyn, g_dyn, node, x, g, jac, flags);
-    return hipGetLastError();
+    return twr_launch(eval_fused_kernel, dim3(g_rom + g_dyn + 2 * n_node), dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn,
+                      g_dyn, node, x, g, jac, flags);
   }
   if (ev) (void)hipEventRecord(ev[0], stream);
   if (n_dyn > 0) {
     const int res = dyn_bpc * n_cu;
     dim3 grid(n_dyn < res ? n_dyn : res);
-    hipLaunchKernelGGL(dyn_kernel, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags);
+    st = twr_first(st, twr_launch(dyn_kernel, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags));
   }
   // optimised-timings problems: the pre-pass (segment lookup -> records), then the persistent kernels
-  if (n_ploc > 0) hipLaunchKernelGGL(phase_locate_kernel, dim3(n_ploc), block, 0, stream, ploc, x);
+  if (n_ploc > 0) st = twr_first(st, twr_launch(phase_locate_kernel, dim3(n_ploc), block, 0, stream, ploc, x));
   if (n_pdyn > 0) {
     // LDS per workgroup: the image of one pass; residency follows from it
     const size_t lds = sizeof(double) * (size_t)((pdyn_img_cap + 1) & ~1);
@@ -2690,7 +2621,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
     const int res = bpc * n_cu;
     dim3 grid(n_pdyn < res ? n_pdyn : res);
     const bool wg = flags & 1, wj = flags & 2;
-#define TWR_PDYN_LAUNCH(NIT, WG, WJ) hipLaunchKernelGGL((dyn_phase_kernel<NIT, WG, WJ>), grid, block, lds, stream, pdyn, n_pdyn, x, g, jac)
+#define TWR_PDYN_LAUNCH(NIT, WG, WJ) st = twr_first(st, twr_launch(dyn_phase_kernel<NIT, WG, WJ>, grid, block, lds, stream, pdyn, n_pdyn, x, g, jac))
     if (pdyn_img_cap <= 40 * 128) {
       if (wg && wj) TWR_PDYN_LAUNCH(40, true, true);
       else if (wj) TWR_PDYN_LAUNCH(40, false, true);
@@ -2720,7 +2651,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
     const int res = bpc * n_cu;
     dim3 grid(n_prom < res ? n_prom : res);
     const bool wg = flags & 1, wj = flags & 2;
-#define TWR_PROM_LAUNCH(NIT, WG, WJ) hipLaunchKernelGGL((rom_phase_kernel<NIT, WG, WJ>), grid, block, lds, stream, prom, n_prom, x, g, jac)
+#define TWR_PROM_LAUNCH(NIT, WG, WJ) st = twr_first(st, twr_launch(rom_phase_kernel<NIT, WG, WJ>, grid, block, lds, stream, prom, n_prom, x, g, jac))
 #define TWR_PROM_FLAGS(NIT)                           \
   {                                                   \
     if (wg && wj) TWR_PROM_LAUNCH(NIT, true, true);   \
@@ -2745,12 +2676,12 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
   if (n_rom > 0) {
     const int res = rom_bpc * n_cu;
     dim3 grid(n_rom < res ? n_rom : res);
-    launch_rom_kernel((int)grid.x, stream, rom, n_rom, x, g, jac, flags);
+    st = twr_first(st, launch_rom_kernel((int)grid.x, stream, rom, n_rom, x, g, jac, flags));
   }
   if (ev) (void)hipEventRecord(ev[2], stream);
-  if (n_node > 0) hipLaunchKernelGGL(node_kernel, dim3(n_node), dim3(256), 0, stream, node, x, g, jac, flags);
+  if (n_node > 0) st = twr_first(st, twr_launch(node_kernel, dim3(n_node), dim3(256), 0, stream, node, x, g, jac, flags));
   if (ev) (void)hipEventRecord(ev[3], stream);
-  return hipGetLastError();
+  return st;
 }
 
 int rom_stage_capacity() { return kRomStage; }
