@@ -306,8 +306,11 @@ def test_page_locked_host_buffers_optimised_timings_and_flags():
         pg[:] = np.nan
         pj[:] = np.nan
         batch.eval_host_pinned(flags)
-        assert np.array_equal(pg, g) if want_g else np.isnan(pg).all(), flags
-        assert np.array_equal(pj, j) if want_j else np.isnan(pj).all(), flags
+        # (the single-output variants are other instruction sequences -- template instantiations / branches with their
+        # own FMA contraction -- so they agree with the combined call to rounding, not bit for bit)
+        same = np.array_equal if flags == ta.EVAL_BOTH else (lambda a, b: np.abs(a - b).max() <= 1e-13 * np.abs(b).max())
+        assert same(pg, g) if want_g else np.isnan(pg).all(), flags
+        assert same(pj, j) if want_j else np.isnan(pj).all(), flags
     # x from pageable memory, outputs zero-copy
     pg[:] = np.nan
     pj[:] = np.nan

@@ -20,7 +20,8 @@ namespace twr {
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
                        const NodeWork* node, int n_node, const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap,
                        const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
-                       double* g, double* jac, int flags, hipStream_t stream, hipEvent_t* ev);
+                       double* g, double* jac, double* dump, int flags, hipStream_t stream, hipEvent_t* ev);
+int dyn_dump_doubles();
 hipError_t launch_check(int n_problems, const int64_t* g_off, const int64_t* j_off, const double* g, const double* jac,
                         int32_t* status, int flags, hipStream_t stream);
 hipError_t launch_score(const NodeWork* work, int n_problems, const double* g, double* scores, hipStream_t stream);
@@ -86,6 +87,7 @@ struct twr_batch {
   twr::RomPhaseWork* d_prom = nullptr;
   int64_t *d_goff = nullptr, *d_joff = nullptr;  // device copies of g_off / j_off (TWR_EVAL_CHECK)
   int32_t* d_status = nullptr;                    // per-problem non-finite flags of the last checked evaluation
+  double* d_dump = nullptr; // where dyn_kernel's first (empty) copy-out of every workgroup goes
   void* d_precs = nullptr;  // scratch: x-dependent DynLoc / RomRec records of the optimised-timings problems
   int n_pdyn = 0, n_ploc = 0, n_prom = 0;
   // lazily sized scratch for twr_batch_eval_host
@@ -565,6 +567,8 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     upload(node.data(), node.size() * sizeof(twr::NodeWork), reinterpret_cast<void**>(&b->d_node));
     upload(b->g_off.data(), b->g_off.size() * sizeof(int64_t), reinterpret_cast<void**>(&b->d_goff));
     upload(b->j_off.data(), b->j_off.size() * sizeof(int64_t), reinterpret_cast<void**>(&b->d_joff));
+    TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_dump), sizeof(double) * (size_t)twr::dyn_dump_doubles()));
+    TWR_HIP(hipMemset(b->d_dump, 0, sizeof(double) * (size_t)twr::dyn_dump_doubles()));
     TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_status), sizeof(int32_t) * (size_t)n_problems));
     TWR_HIP(hipMemset(b->d_status, 0, sizeof(int32_t) * (size_t)n_problems));
     b->n_pdyn = (int)pdyn.size();
@@ -625,6 +629,7 @@ void twr_batch_destroy(twr_batch* b) {
   if (b->d_goff) (void)hipFree(b->d_goff);
   if (b->d_joff) (void)hipFree(b->d_joff);
   if (b->d_status) (void)hipFree(b->d_status);
+  if (b->d_dump) (void)hipFree(b->d_dump);
   if (b->d_swork) (void)hipFree(b->d_swork);
   if (b->d_gwork) (void)hipFree(b->d_gwork);
   for (hipEvent_t e : b->prof_events) (void)hipEventDestroy(e);
@@ -669,7 +674,7 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->d_rom, b->n_rom, b->d_node, b->n_node,
                                   b->d_pdyn, b->n_pdyn, b->pdyn_img_cap, b->d_ploc, b->n_ploc, b->d_prom, b->n_prom,
-                                  b->prom_img_cap, d_x, d_g, d_jac, flags & TWR_EVAL_BOTH, stream, ev);
+                                  b->prom_img_cap, d_x, d_g, d_jac, b->d_dump, flags & TWR_EVAL_BOTH, stream, ev);
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   if (flags & TWR_EVAL_CHECK) {
     e = twr::launch_check(b->n_problems, b->d_goff, b->d_joff, d_g, d_jac, b->d_status, flags & TWR_EVAL_BOTH, stream);

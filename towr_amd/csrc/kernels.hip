@@ -171,22 +171,28 @@ TWR_DEV void sincos_fast(double x, double* __restrict__ s, double* __restrict__ 
     sincos(x, s, c);
     return;
   }
-  const double n = rint(x * 6.36619772367581382433e-01);
-  double r = fma(-n, 1.5707963267948966e+00, x);
-  r = fma(-n, 6.1232339957367574e-17, r);
-  r = fma(-n, 8.4784276603688985e-32, r);
+  // (the constants pass through an empty asm: they are then materialised where they are used -- two s_mov each -- instead
+  // of being hoisted out of the persistent loops, where the register allocator ends up spilling them to scratch)
+  auto K = [](double c) {
+    asm volatile("" : "+s"(c));
+    return c;
+  };
+  const double n = rint(x * K(6.36619772367581382433e-01));
+  double r = fma(-n, K(1.5707963267948966e+00), x);
+  r = fma(-n, K(6.1232339957367574e-17), r);
+  r = fma(-n, K(8.4784276603688985e-32), r);
   const double z = r * r;
-  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  ps = fma(z, ps, 2.75573137070700676789e-06);
-  ps = fma(z, ps, -1.98412698298579493134e-04);
-  ps = fma(z, ps, 8.33333333332248946124e-03);
-  ps = fma(z, ps, -1.66666666666666324348e-01);
+  double ps = fma(z, K(1.58969099521155010221e-10), K(-2.50507602534068634195e-08));
+  ps = fma(z, ps, K(2.75573137070700676789e-06));
+  ps = fma(z, ps, K(-1.98412698298579493134e-04));
+  ps = fma(z, ps, K(8.33333333332248946124e-03));
+  ps = fma(z, ps, K(-1.66666666666666324348e-01));
   const double sr = fma(z * r, ps, r);
-  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-  pc = fma(z, pc, -2.75573143513906633035e-07);
-  pc = fma(z, pc, 2.48015872894767294178e-05);
-  pc = fma(z, pc, -1.38888888888741095749e-03);
-  pc = fma(z, pc, 4.16666666666666019037e-02);
+  double pc = fma(z, K(-1.13596475577881948265e-11), K(2.08757232129817482790e-09));
+  pc = fma(z, pc, K(-2.75573143513906633035e-07));
+  pc = fma(z, pc, K(2.48015872894767294178e-05));
+  pc = fma(z, pc, K(-1.38888888888741095749e-03));
+  pc = fma(z, pc, K(4.16666666666666019037e-02));
   const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
   const int q = (int)n & 3;
   const double ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
@@ -587,7 +593,7 @@ TWR_DEV void copy_out(double* __restrict__ dst, const double* __restrict__ stage
 // loads and stores retire through one in-order counter; an unknown store count would force
 // vmcnt(0), i.e. a full store drain per slice).
 template <int NIT, int kBatch>
-TWR_DEV void copy_out_fixed(double* __restrict__ dst, const double* __restrict__ stage, int n, int par, int lane, int abl = 0) {
+TWR_DEV void copy_out_fixed(double* __restrict__ dst, const double* __restrict__ stage, int n, int par, int lane) {
   // byte offsets as unsigned 32-bit values: one VGPR addresses both the LDS read and the global store (wave-uniform
   // base + 32-bit offset), two VALU instructions per store instead of a 64-bit address computation
   char* al = reinterpret_cast<char*>(dst - par);  // 16-byte aligned
@@ -609,17 +615,18 @@ TWR_DEV void copy_out_fixed(double* __restrict__ dst, const double* __restrict__
     for (int b = 0; b < kBatch; ++b)
       if (it0 + b < NIT) {
         off[b] = min(first + 1024u * (uint32_t)(it0 + b), last);
-#ifdef TWR_ABLATE
-        if (abl & 0x4000) v[b] = make_double2(1.0, 2.0); else
-#endif
         v[b] = *reinterpret_cast<const double2*>(st + off[b]);
       }
 #pragma unroll
     for (int b = 0; b < kBatch; ++b)
       if (it0 + b < NIT) *reinterpret_cast<double2*>(al + off[b]) = v[b];
   }
-  if (par && lane == 0 && n > 0) dst[0] = stage[1];
-  if ((total & 1) && lane == 0 && total - 1 > par) dst[n - 1] = stage[total - 1];
+  // first and last value of the slice (they sit in half pairs when the slice starts / ends on an odd index): stored by
+  // every lane, whatever the parity -- two more store instructions that are ALWAYS issued.  A store inside a divergent
+  // `if` is a branch the compiler must assume not taken when it counts the stores behind a prefetched load, and one
+  // uncounted store is enough to turn the next counted wait into a drain of the whole copy-out.
+  dst[0] = stage[par];
+  dst[n - 1] = stage[total - 1];
 }
 
 // LDS image sizes (doubles).  dynamic: 16 time nodes per wave (~170 values each at 4 ee) -> 22.5 KiB,
@@ -662,14 +669,7 @@ struct Dyn2Front {   // (the base-spline weights are recomputed in the back half
 TWR_DEV double lds_f64(const char* __restrict__ lds, uint32_t byte_off) {
   return *reinterpret_cast<const double*>(lds + byte_off);
 }
-#if defined(TWR_ABLATE) && TWR_ABLATE == 2   // diagnostic: the image fill replaced by an accumulation (math kept, LDS stores gone)
-__device__ double g_abl_sink;
-TWR_DEV void lds_put(char* __restrict__ lds, uint32_t byte_off, double v) {
-  if (v == 1.2345e-300 + byte_off) g_abl_sink = v;
-}
-#else
 TWR_DEV void lds_put(char* __restrict__ lds, uint32_t byte_off, double v) { *reinterpret_cast<double*>(lds + byte_off) = v; }
-#endif
 // staged candidate c of a spline: xs[idx[c]]
 TWR_DEV void gather12s(const char* __restrict__ xs, const uint8_t idx[12], double v[12]) {
   const uint32_t* w = reinterpret_cast<const uint32_t*>(idx);
@@ -909,9 +909,14 @@ TWR_DEV void dyn2_back(const DynWork& w, const DynNode& nd, const DynPut& pu, co
 //   B  back(i): Jacobian blocks -> image
 //   S  xs <- xr (x(i+1));  then issue: front record of slice i+2, xr <- gather x(i+2), mapr <- map(i+3)
 // (`stage`: kDynLds doubles of LDS owned by this wave; the wave takes slices i, i + stride, ...)
+// WANT_G / WANT_J are compile-time, the first iteration copies the not-yet-filled image to a dump region instead of
+// skipping the copy-out, and no store sits in a divergent branch: the number of vector-memory instructions between a
+// prefetch and its use is then a constant on every path, and the compiler's counted waits stay counted.  (With run-time
+// flags and `if (pending)` it had to assume the shortest path -- no stores at all -- and the wait for the put record in
+// the middle of the loop drained the whole copy-out of the previous slice.)
+template <bool WANT_G, bool WANT_J>
 TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double* __restrict__ x, double* __restrict__ g,
-                      double* __restrict__ jac, int flags, double* stage, int lane, int i, int stride) {
-  const bool want_g = flags & 1, want_j = flags & 2;
+                      double* __restrict__ jac, double* __restrict__ dump, double* stage, int lane, int i, int stride) {
   double* gst = stage + kDynG0;
   char* xs = reinterpret_cast<char*>(stage + kDynX0);
   if (i >= n_work) return;
@@ -930,8 +935,20 @@ TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double
     for (int c = 0; c < 4; ++c)
       if (64 * c + lane < kDynXsCap) stage[kDynX0 + 2 + 64 * c + lane] = xr[c];
   };
-  DynWork wp = work[i];   // slice whose image is waiting to be copied out (none yet)
-  bool pending = false;
+  // image -> HBM; the constraint values (6 per time node, contiguous in g) with clamped lanes instead of predicates
+  auto copy_out = [&](double* pdst, double* pg, int nvals, int cnt) {
+    const int ppar = (int)((reinterpret_cast<uintptr_t>(pdst) >> 3) & 1);
+    if (WANT_J) copy_out_fixed<NIT, kDynCopyBatch>(pdst, stage, nvals, ppar, lane);
+    if (WANT_G) {
+      const int last = 6 * cnt - 1;
+      pg[min(lane, last)] = gst[min(lane, last)];
+      pg[min(lane + 64, last)] = gst[min(lane + 64, last)];
+    }
+  };
+  DynWork wp = work[i];   // slice whose image is waiting to be copied out
+  // (nothing is pending in the first iteration: its copy-out goes to the dump region, same instruction count)
+  double* pdst = dump;
+  double* pg = dump + kDynImage + 2;
   DynWork w0 = wp, w1 = wp, w2 = wp;
   DynNode nd0, nd1;
   DynGather ga0, ga1;
@@ -959,34 +976,10 @@ TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double
     double* dst = jac + w0.j_off;
     const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
     Dyn2Front S;
-#ifdef TWR_ABLATE   // diagnostic build only (make ablate): runtime switches in flags bits 8.. (scripts/ablate.py)
-    if (flags & 0x400) {
-      double* sp = reinterpret_cast<double*>(&S);
-      for (int q = 0; q < (int)(sizeof(S) / 8); ++q) sp[q] = 0.25 + q;
-    } else
-#endif
     dyn2_front(nd0, ga0, xs, lane, S);                                                       // F
     const DynPut pu = *gptr<DynPut>(w0.put + ga0.put_off);                                   // P (earlier costs spills: slower)
-#ifdef TWR_ABLATE
-    if (pending && !(flags & 0x100)) {
-#else
-    if (pending) {                                                                           // O
-#endif
-      double* pdst = jac + wp.j_off;
-      const int ppar = (int)((reinterpret_cast<uintptr_t>(pdst) >> 3) & 1);
-      if (want_j) copy_out_fixed<NIT, kDynCopyBatch>(pdst, stage, wp.nvals, ppar, lane, flags);
-      if (want_g) {                                     // 6 constraint values per time node, contiguous in g
-        double* go = g + wp.g_off;
-        if (lane < 6 * wp.cnt) go[lane] = gst[lane];
-        if (lane + 64 < 6 * wp.cnt) go[lane + 64] = gst[lane + 64];
-      }
-    }
-#ifdef TWR_ABLATE
-    if (!(flags & 0x200))
-      dyn2_back(w0, nd0, pu, S, gst, reinterpret_cast<char*>(stage + par), lane, want_g, want_j && !(flags & 0x1000));
-#else
-    dyn2_back(w0, nd0, pu, S, gst, reinterpret_cast<char*>(stage + par), lane, want_g, want_j);   // B
-#endif
+    copy_out(pdst, pg, wp.nvals, wp.cnt);                                                    // O
+    dyn2_back(w0, nd0, pu, S, gst, reinterpret_cast<char*>(stage + par), lane, WANT_G, WANT_J);   // B
     if (has1) stage_x(xr);                                                                   // S
     DynNode nd2 = nd1;
     DynGather ga2 = ga1;
@@ -996,28 +989,20 @@ TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double
     }
     if (has3) mapr = load_map(w3);
     wp = w0;
-    pending = true;
+    pdst = dst;
+    pg = g + w0.g_off;
     w0 = w1; nd0 = nd1; ga0 = ga1;
     w1 = w2; nd1 = nd2; ga1 = ga2;
     w2 = w3;
   }
-  {                                                     // last slice of this workgroup
-    double* pdst = jac + wp.j_off;
-    const int ppar = (int)((reinterpret_cast<uintptr_t>(pdst) >> 3) & 1);
-    if (want_j) copy_out_fixed<NIT, kDynCopyBatch>(pdst, stage, wp.nvals, ppar, lane);
-    if (want_g) {
-      double* go = g + wp.g_off;
-      if (lane < 6 * wp.cnt) go[lane] = gst[lane];
-      if (lane + 64 < 6 * wp.cnt) go[lane + 64] = gst[lane + 64];
-    }
-  }
+  copy_out(pdst, pg, wp.nvals, wp.cnt);                 // last slice of this workgroup
 }
 
-__global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ work, int n_work,
-                                                    const double* __restrict__ x, double* __restrict__ g,
-                                                    double* __restrict__ jac, int flags) {
+template <bool WANT_G, bool WANT_J>
+__global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ work, int n_work, const double* __restrict__ x,
+                                                    double* __restrict__ g, double* __restrict__ jac, double* __restrict__ dump) {
   __shared__ __attribute__((aligned(16))) double stage[kDynLds];
-  dyn_body(work, n_work, x, g, jac, flags, stage, threadIdx.x, blockIdx.x, gridDim.x);
+  dyn_body<WANT_G, WANT_J>(work, n_work, x, g, jac, dump, stage, threadIdx.x, blockIdx.x, gridDim.x);
 }
 
 #endif  // !TWR_TU_ROM
@@ -1025,9 +1010,9 @@ __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ 
 // rom_kernel is compiled in its own translation unit (rom_tu.hip) with a different instruction scheduling
 // strategy: it is store bound and gains 4-5 % from clause-oriented scheduling, the VALU-bound kernels lose.
 constexpr int kRomLds = kRomStage + 2 + 64 + 192;   // doubles: image, per-lane trash slots, g
+template <bool WANT_G, bool WANT_J>
 TWR_DEV void rom_body(const RomWork* __restrict__ work, int n_work, const double* __restrict__ x, double* __restrict__ g,
-                      double* __restrict__ jac, int flags, double* stage, int lane, int i, int stride) {
-  const bool want_g = flags & 1, want_j = flags & 2;
+                      double* __restrict__ jac, double* stage, int lane, int i, int stride) {
   const int trash = kRomStage + 2 + lane;
   double* gst = stage + kRomStage + 2 + 64;
   if (i >= n_work) return;
@@ -1045,33 +1030,16 @@ TWR_DEV void rom_body(const RomWork* __restrict__ work, int n_work, const double
     double* dst = jac + w0.j_off;
     const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
     const int vbase = __builtin_amdgcn_readfirstlane(r0.voff);
-#ifdef TWR_ABLATE
-    if (lane < w0.cnt && !(flags & 0x200)) rom_item(w0, r0, X, gst, stage, par, vbase, trash, lane, want_g, want_j && !(flags & 0x1000));
-#else
-    if (lane < w0.cnt) rom_item(w0, r0, X, gst, stage, par, vbase, trash, lane, want_g, want_j);   // C
-#endif
+    if (lane < w0.cnt) rom_item(w0, r0, X, gst, stage, par, vbase, trash, lane, WANT_G, WANT_J);   // C
     RomRec r2 = r1;
     if (has2) r2 = rom_load_rec(w2, lane);              // A (records first: the wait for x retires them too)
-#ifdef TWR_ABLATE
-    if (has1 && !(flags & 0x400)) rom_load_x(w1, r1, x, X);
-#else
     if (has1) rom_load_x(w1, r1, x, X);
-#endif
-#ifdef TWR_ABLATE
-    if (want_j && !(flags & 0x100))
-#else
-    if (want_j)                                         // B
-#endif
-#ifdef TWR_ABLATE
-      copy_out_fixed<(kRomStage + 2 + 127) / 128, 13>(dst, stage, w0.nvals, par, lane, flags);
-#else
-      copy_out_fixed<(kRomStage + 2 + 127) / 128, 13>(dst, stage, w0.nvals, par, lane);
-#endif
-    if (want_g) {                                       //   3 constraint values per time node, contiguous in g
-      double* go = g + w0.g_off;
+    if (WANT_J) copy_out_fixed<(kRomStage + 2 + 127) / 128, 13>(dst, stage, w0.nvals, par, lane);   // B
+    if (WANT_G) {                                       //   3 constraint values per time node, contiguous in g: clamped
+      double* go = g + w0.g_off;                        //   lanes instead of predicates (see copy_out_fixed)
+      const int last = 3 * w0.cnt - 1;
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
-        if (lane + 64 * t < 3 * w0.cnt) go[lane + 64 * t] = gst[lane + 64 * t];
+      for (int t = 0; t < 3; ++t) go[min(lane + 64 * t, last)] = gst[min(lane + 64 * t, last)];
     }
     w0 = w1; r0 = r1;
     w1 = w2; r1 = r2;
@@ -1079,16 +1047,19 @@ TWR_DEV void rom_body(const RomWork* __restrict__ work, int n_work, const double
 }
 
 #ifdef TWR_TU_ROM
-__global__ __launch_bounds__(64, 1) void rom_kernel(const RomWork* __restrict__ work, int n_work,
-                                                    const double* __restrict__ x, double* __restrict__ g,
-                                                    double* __restrict__ jac, int flags) {
+template <bool WANT_G, bool WANT_J>
+__global__ __launch_bounds__(64, 1) void rom_kernel(const RomWork* __restrict__ work, int n_work, const double* __restrict__ x,
+                                                    double* __restrict__ g, double* __restrict__ jac) {
   __shared__ __attribute__((aligned(16))) double stage[kRomLds];
-  rom_body(work, n_work, x, g, jac, flags, stage, threadIdx.x, blockIdx.x, gridDim.x);
+  rom_body<WANT_G, WANT_J>(work, n_work, x, g, jac, stage, threadIdx.x, blockIdx.x, gridDim.x);
 }
 
 hipError_t launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, const double* x, double* g, double* jac,
                              int flags) {
-  return twr_launch(rom_kernel, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac, flags);
+  const bool wg = flags & 1, wj = flags & 2;
+  if (wg && wj) return twr_launch(rom_kernel<true, true>, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac);
+  if (wj) return twr_launch(rom_kernel<false, true>, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac);
+  return twr_launch(rom_kernel<true, false>, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac);
 }
 #else   // !TWR_TU_ROM
 hipError_t launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, const double* x, double* g, double* jac,
@@ -1259,26 +1230,28 @@ __global__ __launch_bounds__(256, 4) void node_kernel(const NodeWork* __restrict
 // and 40 KB: blocks [0, g_rom) take the rom role (wave 0 only; the image is 39 KB), the next g_dyn blocks the dyn role
 // (both waves, one 20-KB half each), the rest the node role (two families per block) -- the residency per CU of each
 // role is that of its own kernel, and blocks are dispatched in this order, so a later role starts as the earlier drains.
+template <bool WANT_G, bool WANT_J>
 __global__ __launch_bounds__(128, 2) void eval_fused_kernel(const RomWork* __restrict__ rom, int n_rom, int g_rom,
                                                             const DynWork* __restrict__ dyn, int n_dyn, int g_dyn,
                                                             const NodeWork* __restrict__ node, const double* __restrict__ x,
-                                                            double* __restrict__ g, double* __restrict__ jac, int flags) {
+                                                            double* __restrict__ g, double* __restrict__ jac,
+                                                            double* __restrict__ dump) {
   static_assert(2 * kDynLds >= kRomLds && kDynLds >= kStageForce, "LDS of the fused kernel");
   __shared__ __attribute__((aligned(16))) double stage[2 * kDynLds];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   int b = blockIdx.x;
   if (b < g_rom) {
-    if (wave == 0) rom_body(rom, n_rom, x, g, jac, flags, stage, lane, b, g_rom);
+    if (wave == 0) rom_body<WANT_G, WANT_J>(rom, n_rom, x, g, jac, stage, lane, b, g_rom);
     return;
   }
   b -= g_rom;
   if (b < g_dyn) {
-    dyn_body(dyn, n_dyn, x, g, jac, flags, stage + wave * kDynLds, lane, 2 * b + wave, 2 * g_dyn);
+    dyn_body<WANT_G, WANT_J>(dyn, n_dyn, x, g, jac, dump, stage + wave * kDynLds, lane, 2 * b + wave, 2 * g_dyn);
     return;
   }
   b -= g_dyn;
   const int family = 2 * (b & 1) + wave;
-  node_body(node[b >> 1], x, g, jac, flags, stage + wave * kDynLds, family, lane);
+  node_body(node[b >> 1], x, g, jac, (WANT_G ? 1 : 0) | (WANT_J ? 2 : 0), stage + wave * kDynLds, family, lane);
 }
 
 // ---------------------------------------------------------------- optimised timings (PhaseSpline) kernels
@@ -2574,11 +2547,9 @@ static int env_int(const char* name, int dflt) {
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
                        const NodeWork* node, int n_node, const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap,
                        const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
-                       double* g, double* jac, int flags, hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */) {
+                       double* g, double* jac, double* dump /* kDynDump doubles */, int flags, hipStream_t stream,
+                       hipEvent_t* ev /* 4 events or nullptr */) {
   static const int dyn_bpc = env_int("TWR_DYN_BPC", 8), rom_bpc = env_int("TWR_ROM_BPC", 4);
-#ifdef TWR_ABLATE
-  flags |= env_int("TWR_DEBUG_FLAGS", 0) & ~0xFF;
-#endif
   dim3 block(64);
   hipError_t st = hipSuccess;
   if (n_ee < 1 || n_ee > 4) return hipErrorInvalidValue;
@@ -2599,14 +2570,18 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
       if (g_rom > r) g_rom = r;
       if (g_dyn > d) g_dyn = d;
     }
-    return twr_launch(eval_fused_kernel, dim3(g_rom + g_dyn + 2 * n_node), dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn,
-                      g_dyn, node, x, g, jac, flags);
+    const dim3 fgrid(g_rom + g_dyn + 2 * n_node);
+    if ((flags & 3) == 3) return twr_launch(eval_fused_kernel<true, true>, fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump);
+    if (flags & 2) return twr_launch(eval_fused_kernel<false, true>, fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump);
+    return twr_launch(eval_fused_kernel<true, false>, fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump);
   }
   if (ev) (void)hipEventRecord(ev[0], stream);
   if (n_dyn > 0) {
     const int res = dyn_bpc * n_cu;
     dim3 grid(n_dyn < res ? n_dyn : res);
-    st = twr_first(st, twr_launch(dyn_kernel, grid, block, 0, stream, dyn, n_dyn, x, g, jac, flags));
+    if ((flags & 3) == 3) st = twr_first(st, twr_launch(dyn_kernel<true, true>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, dump));
+    else if (flags & 2) st = twr_first(st, twr_launch(dyn_kernel<false, true>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, dump));
+    else st = twr_first(st, twr_launch(dyn_kernel<true, false>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, dump));
   }
   // optimised-timings problems: the pre-pass (segment lookup -> records), then the persistent kernels
   if (n_ploc > 0) st = twr_first(st, twr_launch(phase_locate_kernel, dim3(n_ploc), block, 0, stream, ploc, x));
@@ -2685,6 +2660,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
 }
 
 int rom_stage_capacity() { return kRomStage; }
+int dyn_dump_doubles() { return kDynImage + 2 + 96; }
 #endif  // !TWR_TU_ROM
 
 }  // namespace twr
