@@ -175,6 +175,16 @@ void twr_structure_destroy(twr_structure* s);
  * hardware threads).  On failure nothing is left allocated and out[] is all NULL. */
 int twr_structure_create_many(const twr_model* model, const twr_schedule* schedules, const twr_params* params, int n,
                               int n_threads, twr_structure** out);
+/* The same for a gridded terrain (model->terrain_id == TWR_TERRAIN_CSV_GRID / TWR_TERRAIN_GRID_MAP): every structure
+ * shares `grid` (one device copy per batch).  This is what a sweep over the perception-driven `Grid` terrain of
+ * fpowr (footstep_plan_server.cc:155) uses; grid == NULL is twr_structure_create_many. */
+int twr_structure_create_many_with_grid(const twr_model* model, const twr_schedule* schedules, const twr_params* params, int n,
+                                        int n_threads, const twr_terrain_grid* grid, twr_structure** out);
+/* What a rank needs to rebuild a grid handle it received over the wire (towr_amd/dist.py broadcast_grid): kind (0: CSV
+ * heights, double [rows][cols]; 1: grid_map elevation layer, float, column-major [size_x][size_y]), the two sizes,
+ * resolution and map position (grid_map only), and the cell data (`data` points into the handle; valid until destroy). */
+int twr_terrain_grid_info(const twr_terrain_grid* g, int32_t* kind, int32_t* rows_or_size_x, int32_t* cols_or_size_y,
+                          double* resolution, double* pos_x, double* pos_y, const void** data);
 int twr_structure_sizes(const twr_structure* s, twr_sizes* out);
 int twr_structure_var_set(const twr_structure* s, int i, twr_set_info* out);
 int twr_structure_con_set(const twr_structure* s, int i, twr_set_info* out);

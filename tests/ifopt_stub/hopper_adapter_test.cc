@@ -4,7 +4,8 @@
 // EvalNonzerosOfJacobian(x, values), GetBoundsOnConstraints -- with towr_amd's device sets behind
 // ifopt::ConstraintSet (towr_amd/csrc/ifopt_adapter.h).  Compiled against tests/ifopt_stub (this image has neither
 // ifopt nor Eigen).  The result must equal a direct twr_batch_eval_host call bit for bit, in ifopt's stacking order.
-//   hopper_adapter_test            -> needs a GPU, exit 0 on success
+//   hopper_adapter_test --gpu <sets> [gridmap]  -> needs a GPU, exit 0 on success; `gridmap`: on the `Grid` terrain fpowr
+//                                                  hands the solver (a grid_map elevation layer) instead of flat ground
 //   hopper_adapter_test --no-gpu   -> everything up to the device: expects TWR_ERR_NO_DEVICE to surface as an exception
 #include <ifopt/problem.h>
 
@@ -42,8 +43,26 @@ void expect(bool ok, const char* what) {
 int main(int argc, char** argv) {
   const bool no_gpu = argc > 1 && std::string(argv[1]) == "--no-gpu";
   const int sets = argc > 2 ? std::atoi(argv[2]) : TWR_SETS_TOWR_DEFAULT;
+  const bool gridmap = argc > 3 && std::string(argv[3]) == "gridmap";
   twr_model model;
-  twr_model_preset(TWR_ROBOT_MONOPED, TWR_TERRAIN_FLAT, &model);
+  twr_model_preset(TWR_ROBOT_MONOPED, gridmap ? TWR_TERRAIN_GRID_MAP : TWR_TERRAIN_FLAT, &model);
+  // a perception-style elevation layer: 64 x 40 cells of 4 cm around (0.6, 0), a ramp with two steps (float, column-major
+  // [size_x][size_y] like grid_map's Eigen::MatrixXf)
+  twr_terrain_grid* grid = nullptr;
+  std::vector<float> elevation;
+  if (gridmap) {
+    const int sx = 64, sy = 40;
+    elevation.resize(static_cast<size_t>(sx) * sy);
+    for (int j = 0; j < sy; ++j)
+      for (int i = 0; i < sx; ++i) {
+        const double xw = 0.6 + 0.5 * sx * 0.04 - (i + 0.5) * 0.04;   // cell centre, grid_map convention
+        elevation[i + static_cast<size_t>(j) * sx] = static_cast<float>(0.05 * xw + (xw > 0.4 ? 0.03 : 0.0) + (xw > 0.8 ? 0.04 : 0.0) + 0.002 * j);
+      }
+    if (twr_terrain_grid_map_create(elevation.data(), sx, sy, 0.04, 0.6, 0.0, &grid) != TWR_OK) {
+      std::printf("twr_terrain_grid_map_create: %s\n", twr_last_error());
+      return 2;
+    }
+  }
   twr_schedule sched;
   std::memset(&sched, 0, sizeof(sched));
   sched.n_ee = 1;
@@ -57,7 +76,7 @@ int main(int argc, char** argv) {
 
   std::vector<ifopt::ConstraintSet::Ptr> device_sets;
   try {
-    device_sets = towr_amd::MakeDeviceConstraints(model, sched, prm, /*device=*/0);
+    device_sets = towr_amd::MakeDeviceConstraints(model, sched, prm, /*device=*/0, grid);
   } catch (const std::exception& e) {
     std::printf("MakeDeviceConstraints: %s\n", e.what());
     if (no_gpu) return std::strstr(e.what(), "no HIP device") ? 0 : 2;
@@ -70,7 +89,7 @@ int main(int argc, char** argv) {
 
   // reference data straight from the C ABI (what the adapter must reproduce)
   twr_structure* S = nullptr;
-  twr_structure_create(&model, &sched, &prm, &S);
+  expect(twr_structure_create_with_grid(&model, &sched, &prm, grid, &S) == TWR_OK, "twr_structure_create_with_grid");
   twr_sizes sz;
   twr_structure_sizes(S, &sz);
   const double lin0[3] = {0, 0, 0.5}, ang0[3] = {0, 0, 0}, lin1[3] = {1.0, 0, 0.5}, ee0[3] = {0, 0, 0};  // hopper_example.cc:53-59
@@ -130,9 +149,49 @@ int main(int argc, char** argv) {
   for (int r = 0; bounds && r < sz.n_rows; ++r) bounds = b[r].lower_ == lo[r] && b[r].upper_ == up[r];
   expect(bounds, "GetBounds equals twr_structure_bounds");
 
-  std::printf("hopper through ifopt: n=%d m=%d nnz=%d sets=%d  max|dg|=%g max|dJ|=%g  %s\n", sz.n_vars, sz.n_rows, sz.nnz,
-              sz.n_con_sets, dg, dj, fails ? "FAILED" : "ok");
+  // variable sets the structure does not know: "ee-schedule<ee>" of a problem with fixed timings is an empty block (the
+  // reference's composite may hold it), any other name must throw instead of yielding a silent zero block
+  {
+    const double one[1] = {0.3};
+    bool threw = false, sched_ok = true;
+    try {
+      ifopt::Problem bad;
+      for (int i = 0; i < sz.n_var_sets; ++i) {
+        twr_set_info v;
+        twr_structure_var_set(S, i, &v);
+        bad.AddVariableSet(std::make_shared<PlainVariables>(v.name, x.data() + v.offset, v.size));
+      }
+      bad.AddVariableSet(std::make_shared<PlainVariables>("ee-motoin_0", one, 1));   // a typo'd set name
+      for (auto& c : towr_amd::MakeDeviceConstraints(model, sched, prm, 0, grid)) bad.AddConstraintSet(c);
+      (void)bad.GetJacobianOfConstraints();
+    } catch (const std::exception& e) {
+      threw = std::strstr(e.what(), "unknown variable set") != nullptr;
+    }
+    expect(threw, "FillJacobianBlock throws on an unknown variable set name");
+    if (!(sets & TWR_SET_TOTAL_TIME)) {
+      try {
+        ifopt::Problem okp;
+        for (int i = 0; i < sz.n_var_sets; ++i) {
+          twr_set_info v;
+          twr_structure_var_set(S, i, &v);
+          okp.AddVariableSet(std::make_shared<PlainVariables>(v.name, x.data() + v.offset, v.size));
+        }
+        okp.AddVariableSet(std::make_shared<PlainVariables>("ee-schedule0", one, 1));
+        for (auto& c : towr_amd::MakeDeviceConstraints(model, sched, prm, 0, grid)) okp.AddConstraintSet(c);
+        ifopt::Problem::Jacobian j2 = okp.GetJacobianOfConstraints();
+        j2.makeCompressed();
+        sched_ok = j2.nonZeros() == sz.nnz;
+      } catch (const std::exception&) {
+        sched_ok = false;
+      }
+      expect(sched_ok, "ee-schedule<ee> of a fixed-timing problem is an empty block");
+    }
+  }
+
+  std::printf("hopper through ifopt%s: n=%d m=%d nnz=%d sets=%d  max|dg|=%g max|dJ|=%g  %s\n", gridmap ? " on a grid_map terrain" : "",
+              sz.n_vars, sz.n_rows, sz.nnz, sz.n_con_sets, dg, dj, fails ? "FAILED" : "ok");
   twr_batch_destroy(B);
   twr_structure_destroy(S);
+  twr_terrain_grid_destroy(grid);
   return fails ? 1 : 0;
 }

@@ -13,12 +13,24 @@ sys.path.insert(0, os.environ["TWR_ROOT"])
 import numpy as np, torch, torch.distributed as dist
 import towr_amd as ta
 from towr_amd import sweep
-from towr_amd.dist import broadcast_model, my_shard, gather_scores, best_candidate
+from towr_amd.dist import broadcast_model, broadcast_grid, my_shard, gather_scores, best_candidate
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 model = broadcast_model(ta.model_preset("anymal", "stairs") if rank == 0 else None)
 ref = ta.model_preset("anymal", "stairs")
 assert bytes(model) == bytes(ref), "model blob differs after broadcast"
+# the gridded terrain travels the same way (SURVEY 5 / 8e): a float elevation layer + resolution + position, then CSV heights
+elev = (np.arange(40 * 28, dtype=np.float32).reshape(40, 28) % 17) * 0.01
+gm = broadcast_grid(ta.GridMap(elev, 0.05, (0.7, -0.1)) if rank == 0 else None)
+assert isinstance(gm, ta.GridMap) and gm.elevation.shape == (40, 28) and np.array_equal(np.asarray(gm.elevation), elev)
+assert gm.resolution == 0.05 and gm.position == (0.7, -0.1)
+csv = broadcast_grid(ta.TerrainGrid(np.arange(6 * 9, dtype=np.float64).reshape(6, 9) * 0.02) if rank == 0 else None)
+assert not isinstance(csv, ta.GridMap) and np.array_equal(csv.heights, np.arange(54, dtype=np.float64).reshape(6, 9) * 0.02)
+mg = ta.model_preset("anymal", "grid_map")
+gs = sweep.candidate_structures(mg, sweep.enumerate_candidates(6), threads=2, grid=gm)   # every rank, on ITS copy of the map
+hg = [None] * world
+dist.all_gather_object(hg, hashlib.sha256(b"".join(s_.col_idx.tobytes() for s_ in gs)).digest())
+assert all(x == hg[0] for x in hg)
 cands = sweep.enumerate_candidates(48)
 # SURVEY 8e: shard by a cheap weight, then every rank builds the structures of ITS shard only (threaded library call)
 weights = [int(sweep.candidate_weight(c)) for c in cands]

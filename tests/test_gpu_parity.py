@@ -666,6 +666,38 @@ def test_grid_map_terrain():
         assert_parity(cases[s].S, *_split(batch, g, j, p), rg, rj, "shared map problem %d" % p)
 
 
+def test_grid_map_sweep_through_create_many():
+    """A 64-candidate sweep on the `Grid` terrain fpowr runs on (footstep_plan_server.cc:155): all structures built by
+    ONE threaded twr_structure_create_many_with_grid call, sharing one grid handle (uploaded once); every candidate equals
+    the structure built one by one and the oracle on the same map."""
+    from oracle import binding as ob
+    from towr_amd import sweep
+
+    rng = np.random.default_rng(21)
+    elev = (0.04 * np.arange(60)[:, None] * 0.05 + rng.uniform(0.0, 0.05, size=(60, 44))).astype(np.float32)
+    gm = ta.GridMap(elev, 0.05, (1.2, 0.0))
+    model = ta.model_preset("anymal", "grid_map")
+    cands = sweep.enumerate_candidates(64)
+    structs = sweep.candidate_structures(model, cands, threads=4, grid=gm)
+    assert len({(S.n, S.m, S.nnz) for S in structs}) > 1, "the sweep must be ragged"
+    one = sweep.candidate_structure(model, cands[37], grid=gm)
+    assert one.nnz == structs[37].nnz and np.array_equal(one.col_idx, structs[37].col_idx)
+    batch = ta.Batch(structs, list(range(64)), device=0)
+    xs = _sweep_inputs(structs, model)
+    g, j = batch.eval_host(np.concatenate(xs))
+    assert np.isfinite(j).all()
+    for p in range(0, 64, 3):
+        S = structs[p]
+        prm = S.params
+        P = ob.OracleProblem("anymal", "grid_map", S.schedule.durations(), S.schedule.contact(), dt_dynamic=prm.dt_dynamic,
+                             dt_rom=prm.dt_rom, duration_base_poly=prm.duration_base_poly, polys_per_swing=prm.polys_per_swing,
+                             polys_per_stance_force=prm.polys_per_stance_force, constraint_sets=prm.constraint_sets,
+                             grid_map=(gm.elevation, gm.resolution, gm.position))
+        rg, rp, ci, rj = P.eval(xs[p])
+        assert np.array_equal(rp, S.row_ptr) and np.array_equal(ci, S.col_idx)
+        assert_parity(S, *_split(batch, g, j, p), rg, rj, "grid_map sweep candidate %d" % p, x=xs[p])
+
+
 def test_candidate_scores_and_contact_plans():
     """Sweep post-processing on the device: per-family bound violations (twr_batch_score) against numpy on the oracle's
     g and bounds, and fpowr::ExtractFootstepPlan (footstep_plan_extractor.h:69-133, minus the plane lookup) against

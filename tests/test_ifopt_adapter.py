@@ -35,10 +35,15 @@ def test_adapter_compiles_warning_free_and_fails_loudly_without_a_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sets", [63, 127, 27], ids=["towr_default", "optimised_timings", "hot_path"])
-def test_hopper_through_the_ifopt_surface(sets):
-    """MakeDeviceConstraints -> GetValues / GetBounds / GetJacobian of every set == twr_batch_eval_host, stacked."""
+@pytest.mark.parametrize("sets,terrain", [(63, "flat"), (127, "flat"), (27, "flat"), (63, "gridmap"), (127, "gridmap")],
+                         ids=["towr_default", "optimised_timings", "hot_path", "grid_map_terrain", "grid_map_optimised_timings"])
+def test_hopper_through_the_ifopt_surface(sets, terrain):
+    """MakeDeviceConstraints -> GetValues / GetBounds / GetJacobian of every set == twr_batch_eval_host, stacked; on flat
+    ground (hopper_example.cc) and on the `Grid` terrain fpowr hands the solver (footstep_plan_server.cc:155); an unknown
+    variable-set name must throw, "ee-schedule<ee>" of a fixed-timing problem must not."""
     _build()
-    r = subprocess.run([EXE, "--gpu", str(sets)], capture_output=True, text=True, timeout=300)
+    args = [EXE, "--gpu", str(sets)] + (["gridmap"] if terrain == "gridmap" else [])
+    r = subprocess.run(args, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "max|dg|=0 max|dJ|=0" in r.stdout and " ok" in r.stdout, r.stdout
+    assert ("grid_map terrain" in r.stdout) == (terrain == "gridmap")

@@ -110,6 +110,10 @@ def lib():
         L.twr_structure_destroy.restype = None
         L.twr_structure_create_many.argtypes = [C.POINTER(Model), C.POINTER(Schedule), C.POINTER(Params), C.c_int, C.c_int,
                                                 C.POINTER(C.c_void_p)]
+        L.twr_structure_create_many_with_grid.argtypes = [C.POINTER(Model), C.POINTER(Schedule), C.POINTER(Params), C.c_int,
+                                                          C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.twr_terrain_grid_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                            _dp, _dp, _dp, C.POINTER(C.c_void_p)]
         L.twr_structure_sizes.argtypes = [C.c_void_p, C.POINTER(Sizes)]
         L.twr_structure_var_set.argtypes = [C.c_void_p, C.c_int, C.POINTER(SetInfo)]
         L.twr_structure_con_set.argtypes = [C.c_void_p, C.c_int, C.POINTER(SetInfo)]
@@ -275,15 +279,17 @@ class Structure:
         self._lazy = {}
 
     @classmethod
-    def create_many(cls, model, scheds, params_list, threads=0):
-        """twr_structure_create_many: the candidates of a sweep, built on `threads` host threads (0 = all)."""
+    def create_many(cls, model, scheds, params_list, threads=0, grid=None):
+        """twr_structure_create_many[_with_grid]: the candidates of a sweep, built on `threads` host threads (0 = all);
+        with a gridded terrain they all share `grid`."""
         n = len(scheds)
         assert n == len(params_list) and n > 0
         sa = (Schedule * n)(*scheds)
         pa = (Params * n)(*params_list)
         hs = (C.c_void_p * n)()
-        _check(lib().twr_structure_create_many(C.byref(model), sa, pa, n, int(threads), hs))
-        return [cls(model, scheds[i], params_list[i], _handle=C.c_void_p(hs[i])) for i in range(n)]
+        _check(lib().twr_structure_create_many_with_grid(C.byref(model), sa, pa, n, int(threads),
+                                                         grid._h if grid is not None else None, hs))
+        return [cls(model, scheds[i], params_list[i], grid=grid, _handle=C.c_void_p(hs[i])) for i in range(n)]
 
     def _sets(self, fn, n):
         out = []

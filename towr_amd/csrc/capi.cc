@@ -249,6 +249,11 @@ void twr_structure_destroy(twr_structure* s) { delete s; }
 
 int twr_structure_create_many(const twr_model* model, const twr_schedule* schedules, const twr_params* params, int n,
                               int n_threads, twr_structure** out) {
+  return twr_structure_create_many_with_grid(model, schedules, params, n, n_threads, nullptr, out);
+}
+
+int twr_structure_create_many_with_grid(const twr_model* model, const twr_schedule* schedules, const twr_params* params, int n,
+                                        int n_threads, const twr_terrain_grid* grid, twr_structure** out) {
   if (!model || !schedules || !params || !out || n < 1) return fail(TWR_ERR_INVALID, "bad arguments");
   if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
   n_threads = std::max(1, std::min(n_threads, n));
@@ -258,7 +263,7 @@ int twr_structure_create_many(const twr_model* model, const twr_schedule* schedu
   auto worker = [&](int tid) {
     for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
       // the error string of the failing call lives in the worker's thread_local slot: carry it out
-      if (twr_structure_create(model, &schedules[i], &params[i], &out[i]) != TWR_OK && errs[tid].empty())
+      if (twr_structure_create_with_grid(model, &schedules[i], &params[i], grid, &out[i]) != TWR_OK && errs[tid].empty())
         errs[tid] = "structure " + std::to_string(i) + ": " + twr_last_error();
     }
   };
@@ -274,6 +279,20 @@ int twr_structure_create_many(const twr_model* model, const twr_schedule* schedu
       }
       return fail(TWR_ERR_INVALID, e);
     }
+  return TWR_OK;
+}
+
+int twr_terrain_grid_info(const twr_terrain_grid* g, int32_t* kind, int32_t* rows_or_size_x, int32_t* cols_or_size_y,
+                          double* resolution, double* pos_x, double* pos_y, const void** data) {
+  if (!g || !g->g) return fail(TWR_ERR_INVALID, "null grid");
+  const twr::TerrainGrid& t = *g->g;
+  if (kind) *kind = t.grid_map ? 1 : 0;
+  if (rows_or_size_x) *rows_or_size_x = t.rows;
+  if (cols_or_size_y) *cols_or_size_y = t.cols;
+  if (resolution) *resolution = t.res;
+  if (pos_x) *pos_x = t.pos_x;
+  if (pos_y) *pos_y = t.pos_y;
+  if (data) *data = t.grid_map ? static_cast<const void*>(t.elevation.data()) : static_cast<const void*>(t.heights.data());
   return TWR_OK;
 }
 

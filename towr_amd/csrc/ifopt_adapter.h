@@ -38,8 +38,11 @@ namespace towr_amd {
 // runs once per new x (ifopt calls GetValues / FillJacobianBlock once per set and per variable set).
 class DeviceProblem {
  public:
-  DeviceProblem(const twr_model& model, const twr_schedule& schedule, const twr_params& params, int device = 0) {
-    Check(twr_structure_create(&model, &schedule, &params, &structure_));
+  // `grid`: the gridded terrain for model.terrain_id == TWR_TERRAIN_GRID_MAP (the `Grid` height map fpowr hands
+  // NlpFormulation::terrain_, footstep_plan_server.cc:155) or TWR_TERRAIN_CSV_GRID; nullptr for the analytic terrains.
+  DeviceProblem(const twr_model& model, const twr_schedule& schedule, const twr_params& params, int device = 0,
+                const twr_terrain_grid* grid = nullptr) {
+    Check(twr_structure_create_with_grid(&model, &schedule, &params, grid, &structure_));
     const twr_structure* list[1] = {structure_};
     const int32_t map[1] = {0};
     Check(twr_batch_create(list, 1, map, 1, device, &batch_));
@@ -129,7 +132,15 @@ class DeviceConstraintSet : public ifopt::ConstraintSet {
     problem_->Update(GetVariables()->GetValues());
     size_t v = 0;
     while (v < var_sets_.size() && var_set != var_sets_[v].name) ++v;
-    if (v == var_sets_.size()) return;  // a variable set this structure does not know (e.g. "ee-schedule<i>" with fixed timings)
+    if (v == var_sets_.size()) {
+      // The only variable sets a towr composite can hold beyond the structure's are the "ee-schedule<ee>" sets of a
+      // problem whose phase durations are NOT optimised here (variable_names.h:47,60-63): no dependence, empty block.
+      // Anything else is a mistyped or foreign name: a silent zero block would hide it from Ipopt's derivative test.
+      if (var_set.rfind("ee-schedule", 0) == 0 && var_set.find_first_not_of("0123456789", 11) == std::string::npos && var_set.size() > 11)
+        return;
+      throw std::runtime_error("towr_amd: constraint set '" + std::string(info_.name) + "' asked for the Jacobian w.r.t. unknown variable set '" +
+                               var_set + "'");
+    }
     const int32_t* col_idx = twr_structure_col_idx(problem_->structure());
     const double* val = problem_->jac();
     const int32_t* range = ranges_[v].data();
@@ -152,8 +163,9 @@ class DeviceConstraintSet : public ifopt::ConstraintSet {
 
 // All device sets of one problem (twr_params.constraint_sets), in the reference's relative order.
 inline std::vector<ifopt::ConstraintSet::Ptr> MakeDeviceConstraints(const twr_model& model, const twr_schedule& schedule,
-                                                                    const twr_params& params, int device = 0) {
-  auto problem = std::make_shared<DeviceProblem>(model, schedule, params, device);
+                                                                    const twr_params& params, int device = 0,
+                                                                    const twr_terrain_grid* grid = nullptr) {
+  auto problem = std::make_shared<DeviceProblem>(model, schedule, params, device, grid);
   std::vector<ifopt::ConstraintSet::Ptr> sets;
   for (int i = 0; i < problem->sizes().n_con_sets; ++i) sets.push_back(std::make_shared<DeviceConstraintSet>(problem, i));
   return sets;

@@ -26,6 +26,40 @@ def broadcast_model(model, src=0, device=None):
     return out
 
 
+def broadcast_grid(grid, src=0, device=None):
+    """The gridded terrain of a sweep ("W x H x 4 B if gridded"): rank `src` passes a
+    towr_amd.TerrainGrid (CSV heights) or towr_amd.GridMap (the float elevation layer + resolution + position fpowr
+    hands the solver), the others pass None; everyone returns an equal handle.  Two broadcasts beside the model blob: a
+    48-byte header (kind, sizes, resolution, position) and the cell data."""
+    import torch
+    import torch.distributed as dist
+
+    from . import GridMap, TerrainGrid
+
+    hdr = torch.zeros(6, dtype=torch.float64, device=device)
+    if dist.get_rank() == src:
+        if isinstance(grid, GridMap):
+            hdr.copy_(torch.tensor([1.0, grid.elevation.shape[0], grid.elevation.shape[1], grid.resolution, grid.position[0],
+                                    grid.position[1]], dtype=torch.float64))
+        else:
+            hdr.copy_(torch.tensor([0.0, grid.heights.shape[0], grid.heights.shape[1], 0.0, 0.0, 0.0], dtype=torch.float64))
+    dist.broadcast(hdr, src=src)
+    kind, n0, n1, res, px, py = [float(v) for v in hdr.cpu()]
+    n0, n1 = int(n0), int(n1)
+    data = torch.zeros(n0 * n1, dtype=torch.float32 if kind == 1.0 else torch.float64, device=device)
+    if dist.get_rank() == src:
+        # grid_map's layer is column-major [size_x][size_y]: ship it in storage order
+        flat = grid.elevation.reshape(-1, order="F") if kind == 1.0 else grid.heights.reshape(-1)
+        data.copy_(torch.from_numpy(np.ascontiguousarray(flat)))
+    dist.broadcast(data, src=src)
+    if dist.get_rank() == src:
+        return grid
+    a = data.cpu().numpy()
+    if kind == 1.0:
+        return GridMap(a.reshape((n0, n1), order="F"), res, (px, py))
+    return TerrainGrid(a.reshape(n0, n1))
+
+
 def my_shard(weights, rank, world):
     b = shard_bounds(weights, world)
     return b[rank], b[rank + 1]
