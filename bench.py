@@ -184,6 +184,18 @@ def traffic_from_profile(workload, kernel, problems_per_gpu):
     return None
 
 
+def sweep_traffic_ratio(algorithmic_bytes):
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        per = t.get("sweep_1024", {}).get("hbm_bytes_per_launch", {})
+        if t.get("kernel_source_sha256") == kernel_source_hash() and per:
+            return sum(per.values()) / algorithmic_bytes
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, stream, steps=200, n_total=1024):
     """north_star's scaling claim: the 1024-candidate gait / phase-duration sweep on Stairs (BASELINE C5), a FIXED
     total sharded over the ranks (strong scaling).  Every rank builds only its own contiguous shard (cheap
@@ -280,6 +292,9 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
             "setup_s_per_rank": per_rank_setup,
             # a shard that re-writes < ~220 MB per step keeps its output in the 256-MB Infinity Cache
             "output_MB_per_rank": float(batch.algorithmic_bytes) / 1e6,
+            # HBM traffic of the whole 1024-candidate sweep on ONE GPU over its algorithmic bytes (profiles/traffic.json,
+            # rocprofv3 FETCH_SIZE / WRITE_SIZE passes): every candidate reads its own ~150 KB of tables
+            "traffic_ratio": sweep_traffic_ratio(bytes_total) if world == 1 else None,
             "planner": {"what": "values only -> twr_batch_score -> all-gather of 16 scores per candidate -> arg-min "
                                 "(host-synchronous: one decision per step)",
                         "steps": p_steps, "value": n_total * p_steps / p_elapsed, "unit": "candidates scored/s",

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense one scripts/profile_r02.sh run into the files that are committed under profiles/:
+"""Condense one scripts/profile_r03.sh run into the files that are committed under profiles/:
 <tag>_kernel_stats.csv, <tag>_timings_kernel_stats.csv, <tag>_pmc_summary.txt, traffic.json (+ the bench lines)."""
 import collections
 import csv
@@ -65,6 +65,13 @@ for d in ("tcc1_t", "tcc2_t"):
     tim.update(c)
     for k, v in sorted(c.items()):
         lines.append("%-22s %-26s %.6g" % (k[0], k[1], v))
+lines.append("# --workload sweep --batch 1024 (BASELINE C5 on one GPU: every candidate its own tables)")
+swp = {}
+for d in ("tcc1_s", "tcc2_s"):
+    c = counters(d)
+    swp.update(c)
+    for k, v in sorted(c.items()):
+        lines.append("%-22s %-26s %.6g" % (k[0], k[1], v))
 kern = sorted({k[0] for k in allc})
 lines.append("# derived")
 for k in kern:
@@ -92,6 +99,7 @@ def traffic(c):
 json.dump({"workload": "C3", "problems_per_gpu": 8192, "kernel_source_sha256": kernel_source_hash(),
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = (WRITE_SIZE + 2*FETCH_SIZE) KiB",
            "hbm_bytes_per_launch": traffic(allc),
-           "timings_2048": {"hbm_bytes_per_launch": traffic(tim)}},
+           "timings_2048": {"hbm_bytes_per_launch": traffic(tim)},
+           "sweep_1024": {"hbm_bytes_per_launch": traffic(swp)}},
           open(os.path.join(prof, "traffic.json"), "w"), indent=1)
 print("\n".join(lines[-12:]))
