@@ -172,8 +172,8 @@ def traffic_from_profile(workload, kernel, problems_per_gpu):
         with open(path) as f:
             t = json.load(f)
         if t.get("workload") == "C3" and t.get("kernel_source_sha256") == kernel_source_hash():
-            if workload == "C3" and t.get("problems_per_gpu") == problems_per_gpu:
-                return t.get("hbm_bytes_per_launch", {}).get(kernel)
+            if workload == "C3" and t.get("problems_per_gpu") == problems_per_gpu:   # (kernel names carry template arguments)
+                return sum(v for k, v in t.get("hbm_bytes_per_launch", {}).items() if k.startswith(kernel)) or None
             if workload == "C3+timings" and problems_per_gpu == 2048:   # the --sets timings --batch 2048 passes
                 per = t.get("timings_2048", {}).get("hbm_bytes_per_launch", {})
                 if kernel is None:

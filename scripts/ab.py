@@ -10,7 +10,7 @@ for rep in range(2):
             k, v = kv.split("=")
             env[k] = v
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "3", "--no-cpu-baseline",
-                            "--no-scale-c5"], env=env, capture_output=True, text=True)
+                            "--no-scale-c5", "--no-timings-c3"], env=env, capture_output=True, text=True)
         try:
             d = json.loads(r.stdout.strip().splitlines()[-1])
             k = d["roofline"]["path"]["kernel_ms"]

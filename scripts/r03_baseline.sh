@@ -6,7 +6,7 @@ OUT=gpurun_out/r03_base
 mkdir -p $OUT
 rocprofv3 -L > $OUT/rocprof_L.txt 2>&1
 echo "listing done" 
-B="--steps 30 --warmup 5 --no-cpu-baseline --no-scale-c5"
+B="--steps 30 --warmup 5 --no-cpu-baseline --no-scale-c5 --no-timings-c3"
 python3 bench.py $B --workload sweep --batch 1024 > $OUT/sweep1024.json 2> $OUT/sweep1024.err || exit 1
 python3 bench.py $B --batch 1024 > $OUT/c3_1024.json 2> $OUT/c3_1024.err || exit 1
 python3 bench.py $B --sets timings --batch 2048 > $OUT/timings2048.json 2> $OUT/timings2048.err || exit 1

@@ -2634,6 +2634,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
     else TWR_PROM_LAUNCH(NIT, true, false);           \
   }
     if (prom_img_cap <= 24 * 128) TWR_PROM_FLAGS(24)
+    else if (prom_img_cap <= 32 * 128) TWR_PROM_FLAGS(32)
     else if (prom_img_cap <= 40 * 128) TWR_PROM_FLAGS(40)
     else {
       if (lds > 64 * 1024) {
