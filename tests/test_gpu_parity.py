@@ -536,7 +536,7 @@ def _oracle_for(robot, terrain, S):
                             polys_per_stance_force=p.polys_per_stance_force, constraint_sets=p.constraint_sets)
 
 
-def _run_sweep(robot, terrain, count, sample_idx):
+def _run_sweep(robot, terrain, count, sample_idx, constraint_sets=None, stride=1):
     """One ragged batch of the first `count` enumerated candidates (combo x T x swing scale); every
     output element must be written (NaN pre-fill), the sampled candidates must match the oracle."""
     import torch
@@ -544,8 +544,8 @@ def _run_sweep(robot, terrain, count, sample_idx):
     from towr_amd import sweep
 
     model = ta.model_preset(robot, terrain)
-    cands = sweep.enumerate_candidates(count)
-    structs = sweep.candidate_structures(model, cands)
+    cands = sweep.enumerate_candidates(count * stride)[::stride]
+    structs = sweep.candidate_structures(model, cands, constraint_sets=constraint_sets)
     assert len({(S.n, S.m, S.nnz) for S in structs}) > 1, "the sweep must be ragged"
     batch = ta.Batch(structs, list(range(count)), device=0)
     xs = _sweep_inputs(structs, model)
@@ -597,6 +597,15 @@ def test_sweep_c5_1024_stairs(robot):
     assert len(idx) >= 16
     cands = _run_sweep(robot, "stairs", 1024, list(range(1024)))   # every candidate against the oracle
     assert {c[0] for c in (cands[i] for i in idx)} == {0, 1, 2, 3, 4}
+
+
+def test_sweep_with_optimised_timings_ragged_multi_pass():
+    """96 candidates spread over all five gait combos (every 10th of the enumeration), every constraint name of towr's
+    list + optimised phase durations: 4800 dynamic passes and 2500 range-of-motion passes of DIFFERENT structures on 1024
+    persistent workgroups, i.e. the hand-scheduled pipelines of dyn_phase_kernel / rom_phase_kernel carry records and x
+    of one structure while computing another.  All candidates against the oracle."""
+    cands = _run_sweep("anymal", "stairs", 96, list(range(96)), constraint_sets=127, stride=10)
+    assert {c[0] for c in cands} == {0, 1, 2, 3, 4}
 
 
 @pytest.mark.parametrize("terrain", ["gap", "stairs"])

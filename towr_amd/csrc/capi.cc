@@ -488,7 +488,8 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
             const twr::PhaseTables& pt = S.phase_tables;
             const uint64_t pt_addr = blob + reinterpret_cast<const twr::DevStruct*>(S.blob.data())->o_phase;
             pw.hdr = blob;
-            pw.loc = loc_off + sizeof(twr::DynLoc) * 4 * (size_t)k0;
+            pw.loc = loc_off + sizeof(twr::DynLoc) * (size_t)k0;
+            pw.loc_stride = (int32_t)(sizeof(twr::DynLoc) * (size_t)Kd);
             pw.shared = blob + pt.o_dyn_shared + sizeof(twr::DynShared) * (size_t)k0;
             pw.mput = blob + pt.o_mput;
             pw.fput = blob + pt.o_fput;
@@ -515,7 +516,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
           std::memset(&lw, 0, sizeof(lw));
           lw.blob = blob;
           lw.recs = rs ? prec_bytes + 1 : 0;             // (+1: "present" marker until the buffer address is known)
-          lw.dyn_loc = have_dyn ? loc_off + 1 : 0;
+          lw.dyn_loc = have_dyn ? loc_off + sizeof(twr::DynLoc) * (size_t)Kd * (size_t)e + 1 : 0;
           lw.x_off = b->x_off[p];
           lw.ee = e;
           ploc.push_back(lw);

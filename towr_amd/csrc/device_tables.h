@@ -154,8 +154,9 @@ struct PhaseEe {         // per end-effector: its duration columns inside a time
   int32_t pad;
 };
 static_assert(sizeof(PhaseEe) == 32, "PhaseEe layout");
-// dynamic with optimised timings, per (time node, ee): the x-dependent segment lookup, written by the pre-pass
-// (phase_locate_kernel) into a scratch buffer and read by dyn_phase_kernel (64 B)
+// dynamic with optimised timings, per (ee, time node): the x-dependent segment lookup, written by the pre-pass
+// (phase_locate_kernel) into a scratch buffer -- one contiguous array per (problem, ee), so that a workgroup of the
+// pre-pass writes whole lines -- and read by dyn_phase_kernel (64 B)
 struct DynLoc {
   double tm, Tm, tf, Tf;         // local time in / duration of the active ee-motion and ee-force polynomials
   int32_t xbase_m, xbase_f;      // first x index of their variables
@@ -299,7 +300,7 @@ static_assert(sizeof(NodeWork) == 32, "NodeWork layout");
 struct PDynWork {         // optimised timings: one pass = cnt <= 4 time nodes of "dynamic".  Everything the kernel
                           // needs is an absolute address or a value here: no dependent table lookups per pass.
   uint64_t hdr;           // DevStruct (mass, gravity, inertia)
-  uint64_t loc;           // DynLoc[4 k0 ..] of this problem (scratch, written by the pre-pass)
+  uint64_t loc;           // DynLoc[k0 ..] of ee 0 of this problem (scratch, written by the pre-pass; ee e at + e * loc_stride)
   uint64_t shared;        // DynShared[k0 ..]
   uint64_t mput, fput;    // PhasePutM / PhasePutF arrays of the structure
   uint64_t ee;            // PhaseEe[4]
@@ -309,7 +310,8 @@ struct PDynWork {         // optimised timings: one pass = cnt <= 4 time nodes o
   int32_t off_lin, off_ang, n_ee;
   uint32_t row_off[5];    // PhaseTables::dyn_row_off
   int32_t n_mput, n_fput; // records of real polynomials; four dummy records (one per ee index) follow them
-  int32_t pad[2];
+  int32_t loc_stride;     // bytes between the DynLoc arrays of consecutive end-effectors (= 64 k_dyn)
+  int32_t pad;
 };
 static_assert(sizeof(PDynWork) == 128, "PDynWork layout");
 
@@ -320,7 +322,7 @@ static_assert(sizeof(PDynWork) == 128, "PDynWork layout");
 struct LocWork {          // one (problem, ee)
   uint64_t blob;
   uint64_t recs;          // RomRec[k_rom] (output), 0: no rangeofmotion sets
-  uint64_t dyn_loc;       // DynLoc[4 * k_dyn] of the problem (output; this ee writes entries 4 k + ee), 0: no dynamic set
+  uint64_t dyn_loc;       // DynLoc[k_dyn] of this (problem, ee) (output; one contiguous array per ee), 0: no dynamic set
   int64_t x_off;
   int32_t ee, pad;
   int64_t pad2;

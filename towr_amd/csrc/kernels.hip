@@ -249,18 +249,23 @@ TWR_DEV double sel3(int i, double a, double b, double c) { return i == 0 ? a : (
 // Spline::GetSegmentID + GetLocalTime (src/spline.cc:48-78) on durations that depend on x: the same
 // double-precision accumulation, eps and sequential subtraction as the reference (and the host Locate).
 TWR_DEV int locate_segment(const double* __restrict__ d, int n, double t, double& t_local) {
+  // Branch-free on purpose: with the reference's early `break` every iteration's load waits for the previous compare
+  // (a chain of dependent LDS round trips); predicated, the loads of an unrolled block go out together and only the
+  // additions are sequential.  Same additions and subtractions in the same order, so the same bits.
   const double eps = 1e-10;
-  double acc = 0.0;
+  double acc = 0.0, tl = t;
   int id = n - 1;  // (the reference asserts that a segment is found)
+  bool found = false;
+#pragma unroll 8
   for (int i = 0; i < n; ++i) {
-    acc += d[i];
-    if (acc >= t - eps) {
-      id = i;
-      break;
-    }
+    const double di = d[i];
+    acc += di;
+    const bool hit = !found && acc >= t - eps;
+    id = hit ? i : id;
+    found = found || hit;
+    if (!found && i < n - 1) tl -= di;   // t_local = t - sum of the durations BEFORE the segment, sequentially
   }
-  t_local = t;
-  for (int i = 0; i < id; ++i) t_local -= d[i];
+  t_local = tl;
   return id;
 }
 // node values (p0,v0,p1,v1)[dim] of the active polynomial from its gathered candidates: values that are
@@ -1267,7 +1272,7 @@ __global__ __launch_bounds__(128, 2) void eval_fused_kernel(const RomWork* __res
 // (nodes_variables_phase_based.cc:73-84) of one ee, spread over the lanes of a wave: loads in parallel, only the
 // duration sum is serial.
 TWR_DEV void phase_poly_durations_wave(const PhaseTables* PT, const char* blob, const double* __restrict__ xp, int e,
-                                       double* ph, double* md, int lane) {
+                                       double* ph, double* md, int lane, int nthreads = 64) {
   const int ns = PT->n_phases[e] - 1;
   if (lane < ns) ph[lane] = xp[PT->off_sched[e] + lane];
   __syncthreads();
@@ -1278,7 +1283,7 @@ TWR_DEV void phase_poly_durations_wave(const PhaseTables* PT, const char* blob, 
   }
   __syncthreads();
   const PhasePoly* mp = tbl<PhasePoly>(blob, PT->o_mpoly[e]);
-  for (int q = lane; q < PT->n_mpoly[e]; q += 64) md[q] = ph[mp[q].phase] / mp[q].n_in_phase;
+  for (int q = lane; q < PT->n_mpoly[e]; q += nthreads) md[q] = ph[mp[q].phase] / mp[q].n_in_phase;
   __syncthreads();
 }
 
@@ -1351,10 +1356,10 @@ struct APut {          // put offsets of a pass: PhasePutM row j, PhasePutF row 
   double pf[3];
   twr_v4f pe[2];
 };
-TWR_DEV void pdyn_issue_rec(uint64_t shared, uint64_t loc, int cnt, int n_ee, int lane, ARec& a) {
+TWR_DEV void pdyn_issue_rec(uint64_t shared, uint64_t loc, int loc_stride, int cnt, int n_ee, int lane, ARec& a) {
   const int n = min(lane >> 4, cnt - 1), e = min((lane >> 2) & 3, n_ee - 1);   // (ee >= n_ee read ee n_ee-1 and are neutralised)
   const char* sh = reinterpret_cast<const char*>(shared) + sizeof(DynShared) * (size_t)n;
-  const char* lc = reinterpret_cast<const char*>(loc) + sizeof(DynLoc) * (size_t)(n * 4 + e);
+  const char* lc = reinterpret_cast<const char*>(loc) + (size_t)e * (size_t)loc_stride + sizeof(DynLoc) * (size_t)n;
   aload(a.sh, sh);
   aload(a.q6, sh + offsetof(DynShared, q6));
 #pragma unroll
@@ -1782,7 +1787,7 @@ __global__ __launch_bounds__(64, 1) void dyn_phase_kernel(const PDynWork* __rest
   {
     ARec ar;
     AIn ai;
-    pdyn_issue_rec(w0.shared, w0.loc, w0.cnt, n_ee, lane, ar);
+    pdyn_issue_rec(w0.shared, w0.loc, w0.loc_stride, w0.cnt, n_ee, lane, ar);
     pdyn_wait_rec<0>(ar, r0);
     pdyn_issue_in(w0, r0, x, lane, ai);
     pdyn_wait_in<0>(ai, in);
@@ -1794,7 +1799,7 @@ __global__ __launch_bounds__(64, 1) void dyn_phase_kernel(const PDynWork* __rest
     ARec ar;
     AIn ai;
     if (WANT_J) pdyn_issue_put(w0, r0, lane, ap);                                   // P
-    pdyn_issue_rec(w1.shared, w1.loc, w1.cnt, n_ee, lane, ar);                      // R
+    pdyn_issue_rec(w1.shared, w1.loc, w1.loc_stride, w1.cnt, n_ee, lane, ar);                      // R
     const int nv = w0.cnt * w0.node_vals;
     if (WANT_J) lds_clear(pdyn_lds, nv, lane);
     PDynVals V;
@@ -1820,67 +1825,88 @@ __global__ __launch_bounds__(64, 1) void dyn_phase_kernel(const PDynWork* __rest
 // Optimised timings, pre-pass: one workgroup per (problem, ee) resolves the x-dependent part of every time node of
 // the dynamic and the rangeofmotion-<ee> grids -- phase and polynomial durations, active polynomials, local times,
 // current phase (PhaseDurations::SetVariables, ConvertPhaseToPolyDurations, Spline::GetSegmentID / GetLocalTime) -- into
-// DynLoc / RomRec records in the batch's scratch buffer.
-__global__ __launch_bounds__(64) void phase_locate_kernel(const LocWork* __restrict__ work, const double* __restrict__ x) {
+// DynLoc / RomRec records in the batch's scratch buffer.  256 threads, one per time node: a lookup is a chain of ~60
+// dependent LDS reads (the reference's sequential accumulation, kept bit for bit), so the kernel lives on waves in flight
+// (one wave per workgroup, four time nodes per lane: 0.094 ms per 2048 C3 problems; this form: see DESIGN 6.0).
+constexpr int kLocateThreads = 256;
+__global__ __launch_bounds__(kLocateThreads) void phase_locate_kernel(const LocWork* __restrict__ work, const double* __restrict__ x) {
   __shared__ double s_ph[TWR_MAX_PHASES_DEV], s_md[kMaxPhasePolys], s_fd[kMaxPhasePolys];
+  // the records of one block of time nodes are staged in LDS and leave as one contiguous, fully coalesced stream
+  // (a lane storing its own 64-byte record touches 32 lines per store instruction)
+  __shared__ __attribute__((aligned(16))) char s_rec[kLocateThreads * 64];
+  static_assert(sizeof(DynLoc) == 64 && sizeof(RomRec) == 64, "record staging");
   const LocWork lw = work[blockIdx.x];
   const char* blob = reinterpret_cast<const char*>(lw.blob);
   const DevStruct* H = reinterpret_cast<const DevStruct*>(blob);
   const PhaseTables* PT = tbl<PhaseTables>(blob, H->o_phase);
   const int lane = threadIdx.x, e = lw.ee;
-  phase_poly_durations_wave(PT, blob, x + lw.x_off, e, s_ph, s_md, lane);
+  phase_poly_durations_wave(PT, blob, x + lw.x_off, e, s_ph, s_md, lane, kLocateThreads);
   const PhasePoly* mp = tbl<PhasePoly>(blob, PT->o_mpoly[e]);
   const int last_phase = PT->n_phases[e] - 1;
+  auto flush = [&](char* dst, int n_recs) {   // s_rec[0 .. 64 n_recs) -> dst, 16 bytes per thread and round
+    __syncthreads();
+    for (int c = lane; c < 4 * n_recs; c += kLocateThreads)
+      reinterpret_cast<uint4*>(dst)[c] = reinterpret_cast<const uint4*>(s_rec)[c];
+    __syncthreads();
+  };
   if (lw.dyn_loc) {
     const PhasePoly* fp = tbl<PhasePoly>(blob, PT->o_fpoly[e]);
-    for (int q = lane; q < PT->n_fpoly[e]; q += 64) s_fd[q] = s_ph[fp[q].phase] / fp[q].n_in_phase;
+    for (int q = lane; q < PT->n_fpoly[e]; q += kLocateThreads) s_fd[q] = s_ph[fp[q].phase] / fp[q].n_in_phase;
     __syncthreads();
     const double* tg = tbl<double>(blob, PT->o_tdyn);
-    DynLoc* out = reinterpret_cast<DynLoc*>(lw.dyn_loc);
-    for (int k = lane; k < PT->k_dyn; k += 64) {
-      const double t = tg[k];
-      double tlm, tlf, tlp;
-      const int qm = locate_segment(s_md, PT->n_mpoly[e], t, tlm);
-      const int qf = locate_segment(s_fd, PT->n_fpoly[e], t, tlf);
-      const int cur = locate_segment(s_ph, PT->n_phases[e], t, tlp);
-      const PhasePoly pm = mp[qm], pf = fp[qf];
-      DynLoc o;
-      o.tm = tlm; o.Tm = s_md[qm];
-      o.tf = tlf; o.Tf = s_fd[qf];
-      o.xbase_m = pm.xbase; o.xbase_f = pf.xbase;
-      const uint64_t sm = slots_of(pm.cand), sf = slots_of(pf.cand);
-      o.slots_m[0] = (uint32_t)sm; o.slots_m[1] = (uint32_t)(sm >> 32);
-      o.slots_f[0] = (uint32_t)sf; o.slots_f[1] = (uint32_t)(sf >> 32);
-      o.im = (uint16_t)(PT->mput_base[e] + qm); o.jf = (uint16_t)(PT->fput_base[e] + qf);
-      o.cur = (uint8_t)cur;
-      o.flags = (uint8_t)((cur == last_phase ? 1 : 0) | (meta_shared(pm.meta) ? 2 : 0));
-      o.np_m = (uint8_t)(pm.n_in_phase | (pm.poly_in_phase << 4));
-      o.np_f = (uint8_t)(pf.n_in_phase | (pf.poly_in_phase << 4));
-      out[(size_t)k * 4 + e] = o;
+    const int K = PT->k_dyn;
+    for (int k0 = 0; k0 < K; k0 += kLocateThreads) {
+      const int k = k0 + lane;
+      if (k < K) {
+        const double t = tg[k];
+        double tlm, tlf, tlp;
+        const int qm = locate_segment(s_md, PT->n_mpoly[e], t, tlm);
+        const int qf = locate_segment(s_fd, PT->n_fpoly[e], t, tlf);
+        const int cur = locate_segment(s_ph, PT->n_phases[e], t, tlp);
+        const PhasePoly pm = mp[qm], pf = fp[qf];
+        DynLoc o;
+        o.tm = tlm; o.Tm = s_md[qm];
+        o.tf = tlf; o.Tf = s_fd[qf];
+        o.xbase_m = pm.xbase; o.xbase_f = pf.xbase;
+        const uint64_t sm = slots_of(pm.cand), sf = slots_of(pf.cand);
+        o.slots_m[0] = (uint32_t)sm; o.slots_m[1] = (uint32_t)(sm >> 32);
+        o.slots_f[0] = (uint32_t)sf; o.slots_f[1] = (uint32_t)(sf >> 32);
+        o.im = (uint16_t)(PT->mput_base[e] + qm); o.jf = (uint16_t)(PT->fput_base[e] + qf);
+        o.cur = (uint8_t)cur;
+        o.flags = (uint8_t)((cur == last_phase ? 1 : 0) | (meta_shared(pm.meta) ? 2 : 0));
+        o.np_m = (uint8_t)(pm.n_in_phase | (pm.poly_in_phase << 4));
+        o.np_f = (uint8_t)(pf.n_in_phase | (pf.poly_in_phase << 4));
+        reinterpret_cast<DynLoc*>(s_rec)[lane] = o;
+      }
+      flush(reinterpret_cast<char*>(lw.dyn_loc) + sizeof(DynLoc) * (size_t)k0, min(kLocateThreads, K - k0));
     }
   }
   if (!lw.recs) return;
   const double* tg = tbl<double>(blob, PT->o_trom);
   const RomRec* base = tbl<RomRec>(blob, PT->o_rom_recs[e]);  // base-spline part (tb, iTb, q6) is x-independent
-  RomRec* out = reinterpret_cast<RomRec*>(lw.recs);
-  for (int k = lane; k < PT->k_rom; k += 64) {
-    const double t = tg[k];
-    double tlm, tlp;
-    const int qm = locate_segment(s_md, PT->n_mpoly[e], t, tlm);
-    const int cur = locate_segment(s_ph, PT->n_phases[e], t, tlp);
-    const PhasePoly pm = mp[qm];
-    RomRec r = base[k];
-    r.tm = tlm;
-    r.iTm = 1.0 / s_md[qm];
-    r.xbase = pm.xbase;
-    r.meta = pm.meta;
-    const uint64_t slots = slots_of(pm.cand);
-    r.slots[0] = (uint32_t)slots;
-    r.slots[1] = (uint32_t)(slots >> 32);
-    r.voff = 0;
-    r.pad[0] = (uint32_t)pm.base_all | ((uint32_t)cur << 16) | ((cur == last_phase ? 1u : 0u) << 24);
-    r.pad[1] = (uint32_t)pm.n_in_phase | ((uint32_t)pm.poly_in_phase << 8);
-    out[k] = r;
+  const int K = PT->k_rom;
+  for (int k0 = 0; k0 < K; k0 += kLocateThreads) {
+    const int k = k0 + lane;
+    if (k < K) {
+      const double t = tg[k];
+      double tlm, tlp;
+      const int qm = locate_segment(s_md, PT->n_mpoly[e], t, tlm);
+      const int cur = locate_segment(s_ph, PT->n_phases[e], t, tlp);
+      const PhasePoly pm = mp[qm];
+      RomRec r = base[k];
+      r.tm = tlm;
+      r.iTm = 1.0 / s_md[qm];
+      r.xbase = pm.xbase;
+      r.meta = pm.meta;
+      const uint64_t slots = slots_of(pm.cand);
+      r.slots[0] = (uint32_t)slots;
+      r.slots[1] = (uint32_t)(slots >> 32);
+      r.voff = 0;
+      r.pad[0] = (uint32_t)pm.base_all | ((uint32_t)cur << 16) | ((cur == last_phase ? 1u : 0u) << 24);
+      r.pad[1] = (uint32_t)pm.n_in_phase | ((uint32_t)pm.poly_in_phase << 8);
+      reinterpret_cast<RomRec*>(s_rec)[lane] = r;
+    }
+    flush(reinterpret_cast<char*>(lw.recs) + sizeof(RomRec) * (size_t)k0, min(kLocateThreads, K - k0));
   }
 }
 
@@ -2584,7 +2610,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
     else st = twr_first(st, twr_launch(dyn_kernel<true, false>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, dump));
   }
   // optimised-timings problems: the pre-pass (segment lookup -> records), then the persistent kernels
-  if (n_ploc > 0) st = twr_first(st, twr_launch(phase_locate_kernel, dim3(n_ploc), block, 0, stream, ploc, x));
+  if (n_ploc > 0) st = twr_first(st, twr_launch(phase_locate_kernel, dim3(n_ploc), dim3(kLocateThreads), 0, stream, ploc, x));
   if (n_pdyn > 0) {
     // LDS per workgroup: the image of one pass; residency follows from it
     const size_t lds = sizeof(double) * (size_t)((pdyn_img_cap + 1) & ~1);

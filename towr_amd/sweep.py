@@ -32,15 +32,15 @@ def candidate_inputs(model, cand, k_nodes=200, constraint_sets=None):
     return sched, params_default(dt_dynamic=dt, dt_rom=dt, **kw)
 
 
-def candidate_structure(model, cand, k_nodes=200, grid=None):
-    return Structure(model, *candidate_inputs(model, cand, k_nodes), grid=grid)
+def candidate_structure(model, cand, k_nodes=200, grid=None, constraint_sets=None):
+    return Structure(model, *candidate_inputs(model, cand, k_nodes, constraint_sets), grid=grid)
 
 
-def candidate_structures(model, cands, k_nodes=200, threads=0, grid=None):
+def candidate_structures(model, cands, k_nodes=200, threads=0, grid=None, constraint_sets=None):
     """The structures of a list of candidates, built in one multi-threaded library call
     (twr_structure_create_many[_with_grid]; `grid`: the shared gridded terrain of the sweep).  A rank calls this for
     ITS shard only."""
-    inputs = [candidate_inputs(model, c, k_nodes) for c in cands]
+    inputs = [candidate_inputs(model, c, k_nodes, constraint_sets) for c in cands]
     return Structure.create_many(model, [i[0] for i in inputs], [i[1] for i in inputs], threads, grid=grid)
 
 
