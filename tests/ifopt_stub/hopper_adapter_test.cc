@@ -149,11 +149,10 @@ int main(int argc, char** argv) {
   for (int r = 0; bounds && r < sz.n_rows; ++r) bounds = b[r].lower_ == lo[r] && b[r].upper_ == up[r];
   expect(bounds, "GetBounds equals twr_structure_bounds");
 
-  // variable sets the structure does not know: "ee-schedule<ee>" of a problem with fixed timings is an empty block (the
-  // reference's composite may hold it), any other name must throw instead of yielding a silent zero block
+  // a variable set the structure does not know (a typo'd name) must throw instead of yielding a silent zero block
   {
     const double one[1] = {0.3};
-    bool threw = false, sched_ok = true;
+    bool threw = false;
     try {
       ifopt::Problem bad;
       for (int i = 0; i < sz.n_var_sets; ++i) {
@@ -161,31 +160,13 @@ int main(int argc, char** argv) {
         twr_structure_var_set(S, i, &v);
         bad.AddVariableSet(std::make_shared<PlainVariables>(v.name, x.data() + v.offset, v.size));
       }
-      bad.AddVariableSet(std::make_shared<PlainVariables>("ee-motoin_0", one, 1));   // a typo'd set name
+      bad.AddVariableSet(std::make_shared<PlainVariables>("ee-motoin_0", one, 1));
       for (auto& c : towr_amd::MakeDeviceConstraints(model, sched, prm, 0, grid)) bad.AddConstraintSet(c);
       (void)bad.GetJacobianOfConstraints();
     } catch (const std::exception& e) {
       threw = std::strstr(e.what(), "unknown variable set") != nullptr;
     }
     expect(threw, "FillJacobianBlock throws on an unknown variable set name");
-    if (!(sets & TWR_SET_TOTAL_TIME)) {
-      try {
-        ifopt::Problem okp;
-        for (int i = 0; i < sz.n_var_sets; ++i) {
-          twr_set_info v;
-          twr_structure_var_set(S, i, &v);
-          okp.AddVariableSet(std::make_shared<PlainVariables>(v.name, x.data() + v.offset, v.size));
-        }
-        okp.AddVariableSet(std::make_shared<PlainVariables>("ee-schedule0", one, 1));
-        for (auto& c : towr_amd::MakeDeviceConstraints(model, sched, prm, 0, grid)) okp.AddConstraintSet(c);
-        ifopt::Problem::Jacobian j2 = okp.GetJacobianOfConstraints();
-        j2.makeCompressed();
-        sched_ok = j2.nonZeros() == sz.nnz;
-      } catch (const std::exception&) {
-        sched_ok = false;
-      }
-      expect(sched_ok, "ee-schedule<ee> of a fixed-timing problem is an empty block");
-    }
   }
 
   std::printf("hopper through ifopt%s: n=%d m=%d nnz=%d sets=%d  max|dg|=%g max|dJ|=%g  %s\n", gridmap ? " on a grid_map terrain" : "",

@@ -40,7 +40,7 @@ def test_adapter_compiles_warning_free_and_fails_loudly_without_a_gpu():
 def test_hopper_through_the_ifopt_surface(sets, terrain):
     """MakeDeviceConstraints -> GetValues / GetBounds / GetJacobian of every set == twr_batch_eval_host, stacked; on flat
     ground (hopper_example.cc) and on the `Grid` terrain fpowr hands the solver (footstep_plan_server.cc:155); an unknown
-    variable-set name must throw, "ee-schedule<ee>" of a fixed-timing problem must not."""
+    variable-set name must throw."""
     _build()
     args = [EXE, "--gpu", str(sets)] + (["gridmap"] if terrain == "gridmap" else [])
     r = subprocess.run(args, capture_output=True, text=True, timeout=300)

@@ -129,18 +129,16 @@ class DeviceConstraintSet : public ifopt::ConstraintSet {
   }
 
   void FillJacobianBlock(std::string var_set, Jacobian& jac) const override {
-    problem_->Update(GetVariables()->GetValues());
+    // The variable composite must be exactly the structure's sets (towr only adds "ee-schedule<ee>" when the durations
+    // are optimised, nlp_formulation.cc:88-92, and then TWR_SET_TOTAL_TIME puts them into the structure too).  A name
+    // the structure does not know is a mistyped or foreign set: a silent zero block would hide it from Ipopt's
+    // derivative test, so it throws -- before the evaluation, whose own check would only report a size mismatch.
     size_t v = 0;
     while (v < var_sets_.size() && var_set != var_sets_[v].name) ++v;
-    if (v == var_sets_.size()) {
-      // The only variable sets a towr composite can hold beyond the structure's are the "ee-schedule<ee>" sets of a
-      // problem whose phase durations are NOT optimised here (variable_names.h:47,60-63): no dependence, empty block.
-      // Anything else is a mistyped or foreign name: a silent zero block would hide it from Ipopt's derivative test.
-      if (var_set.rfind("ee-schedule", 0) == 0 && var_set.find_first_not_of("0123456789", 11) == std::string::npos && var_set.size() > 11)
-        return;
+    if (v == var_sets_.size())
       throw std::runtime_error("towr_amd: constraint set '" + std::string(info_.name) + "' asked for the Jacobian w.r.t. unknown variable set '" +
                                var_set + "'");
-    }
+    problem_->Update(GetVariables()->GetValues());
     const int32_t* col_idx = twr_structure_col_idx(problem_->structure());
     const double* val = problem_->jac();
     const int32_t* range = ranges_[v].data();
