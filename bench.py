@@ -301,13 +301,15 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
                         "ms_per_step": p_elapsed / p_steps * 1e3, "best_candidate": int(best[0])}}
 
 
-def timings_c3(ta, torch, dist, model, world, rank, dev, dev_index, backend, stream, steps=20, B=2048):
-    """The optimised-timings mode of the same C3 problem (Parameters::OptimizePhaseDurations: ee-schedule variables,
-    x-dependent active polynomials, rows that hold every variable of every ee set): 2048 problems per GPU, per-kernel HIP
-    events, roofline of the dominant kernel and of the whole path (SURVEY 8f #2)."""
+def timings_c3(ta, torch, dist, model, world, rank, dev, dev_index, backend, stream, steps=20, B=2048, constraint_sets=127):
+    """Another constraint list on the same C3 problem, driver-timed beside the headline: constraint_sets = 127 is the
+    optimised-timings mode (Parameters::OptimizePhaseDurations: ee-schedule variables, x-dependent active polynomials,
+    rows that hold every variable of every ee set; 2048 problems per GPU), 63 is towr's whole default
+    constraint list (+ splineacc-base-*, swing-*; 8192 problems per GPU).  Per-kernel HIP events, roofline of the dominant
+    kernel and of the whole path."""
     m = ta.Model.from_buffer_copy(bytes(model))
     m.terrain_id = ta.TERRAINS["flat"]
-    sched, params, S = build_case(ta, m, constraint_sets=127)
+    sched, params, S = build_case(ta, m, constraint_sets=constraint_sets)
     batch = ta.Batch([S], [0] * B, device=dev_index)
     base = perturbed_inputs(S, m, min(B, 256), first_seed=rank * 100000)
     x = torch.from_numpy(np.tile(base, ((B + base.shape[0] - 1) // base.shape[0], 1))[:B].reshape(-1)).to(dev)
@@ -333,19 +335,21 @@ def timings_c3(ta, torch, dist, model, world, rank, dev, dev_index, backend, str
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else None)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    names = {"dynamic": "twr::phase_locate_kernel + twr::dyn_phase_kernel", "rangeofmotion": "twr::rom_phase_kernel",
-             "nodes": "twr::node_kernel"}
+    timings = bool(constraint_sets & 64)
+    names = {"dynamic": "twr::phase_locate_kernel + twr::dyn_phase_kernel" if timings else "twr::dyn_kernel",
+             "rangeofmotion": "twr::rom_phase_kernel" if timings else "twr::rom_kernel", "nodes": "twr::node_kernel"}
     kbytes = batch.kernel_bytes()
     dom = max(kern_ms, key=kern_ms.get)
     path_ms = sum(kern_ms.values())
-    traffic = traffic_from_profile("C3+timings", None, B)
+    traffic = traffic_from_profile("C3+timings", None, B) if timings else None
     dom_traffic = None
     if traffic:   # the dynamic interval holds the pre-pass and the kernel: both are charged
         keys = {"dynamic": ["twr::dyn_phase_kernel", "twr::phase_locate_kernel"], "rangeofmotion": ["twr::rom_phase_kernel"],
                 "nodes": ["twr::node_kernel"]}[dom]
         vals = [v for k, v in traffic.items() if any(k.startswith(q) for q in keys)]
         dom_traffic = sum(vals) if vals else None
-    return {"workload": "C3 with optimised phase durations: n=%d m=%d nnz=%d, %d problems/GPU" % (S.n, S.m, S.nnz, B),
+    return {"workload": "C3 with %s: n=%d m=%d nnz=%d, %d problems/GPU"
+                        % ("optimised phase durations" if timings else "towr's whole default constraint list", S.n, S.m, S.nnz, B),
             "problems_per_gpu": B, "steps": steps, "value": B * world * steps / elapsed, "unit": "callbacks/s",
             "ms_per_step": elapsed / steps * 1e3, "bytes_per_callback": S.algorithmic_bytes,
             "roofline": {"bound": "hbm", "achieved": kbytes[dom] / (kern_ms[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -372,7 +376,8 @@ def main():
                          "optimised phase durations (ee-schedule variables, all-variables rows); c3 only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scale-c5", action="store_true", help="skip the strong-scaling C5 leg of the default run")
-    ap.add_argument("--no-timings-c3", action="store_true", help="skip the optimised-timings leg of the default run")
+    ap.add_argument("--no-timings-c3", action="store_true",
+                    help="skip the optimised-timings and the whole-default-list legs of the default run")
     args = ap.parse_args()
 
     import torch
@@ -476,10 +481,7 @@ def main():
         elapsed = float(t.item())
 
     # sanity: the outputs are finite (no work skipped / no garbage)
-    if os.environ.get("TWR_DEBUG_FLAGS") and "ablate" not in os.path.basename(ta.LIB_PATH):
-        raise SystemExit("TWR_DEBUG_FLAGS is only meaningful with a diagnostic library (TWR_AMD_LIB=.../libtowr_amd_ablate*.so)")
-    if not os.environ.get("TWR_DEBUG_FLAGS"):   # (diagnostic ablation builds write garbage on purpose)
-        assert bool(torch.isfinite(g).all()) and bool(torch.isfinite(jac).all())
+    assert bool(torch.isfinite(g).all()) and bool(torch.isfinite(jac).all())
 
     if rank == 0:
         callbacks = n_all * args.steps
@@ -526,13 +528,16 @@ def main():
     default_run = args.workload == "c3" and args.sets == "hot"
     if default_run and not (args.no_scale_c5 and args.no_timings_c3):
         del x, g, jac, batch
+    a3 = None
     if default_run and not args.no_timings_c3:
         t3 = timings_c3(ta, torch, dist, model, world, rank, dev, dev_index, backend, stream)
+        a3 = timings_c3(ta, torch, dist, model, world, rank, dev, dev_index, backend, stream, B=8192, constraint_sets=63)
     if default_run and not args.no_scale_c5:
         c5 = scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, stream)
     if rank == 0:
         if t3 is not None:
             out["timings_c3"] = t3
+            out["all_sets_c3"] = a3
         if c5 is not None:
             out["scale_c5"] = c5
         print(json.dumps(out), flush=True)

@@ -160,7 +160,8 @@ int main(int argc, char** argv) {
         twr_structure_var_set(S, i, &v);
         bad.AddVariableSet(std::make_shared<PlainVariables>(v.name, x.data() + v.offset, v.size));
       }
-      bad.AddVariableSet(std::make_shared<PlainVariables>("ee-motoin_0", one, 1));
+      // (an empty set, so that the variable count still matches and the name check is what is reached)
+      bad.AddVariableSet(std::make_shared<PlainVariables>("ee-motoin_0", one, 0));
       for (auto& c : towr_amd::MakeDeviceConstraints(model, sched, prm, 0, grid)) bad.AddConstraintSet(c);
       (void)bad.GetJacobianOfConstraints();
     } catch (const std::exception& e) {

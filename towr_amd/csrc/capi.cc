@@ -17,7 +17,7 @@
 #include "structure.h"
 
 namespace twr {
-hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
+hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom, int rom_max_vals,
                        const NodeWork* node, int n_node, const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap,
                        const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
                        double* g, double* jac, double* dump, int flags, hipStream_t stream, hipEvent_t* ev);
@@ -62,6 +62,7 @@ struct twr_batch {
   int device = 0;
   int n_problems = 0, n_ee = 0;
   int n_dyn = 0, n_rom = 0, n_node = 0, n_cu = 0;
+  int rom_max_vals = 0;                      // Jacobian values of the largest rom slice (picks the copy-out length)
   std::vector<int64_t> x_off, g_off, j_off;  // n_problems+1
   std::vector<void*> blobs;                  // device blobs, one per distinct structure
   std::vector<void*> grids;                  // device copies of the distinct gridded terrains
@@ -123,20 +124,35 @@ void copy_set(const twr::SetInfo& s, twr_set_info* out) {
 // slice fits the LDS image of the kernel.  Returns (k0, cnt) pairs.
 std::vector<std::pair<int, int>> chunk(const std::vector<int32_t>& row_ptr, int row0, int rows_per_k, int K, int cap,
                                        int max_cnt) {
-  std::vector<std::pair<int, int>> out;
-  int k0 = 0;
-  while (k0 < K) {
-    int k1 = k0;
-    while (k1 < K && k1 - k0 < max_cnt && row_ptr[row0 + rows_per_k * (k1 + 1)] - row_ptr[row0 + rows_per_k * k0] <= cap)
-      ++k1;
-    if (k1 == k0) throw std::runtime_error("one time node exceeds the LDS staging capacity");
+  // Balanced: the fewest runs that respect max_cnt and the capacity, of (nearly) equal length -- K = 200 gives 4 x 50
+  // rather than 64 + 64 + 64 + 8.  A kernel with a compile-time number of copy-out stores pays the full count for a
+  // short tail run too.
+  auto vals = [&](int k0, int k1) { return row_ptr[row0 + rows_per_k * k1] - row_ptr[row0 + rows_per_k * k0]; };
+  auto greedy = [&](int limit, std::vector<std::pair<int, int>>& out) {
+    out.clear();
+    for (int k0 = 0; k0 < K;) {
+      int k1 = k0;
+      while (k1 < K && k1 - k0 < limit && vals(k0, k1 + 1) <= cap) ++k1;
+      if (k1 == k0) throw std::runtime_error("one time node exceeds the LDS staging capacity");
+      out.push_back({k0, k1 - k0});
+      k0 = k1;
+    }
+  };
+  std::vector<std::pair<int, int>> out, best;
+  greedy(max_cnt, best);                                 // the minimum number of runs
+  static const bool balanced = [] { const char* e = getenv("TWR_ROM_BALANCED"); return !e || atoi(e) != 0; }();
+  if (balanced)
+    for (int limit = (K + (int)best.size() - 1) / (int)best.size(); limit < max_cnt; ++limit) {
+      greedy(limit, out);                                // the smallest run length that still needs no more runs
+      if (out.size() == best.size()) {
+        best = out;
+        break;
+      }
+    }
+  for (const auto& r : best)
     // copy_out_fixed clamps its tail iterations to the last complete pair of the slice: a slice must hold one
-    if (row_ptr[row0 + rows_per_k * k1] - row_ptr[row0 + rows_per_k * k0] < 4)
-      throw std::runtime_error("a time-node run with fewer than 4 Jacobian values cannot be staged");
-    out.push_back({k0, k1 - k0});
-    k0 = k1;
-  }
-  return out;
+    if (vals(r.first, r.first + r.second) < 4) throw std::runtime_error("a time-node run with fewer than 4 Jacobian values cannot be staged");
+  return best;
 }
 }  // namespace
 
@@ -410,6 +426,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     std::vector<twr::RomPhaseWork> prom;
     size_t prec_bytes = 0;  // offsets into the scratch buffer are stored first and rebased after hipMalloc
     std::vector<int> dyn_first, rom_first;  // first work item of every problem (+ end)
+    static const int rom_nodes = [] { const char* e = getenv("TWR_ROM_NODES"); return e && atoi(e) > 0 ? std::min(64, atoi(e)) : 64; }();
     // run lists are identical for problems that share a structure: build once per structure
     std::vector<std::vector<std::vector<std::pair<int, int>>>> runs_rom(n_structs);
     for (int i = 0; i < n_structs; ++i) {
@@ -418,7 +435,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
       if (S.timings) continue;  // optimised timings: PhaseWork items below
       for (int e = 0; e < S.n_ee; ++e)
         if (const twr::SetInfo* rs = S.FindSet("rangeofmotion-" + std::to_string(e)))
-          runs_rom[i].push_back(chunk(S.row_ptr, rs->offset, 3, (int)S.grid_rom.size(), twr::rom_stage_capacity(), 64));
+          runs_rom[i].push_back(chunk(S.row_ptr, rs->offset, 3, (int)S.grid_rom.size(), twr::rom_stage_capacity(), rom_nodes));
     }
     for (int p = 0; p < n_problems; ++p) {
       int si = struct_of_problem[p];
@@ -467,6 +484,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
           w.off_ang = S.off_base_ang;
           w.cnt = r.second;
           w.nvals = S.row_ptr[rs.offset + 3 * (r.first + r.second)] - S.row_ptr[rs.offset + 3 * r.first];
+          b->rom_max_vals = std::max(b->rom_max_vals, w.nvals);
           rom.push_back(w);
         }
       }
@@ -692,7 +710,7 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
   hipEvent_t* ev = nullptr;
   if (b->prof_count < b->prof_capacity) ev = b->prof_events.data() + 4 * b->prof_count++;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-  hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->d_rom, b->n_rom, b->d_node, b->n_node,
+  hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->d_rom, b->n_rom, b->rom_max_vals, b->d_node, b->n_node,
                                   b->d_pdyn, b->n_pdyn, b->pdyn_img_cap, b->d_ploc, b->n_ploc, b->d_prom, b->n_prom,
                                   b->prom_img_cap, d_x, d_g, d_jac, b->d_dump, flags & TWR_EVAL_BOTH, stream, ev);
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));

@@ -1015,9 +1015,14 @@ __global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ 
 // rom_kernel is compiled in its own translation unit (rom_tu.hip) with a different instruction scheduling
 // strategy: it is store bound and gains 4-5 % from clause-oriented scheduling, the VALU-bound kernels lose.
 constexpr int kRomLds = kRomStage + 2 + 64 + 192;   // doubles: image, per-lane trash slots, g
-template <bool WANT_G, bool WANT_J>
+// NIT = store instructions of the copy-out: the launcher picks the smallest instantiation that covers the largest slice
+// of the batch.  The stores past the end of a slice are re-stores of its last pair -- no HBM traffic, but requests all
+// the same: C3's balanced 50-node slices need 34, and 34 instead of 38 is worth 4 % of the kernel (A/B on one box: 0.925
+// -> 0.883 ms together with the balanced slices; five 40-node slices with 27 stores each: 0.965 ms -- large slices win).
+template <int NIT, bool WANT_G, bool WANT_J>
 TWR_DEV void rom_body(const RomWork* __restrict__ work, int n_work, const double* __restrict__ x, double* __restrict__ g,
                       double* __restrict__ jac, double* stage, int lane, int i, int stride) {
+  static_assert(NIT * 128 <= kRomStage + 2 + 127, "copy-out longer than the image");
   const int trash = kRomStage + 2 + lane;
   double* gst = stage + kRomStage + 2 + 64;
   if (i >= n_work) return;
@@ -1039,7 +1044,7 @@ TWR_DEV void rom_body(const RomWork* __restrict__ work, int n_work, const double
     RomRec r2 = r1;
     if (has2) r2 = rom_load_rec(w2, lane);              // A (records first: the wait for x retires them too)
     if (has1) rom_load_x(w1, r1, x, X);
-    if (WANT_J) copy_out_fixed<(kRomStage + 2 + 127) / 128, 13>(dst, stage, w0.nvals, par, lane);   // B
+    if (WANT_J) copy_out_fixed<NIT, 13>(dst, stage, w0.nvals, par, lane);   // B
     if (WANT_G) {                                       //   3 constraint values per time node, contiguous in g: clamped
       double* go = g + w0.g_off;                        //   lanes instead of predicates (see copy_out_fixed)
       const int last = 3 * w0.cnt - 1;
@@ -1051,24 +1056,35 @@ TWR_DEV void rom_body(const RomWork* __restrict__ work, int n_work, const double
   }
 }
 
+constexpr int kRomNitMax = (kRomStage + 2 + 127) / 128;   // 38
 #ifdef TWR_TU_ROM
-template <bool WANT_G, bool WANT_J>
+template <int NIT, bool WANT_G, bool WANT_J>
 __global__ __launch_bounds__(64, 1) void rom_kernel(const RomWork* __restrict__ work, int n_work, const double* __restrict__ x,
                                                     double* __restrict__ g, double* __restrict__ jac) {
   __shared__ __attribute__((aligned(16))) double stage[kRomLds];
-  rom_body<WANT_G, WANT_J>(work, n_work, x, g, jac, stage, threadIdx.x, blockIdx.x, gridDim.x);
+  rom_body<NIT, WANT_G, WANT_J>(work, n_work, x, g, jac, stage, threadIdx.x, blockIdx.x, gridDim.x);
 }
 
-hipError_t launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, const double* x, double* g, double* jac,
-                             int flags) {
+// max_vals: Jacobian values of the largest slice of the batch
+hipError_t launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, int max_vals, const double* x, double* g,
+                             double* jac, int flags) {
   const bool wg = flags & 1, wj = flags & 2;
-  if (wg && wj) return twr_launch(rom_kernel<true, true>, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac);
-  if (wj) return twr_launch(rom_kernel<false, true>, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac);
-  return twr_launch(rom_kernel<true, false>, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac);
+  const int need = (max_vals + 1 + 2 + 127) / 128;   // (+ parity shift, rounded up to whole store instructions)
+#define TWR_ROM_LAUNCH(NIT)                                                                                                  \
+  {                                                                                                                          \
+    if (wg && wj) return twr_launch(rom_kernel<NIT, true, true>, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac);    \
+    if (wj) return twr_launch(rom_kernel<NIT, false, true>, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac);         \
+    return twr_launch(rom_kernel<NIT, true, false>, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac);                 \
+  }
+  if (need <= 26) TWR_ROM_LAUNCH(26)
+  if (need <= 30) TWR_ROM_LAUNCH(30)
+  if (need <= 34) TWR_ROM_LAUNCH(34)
+  TWR_ROM_LAUNCH(kRomNitMax)
+#undef TWR_ROM_LAUNCH
 }
 #else   // !TWR_TU_ROM
-hipError_t launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, const double* x, double* g, double* jac,
-                             int flags);
+hipError_t launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, int max_vals, const double* x, double* g,
+                             double* jac, int flags);
 
 // all terrain-ee-motion_e (terrain_constraint.cc:57-108), force-ee-force_e, splineacc-base-* and
 // swing-ee-motion_e sets of one problem.  One workgroup of four waves per problem, one wave per family
@@ -1246,7 +1262,7 @@ __global__ __launch_bounds__(128, 2) void eval_fused_kernel(const RomWork* __res
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   int b = blockIdx.x;
   if (b < g_rom) {
-    if (wave == 0) rom_body<WANT_G, WANT_J>(rom, n_rom, x, g, jac, stage, lane, b, g_rom);
+    if (wave == 0) rom_body<kRomNitMax, WANT_G, WANT_J>(rom, n_rom, x, g, jac, stage, lane, b, g_rom);
     return;
   }
   b -= g_rom;
@@ -2571,7 +2587,7 @@ static int env_int(const char* name, int dflt) {
   return v > 0 ? v : dflt;
 }
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
-                       const NodeWork* node, int n_node, const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap,
+                       int rom_max_vals, const NodeWork* node, int n_node, const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap,
                        const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
                        double* g, double* jac, double* dump /* kDynDump doubles */, int flags, hipStream_t stream,
                        hipEvent_t* ev /* 4 events or nullptr */) {
@@ -2678,7 +2694,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
   if (n_rom > 0) {
     const int res = rom_bpc * n_cu;
     dim3 grid(n_rom < res ? n_rom : res);
-    st = twr_first(st, launch_rom_kernel((int)grid.x, stream, rom, n_rom, x, g, jac, flags));
+    st = twr_first(st, launch_rom_kernel((int)grid.x, stream, rom, n_rom, rom_max_vals, x, g, jac, flags));
   }
   if (ev) (void)hipEventRecord(ev[2], stream);
   if (n_node > 0) st = twr_first(st, twr_launch(node_kernel, dim3(n_node), dim3(256), 0, stream, node, x, g, jac, flags));
