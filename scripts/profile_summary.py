@@ -18,8 +18,8 @@ prof = os.path.join(ROOT, "profiles")
 
 
 def find(d, pat):
-    f = glob.glob(os.path.join(out, d, "**", pat), recursive=True)
-    return f[0] if f else None
+    f = glob.glob(os.path.join(out, d, "**", pat), recursive=True)   # (a merged output directory may hold older runs too)
+    return max(f, key=os.path.getmtime) if f else None
 
 
 def keep_twr(src, dst):
