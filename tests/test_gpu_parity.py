@@ -857,6 +857,31 @@ def test_eval_is_graph_capturable_and_stream_ordered():
     rg, _, _, rj = case.P.eval(xs2[17])
     assert_parity(S, g.cpu().numpy()[batch.g_off[17]:batch.g_off[18]], jac.cpu().numpy()[batch.jac_off[17]:batch.jac_off[18]],
                   rg, rj, "graph replay", x=xs2[17])
+    # optimised timings: pre-pass + the dynamic-LDS kernels inside a graph, incl. a structure whose images exceed 64 KB
+    # (the LDS limit of those instantiations is raised at batch creation, not at launch)
+    big = Case("biped", "gap", _many_phases(2, 31, 2), constraint_sets=127)
+    small = Case("biped", "stairs", ta.gait_combo(2, 0, 2.0), constraint_sets=127)
+    tb = ta.Batch([big.S, small.S], [0, 1, 1, 0], device=0)
+    txs = [c.x_perturbed(30 + i, 1.2) for i, c in enumerate([big, small, small, big])]
+    tx = torch.from_numpy(np.concatenate(txs)).to(dev)
+    tg = torch.zeros(int(tb.g_off[-1]), dtype=torch.float64, device=dev)
+    tj = torch.zeros(int(tb.jac_off[-1]), dtype=torch.float64, device=dev)
+    with torch.cuda.stream(side):
+        tb.eval_device(tx.data_ptr(), tg.data_ptr(), tj.data_ptr(), ta.EVAL_BOTH, side.cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    eg, ej = tg.clone(), tj.clone()
+    tgraph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(tgraph):
+        tb.eval_device(tx.data_ptr(), tg.data_ptr(), tj.data_ptr(), ta.EVAL_BOTH, torch.cuda.current_stream().cuda_stream)
+    tg.zero_()
+    tj.zero_()
+    tgraph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(tg, eg) and torch.equal(tj, ej)
+    rg, _, _, rj = big.P.eval(txs[3])
+    assert_parity(big.S, tg.cpu().numpy()[tb.g_off[3]:tb.g_off[4]], tj.cpu().numpy()[tb.jac_off[3]:tb.jac_off[4]], rg, rj,
+                  "graph replay, optimised timings", x=txs[3])
     # two batches, two streams, in flight together
     batch2 = ta.Batch([S], [0] * B, device=0)
     g2, j2 = torch.zeros_like(g), torch.zeros_like(jac)

@@ -22,6 +22,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
                        const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
                        double* g, double* jac, double* dump, int flags, hipStream_t stream, hipEvent_t* ev);
 int dyn_dump_doubles();
+hipError_t prepare_phase_kernels(int pdyn_img_cap, int prom_img_cap);
 hipError_t launch_check(int n_problems, const int64_t* g_off, const int64_t* j_off, const double* g, const double* jac,
                         int32_t* status, int flags, hipStream_t stream);
 hipError_t launch_score(const NodeWork* work, int n_problems, const double* g, double* scores, hipStream_t stream);
@@ -542,7 +543,9 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
           any_rom = true;
           const int K = (int)S.grid_rom.size(), nv = S.phase_tables.rom_node_vals[e];
           static const int prom_nodes = [] { const char* e = getenv("TWR_PROM_NODES"); return e && atoi(e) > 0 ? std::min(16, atoi(e)) : 16; }();
-          const int run = std::max(1, std::min(prom_nodes, (160 * 128) / nv));   // time nodes per pass (four lanes each)
+          const int run_max = std::max(1, std::min(prom_nodes, (160 * 128) / nv));   // time nodes per pass (four lanes each)
+          const int n_pass = (K + run_max - 1) / run_max;
+          const int run = (K + n_pass - 1) / n_pass;                  // balanced: no short tail pass (it pays the full copy-out)
           b->prom_img_cap = std::max(b->prom_img_cap, run * nv);
           for (int k0 = 0; k0 < K; k0 += run) {
             twr::RomPhaseWork rw;
@@ -644,6 +647,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
       }
       upload(pdyn.data(), pdyn.size() * sizeof(twr::PDynWork), reinterpret_cast<void**>(&b->d_pdyn));
     }
+    TWR_HIP(twr::prepare_phase_kernels(b->pdyn_img_cap, b->prom_img_cap));
     *out = b.release();
     return TWR_OK;
   } catch (const std::exception& e) {

@@ -630,6 +630,7 @@ TWR_DEV void copy_out_fixed(double* __restrict__ dst, const double* __restrict__
   // every lane, whatever the parity -- two more store instructions that are ALWAYS issued.  A store inside a divergent
   // `if` is a branch the compiler must assume not taken when it counts the stores behind a prefetched load, and one
   // uncounted store is enough to turn the next counted wait into a drain of the whole copy-out.
+  // (A/B on one box, rom_kernel: these two as `if (lane == 0)` stores cost 4 %: 0.876 -> 0.914 ms)
   dst[0] = stage[par];
   dst[n - 1] = stage[total - 1];
 }
@@ -1019,6 +1020,9 @@ constexpr int kRomLds = kRomStage + 2 + 64 + 192;   // doubles: image, per-lane 
 // of the batch.  The stores past the end of a slice are re-stores of its last pair -- no HBM traffic, but requests all
 // the same: C3's balanced 50-node slices need 34, and 34 instead of 38 is worth 4 % of the kernel (A/B on one box: 0.925
 // -> 0.883 ms together with the balanced slices; five 40-node slices with 27 stores each: 0.965 ms -- large slices win).
+// (The hand-scheduled form of dyn_phase_kernel -- asm loads into AGPRs, one counted wait behind the copy-out -- was built
+// for this loop too and is SLOWER here, 0.98 vs 0.90 ms on one box: the compiler's clause-oriented schedule of the 28
+// loads with scalar bases and immediate offsets beats 28 separate asm loads with per-lane 64-bit addresses.)
 template <int NIT, bool WANT_G, bool WANT_J>
 TWR_DEV void rom_body(const RomWork* __restrict__ work, int n_work, const double* __restrict__ x, double* __restrict__ g,
                       double* __restrict__ jac, double* stage, int lane, int i, int stride) {
@@ -2644,13 +2648,6 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
       else if (wj) TWR_PDYN_LAUNCH(40, false, true);
       else TWR_PDYN_LAUNCH(40, true, false);
     } else {
-      if (lds > 64 * 1024) {
-        const void* fn = wg && wj ? reinterpret_cast<const void*>(dyn_phase_kernel<0, true, true>)
-                                  : (wj ? reinterpret_cast<const void*>(dyn_phase_kernel<0, false, true>)
-                                        : reinterpret_cast<const void*>(dyn_phase_kernel<0, true, false>));
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-      }
       if (wg && wj) TWR_PDYN_LAUNCH(0, true, true);
       else if (wj) TWR_PDYN_LAUNCH(0, false, true);
       else TWR_PDYN_LAUNCH(0, true, false);
@@ -2679,13 +2676,6 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
     else if (prom_img_cap <= 32 * 128) TWR_PROM_FLAGS(32)
     else if (prom_img_cap <= 40 * 128) TWR_PROM_FLAGS(40)
     else {
-      if (lds > 64 * 1024) {
-        const void* fn = wg && wj ? reinterpret_cast<const void*>(rom_phase_kernel<0, true, true>)
-                                  : (wj ? reinterpret_cast<const void*>(rom_phase_kernel<0, false, true>)
-                                        : reinterpret_cast<const void*>(rom_phase_kernel<0, true, false>));
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-      }
       TWR_PROM_FLAGS(0)
     }
 #undef TWR_PROM_FLAGS
@@ -2702,6 +2692,25 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
   return st;
 }
 
+// Images of more than 64 KB need the dynamic-LDS limit of the run-time-length instantiations raised; done when a batch
+// is created (on its device, always to the whole 160 KB of a CU), not at launch: an evaluation must stay capturable
+// in a hipGraph.
+hipError_t prepare_phase_kernels(int pdyn_img_cap, int prom_img_cap) {
+  const int whole = 160 * 1024;
+  hipError_t st = hipSuccess;
+  auto raise = [&](const void* fn) { st = twr_first(st, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, whole)); };
+  if ((size_t)pdyn_img_cap * sizeof(double) > 64 * 1024) {
+    raise(reinterpret_cast<const void*>(dyn_phase_kernel<0, true, true>));
+    raise(reinterpret_cast<const void*>(dyn_phase_kernel<0, false, true>));
+    raise(reinterpret_cast<const void*>(dyn_phase_kernel<0, true, false>));
+  }
+  if ((size_t)prom_img_cap * sizeof(double) > 64 * 1024) {
+    raise(reinterpret_cast<const void*>(rom_phase_kernel<0, true, true>));
+    raise(reinterpret_cast<const void*>(rom_phase_kernel<0, false, true>));
+    raise(reinterpret_cast<const void*>(rom_phase_kernel<0, true, false>));
+  }
+  return st;
+}
 int rom_stage_capacity() { return kRomStage; }
 int dyn_dump_doubles() { return kDynImage + 2 + 96; }
 #endif  // !TWR_TU_ROM
