@@ -268,6 +268,41 @@ def test_create_many_equals_one_by_one():
         ta.Structure.create_many(m, [many[0].schedule, many[1].schedule], [many[0].params, bad], threads=2)
 
 
+def test_create_many_with_a_shared_grid_and_grid_info():
+    """twr_structure_create_many_with_grid: every structure of a sweep over a gridded terrain shares one grid handle;
+    a gridded terrain id without a grid (or with the other kind of grid) is rejected; twr_terrain_grid_info returns what
+    a rank needs to rebuild the handle (dist.broadcast_grid)."""
+    import ctypes as C
+
+    from towr_amd import sweep
+
+    elev = (np.arange(30 * 22, dtype=np.float32).reshape(30, 22) % 13) * 0.01
+    gm = ta.GridMap(elev, 0.05, (0.8, -0.2))
+    csv = ta.TerrainGrid(np.arange(6 * 9, dtype=np.float64).reshape(6, 9) * 0.02)
+    m = ta.model_preset("anymal", "grid_map")
+    cands = sweep.enumerate_candidates(1040)[::97]
+    many = sweep.candidate_structures(m, cands, threads=3, grid=gm)
+    for c, S in zip(cands, many):
+        one = sweep.candidate_structure(m, c, grid=gm)
+        assert (S.n, S.m, S.nnz) == (one.n, one.m, one.nnz) and np.array_equal(S.col_idx, one.col_idx)
+    with pytest.raises(ta.TowrError, match="grid"):
+        sweep.candidate_structures(m, cands[:2], threads=2)               # gridded terrain id, no grid
+    with pytest.raises(ta.TowrError, match="kind"):
+        sweep.candidate_structures(m, cands[:2], threads=2, grid=csv)     # CSV heights for a grid_map terrain
+    for handle, kind, shape, res, pos, dtype in ((gm, 1, (30, 22), 0.05, (0.8, -0.2), np.float32), (csv, 0, (6, 9), None, None, np.float64)):
+        k, n0, n1 = C.c_int32(), C.c_int32(), C.c_int32()
+        r, px, py = C.c_double(), C.c_double(), C.c_double()
+        data = C.c_void_p()
+        ta._check(ta.lib().twr_terrain_grid_info(handle._h, C.byref(k), C.byref(n0), C.byref(n1), C.byref(r), C.byref(px), C.byref(py),
+                                                 C.byref(data)))
+        assert (k.value, n0.value, n1.value) == (kind,) + shape
+        got = np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_float if kind else C.c_double)), shape=(shape[0] * shape[1],))
+        want = handle.elevation.reshape(-1, order="F") if kind else handle.heights.reshape(-1)
+        assert np.array_equal(got, want)
+        if kind:
+            assert (r.value, px.value, py.value) == (res,) + pos
+
+
 def test_base_motion_needs_the_initial_base_height():
     """twr_params_default leaves base_z_init unset (NaN): enabling baseMotion without it is rejected instead of
     silently producing the infeasible bounds [-0.02, 0.1] (base_motion_constraint.cc:51-55)."""
