@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__(256, 4) void node_kernel(const NodeWork* __restrict
 // and 40 KB: blocks [0, g_rom) take the rom role (wave 0 only; the image is 39 KB), the next g_dyn blocks the dyn role
 // (both waves, one 20-KB half each), the rest the node role (two families per block) -- the residency per CU of each
 // role is that of its own kernel, and blocks are dispatched in this order, so a later role starts as the earlier drains.
-template <bool WANT_G, bool WANT_J>
+template <int ROM_NIT, bool WANT_G, bool WANT_J>
 __global__ __launch_bounds__(128, 2) void eval_fused_kernel(const RomWork* __restrict__ rom, int n_rom, int g_rom,
                                                             const DynWork* __restrict__ dyn, int n_dyn, int g_dyn,
                                                             const NodeWork* __restrict__ node, const double* __restrict__ x,
@@ -1266,7 +1266,7 @@ __global__ __launch_bounds__(128, 2) void eval_fused_kernel(const RomWork* __res
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   int b = blockIdx.x;
   if (b < g_rom) {
-    if (wave == 0) rom_body<kRomNitMax, WANT_G, WANT_J>(rom, n_rom, x, g, jac, stage, lane, b, g_rom);
+    if (wave == 0) rom_body<ROM_NIT, WANT_G, WANT_J>(rom, n_rom, x, g, jac, stage, lane, b, g_rom);
     return;
   }
   b -= g_rom;
@@ -2617,9 +2617,18 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
       if (g_dyn > d) g_dyn = d;
     }
     const dim3 fgrid(g_rom + g_dyn + 2 * n_node);
-    if ((flags & 3) == 3) return twr_launch(eval_fused_kernel<true, true>, fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump);
-    if (flags & 2) return twr_launch(eval_fused_kernel<false, true>, fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump);
-    return twr_launch(eval_fused_kernel<true, false>, fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump);
+    const int need = (rom_max_vals + 1 + 2 + 127) / 128;   // copy-out length of the rom role (see launch_rom_kernel)
+#define TWR_FUSED_LAUNCH(NIT)                                                                                                          \
+  {                                                                                                                                    \
+    if ((flags & 3) == 3)                                                                                                              \
+      return twr_launch(eval_fused_kernel<NIT, true, true>, fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump);   \
+    if (flags & 2)                                                                                                                     \
+      return twr_launch(eval_fused_kernel<NIT, false, true>, fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump);  \
+    return twr_launch(eval_fused_kernel<NIT, true, false>, fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump);    \
+  }
+    if (need <= 34) TWR_FUSED_LAUNCH(34)
+    TWR_FUSED_LAUNCH(kRomNitMax)
+#undef TWR_FUSED_LAUNCH
   }
   if (ev) (void)hipEventRecord(ev[0], stream);
   if (n_dyn > 0) {
