@@ -497,6 +497,82 @@ def test_nearest_plane_known_answers():
     assert np.allclose(w2, [[np.cos(0.6), np.sin(0.6)]], rtol=0, atol=1e-15)
 
 
+def test_third_party_restatements_against_independent_implementations():
+    """tf's quaternion -> matrix, boost::geometry's point-polygon distance and grid_map's bilinear atPosition are absent
+    from /root/reference (third party), so the oracle restates them from their published algorithms.  Besides the hand
+    known-answers above they are cross-checked here against implementations that share no code with the oracle: scipy's
+    Rotation, a brute-force numpy point-in-polygon / segment-distance, scipy's RegularGridInterpolator."""
+    from scipy.interpolate import RegularGridInterpolator
+    from scipy.spatial.transform import Rotation
+
+    rng = np.random.default_rng(2024)
+    # (1) PlanarRegionsToPolygons: R(q) (x, y, 0) + position, any (non-unit) quaternion
+    for _ in range(40):
+        q = rng.normal(size=4) * rng.uniform(0.2, 3.0)
+        pos = rng.uniform(-2, 2, size=3)
+        pts = rng.uniform(-1, 1, size=(5, 2))
+        got = ob.planes_world_xy([list(pos) + list(q)], pts, [0, 5])
+        R = Rotation.from_quat(q).as_matrix()                       # scipy: [x, y, z, w], normalises
+        want = (R @ np.c_[pts, np.zeros(5)].T).T[:, :2] + pos[:2]
+        assert np.abs(got - want).max() <= 1e-13
+
+    # (2) nearest polygon: 0 inside (even-odd ray casting), else the distance to the closest boundary segment
+    def brute(polys, px, py):
+        best, arg = np.inf, -1
+        for i, P in enumerate(polys):
+            inside = False
+            for (x0, y0), (x1, y1) in zip(P[:-1], P[1:]):
+                if (y0 > py) != (y1 > py) and px < x0 + (py - y0) * (x1 - x0) / (y1 - y0):
+                    inside = not inside
+            d = 0.0
+            if not inside:
+                d = np.inf
+                for a, b in zip(P[:-1], P[1:]):
+                    ab, ap = b - a, np.array([px, py]) - a
+                    t = np.clip(ap @ ab / max(ab @ ab, 1e-300), 0.0, 1.0)
+                    d = min(d, float(np.hypot(*(ap - t * ab))))
+            if d < best:
+                best, arg = d, i
+        return arg, best
+
+    for trial in range(30):
+        polys = []
+        for _ in range(int(rng.integers(2, 7))):
+            k = int(rng.integers(3, 9))
+            ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+            rad = rng.uniform(0.2, 1.0, k)                           # star-shaped: concave corners happen
+            P = np.stack([rad * np.cos(ang), rad * np.sin(ang)], axis=1) + rng.uniform(-3, 3, size=2)
+            if trial % 2:
+                P = P[::-1]                                          # either orientation
+            polys.append(np.concatenate([P, P[:1]]))                 # closed ring
+        xy = np.concatenate(polys)
+        start = np.concatenate([[0], np.cumsum([len(P) for P in polys])])
+        for _ in range(60):
+            px, py = rng.uniform(-4.5, 4.5, size=2)
+            arg, best = brute(polys, px, py)
+            # skip near-ties and points within 1e-9 of a boundary (there the tie / boundary rules of boost decide)
+            d_all = sorted(brute([P], px, py)[1] for P in polys)
+            if d_all[1] - d_all[0] < 1e-9 or 0 < best < 1e-9:
+                continue
+            assert ob.nearest_plane(xy, start, px, py) == arg, (trial, px, py)
+
+    # (3) Grid: bilinear interpolation between cell centres, strictly inside the map
+    for _ in range(6):
+        sx, sy = int(rng.integers(5, 30)), int(rng.integers(5, 30))
+        res = float(rng.uniform(0.02, 0.2))
+        pos = tuple(rng.uniform(-1, 1, size=2))
+        el = rng.uniform(-0.5, 0.5, size=(sx, sy)).astype(np.float32)
+        P = ob.OracleProblem("monoped", "grid_map", [[0.4, 0.2, 0.4]], [1], grid_map=(el, res, pos))
+        cx = pos[0] + 0.5 * sx * res - (np.arange(sx) + 0.5) * res    # grid_map: cell (i, j) centre, descending in i, j
+        cy = pos[1] + 0.5 * sy * res - (np.arange(sy) + 0.5) * res
+        f = RegularGridInterpolator((cx[::-1], cy[::-1]), el[::-1, ::-1].astype(np.float64), method="linear")
+        for _ in range(40):
+            x = rng.uniform(cx[-1] + 1e-6, cx[0] - 1e-6)
+            y = rng.uniform(cy[-1] + 1e-6, cy[0] - 1e-6)
+            h = P.terrain_probe(x, y)[0]
+            assert abs(h - float(f([[x, y]])[0])) <= 2e-7 and h == float(np.float32(h))
+
+
 def test_initial_guess_samples_known_answer():
     """fpowr::ExtractInitialGuess (initial_guess_extractor.h:17-34).  At a base-spline node time the state is that
     node's variables: hopper, base polynomials of 0.1 s, variable layout [p0 v0 | p1 v1 | ...] per base set
