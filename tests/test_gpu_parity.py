@@ -643,6 +643,58 @@ def test_eval_check_flags_nonfinite_problems():
     assert (batch.status(st) & 2).sum() == 0
 
 
+def test_hostile_x_is_contained():
+    """A line search can hand the callback anything.  Everything an index is derived from on the device goes through a
+    clamp or a range check (locate_segment, the grid cell of a foothold), so NaN / Inf / 1e300 / negative or zero phase
+    durations in some problems of a batch must neither fault nor hang, the poisoned problems are flagged by
+    TWR_EVAL_CHECK and every other problem keeps the bits of a clean run."""
+    import torch
+
+    rng = np.random.default_rng(11)
+    rough = (rng.uniform(-0.05, 0.3, size=(40, 30)).astype(np.float32), 0.05, (1.0, 0.1))
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    for sets, terrain, kw in ((127, "grid_map", dict(grid=rough)), (127, "stairs", {}), (63, "grid_map", dict(grid=rough))):
+        case = Case("anymal", terrain, ta.gait_combo(4, 1, 2.0), constraint_sets=sets, **kw)
+        S = case.S
+        B = 12
+        clean = [case.x_perturbed(i, 1.6) for i in range(B)]
+        xs = [x.copy() for x in clean]
+        poison = [float("nan"), float("inf"), -float("inf"), 1e300, -1e300, 0.0, -0.3]
+        bad = {}
+        motion = [v for v in S.var_sets if v["name"].startswith("ee-motion")]
+        sched = [v for v in S.var_sets if v["name"].startswith("ee-schedule")]
+        for i, val in enumerate(poison):
+            p = 1 + i
+            if sched and i % 2 == 0:
+                v = sched[i % len(sched)]
+                xs[p][v["offset"] + i % v["size"]] = val                     # a phase duration
+            elif val != 0.0 and val != -0.3:
+                v = motion[i % len(motion)]
+                xs[p][v["offset"]:v["offset"] + min(v["size"], 9)] = val       # foothold / swing node values
+            else:
+                continue
+            bad[p] = val
+        batch = ta.Batch([S], [0] * B, device=0)
+        out = []
+        for X in (clean, xs):
+            x = torch.from_numpy(np.concatenate(X)).to(dev)
+            g = torch.full((int(batch.g_off[-1]),), 7.0, dtype=torch.float64, device=dev)
+            jac = torch.full((int(batch.jac_off[-1]),), 7.0, dtype=torch.float64, device=dev)
+            batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH | ta.EVAL_CHECK, st)
+            status = batch.status(st)
+            out.append((g.cpu().numpy(), jac.cpu().numpy(), status))
+        (g0, j0, s0), (g1, j1, s1) = out
+        assert (s0 == 0).all()
+        for p in range(B):
+            a, b = _split(batch, g0, j0, p), _split(batch, g1, j1, p)
+            if p in bad:
+                if not np.isfinite(bad[p]):
+                    assert s1[p] != 0, (sets, terrain, p, bad[p])
+            else:
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and s1[p] == 0, (sets, terrain, p)
+
+
 def test_grid_map_terrain():
     """`Grid` (grid_height_map.h:15-60), the terrain fpowr feeds the solver: float bilinear sample of the grid_map
     elevation layer, central-difference slopes, FLT_MAX outside -- terrain and force rows vs the oracle, with footholds
