@@ -984,7 +984,13 @@ TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double
     Dyn2Front S;
     dyn2_front(nd0, ga0, xs, lane, S);                                                       // F
     const DynPut pu = *gptr<DynPut>(w0.put + ga0.put_off);                                   // P (earlier costs spills: slower)
+    // (the copy-out runs at raised wave priority: with two waves per SIMD a wave in its store phase then gets its LDS
+    // reads and stores issued ahead of its neighbour's math, which keeps the store stream of the CU steadier -- A/B on one
+    // box 0.602-0.608 -> 0.591-0.596 ms; raised priority around the prefetches as well, or in rom_kernel, which runs one
+    // wave per SIMD, is neutral to slower)
+    __builtin_amdgcn_s_setprio(3);
     copy_out(pdst, pg, wp.nvals, wp.cnt);                                                    // O
+    __builtin_amdgcn_s_setprio(0);
     dyn2_back(w0, nd0, pu, S, gst, reinterpret_cast<char*>(stage + par), lane, WANT_G, WANT_J);   // B
     if (has1) stage_x(xr);                                                                   // S
     DynNode nd2 = nd1;
@@ -2153,7 +2159,9 @@ __global__ __launch_bounds__(64, 1) void rom_phase_kernel(const RomPhaseWork* __
     romp_issue_in(w1, r1, x, lane, ai);                                              // X
     if (WANT_J) {                                                                    // S
       double* dst = jac + w0.j_off;
+      __builtin_amdgcn_s_setprio(3);   // six workgroups per CU: as in dyn_kernel, the streaming wave goes first (-2 %)
       stream_out<NIT>(dst, romp_lds, nv, (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1), lane);
+      __builtin_amdgcn_s_setprio(0);
     }
     romp_wait_in<(WANT_J ? (NIT < 63 ? NIT : 63) : 0)>(ai, in);   // (NIT = 0: drains the copy-out)
     w0 = w1;
