@@ -491,7 +491,9 @@ def main():
         achieved = kbytes[dom] / (kern_ms[dom] * 1e-3) / 1e9
         path_ms = sum(kern_ms.values())
         path_achieved = alg_bytes / (path_ms * 1e-3) / 1e9
-        names = {"dynamic": "twr::dyn_kernel", "rangeofmotion": "twr::rom_kernel", "nodes": "twr::node_kernel"}
+        names = {"dynamic": "twr::dyn_kernel", "rangeofmotion": "twr::rom_kernel",
+                 # batches that carry the hot-path sets only run the two-family node kernel
+                 "nodes": "twr::node_kernel2" if (args.workload != "c3" or args.sets == "hot") else "twr::node_kernel"}
         if args.workload == "c3" and args.sets == "timings":
             names.update(dynamic="twr::dyn_phase_kernel", rangeofmotion="twr::rom_phase_kernel")
         out = {

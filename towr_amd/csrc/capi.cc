@@ -18,7 +18,7 @@
 
 namespace twr {
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom, int rom_max_vals,
-                       const NodeWork* node, int n_node, const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap,
+                       const NodeWork* node, int n_node, int node_families, const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap,
                        const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
                        double* g, double* jac, double* dump, int flags, hipStream_t stream, hipEvent_t* ev);
 int dyn_dump_doubles();
@@ -63,6 +63,7 @@ struct twr_batch {
   int device = 0;
   int n_problems = 0, n_ee = 0;
   int n_dyn = 0, n_rom = 0, n_node = 0, n_cu = 0;
+  int node_families = 4;                     // 2 when no problem has more than terrain-* / force-* work for the node kernel
   int rom_max_vals = 0;                      // Jacobian values of the largest rom slice (picks the copy-out length)
   std::vector<int64_t> x_off, g_off, j_off;  // n_problems+1
   std::vector<void*> blobs;                  // device blobs, one per distinct structure
@@ -599,6 +600,9 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     b->n_dyn = (int)dyn.size();
     b->n_rom = (int)rom.size();
     b->n_node = (int)node.size();
+    b->node_families = 2;
+    for (int i = 0; i < n_structs; ++i)
+      if (structs[i]->s.params.constraint_sets & ~(TWR_SET_TERRAIN | TWR_SET_DYNAMIC | TWR_SET_ROM | TWR_SET_FORCE)) b->node_families = 4;
     auto upload = [&](const void* src, size_t bytes, void** dst) {
       TWR_HIP(hipMalloc(dst, bytes));
       TWR_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
@@ -714,7 +718,7 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
   hipEvent_t* ev = nullptr;
   if (b->prof_count < b->prof_capacity) ev = b->prof_events.data() + 4 * b->prof_count++;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-  hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->d_rom, b->n_rom, b->rom_max_vals, b->d_node, b->n_node,
+  hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->d_rom, b->n_rom, b->rom_max_vals, b->d_node, b->n_node, b->node_families,
                                   b->d_pdyn, b->n_pdyn, b->pdyn_img_cap, b->d_ploc, b->n_ploc, b->d_prom, b->n_prom,
                                   b->prom_img_cap, d_x, d_g, d_jac, b->d_dump, flags & TWR_EVAL_BOTH, stream, ev);
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));

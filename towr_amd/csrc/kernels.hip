@@ -1256,6 +1256,17 @@ __global__ __launch_bounds__(256, 4) void node_kernel(const NodeWork* __restrict
   node_body(work[blockIdx.x], x, g, jac, flags, stage_all + kNodeStageOff[family], family, threadIdx.x & 63);
 }
 
+// Batches whose problems carry terrain-* and force-* sets only (the hot-path sets): workgroups of those two families.
+// The kernel is one chain of dependent loads per wave (work item -> header -> rows -> x) and lives on occupancy; with
+// four-wave workgroups two waves of each would find no work, i.e. 8 busy waves per CU instead of 16
+// (A/B on one box, 8192 C3 problems: 0.054 -> see DESIGN 6.0).
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4))) void node_kernel2(const NodeWork* __restrict__ work, const double* __restrict__ x,
+                                                    double* __restrict__ g, double* __restrict__ jac, int flags) {
+  __shared__ __attribute__((aligned(16))) double stage_all[kStageTerrain + kStageForce];
+  const int family = threadIdx.x >> 6;  // wave-uniform
+  node_body(work[blockIdx.x], x, g, jac, flags, stage_all + kNodeStageOff[family], family, threadIdx.x & 63);
+}
+
 // Small and mid-size batches: the three kernels above as ONE launch, so that their pipeline fills and drains overlap
 // instead of adding up (three dependent launches cost ~14 us of a 19-us step at 32 candidates).  Workgroups of two waves
 // and 40 KB: blocks [0, g_rom) take the rom role (wave 0 only; the image is 39 KB), the next g_dyn blocks the dyn role
@@ -2599,8 +2610,8 @@ static int env_int(const char* name, int dflt) {
   return v > 0 ? v : dflt;
 }
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
-                       int rom_max_vals, const NodeWork* node, int n_node, const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap,
-                       const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
+                       int rom_max_vals, const NodeWork* node, int n_node, int node_families /* 2: terrain + force only; 4 */,
+                       const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap, const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
                        double* g, double* jac, double* dump /* kDynDump doubles */, int flags, hipStream_t stream,
                        hipEvent_t* ev /* 4 events or nullptr */) {
   static const int dyn_bpc = env_int("TWR_DYN_BPC", 8), rom_bpc = env_int("TWR_ROM_BPC", 4);
@@ -2704,7 +2715,10 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
     st = twr_first(st, launch_rom_kernel((int)grid.x, stream, rom, n_rom, rom_max_vals, x, g, jac, flags));
   }
   if (ev) (void)hipEventRecord(ev[2], stream);
-  if (n_node > 0) st = twr_first(st, twr_launch(node_kernel, dim3(n_node), dim3(256), 0, stream, node, x, g, jac, flags));
+  if (n_node > 0 && node_families == 2)
+    st = twr_first(st, twr_launch(node_kernel2, dim3(n_node), dim3(128), 0, stream, node, x, g, jac, flags));
+  else if (n_node > 0)
+    st = twr_first(st, twr_launch(node_kernel, dim3(n_node), dim3(256), 0, stream, node, x, g, jac, flags));
   if (ev) (void)hipEventRecord(ev[3], stream);
   return st;
 }
