@@ -27,6 +27,13 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def dist_on(world):
+    """torch.distributed is initialised for more than one rank -- or, as a rehearsal of the multi-GPU code path on a
+    one-GPU box, when TWR_BENCH_FORCE_DIST is set (world size 1 under torch.distributed.run: the same RCCL init,
+    broadcast, barriers, all-gather and all-reduce as on an 8-GPU node)."""
+    return world > 1 or bool(os.environ.get("TWR_BENCH_FORCE_DIST"))
+
+
 def build_case(ta, model, K=200, T=2.0, combo=1, constraint_sets=27):
     sched = ta.gait_combo(model.n_ee, combo, T)
     dt = T / (K - 1.5)  # reference rule floor(T/dt)+2 then yields K nodes
@@ -221,13 +228,13 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
     for _ in range(10):
         batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     t2 = time.perf_counter()
     for _ in range(steps):
         batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     elapsed = time.perf_counter() - t2
     assert bool(torch.isfinite(g).all()) and bool(torch.isfinite(jac).all())
@@ -235,7 +242,7 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
                          device=dev if backend == "nccl" else None)
     tot = stats.clone()
     stats0 = stats.clone()
-    if world > 1:
+    if dist_on(world):
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     elapsed, setup_max, build_max = float(stats[0]), float(stats[1]), float(stats[2])
@@ -244,7 +251,7 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
     mine_t = torch.tensor([float(stats0[0]) / steps * 1e3, float(stats0[1])], dtype=torch.float64,
                           device=dev if backend == "nccl" else None)
     per_rank = [mine_t.clone() for _ in range(world)]
-    if world > 1:
+    if dist_on(world):
         dist.all_gather(per_rank, mine_t)
     per_rank_ms = [float(t_[0]) for t_ in per_rank]
     per_rank_setup = [float(t_[1]) for t_ in per_rank]
@@ -258,24 +265,24 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
         batch.eval_device(x.data_ptr(), g.data_ptr(), 0, ta.EVAL_VALUES, stream)
         batch.score_device(g.data_ptr(), scores.data_ptr(), stream)
         table = scores
-        if world > 1:
+        if dist_on(world):
             table = gather_scores(scores if backend == "nccl" else scores.cpu(), sizes)
         return best_candidate(table)
 
     for _ in range(3):
         best = planner_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     p_steps = max(20, steps // 4)
     t3 = time.perf_counter()
     for _ in range(p_steps):
         best = planner_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     p_elapsed = torch.tensor([time.perf_counter() - t3], dtype=torch.float64, device=dev if backend == "nccl" else None)
-    if world > 1:
+    if dist_on(world):
         dist.all_reduce(p_elapsed, op=dist.ReduceOp.MAX)
     p_elapsed = float(p_elapsed[0])
     return {"workload": "C5 sweep: %d enumerated ANYmal candidates (combo x T x swing scale) on Stairs, K=200, ragged"
@@ -285,7 +292,7 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
             "path_GBps": bytes_total * steps / elapsed / 1e9,
             "shards": [bounds[r + 1] - bounds[r] for r in range(world)],
             "setup_s": setup_max, "structure_build_s": build_max, "build_threads_per_rank": threads,
-            "world_size": world, "backend": backend if world > 1 else "none (single process)",
+            "world_size": world, "backend": backend if dist_on(world) else "none (single process)",
             "rccl_ranks": world if (world > 1 and backend == "nccl") else (1 if world == 1 else 0),
             "device_count": torch.cuda.device_count(),
             "ms_per_step_per_rank": {"min": min(per_rank_ms), "max": max(per_rank_ms), "all": per_rank_ms},
@@ -319,19 +326,19 @@ def timings_c3(ta, torch, dist, model, world, rank, dev, dev_index, backend, str
         batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)
     batch.profile_begin(steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kern_ms, n_prof = batch.profile_end()
     assert n_prof == steps
     assert bool(torch.isfinite(g).all()) and bool(torch.isfinite(jac).all())
-    if world > 1:
+    if dist_on(world):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else None)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -399,7 +406,7 @@ def main():
     dev = torch.device("cuda", dev_index)
 
     # --- the single collective of the design: rank 0 broadcasts the POD robot/terrain model (RCCL)
-    if world > 1:
+    if dist_on(world):
         from towr_amd.dist import broadcast_model
 
         if backend == "nccl":
@@ -459,20 +466,20 @@ def main():
     # HIP events on the launch stream bracket each of the three kernels of every timed step
     batch.profile_begin(args.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kern_ms, n_prof = batch.profile_end()
     assert n_prof == args.steps
 
     per_rank_ms = [elapsed / args.steps * 1e3]
-    if world > 1:
+    if dist_on(world):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else None)
         every = [t.clone() for _ in range(world)]
         dist.all_gather(every, t)
@@ -501,7 +508,7 @@ def main():
             "value": callbacks / elapsed,
             "unit": "callbacks/s",
             "n_gpus": world,
-            "backend": backend if world > 1 else "none (single process)", "device_count": torch.cuda.device_count(),
+            "backend": backend if dist_on(world) else "none (single process)", "device_count": torch.cuda.device_count(),
             "ms_per_step_per_rank": per_rank_ms,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -543,7 +550,7 @@ def main():
         if c5 is not None:
             out["scale_c5"] = c5
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on(world):
         dist.destroy_process_group()
 
 

@@ -90,3 +90,61 @@ def test_two_rank_gloo_broadcast_and_sharding(tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ALL RANKS OK [(0, 0, " in out.stdout and "(1, " in out.stdout, out.stdout
+
+
+RCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["TWR_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+import towr_amd as ta
+from towr_amd import sweep
+from towr_amd.dist import broadcast_model, broadcast_grid, gather_scores, best_candidate
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=dev)            # exactly what bench.py does on a multi-GPU node
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+model = broadcast_model(ta.model_preset("anymal", "stairs"), src=0, device=dev)
+assert bytes(model) == bytes(ta.model_preset("anymal", "stairs"))
+elev = (np.arange(24 * 18, dtype=np.float32).reshape(24, 18) % 11) * 0.01
+gm = broadcast_grid(ta.GridMap(elev, 0.05, (0.7, -0.1)), src=0, device=dev)
+assert np.array_equal(np.asarray(gm.elevation), elev)
+cands = sweep.enumerate_candidates(12)
+structs = sweep.candidate_structures(model, cands, threads=2)
+batch = ta.Batch(structs, list(range(len(structs))), device=0)
+ee = [[model.nominal_stance[e][0], model.nominal_stance[e][1], 0.0] for e in range(model.n_ee)]
+z = -model.nominal_stance[0][2]
+x = torch.from_numpy(np.concatenate([s.initial_guess([0, 0, z], [0, 0, 0], [2.0, 0, z], [0, 0, 0], ee) for s in structs])).to(dev)
+g = torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+batch.eval_device(x.data_ptr(), g.data_ptr(), 0, ta.EVAL_VALUES, st)
+scores = torch.empty((len(structs), 16), dtype=torch.float64, device=dev)
+batch.score_device(g.data_ptr(), scores.data_ptr(), st)
+table = gather_scores(scores, [len(structs)])           # device tensors through RCCL's all-gather
+assert table.is_cuda and torch.equal(table, scores)
+t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+best = best_candidate(table)[0]
+assert 0 <= best < len(structs)
+dist.destroy_process_group()
+print("RCCL_OK", best)
+'''
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_rccl_backend_single_rank(tmp_path):
+    """The collectives of towr_amd.dist and bench.py on DEVICE tensors through the RCCL backend (world size 1 -- the
+    pool's boxes have one GPU): a helper that hands RCCL a host tensor, or an init that the ROCm build rejects, fails
+    here instead of on the 8-GPU node."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, TWR_ROOT=ROOT, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
