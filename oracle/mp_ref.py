@@ -457,6 +457,7 @@ def cases():
         "anymal_walk_stairs": dict(robot="anymal", terrain="stairs", phases=_gait(4, 0, 2.4), seed=14),
         "hyq_gallop_slope": dict(robot="hyq", terrain="slope", phases=_gait(4, 4, 2.2), seed=15),
         "go1_pace_chimney": dict(robot="go1", terrain="chimney", phases=_gait(4, 2, 1.8), seed=16),
+        "hyq_bound_chimney_lr": dict(robot="hyq", terrain="chimney_lr", phases=_gait(4, 3, 2.0), seed=23),
         # towr's whole default constraint list (adds splineacc-base-* and swing-*)
         "full_biped_walk_block": dict(robot="biped", terrain="block", phases=_gait(2, 0, 2.0), seed=17, sets=TOWR_DEFAULT),
         "full_anymal_trot_gap": dict(robot="anymal", terrain="gap", phases=_gait(4, 1, 2.0), seed=18, sets=TOWR_DEFAULT),
