@@ -2618,7 +2618,9 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
   dim3 block(64);
   hipError_t st = hipSuccess;
   if (n_ee < 1 || n_ee > 4) return hipErrorInvalidValue;
-  static const int fused_max = env_int("TWR_FUSED_MAX_ROM", 4096);   // rom slices up to which the fused launch is used
+  // rom slices up to which the fused launch is used (round-3 re-tune on one box, ragged sweep, fused vs three launches:
+  // 320 / 400 / 512 candidates 75 / 98 / 126 vs 83 / 104 / 128 us per step, 768 / 1024: 187 / 250 vs 183 / 235)
+  static const int fused_max = env_int("TWR_FUSED_MAX_ROM", 8192);
   if (!ev && n_pdyn == 0 && n_prom == 0 && n_rom > 0 && n_dyn > 0 && n_rom <= fused_max) {
     const int cap = rom_bpc * n_cu;
     int g_rom = n_rom < cap ? n_rom : cap, g_dyn = (n_dyn + 1) / 2 < cap ? (n_dyn + 1) / 2 : cap;
@@ -2629,7 +2631,9 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
     // 31.6 us per step; from 200 candidates on the extra rounds cost more than the overlap gains).
     // TWR_FUSED_SPLIT = eighths of the residency given to rom (experiments; 8 = never split).
     static const int split_env = env_int("TWR_FUSED_SPLIT", 0);
-    const int split = split_env > 0 ? split_env : (n_rom <= 2560 ? 4 : 8);
+    // (round 3: five eighths for rom up to 3200 slices -- 128 / 160 / 200 candidates 27.5 / 33.5 / 40.5 us against 27.7 / 33.9 /
+    // 44.0 us with the round-2 rule "half each up to 2560"; from 256 candidates on unsplit is as good or better)
+    const int split = split_env > 0 ? split_env : (n_rom <= 3200 ? 5 : 8);
     if (split < 8 && g_rom + g_dyn > cap) {
       const int r = cap * split / 8, d = cap - r;
       if (g_rom > r) g_rom = r;
