@@ -21,6 +21,8 @@ pmc sq1 "" SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY S
 pmc sq2 "" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM || exit 1
 pmc tcc1 "" FETCH_SIZE || exit 1
 pmc tcc2 "" WRITE_SIZE || exit 1
+pmc sq1_t "--sets timings --batch 2048" SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS || exit 1
+pmc sq2_t "--sets timings --batch 2048" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM || exit 1
 pmc tcc1_t "--sets timings --batch 2048" FETCH_SIZE || exit 1
 pmc tcc2_t "--sets timings --batch 2048" WRITE_SIZE || exit 1
 pmc tcc1_s "--workload sweep --batch 1024" FETCH_SIZE || exit 1

@@ -60,7 +60,7 @@ for d in ("sq1", "sq2", "tcc1", "tcc2"):
         lines.append("%-22s %-26s %.6g" % (k[0], k[1], v))
 lines.append("# --sets timings --batch 2048")
 tim = {}
-for d in ("tcc1_t", "tcc2_t"):
+for d in ("sq1_t", "sq2_t", "tcc1_t", "tcc2_t"):
     c = counters(d)
     tim.update(c)
     for k, v in sorted(c.items()):
@@ -72,10 +72,9 @@ for d in ("tcc1_s", "tcc2_s"):
     swp.update(c)
     for k, v in sorted(c.items()):
         lines.append("%-22s %-26s %.6g" % (k[0], k[1], v))
-kern = sorted({k[0] for k in allc})
 lines.append("# derived")
-for k in kern:
-    g = lambda n: allc.get((k, n))
+for k, src in [(k_, allc) for k_ in sorted({k[0] for k in allc})] + [(k_, tim) for k_ in sorted({k[0] for k in tim})]:
+    g = lambda n: src.get((k, n))
     if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"):
         lines.append("%-22s LDS bank conflict / idx active = %.3f" % (k, g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")))
     if g("SQ_ACTIVE_INST_VALU") is not None and g("SQ_WAVE_CYCLES"):
