@@ -84,8 +84,7 @@ struct twr_batch {
   twr::NodeWork* d_node = nullptr;
   // optimised-timings problems have their own work lists
   twr::PDynWork* d_pdyn = nullptr;
-  int pdyn_img_cap = 0, prom_img_cap = 0;    // ... and of the rom_phase_kernel's (largest pass of the batch)
-  int pdyn_img_cap_unused_ = 0;                      // doubles of the dyn_phase_kernel's LDS image (largest group of the batch)
+  int pdyn_img_cap = 0, prom_img_cap = 0;    // doubles of the LDS images of dyn_phase_kernel / rom_phase_kernel (largest pass of the batch)
   twr::LocWork* d_ploc = nullptr;
   twr::RomPhaseWork* d_prom = nullptr;
   int64_t *d_goff = nullptr, *d_joff = nullptr;  // device copies of g_off / j_off (TWR_EVAL_CHECK)
@@ -434,7 +433,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     for (int i = 0; i < n_structs; ++i) {
       const twr::Structure& S = structs[i]->s;
       // families that are switched off (twr_params.constraint_sets) simply have no work items
-      if (S.timings) continue;  // optimised timings: PhaseWork items below
+      if (S.timings) continue;  // optimised timings: PDynWork / LocWork / RomPhaseWork items below
       for (int e = 0; e < S.n_ee; ++e)
         if (const twr::SetInfo* rs = S.FindSet("rangeofmotion-" + std::to_string(e)))
           runs_rom[i].push_back(chunk(S.row_ptr, rs->offset, 3, (int)S.grid_rom.size(), twr::rom_stage_capacity(), rom_nodes));

@@ -315,7 +315,7 @@ struct PDynWork {         // optimised timings: one pass = cnt <= 4 time nodes o
 };
 static_assert(sizeof(PDynWork) == 128, "PDynWork layout");
 
-// Optimised timings, rangeofmotion-<ee>: a light pre-pass (rom_locate_kernel) turns the x-dependent segment
+// Optimised timings, rangeofmotion-<ee>: the pre-pass (phase_locate_kernel) turns the x-dependent segment
 // lookup into RomRec records in a scratch buffer, so that the persistent kernel sees the same two-step
 // record -> x dependency as the fixed-timing kernel.  The records carry the phase data in RomRec::pad:
 //   pad[0] = base_all | current phase << 16 | in_last_phase << 24,  pad[1] = n_in_phase | poly_in_phase << 8
@@ -328,7 +328,7 @@ struct LocWork {          // one (problem, ee)
   int64_t pad2;
 };
 static_assert(sizeof(LocWork) == 48, "LocWork layout");
-struct RomPhaseWork {     // cnt <= 32 time nodes of one (problem, ee)
+struct RomPhaseWork {     // one pass: cnt <= 16 time nodes of one (problem, ee), four lanes each
   uint64_t recs;          // RomRec[k0..] written by the pre-pass
   int64_t x_off, g_off, j_off;  // problem's x; first constraint value / first Jacobian value of the run
   int32_t off_lin, off_ang;

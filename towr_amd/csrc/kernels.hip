@@ -1,12 +1,13 @@
 // HIP kernels (gfx950 / CDNA4) for towr's NLP constraint + Jacobian callback.
 //
-// Three launches per callback batch (dynamic, range of motion, node-based sets), one stream.
+// Three launches per callback batch (dynamic, range of motion, node-based sets), one stream; batches of up to 8192
+// rom slices run the same three bodies as block roles of ONE launch (eval_fused_kernel).
 // A dyn/rom workgroup is one wavefront (64 lanes); it walks a strided list of work items, each one a
 // *contiguous* slice of one problem's CSR value array:
-//   dyn_kernel   dynamic           : 16 consecutive time nodes k, FOUR lanes per node (6 rows each)
+//   dyn_kernel   dynamic           : <= 16 consecutive time nodes k, FOUR lanes per node (6 rows each)
 //   rom_kernel   rangeofmotion-ee  : lanes = consecutive time nodes k               (3 rows each)
 //   node_kernel  terrain-* / force-* / splineacc-base-* / swing-* (+ totalduration-*) of one problem:
-//                four waves, one per family, lanes = spline nodes / rows
+//                four waves, one per family, lanes = spline nodes / rows (node_kernel2: the first two families only)
 //   phase_locate_kernel + dyn_phase_kernel / rom_phase_kernel: the same math for problems with optimised phase
 //                durations (x-dependent active polynomials, rows that hold all variables of every ee set): 16 resp. 4
 //                lanes per time node, expanded rows assembled in LDS
