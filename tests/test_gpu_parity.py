@@ -947,3 +947,36 @@ def test_eval_is_graph_capturable_and_stream_ordered():
         batch2.eval_device(x.data_ptr(), g2.data_ptr(), j2.data_ptr(), ta.EVAL_BOTH, s2.cuda_stream)
     torch.cuda.synchronize()
     assert torch.equal(g, g2) and torch.equal(jac, j2)
+
+
+def test_bench_prints_one_contract_line():
+    """`python bench.py` as the driver runs it (N = 1; fewer steps): exactly one JSON line on stdout with the contract's keys,
+    the `roofline` and `cpu_baseline` objects and the extra legs of the default run."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1"], capture_output=True,
+                       text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "callbacks/s" and d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["problems_per_gpu"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.2 < rf["frac"] < 1.0
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9) <= 1e-6 * rf["achieved"]
+    assert rf["traffic"] is None or 0.9 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.2
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 1.0 and cb["unit"] == "callbacks/s" and cb["sample"]
+    for leg in ("timings_c3", "all_sets_c3", "scale_c5"):
+        assert d[leg]["value"] > 0 and d[leg]["unit"] == "callbacks/s", leg
+    assert d["scale_c5"]["candidates"] == 1024 and d["scale_c5"]["world_size"] == 1
