@@ -285,7 +285,13 @@ int twr_structure_create_many_with_grid(const twr_model* model, const twr_schedu
     }
   };
   std::vector<std::thread> pool;
-  for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker, t);
+  for (int t = 1; t < n_threads; ++t) {
+    try {
+      pool.emplace_back(worker, t);
+    } catch (const std::exception&) {   // no more threads to be had: the ones that run share the work
+      break;
+    }
+  }
   worker(0);
   for (auto& t : pool) t.join();
   for (const std::string& e : errs)
