@@ -10,6 +10,9 @@
  *   - all functions return TWR_OK (0) or a negative error code; twr_last_error() gives
  *     the message of the last failure on the calling thread.  No exceptions cross the ABI.
  *   - handles are thread-compatible: distinct handles may be used from distinct threads.
+ *   - devices: a batch (and a twr_planes handle) lives on the device it was created for.  Every entry point makes
+ *     that device current for its own HIP calls and restores the calling thread's current device before it
+ *     returns; none reads or clears the thread's sticky HIP error.
  *   - "x" is the stacked ifopt variable vector in the reference order
  *        base-lin | base-ang | ee-motion_0.. | ee-force_0.. [| ee-schedule0..]   (nlp_formulation.cc:63-93)
  *     "g" are the stacked constraint values and "jac" the Jacobian non-zeros in the CSR

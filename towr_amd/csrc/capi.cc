@@ -42,6 +42,26 @@ struct twr_terrain_grid {
   std::shared_ptr<twr::TerrainGrid> g;
 };
 
+// Makes `device` current for a scope and restores the calling thread's device afterwards: no entry point of the library
+// leaves its caller on another device (one process may drive several GPUs).  The caller's error state is not touched.
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  hipError_t status = hipSuccess;
+  explicit DeviceScope(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) {
+      status = hipSetDevice(device);
+      switched = status == hipSuccess;
+    }
+  }
+  ~DeviceScope() {
+    if (switched && prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 struct twr_planes {
   int device = 0;
   std::vector<int32_t> start;      // polygon r = points [start[r], start[r+1])
@@ -50,12 +70,9 @@ struct twr_planes {
   int32_t* d_start = nullptr;
   ~twr_planes() {                  // (also runs on the error paths of twr_planes_create)
     if (!d_xy && !d_start) return;
-    int cur = -1;
-    (void)hipGetDevice(&cur);
-    if (cur != device) (void)hipSetDevice(device);
+    DeviceScope on(device);
     if (d_xy) (void)hipFree(d_xy);
     if (d_start) (void)hipFree(d_start);
-    if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
   }
 };
 
@@ -387,7 +404,8 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
       return fail(TWR_ERR_NO_DEVICE, "no HIP device visible: towr_amd has no CPU fallback");
     if (device < 0 || device >= n_dev) return fail(TWR_ERR_INVALID, "device ordinal out of range");
-    TWR_HIP(hipSetDevice(device));
+    DeviceScope on(device);
+    TWR_HIP(on.status);
     b->device = device;
     b->n_problems = n_problems;
     b->n_ee = structs[0]->s.n_ee;
@@ -667,7 +685,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
 
 void twr_batch_destroy(twr_batch* b) {
   if (!b) return;
-  (void)hipSetDevice(b->device);
+  DeviceScope on(b->device);
   for (void* d : b->blobs) (void)hipFree(d);
   for (void* d : b->grids) (void)hipFree(d);
   if (b->d_dyn) (void)hipFree(b->d_dyn);
@@ -711,15 +729,8 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
     return fail(TWR_ERR_INVALID, "missing output buffer");
   // One process may drive several devices: the launch needs the batch's device current.  The calling thread's current
   // device is restored afterwards and its error state is left alone (the launch's own status is what is returned).
-  int cur_dev = -1;
-  if (hipGetDevice(&cur_dev) != hipSuccess) cur_dev = -1;
-  const bool switch_dev = cur_dev != b->device;
-  if (switch_dev && hipSetDevice(b->device) != hipSuccess) return fail(TWR_ERR_HIP, "hipSetDevice failed");
-  struct Restore {
-    int dev;
-    bool on;
-    ~Restore() { if (on && dev >= 0) (void)hipSetDevice(dev); }
-  } restore{cur_dev, switch_dev};
+  DeviceScope on(b->device);
+  if (on.status != hipSuccess) return fail(TWR_ERR_HIP, "hipSetDevice failed");
   hipEvent_t* ev = nullptr;
   if (b->prof_count < b->prof_capacity) ev = b->prof_events.data() + 4 * b->prof_count++;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
@@ -737,7 +748,8 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
 int twr_batch_status(twr_batch* b, int32_t* h_status, void* hip_stream) {
   if (!b || !h_status) return fail(TWR_ERR_INVALID, "null argument");
   try {
-    TWR_HIP(hipSetDevice(b->device));
+    DeviceScope on(b->device);
+    TWR_HIP(on.status);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     TWR_HIP(hipMemcpyAsync(h_status, b->d_status, sizeof(int32_t) * (size_t)b->n_problems, hipMemcpyDeviceToHost, stream));
     TWR_HIP(hipStreamSynchronize(stream));
@@ -750,7 +762,8 @@ int twr_batch_status(twr_batch* b, int32_t* h_status, void* hip_stream) {
 int twr_batch_profile_begin(twr_batch* b, int max_evals) {
   if (!b || max_evals < 1) return fail(TWR_ERR_INVALID, "bad arguments");
   try {
-    TWR_HIP(hipSetDevice(b->device));
+    DeviceScope on(b->device);
+    TWR_HIP(on.status);
     for (hipEvent_t e : b->prof_events) (void)hipEventDestroy(e);
     b->prof_events.assign(4 * (size_t)max_evals, nullptr);
     for (auto& e : b->prof_events) TWR_HIP(hipEventCreate(&e));
@@ -788,7 +801,8 @@ int twr_batch_profile_end(twr_batch* b, double avg_ms[3], int* n_evals) {
 int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_jac, int flags) {
   if (!b || !h_x) return fail(TWR_ERR_INVALID, "null argument");
   try {
-    TWR_HIP(hipSetDevice(b->device));
+    DeviceScope on(b->device);
+    TWR_HIP(on.status);
     const size_t nx = b->x_off.back(), ng = b->g_off.back(), nj = b->j_off.back();
     if (!b->d_x) {
       TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_x), nx * sizeof(double)));
@@ -843,7 +857,8 @@ int twr_structure_sample_count(const twr_structure* s, double dt, int32_t* n_sam
 int twr_batch_sample(twr_batch* b, const double* d_x, double dt, double* d_out, int64_t problem_stride, void* hip_stream) {
   if (!b || !d_x || !d_out) return fail(TWR_ERR_INVALID, "null argument");
   try {
-    TWR_HIP(hipSetDevice(b->device));
+    DeviceScope on(b->device);
+    TWR_HIP(on.status);
     if (!b->d_swork || b->swork_dt != dt || b->swork_stride != problem_stride) {  // (re)build the work list
       std::vector<twr::SampleWork> work;
       for (int p = 0; p < b->n_problems; ++p) {
@@ -884,7 +899,8 @@ int twr_batch_initial_guess(twr_batch* b, const double* d_x, const double* d_tim
   if (!b || !d_x || !d_times || !d_out || n_times < 1) return fail(TWR_ERR_INVALID, "bad arguments");
   if ((int64_t)n_times * 49 > problem_stride) return fail(TWR_ERR_INVALID, "problem_stride too small for the records");
   try {
-    TWR_HIP(hipSetDevice(b->device));
+    DeviceScope on(b->device);
+    TWR_HIP(on.status);
     if (!b->d_gwork || b->gwork_times != n_times || b->gwork_stride != problem_stride) {
       std::vector<twr::SampleWork> work;
       for (int p = 0; p < b->n_problems; ++p) {
@@ -952,15 +968,13 @@ int twr_planes_create(const double* regions, const double* boundary_xy, const in
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) return fail(TWR_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= n_dev) return fail(TWR_ERR_INVALID, "device ordinal out of range");
-    int cur = -1;
-    (void)hipGetDevice(&cur);
-    TWR_HIP(hipSetDevice(device));
+    DeviceScope on(device);
+    TWR_HIP(on.status);
     const int n_pts = pl->start.back();
     TWR_HIP(hipMalloc(reinterpret_cast<void**>(&pl->d_xy), std::max<size_t>(16, pl->world_xy.size() * sizeof(double))));
     TWR_HIP(hipMalloc(reinterpret_cast<void**>(&pl->d_start), pl->start.size() * sizeof(int32_t)));
     if (n_pts > 0) TWR_HIP(hipMemcpy(pl->d_xy, pl->world_xy.data(), pl->world_xy.size() * sizeof(double), hipMemcpyHostToDevice));
     TWR_HIP(hipMemcpy(pl->d_start, pl->start.data(), pl->start.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
     *out = pl.release();
     return TWR_OK;
   } catch (const std::exception& e) {
@@ -980,7 +994,8 @@ int twr_batch_contact_planes(twr_batch* b, const twr_planes* planes, const doubl
                              int32_t max_steps, int32_t* d_plane_index, void* hip_stream) {
   if (!b || !planes || !d_plan || !d_counts || !d_plane_index || max_steps < 1) return fail(TWR_ERR_INVALID, "bad arguments");
   if (planes->device != b->device) return fail(TWR_ERR_INVALID, "planes and batch live on different devices");
-  if (hipSetDevice(b->device) != hipSuccess) return fail(TWR_ERR_HIP, "hipSetDevice failed");
+  DeviceScope on(b->device);
+  if (on.status != hipSuccess) return fail(TWR_ERR_HIP, "hipSetDevice failed");
   hipError_t e = twr::launch_planes(d_plan, d_counts, planes->d_xy, planes->d_start, (int)planes->start.size() - 1, b->n_problems,
                                     max_steps, b->n_ee, d_plane_index, static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -989,7 +1004,8 @@ int twr_batch_contact_planes(twr_batch* b, const twr_planes* planes, const doubl
 
 int twr_batch_score(twr_batch* b, const double* d_g, double* d_scores, void* hip_stream) {
   if (!b || !d_g || !d_scores) return fail(TWR_ERR_INVALID, "null argument");
-  if (hipSetDevice(b->device) != hipSuccess) return fail(TWR_ERR_HIP, "hipSetDevice failed");
+  DeviceScope on(b->device);
+  if (on.status != hipSuccess) return fail(TWR_ERR_HIP, "hipSetDevice failed");
   hipError_t e = twr::launch_score(b->d_node, b->n_problems, d_g, d_scores, static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   return TWR_OK;
@@ -1007,7 +1023,8 @@ int twr_batch_contact_plan(twr_batch* b, const double* d_x, double dt, double ti
                            int32_t* d_counts, void* hip_stream) {
   if (!b || !d_x || !d_out || !d_counts || max_steps < 1 || !(dt > 0)) return fail(TWR_ERR_INVALID, "bad arguments");
   try {
-    TWR_HIP(hipSetDevice(b->device));
+    DeviceScope on(b->device);
+    TWR_HIP(on.status);
     int n_max = 0;
     for (int p = 0; p < b->n_problems; ++p) {
       if (!b->sample_ok[p]) throw std::runtime_error("too many polynomials per spline for trajectory sampling");
@@ -1028,7 +1045,8 @@ int twr_batch_contact_plan(twr_batch* b, const double* d_x, double dt, double ti
 int twr_batch_host_buffers(twr_batch* b, double** h_x, double** h_g, double** h_jac) {
   if (!b) return fail(TWR_ERR_INVALID, "null batch");
   try {
-    TWR_HIP(hipSetDevice(b->device));
+    DeviceScope on(b->device);
+    TWR_HIP(on.status);
     if (!b->p_x) {
       TWR_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->p_x), b->x_off.back() * sizeof(double), hipHostMallocDefault));
       TWR_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->p_g), b->g_off.back() * sizeof(double), hipHostMallocDefault));
