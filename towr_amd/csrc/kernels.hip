@@ -837,21 +837,23 @@ TWR_DEV void dyn2_back(const DynWork& w, const DynNode& nd, const DynPut& pu, co
       go[4] = m * cdd[1] - F[1];
       go[5] = m * cdd[2] - F[2] + m * H->gravity;
     }
-    if (want_j) {  // base-lin block: ang rows -sum_i [f_i]x J_pos, lin rows m J_acc (:103-121)
-      char* lin[3] = {nb + nd.rl[0], nb + nd.rl[1], nb + nd.rl[2]};
+  }
+  if (want_j) {  // base-lin block: ang rows -sum_i [f_i]x J_pos, lin rows m J_acc (:103-121).  Every lane of the quad stores
+                 // the nine values of ONE node value j = role (all four roles busy instead of role 3 storing all 36)
+    const double wPj = role == 0 ? wP[0] : (role == 1 ? wP[1] : (role == 2 ? wP[2] : wP[3]));
+    const double wAj = role == 0 ? wA[0] : (role == 1 ? wA[1] : (role == 2 ? wA[2] : wA[3]));
+    const uint32_t o2 = 16u * (uint32_t)role, o1 = 8u * (uint32_t)role;
+    lds_put(row[0], o2, -crs<0, 1>(F) * wPj);
+    lds_put(row[0], o2 + 8, -crs<0, 2>(F) * wPj);
+    lds_put(row[1], o2, -crs<1, 0>(F) * wPj);
+    lds_put(row[1], o2 + 8, -crs<1, 2>(F) * wPj);
+    lds_put(row[2], o2, -crs<2, 0>(F) * wPj);
+    lds_put(row[2], o2 + 8, -crs<2, 1>(F) * wPj);
+    const double ma = m * wAj;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        lds_put(row[0], 8 * (2 * j + 0), -crs<0, 1>(F) * wP[j]);
-        lds_put(row[0], 8 * (2 * j + 1), -crs<0, 2>(F) * wP[j]);
-        lds_put(row[1], 8 * (2 * j + 0), -crs<1, 0>(F) * wP[j]);
-        lds_put(row[1], 8 * (2 * j + 1), -crs<1, 2>(F) * wP[j]);
-        lds_put(row[2], 8 * (2 * j + 0), -crs<2, 0>(F) * wP[j]);
-        lds_put(row[2], 8 * (2 * j + 1), -crs<2, 1>(F) * wP[j]);
-#pragma unroll
-        for (int d = 0; d < 3; ++d) lds_put(lin[d], 8 * j, m * wA[j]);
-      }
-    }
-  } else if (want_j) {
+    for (int d = 0; d < 3; ++d) lds_put(nb + nd.rl[d], o1, ma);
+  }
+  if (role != 3 && want_j) {
     // --- base-ang block (:123-165), Euler dimension d = role, factored (derivation: see pdyn_math)
     const double dMx_dy[3] = {-sy * cz, -sy * sz, -cy};
     const double dMx_dz[3] = {-cy * sz, cy * cz, 0.0};
