@@ -104,6 +104,17 @@ def host_cores():
     return max(1, n), source
 
 
+def ranks_on_node():
+    """Ranks that share this node's host cores (torch.distributed.run exports LOCAL_WORLD_SIZE)."""
+    return max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+
+
+def build_threads():
+    """Host threads ONE rank may use for structure builds: this process's share of the node -- the cores it may run on,
+    divided by the ranks of the node, at most 64 (eight ranks on a 256-thread node get 32 each, not 64 each)."""
+    return max(1, min(64, host_cores()[0] // ranks_on_node()))
+
+
 def cpu_baseline(sched, params, x, terrain, budget_s=3.0):
     """The oracle ("port" of the reference's Eigen CPU path, reference-shaped: per time node and per variable
     set) timed on this box's host cores, SURVEY 8d / BASELINE.md section 3: built -O3 -march=native ON THIS BOX
@@ -213,10 +224,13 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
     m5 = ta.Model.from_buffer_copy(bytes(model))
     m5.terrain_id = ta.TERRAINS["stairs"]
     cands = sweep.enumerate_candidates(n_total)
-    bounds = sweep.shard_bounds([sweep.candidate_weight(c) for c in cands], world)
-    lo, hi = bounds[rank], bounds[rank + 1]
-    threads = min(host_cores()[0], 64)   # per rank
+    threads = build_threads()   # per rank: the node's cores are shared by LOCAL_WORLD_SIZE ranks
     t0 = time.perf_counter()
+    # shards by BYTES per callback, exact: every rank computes the same list (pattern only, no device tables)
+    weights = sweep.candidate_bytes(m5, cands, threads=threads) if world > 1 else [1.0] * n_total
+    bounds = sweep.shard_bounds(weights, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    t_w = time.perf_counter() - t0
     mine = sweep.candidate_structures(m5, cands[lo:hi], threads=threads)
     t1 = time.perf_counter()
     batch = ta.Batch(mine, list(range(len(mine))), device=dev_index)
@@ -291,7 +305,8 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
             "value": n_total * steps / elapsed, "unit": "callbacks/s", "ms_per_step": elapsed / steps * 1e3,
             "path_GBps": bytes_total * steps / elapsed / 1e9,
             "shards": [bounds[r + 1] - bounds[r] for r in range(world)],
-            "setup_s": setup_max, "structure_build_s": build_max, "build_threads_per_rank": threads,
+            "setup_s": setup_max, "structure_build_s": build_max, "build_threads_per_rank": threads, "ranks_on_node": ranks_on_node(),
+            "shard_weights": "8 (n + m + nnz) per candidate (twr_candidate_bytes), %.3f s on this rank" % t_w if world > 1 else "one shard",
             "world_size": world, "backend": backend if dist_on(world) else "none (single process)",
             "rccl_ranks": world if (world > 1 and backend == "nccl") else (1 if world == 1 else 0),
             "device_count": torch.cuda.device_count(),
@@ -442,9 +457,9 @@ def main():
 
         n_all = (args.batch or 128) * world
         cands = sweep.enumerate_candidates(n_all)
-        bounds = sweep.shard_bounds([sweep.candidate_weight(c) for c in cands], world)
         t_setup = time.perf_counter()
-        mine = sweep.candidate_structures(model, cands[bounds[rank]:bounds[rank + 1]])   # this rank's shard only
+        bounds = sweep.shard_bounds(sweep.candidate_bytes(model, cands, threads=build_threads()) if world > 1 else [1.0] * n_all, world)
+        mine = sweep.candidate_structures(model, cands[bounds[rank]:bounds[rank + 1]], threads=build_threads())   # this rank's shard only
         batch = ta.Batch(mine, list(range(len(mine))), device=dev_index)
         setup_s = time.perf_counter() - t_setup
         x_host = np.concatenate([perturbed_inputs(s_, model, 1, first_seed=bounds[rank] + i_)[0]

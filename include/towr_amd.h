@@ -183,6 +183,17 @@ int twr_structure_create_many(const twr_model* model, const twr_schedule* schedu
  * fpowr (footstep_plan_server.cc:155) uses; grid == NULL is twr_structure_create_many. */
 int twr_structure_create_many_with_grid(const twr_model* model, const twr_schedule* schedules, const twr_params* params, int n,
                                         int n_threads, const twr_terrain_grid* grid, twr_structure** out);
+/* Sharding a sweep over ranks / devices (contiguous shards balanced by BYTES, not counts -- candidates are
+ * ragged).  twr_candidate_bytes: bytes[i] = 8 (n + m + nnz) of candidate i, the bytes one callback of it moves; builds
+ * only the variable layout, the time tables and the CSR pattern (no device tables), on n_threads host threads (<= 0:
+ * all).  Every rank computes the same numbers from the same candidate list, so no exchange is needed.
+ * twr_shard_bounds: bounds[0..world], rank r owns candidates [bounds[r], bounds[r+1]); the boundary of rank r is the
+ * prefix whose weight sum is closest to r / world of the total; never an empty shard; TWR_ERR_INVALID when n < world
+ * (on every rank alike).  The reference has no counterpart: fpowr solves one gait per goal
+ * (fpowr/src/footstep_plan_server.cc:191-200). */
+int twr_candidate_bytes(const twr_model* model, const twr_schedule* schedules, const twr_params* params, int n, int n_threads,
+                        int64_t* bytes /* n */);
+int twr_shard_bounds(const double* weights /* n */, int n, int world, int32_t* bounds /* world + 1 */);
 /* What a rank needs to rebuild a grid handle it received over the wire (towr_amd/dist.py broadcast_grid): kind (0: CSV
  * heights, double [rows][cols]; 1: grid_map elevation layer, float, column-major [size_x][size_y]), the two sizes,
  * resolution and map position (grid_map only), and the cell data (`data` points into the handle; valid until destroy). */
@@ -306,7 +317,11 @@ int twr_planes_world_xy(const twr_planes* planes, double* world_xy);
 int twr_batch_contact_planes(twr_batch* b, const twr_planes* planes, const double* d_plan, const int32_t* d_counts,
                              int32_t max_steps, int32_t* d_plane_index, void* hip_stream);
 
-/* Convenience for single-problem / adapter use: host buffers, synchronous (H2D, eval, D2H). */
+/* Convenience for single-problem / adapter use: host buffers, synchronous (H2D, eval, D2H).  Runs on a NON-BLOCKING
+ * stream the batch owns (created on first use), not on the NULL stream: it neither waits for nor holds up work the host
+ * application has in flight on the NULL stream or on its own blocking streams; the call returns when its own chain is
+ * done.  flags select what is evaluated and copied back (TWR_EVAL_VALUES alone moves no Jacobian over PCIe: the ifopt
+ * adapter evaluates values for eval_g and adds the Jacobian only when eval_jac_g asks for it). */
 int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_jac, int flags);
 /* Page-locked host buffers owned by the batch (x, g, jac of the whole batch layout), allocated on first
  * use.  Passing exactly these pointers to twr_batch_eval_host makes the transfers DMA directly from / into

@@ -8,7 +8,9 @@ analytic derivative at all, so a wrong closed form in the oracle (or in the
 reference restatement) cannot hide.
 
 Run as a script to (re)generate tests/golden/mp_*.npz:
-    python -m oracle.mp_ref            # all cases, ~10 min on 8 cores
+    python -m oracle.mp_ref            # all cases, ~25 min on 8 cores (MP_REF_PROCS sets the worker count)
+    python -m oracle.mp_ref c2_biped_walk_flat_k100 c3_anymal_trot_flat_k200 c5_anymal_walk_stairs_k200
+                                       # the BASELINE-size cases only (round 4), ~12 min on 5 cores
 
 Double-precision inputs that the reference computes in double (time grids,
 polynomial durations, active segment, local time) are computed here in Python
@@ -448,6 +450,16 @@ def _gait(n_ee, combo, T):
     return [list(map(float, p)) for p in pd], con
 
 
+def _sweep_candidate(index):
+    # input construction only: candidate `index` of the C5 enumeration through the product's host-side gait
+    # tables (towr_amd.sweep; no device involved).  The fixture stores the resulting phase durations explicitly.
+    import towr_amd as ta
+    from towr_amd import sweep
+    combo, T, scale = sweep.enumerate_candidates(index + 1)[index]
+    sched = ta.gait_combo(4, combo, T, scale)
+    return [list(map(float, p)) for p in sched.durations()], [int(c) for c in sched.contact()]
+
+
 def cases():
     hop = ([[0.4, 0.2, 0.4, 0.2, 0.4, 0.2, 0.2]], [1])
     return {
@@ -467,6 +479,13 @@ def cases():
         "timings_anymal_trot_gap": dict(robot="anymal", terrain="gap", phases=_gait(4, 1, 2.0), seed=21, sets=TOWR_DEFAULT | 64),
         # every Parameters::ConstraintName at once (adds baseMotion)
         "every_biped_run_slope": dict(robot="biped", terrain="slope", phases=_gait(2, 1, 1.6), seed=22, sets=255),
+        # BASELINE sizes (dt = T / (K - 1.5), so that floor(T/dt) + 2 = K time nodes; time_discretization_constraint.cc:41-49):
+        # C2 biped K = 100, C3 ANYmal trot K = 200, and candidate 30 of the C5 enumeration (walk, T = 1.4, swing scale
+        # 0.864) on Stairs at K = 200.  These stress the accumulated-time / eps junction rule (spline.cc:51-60) at
+        # dt = T / 198.5, where the default-discretisation fixtures above cannot.
+        "c2_biped_walk_flat_k100": dict(robot="biped", terrain="flat", phases=_gait(2, 0, 2.0), seed=24, k_nodes=100),
+        "c3_anymal_trot_flat_k200": dict(robot="anymal", terrain="flat", phases=_gait(4, 1, 2.0), seed=25, k_nodes=200),
+        "c5_anymal_walk_stairs_k200": dict(robot="anymal", terrain="stairs", phases=_sweep_candidate(30), seed=26, k_nodes=200),
     }
 
 
@@ -509,7 +528,15 @@ def _col(j):
 
 def generate(name, spec, outdir, procs=8):
     pd, con = spec["phases"]
-    L = Layout(spec["robot"], pd, con, optimize_timings=bool(spec.get("sets", HOT_PATH) & 64))
+    dts = {}
+    if "k_nodes" in spec:
+        T = 0.0
+        for d in pd[0]:
+            T += d
+        dts = dict(dt_dyn=T / (spec["k_nodes"] - 1.5), dt_rom=T / (spec["k_nodes"] - 1.5))
+    L = Layout(spec["robot"], pd, con, optimize_timings=bool(spec.get("sets", HOT_PATH) & 64), **dts)
+    if "k_nodes" in spec:
+        assert len(L.grid_dyn) == spec["k_nodes"] and len(L.grid_rom) == spec["k_nodes"]
     x64 = make_x(L, spec["seed"])
     x = [mpf(float(v)) for v in x64]
     sets = spec.get("sets", HOT_PATH)
@@ -527,7 +554,8 @@ def generate(name, spec, outdir, procs=8):
         os.path.join(outdir, "mp_%s.npz" % name), robot=spec["robot"], terrain=spec["terrain"],
         n_phases=np.array([len(p) for p in pd]), phase_durations=np.concatenate([np.array(p) for p in pd]),
         contact_at_start=np.array(con), constraint_sets=np.int32(sets), x=x64, g=np.array([float(v) for v in g]),
-        jac_row=np.array(rows, dtype=np.int32), jac_col=np.array(cidx, dtype=np.int32), jac_val=np.array(vals))
+        jac_row=np.array(rows, dtype=np.int32), jac_col=np.array(cidx, dtype=np.int32), jac_val=np.array(vals),
+        dt_dynamic=np.float64(dts.get("dt_dyn", 0.1)), dt_rom=np.float64(dts.get("dt_rom", 0.08)))
     print(name, "n", L.n, "m", len(g), "nnz(true)", len(vals), flush=True)
 
 
@@ -538,4 +566,4 @@ if __name__ == "__main__":
     for name, spec in cases().items():
         if only and name not in only:
             continue
-        generate(name, spec, out)
+        generate(name, spec, out, procs=int(os.environ.get("MP_REF_PROCS", "8")))

@@ -8,6 +8,6 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_extra
 mkdir -p $OUT
-rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_WAVE_CYCLES SQ_WAIT_INST_ANY \
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_WAVE_CYCLES SQ_WAIT_INST_ANY \
   --output-format csv -d $OUT/a -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scale-c5 --no-timings-c3 > $OUT/a.log 2>&1 || exit 1
 echo done

@@ -8,13 +8,13 @@ TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 B="--steps 20 --warmup 3 --no-cpu-baseline --no-scale-c5 --no-timings-c3"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -- python3 bench.py $B > $OUT/bench_under_rocprof.json 2> $OUT/ktrace.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -- python3 bench.py $B > $OUT/bench_under_rocprof.json 2> $OUT/ktrace.err || exit 1
 echo "ktrace done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace_t -- python3 bench.py $B --sets timings --batch 2048 > $OUT/bench_timings_under_rocprof.json 2> $OUT/ktrace_t.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace_t -- python3 bench.py $B --sets timings --batch 2048 > $OUT/bench_timings_under_rocprof.json 2> $OUT/ktrace_t.err || exit 1
 echo "ktrace timings done"
 pmc() { # name bench-args counters...
   name=$1; shift; extra=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scale-c5 --no-timings-c3 $extra > $OUT/$name.log 2>&1 || return 1
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scale-c5 --no-timings-c3 $extra > $OUT/$name.log 2>&1 || return 1
   echo "pmc $name done"
 }
 pmc sq1 "" SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS || exit 1

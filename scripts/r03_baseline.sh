@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/r03_base
 mkdir -p $OUT
-rocprofv3 -L > $OUT/rocprof_L.txt 2>&1
+timeout -k 10 120 rocprofv3 -L > $OUT/rocprof_L.txt 2>&1
 echo "listing done" 
 B="--steps 30 --warmup 5 --no-cpu-baseline --no-scale-c5 --no-timings-c3"
 python3 bench.py $B --workload sweep --batch 1024 > $OUT/sweep1024.json 2> $OUT/sweep1024.err || exit 1
@@ -12,7 +12,7 @@ python3 bench.py $B --batch 1024 > $OUT/c3_1024.json 2> $OUT/c3_1024.err || exit
 python3 bench.py $B --sets timings --batch 2048 > $OUT/timings2048.json 2> $OUT/timings2048.err || exit 1
 echo "bench done"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/sweep_$c -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scale-c5 --workload sweep --batch 1024 > $OUT/sweep_$c.log 2>&1 || exit 1
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/sweep_$c -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scale-c5 --workload sweep --batch 1024 > $OUT/sweep_$c.log 2>&1 || exit 1
   echo "pmc $c done"
 done
 python3 - <<'PY'

@@ -149,7 +149,68 @@ int main(int argc, char** argv) {
   for (int r = 0; bounds && r < sz.n_rows; ++r) bounds = b[r].lower_ == lo[r] && b[r].upper_ == up[r];
   expect(bounds, "GetBounds equals twr_structure_bounds");
 
-  // a variable set the structure does not know (a typo'd name) must throw instead of yielding a silent zero block
+  // evaluate what was asked (time_discretization_constraint.cc:65-96): Ipopt's eval_g, eval_g (line-search trial point),
+  // eval_jac_g on that point = two values-only evaluations and ONE Jacobian-only evaluation, nothing more
+  {
+    const auto* first = dynamic_cast<const towr_amd::DeviceConstraintSet*>(device_sets[0].get());
+    expect(first != nullptr, "device sets are DeviceConstraintSet objects");
+    const towr_amd::DeviceProblem& dp = first->problem();
+    const long v0 = dp.value_evaluations(), j0 = dp.jacobian_evaluations();
+    std::vector<double> xa = x, xb = x;
+    xa[5] += 2e-3;
+    xb[5] -= 1e-3;
+    (void)nlp.EvaluateConstraints(xa.data());                       // eval_g
+    ifopt::Problem::VectorXd gb = nlp.EvaluateConstraints(xb.data());   // eval_g at the accepted trial point
+    expect(dp.value_evaluations() == v0 + 2 && dp.jacobian_evaluations() == j0, "eval_g, eval_g: two values-only evaluations");
+    nlp.EvalNonzerosOfJacobian(xb.data(), vals.data());             // eval_jac_g on the same x
+    expect(dp.value_evaluations() == v0 + 2 && dp.jacobian_evaluations() == j0 + 1, "eval_jac_g on a known x: one Jacobian-only evaluation");
+    nlp.EvalNonzerosOfJacobian(xb.data(), vals.data());             // again: nothing to do
+    (void)nlp.EvaluateConstraints(xb.data());
+    expect(dp.value_evaluations() == v0 + 2 && dp.jacobian_evaluations() == j0 + 1, "same x again: no evaluation");
+    expect(twr_batch_eval_host(B, xb.data(), g_ref.data(), j_ref.data(), TWR_EVAL_BOTH) == TWR_OK, "twr_batch_eval_host");
+    double d2 = 0;
+    for (int i = 0; i < sz.n_rows; ++i) d2 = std::fmax(d2, std::fabs(gb[i] - g_ref[i]));
+    for (int k = 0; k < sz.nnz; ++k) d2 = std::fmax(d2, std::fabs(vals[k] - j_ref[k]));
+    expect(d2 == 0.0, "values-only + Jacobian-only evaluations equal one evaluation of both");
+  }
+
+  // a host NLP with a variable set of its own (ifopt convention: constraints leave the blocks of sets they do not depend on
+  // empty): the device sets read their x by name and return an empty block for the foreign set
+  {
+    const double slack[3] = {0.1, 0.2, 0.3};
+    ifopt::Problem host;
+    for (int i = 0; i < sz.n_var_sets; ++i) {
+      twr_set_info v;
+      twr_structure_var_set(S, i, &v);
+      if (i == 1) host.AddVariableSet(std::make_shared<PlainVariables>("slack-of-the-host", slack, 3));   // in the middle
+      host.AddVariableSet(std::make_shared<PlainVariables>(v.name, x.data() + v.offset, v.size));
+    }
+    bool ok = true;
+    try {
+      for (auto& c : towr_amd::MakeDeviceConstraints(model, sched, prm, 0, grid)) host.AddConstraintSet(c);
+      expect(twr_batch_eval_host(B, x.data(), g_ref.data(), j_ref.data(), TWR_EVAL_BOTH) == TWR_OK, "twr_batch_eval_host");
+      ifopt::Problem::Jacobian jh = host.GetJacobianOfConstraints();
+      jh.makeCompressed();
+      ok = jh.nonZeros() == sz.nnz;
+      twr_set_info v1;
+      twr_structure_var_set(S, 1, &v1);
+      for (int r = 0; ok && r < sz.n_rows; ++r) {
+        int k = rp[r];
+        for (const auto& kv : jh.row(r)) {
+          const int col = kv.first < v1.offset ? kv.first : kv.first - 3;   // the foreign set sits in front of variable set 1
+          ok = ok && !(kv.first >= v1.offset && kv.first < v1.offset + 3) && k < rp[r + 1] && ci[k] == col && kv.second == j_ref[k];
+          ++k;
+        }
+        ok = ok && k == rp[r + 1];
+      }
+    } catch (const std::exception& e) {
+      std::fprintf(stderr, "foreign variable set: %s\n", e.what());
+      ok = false;
+    }
+    expect(ok, "a foreign variable set gets an empty block and does not disturb the towr sets");
+  }
+
+  // a towr-style variable-set name the structure does not know (a typo) must throw instead of yielding a silent zero block
   {
     const double one[1] = {0.3};
     bool threw = false;
@@ -160,14 +221,13 @@ int main(int argc, char** argv) {
         twr_structure_var_set(S, i, &v);
         bad.AddVariableSet(std::make_shared<PlainVariables>(v.name, x.data() + v.offset, v.size));
       }
-      // (an empty set, so that the variable count still matches and the name check is what is reached)
-      bad.AddVariableSet(std::make_shared<PlainVariables>("ee-motoin_0", one, 0));
+      bad.AddVariableSet(std::make_shared<PlainVariables>("ee-motoin_0", one, 1));
       for (auto& c : towr_amd::MakeDeviceConstraints(model, sched, prm, 0, grid)) bad.AddConstraintSet(c);
       (void)bad.GetJacobianOfConstraints();
     } catch (const std::exception& e) {
       threw = std::strstr(e.what(), "unknown variable set") != nullptr;
     }
-    expect(threw, "FillJacobianBlock throws on an unknown variable set name");
+    expect(threw, "FillJacobianBlock throws on an unknown towr-style variable set name");
   }
 
   std::printf("hopper through ifopt%s: n=%d m=%d nnz=%d sets=%d  max|dg|=%g max|dJ|=%g  %s\n", gridmap ? " on a grid_map terrain" : "",

@@ -16,22 +16,88 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-def _build():
+def _build(name="sweep_example", extra=()):
     out = os.path.join(ROOT, "examples", "_build")
     os.makedirs(out, exist_ok=True)
-    exe = os.path.join(out, "sweep_example")
+    exe = os.path.join(out, name)
     cmd = [HIPCC, "-std=c++17", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "examples", "sweep_example.cc"), "-L", os.path.join(ROOT, "towr_amd"), "-ltowr_amd",
+           os.path.join(ROOT, "examples", name + ".cc"), "-L", os.path.join(ROOT, "towr_amd"), "-ltowr_amd", *extra,
            "-Wl,-rpath," + os.path.join(ROOT, "towr_amd"), "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     return exe
 
 
+def _build_multi():
+    """examples/sweep_multi_gpu.cc: the C++ caller's multi-GPU sweep, straight on librccl (no torch)."""
+    return _build("sweep_multi_gpu", ("-lrccl", "-pthread"))
+
+
 def test_cpp_example_compiles():
     """(CPU tier: hipcc compiles and links the example against the C ABI without a GPU)"""
     ta.lib()
     assert os.path.exists(_build())
+
+
+def test_cpp_multi_gpu_example_compiles_and_fails_loudly_without_a_gpu():
+    """(CPU tier) -Wall -Werror against include/towr_amd.h + <rccl/rccl.h>; without a device it must say so, not fall back."""
+    import torch
+
+    ta.lib()
+    exe = _build_multi()
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    r = subprocess.run([exe, "16"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "no HIP device" in r.stderr, r.stdout + r.stderr
+
+
+def _python_decision(n):
+    """The same sweep through the ctypes mirror: values -> twr_batch_score -> towr_amd.dist.best_candidate."""
+    import torch
+
+    from towr_amd.dist import best_candidate
+
+    model = ta.model_preset("anymal", "stairs")
+    structs = sweep.candidate_structures(model, sweep.enumerate_candidates(n))
+    batch = ta.Batch(structs, list(range(n)), device=0)
+    ee0 = [[0.34, 0.19, 0], [0.34, -0.19, 0], [-0.34, 0.19, 0], [-0.34, -0.19, 0]]
+    x = np.concatenate([s.initial_guess([0, 0, 0.5], [0, 0, 0], [2.0, 0, 0.5], [0, 0, 0], ee0) for s in structs])
+    xd = torch.from_numpy(x).cuda()
+    g = torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device="cuda")
+    sc = torch.empty((n, 16), dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    batch.eval_device(xd.data_ptr(), g.data_ptr(), 0, ta.EVAL_VALUES, st)
+    batch.score_device(g.data_ptr(), sc.data_ptr(), st)
+    torch.cuda.synchronize()
+    return best_candidate(sc)
+
+
+@pytest.mark.gpu
+def test_cpp_multi_gpu_example_picks_the_python_paths_candidate():
+    """One device: (a) RCCL world of one rank -- ncclCommInitAll, the model broadcast and the score all-gather really go
+    through librccl; (b) no collective, one rank; (c) no collective, THREE ranks (threads) sharing device 0 -- byte-weighted
+    shards, host-side gather; (d) one process per device, world 1 (ncclCommInitRank + id file).  All four pick the
+    candidate towr_amd.dist.best_candidate picks, with the same score."""
+    import tempfile
+
+    exe = _build_multi()
+    n = 96
+    best_py, score_py = _python_decision(n)
+    runs = [[exe, str(n)], [exe, str(n), "--no-collective"], [exe, str(n), "--no-collective", "--devices", "0,0,0", "--jacobian"]]
+    with tempfile.TemporaryDirectory() as tmp:
+        runs.append([exe, str(n), "--rank", "0", "--world", "1", "--id-file", os.path.join(tmp, "rccl_id")])
+        for cmd in runs:
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+            assert r.returncode == 0, " ".join(cmd) + "\n" + r.stdout + r.stderr
+            m = re.search(r"^best candidate (\d+) score ([0-9.eE+-]+)$", r.stdout, re.M)
+            assert m, r.stdout
+            assert int(m.group(1)) == best_py and abs(float(m.group(2)) - score_py) <= 1e-9 * max(1.0, abs(score_py)), \
+                (cmd, r.stdout, best_py, score_py)
+            if "0,0,0" in cmd:
+                shards = re.findall(r"rank (\d): shard \[(\d+), (\d+)\)", r.stdout)
+                lo, hi = [int(s[1]) for s in shards], [int(s[2]) for s in shards]
+                assert lo[0] == 0 and hi[-1] == n and lo[1:] == hi[:-1] and all(abs(b - a - 32) <= 1 for a, b in zip(lo, hi)), r.stdout
 
 
 @pytest.mark.gpu

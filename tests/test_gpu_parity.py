@@ -50,8 +50,9 @@ def test_gpu_matches_mpmath_golden(path):
     sets = int(d["constraint_sets"]) if "constraint_sets" in d.files else 27
     if sets & 64 and not getattr(ta, "SUPPORTS_OPTIMISED_TIMINGS", False):
         pytest.skip("optimised timings (SURVEY 8f #2): oracle and fixtures exist, the device path is next")
+    dts = dict(dt_dynamic=float(d["dt_dynamic"]), dt_rom=float(d["dt_rom"])) if "dt_dynamic" in d.files else {}
     case = Case(str(d["robot"]), str(d["terrain"]), ta.schedule(pd, list(d["contact_at_start"])), constraint_sets=sets,
-                base_z_init=0.6)
+                base_z_init=0.6, **dts)
     S = case.S
     batch, g, j = _eval_case(case, [d["x"]])
     assert np.abs(g - d["g"]).max() <= 1e-12 * np.abs(d["g"]).max()

@@ -24,8 +24,10 @@ def load_fixture(path):
         pd.append(d["phase_durations"][o:o + k])
         o += k
     sets = int(d["constraint_sets"]) if "constraint_sets" in d.files else ob.SETS_HOT_PATH
+    # (fixtures at BASELINE sizes carry their discretisation; the older ones use the reference defaults 0.1 / 0.08)
+    dts = dict(dt_dynamic=float(d["dt_dynamic"]), dt_rom=float(d["dt_rom"])) if "dt_dynamic" in d.files else {}
     P = ob.OracleProblem(str(d["robot"]), str(d["terrain"]), pd, list(d["contact_at_start"]), constraint_sets=sets,
-                         base_z_init=0.6)
+                         base_z_init=0.6, **dts)
     return d, P
 
 

@@ -248,6 +248,17 @@ def test_sweep_enumeration_and_sharding():
         sweep.shard_bounds([1, 1], 4)
     assert sweep.shard_bounds([9, 1, 1], 3) == [0, 1, 2, 3]   # never an empty shard
     assert sweep.shard_bounds([1, 1, 50], 3) == [0, 1, 2, 3]
+    # the weight is BYTES per callback.  twr_candidate_bytes gives 8 (n + m + nnz) exactly, without building
+    # the device tables; a sweep that mixes time-node counts is then balanced by bytes, not by candidate count
+    sub = c[:64:4]
+    assert sweep.candidate_bytes(m, sub, threads=2).tolist() == sizes
+    mixed_k = [200] * 8 + [100] * 8
+    wb = sweep.candidate_bytes(m, c[:16], k_nodes=mixed_k, threads=2)
+    assert wb[:8].min() > 1.9 * wb[8:].max()
+    b = sweep.shard_bounds(wb, 2)
+    assert b[1] in (5, 6)       # about two thirds of the bytes sit in the first eight candidates
+    with pytest.raises(ta.TowrError):
+        sweep.candidate_bytes(m, c[:2], constraint_sets=0)
 
 
 def test_create_many_equals_one_by_one():

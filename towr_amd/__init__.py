@@ -112,6 +112,9 @@ def lib():
                                                 C.POINTER(C.c_void_p)]
         L.twr_structure_create_many_with_grid.argtypes = [C.POINTER(Model), C.POINTER(Schedule), C.POINTER(Params), C.c_int,
                                                           C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.twr_candidate_bytes.argtypes = [C.POINTER(Model), C.POINTER(Schedule), C.POINTER(Params), C.c_int, C.c_int,
+                                          C.POINTER(C.c_int64)]
+        L.twr_shard_bounds.argtypes = [_dp, C.c_int, C.c_int, C.POINTER(C.c_int32)]
         L.twr_terrain_grid_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                             _dp, _dp, _dp, C.POINTER(C.c_void_p)]
         L.twr_structure_sizes.argtypes = [C.c_void_p, C.POINTER(Sizes)]

@@ -112,6 +112,9 @@ struct twr_batch {
   // lazily sized scratch for twr_batch_eval_host
   double *d_x = nullptr, *d_g = nullptr, *d_j = nullptr;
   double *p_x = nullptr, *p_g = nullptr, *p_j = nullptr;  // page-locked host buffers (twr_batch_host_buffers)
+  // twr_batch_eval_host runs on a stream of the batch's own (non-blocking: it neither waits for nor holds up work the host
+  // application has on the NULL stream or on other blocking streams); created on first use
+  hipStream_t host_stream = nullptr;
   // optional per-kernel timing (twr_batch_profile_begin/end): 4 events per recorded eval
   std::vector<hipEvent_t> prof_events;
   int prof_capacity = 0, prof_count = 0;
@@ -128,6 +131,15 @@ int fail(int code, const std::string& msg) {
     hipError_t e_ = (call);                                                                        \
     if (e_ != hipSuccess) throw std::runtime_error(std::string(#call) + ": " + hipGetErrorString(e_)); \
   } while (0)
+
+void check_params(const twr_params& p) {   // throws: what twr_structure_create rejects before it builds anything
+  if (p.polys_per_swing < 1 || p.polys_per_stance_force < 1) throw std::runtime_error("polynomials per phase must be >= 1");
+  if (p.constraint_sets <= 0 || (p.constraint_sets & ~TWR_SETS_EVERY))
+    throw std::runtime_error("constraint_sets must be a non-empty mask of TWR_SET_* bits");
+  if ((p.constraint_sets & TWR_SET_BASE_ROM) && !std::isfinite(p.base_z_init))
+    throw std::runtime_error("TWR_SET_BASE_ROM needs twr_params.base_z_init (the initial base height; "
+                             "base_motion_constraint.cc:51-55 reads it from the spline)");
+}
 
 void copy_set(const twr::SetInfo& s, twr_set_info* out) {
   std::memset(out, 0, sizeof(*out));
@@ -264,13 +276,7 @@ int twr_structure_create_with_grid(const twr_model* model, const twr_schedule* s
     h->s.model = *model;
     h->s.schedule = *schedule;
     h->s.params = *params;
-    if (params->polys_per_swing < 1 || params->polys_per_stance_force < 1)
-      throw std::runtime_error("polynomials per phase must be >= 1");
-    if (params->constraint_sets <= 0 || (params->constraint_sets & ~TWR_SETS_EVERY))
-      throw std::runtime_error("constraint_sets must be a non-empty mask of TWR_SET_* bits");
-    if ((params->constraint_sets & TWR_SET_BASE_ROM) && !std::isfinite(params->base_z_init))
-      throw std::runtime_error("TWR_SET_BASE_ROM needs twr_params.base_z_init (the initial base height; "
-                               "base_motion_constraint.cc:51-55 reads it from the spline)");
+    check_params(*params);
     h->s.Build();
     *out = h.release();
     return TWR_OK;
@@ -319,6 +325,70 @@ int twr_structure_create_many_with_grid(const twr_model* model, const twr_schedu
       }
       return fail(TWR_ERR_INVALID, e);
     }
+  return TWR_OK;
+}
+
+// Bytes one callback of every candidate moves, 8 (n + m + nnz): the weight SURVEY 8e shards a sweep by.  Only the
+// variable layout, the time tables and the CSR pattern are built (no device tables), on n_threads host threads.
+int twr_candidate_bytes(const twr_model* model, const twr_schedule* schedules, const twr_params* params, int n, int n_threads,
+                        int64_t* bytes) {
+  if (!model || !schedules || !params || !bytes || n < 1) return fail(TWR_ERR_INVALID, "bad arguments");
+  if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+  n_threads = std::max(1, std::min(n_threads, n));
+  std::vector<std::string> errs(n_threads);
+  std::atomic<int> next(0);
+  auto worker = [&](int tid) {
+    for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+      try {
+        twr::Structure s;
+        s.model = *model;
+        s.schedule = schedules[i];
+        s.params = params[i];
+        check_params(params[i]);
+        s.BuildSizes();
+        bytes[i] = 8 * ((int64_t)s.n_vars + s.n_rows + s.nnz);
+      } catch (const std::exception& e) {
+        if (errs[tid].empty()) errs[tid] = "candidate " + std::to_string(i) + ": " + e.what();
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < n_threads; ++t) {
+    try {
+      pool.emplace_back(worker, t);
+    } catch (const std::exception&) {
+      break;
+    }
+  }
+  worker(0);
+  for (auto& t : pool) t.join();
+  for (const std::string& e : errs)
+    if (!e.empty()) return fail(TWR_ERR_INVALID, e);
+  return TWR_OK;
+}
+
+// Contiguous shards balanced by the prefix sum of the weights: rank r owns [bounds[r], bounds[r + 1]).  Never an empty
+// shard; TWR_ERR_INVALID (on every rank alike: the arguments are the same everywhere) when there are fewer candidates
+// than ranks.  The boundary is the prefix whose sum is closest to r / world of the total (ties: the earlier one).
+int twr_shard_bounds(const double* weights, int n, int world, int32_t* bounds) {
+  if (!weights || !bounds || n < 1) return fail(TWR_ERR_INVALID, "bad arguments");
+  if (world < 1 || world > n)
+    return fail(TWR_ERR_INVALID, "cannot shard " + std::to_string(n) + " candidates over " + std::to_string(world) +
+                                     " ranks: every rank needs at least one");
+  std::vector<double> csum(n + 1, 0.0);
+  for (int i = 0; i < n; ++i) {
+    if (!(weights[i] >= 0.0)) return fail(TWR_ERR_INVALID, "negative or NaN weight");
+    csum[i + 1] = csum[i] + weights[i];
+  }
+  const double total = csum[n];
+  bounds[0] = 0;
+  for (int r = 1; r < world; ++r) {
+    const double target = total * r / world;
+    int i = (int)(std::lower_bound(csum.begin(), csum.end(), target) - csum.begin());   // first prefix >= target
+    if (i > 0 && std::fabs(csum[i - 1] - target) <= std::fabs(csum[std::min(i, n)] - target)) --i;
+    bounds[r] = std::min(std::max(i, bounds[r - 1] + 1), n - (world - r));
+  }
+  bounds[world] = n;
   return TWR_OK;
 }
 
@@ -708,6 +778,7 @@ void twr_batch_destroy(twr_batch* b) {
   if (b->p_x) (void)hipHostFree(b->p_x);
   if (b->p_g) (void)hipHostFree(b->p_g);
   if (b->p_j) (void)hipHostFree(b->p_j);
+  if (b->host_stream) (void)hipStreamDestroy(b->host_stream);
   delete b;
 }
 
@@ -809,7 +880,9 @@ int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_
       TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_g), ng * sizeof(double)));
       TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_j), nj * sizeof(double)));
     }
-    // one stream-ordered chain and a single synchronisation (with page-locked buffers the copies are DMA)
+    if (!b->host_stream) TWR_HIP(hipStreamCreateWithFlags(&b->host_stream, hipStreamNonBlocking));
+    hipStream_t hs = b->host_stream;
+    // one stream-ordered chain on the batch's own stream and a single synchronisation (with page-locked buffers the copies are DMA)
     static const bool zero_copy = [] { const char* e = getenv("TWR_HOST_ZERO_COPY"); return !e || atoi(e) != 0; }();
     static const bool zero_copy_x = [] { const char* e = getenv("TWR_HOST_ZERO_COPY_X"); return !e || atoi(e) != 0; }();
     const bool zc = zero_copy && b->p_g && h_g == b->p_g && h_jac == b->p_j && nj * sizeof(double) <= (size_t)(32u << 20);
@@ -817,7 +890,7 @@ int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_
     if (zc && zero_copy_x && h_x == b->p_x) {   // x too: the kernels gather it straight from the page-locked buffer
       TWR_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(const_cast<double**>(&dx)), b->p_x, 0));
     } else {
-      TWR_HIP(hipMemcpyAsync(b->d_x, h_x, nx * sizeof(double), hipMemcpyHostToDevice, nullptr));
+      TWR_HIP(hipMemcpyAsync(b->d_x, h_x, nx * sizeof(double), hipMemcpyHostToDevice, hs));
     }
     if (zc) {
       // The batch's own page-locked buffers, small batch (the single-problem callback of the ifopt adapter): the
@@ -826,18 +899,18 @@ int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_
       double *dg = nullptr, *dj = nullptr;
       TWR_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dg), b->p_g, 0));
       TWR_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dj), b->p_j, 0));
-      int rc0 = twr_batch_eval(b, dx, dg, dj, flags, nullptr);
+      int rc0 = twr_batch_eval(b, dx, dg, dj, flags, hs);
       if (rc0 != TWR_OK) return rc0;
-      TWR_HIP(hipStreamSynchronize(nullptr));
+      TWR_HIP(hipStreamSynchronize(hs));
       return TWR_OK;
     }
-    int rc = twr_batch_eval(b, b->d_x, b->d_g, b->d_j, flags, nullptr);
+    int rc = twr_batch_eval(b, b->d_x, b->d_g, b->d_j, flags, hs);
     if (rc != TWR_OK) return rc;
     if ((flags & TWR_EVAL_VALUES) && h_g)
-      TWR_HIP(hipMemcpyAsync(h_g, b->d_g, ng * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+      TWR_HIP(hipMemcpyAsync(h_g, b->d_g, ng * sizeof(double), hipMemcpyDeviceToHost, hs));
     if ((flags & TWR_EVAL_JACOBIAN) && h_jac)
-      TWR_HIP(hipMemcpyAsync(h_jac, b->d_j, nj * sizeof(double), hipMemcpyDeviceToHost, nullptr));
-    TWR_HIP(hipStreamSynchronize(nullptr));
+      TWR_HIP(hipMemcpyAsync(h_jac, b->d_j, nj * sizeof(double), hipMemcpyDeviceToHost, hs));
+    TWR_HIP(hipStreamSynchronize(hs));
     return TWR_OK;
   } catch (const std::exception& e) {
     return fail(TWR_ERR_HIP, e.what());

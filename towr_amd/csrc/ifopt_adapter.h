@@ -34,8 +34,8 @@
 
 namespace towr_amd {
 
-// One problem on one GPU.  All adapter sets of a problem share it; x is uploaded and the fused kernel
-// runs once per new x (ifopt calls GetValues / FillJacobianBlock once per set and per variable set).
+// One problem on one GPU.  All adapter sets of a problem share it; x is uploaded and the kernels run once per new x and
+// kind of result (ifopt calls GetValues / FillJacobianBlock once per set and per variable set).
 class DeviceProblem {
  public:
   // `grid`: the gridded terrain for model.terrain_id == TWR_TERRAIN_GRID_MAP (the `Grid` height map fpowr hands
@@ -51,6 +51,11 @@ class DeviceProblem {
     lower_.resize(sizes_.n_rows);
     upper_.resize(sizes_.n_rows);
     Check(twr_structure_bounds(structure_, lower_.data(), upper_.data()));
+    for (int i = 0; i < sizes_.n_var_sets; ++i) {
+      twr_set_info v;
+      Check(twr_structure_var_set(structure_, i, &v));
+      var_sets_.push_back(v);
+    }
   }
   ~DeviceProblem() {
     twr_batch_destroy(batch_);
@@ -59,14 +64,33 @@ class DeviceProblem {
   DeviceProblem(const DeviceProblem&) = delete;
   DeviceProblem& operator=(const DeviceProblem&) = delete;
 
-  // Composite::GetValues() of the variable composite, stacked in ifopt order.
-  void Update(const Eigen::VectorXd& x) {
-    if (x.size() != sizes_.n_vars) throw std::runtime_error("towr_amd: variable count mismatch");
-    if (valid_ && std::memcmp(x.data(), x_, sizeof(double) * sizes_.n_vars) == 0) return;
-    std::memcpy(x_, x.data(), sizeof(double) * sizes_.n_vars);
-    Check(twr_batch_eval_host(batch_, x_, g_, jac_, TWR_EVAL_BOTH));
-    valid_ = true;
+  // Brings the device results for the current x up to date, evaluating ONLY what is asked for (the reference's sets do the
+  // same: GetValues computes values, FillJacobianBlock derivatives -- time_discretization_constraint.cc:65-96).  Ipopt
+  // calls eval_g far more often than eval_jac_g (every line-search trial point), and a values-only evaluation does not
+  // move the 8 * nnz bytes of the Jacobian over PCIe.  `want` = TWR_EVAL_VALUES or TWR_EVAL_JACOBIAN: a new x evaluates
+  // just that; the first FillJacobianBlock on an x whose values are already there adds the Jacobian alone.
+  // x is gathered set by set, BY NAME, from the variable composite (Composite::GetComponent), so a host NLP may hold
+  // further variable sets of its own, in any position: they are simply not read.
+  void Update(const ifopt::ConstraintSet::VariablesPtr& vars, int want) {
+    bool same = have_ != 0;
+    for (const twr_set_info& v : var_sets_) {
+      const Eigen::VectorXd xv = vars->GetComponent(v.name)->GetValues();
+      if (static_cast<int>(xv.size()) != v.size) throw std::runtime_error(std::string("towr_amd: variable set '") + v.name + "' has another size than the structure's");
+      if (same && std::memcmp(xv.data(), x_ + v.offset, sizeof(double) * v.size) != 0) same = false;
+      if (!same) std::memcpy(x_ + v.offset, xv.data(), sizeof(double) * v.size);
+    }
+    if (!same) have_ = 0;
+    const int need = want & ~have_;
+    if (!need) return;
+    Check(twr_batch_eval_host(batch_, x_, g_, jac_, need));
+    have_ |= need;
+    n_value_evals_ += (need & TWR_EVAL_VALUES) != 0;
+    n_jacobian_evals_ += (need & TWR_EVAL_JACOBIAN) != 0;
   }
+  // evaluations launched so far (tests; a solver log can show the eval_g : eval_jac_g ratio with them)
+  long value_evaluations() const { return n_value_evals_; }
+  long jacobian_evaluations() const { return n_jacobian_evals_; }
+  const std::vector<twr_set_info>& var_sets() const { return var_sets_; }
   const twr_structure* structure() const { return structure_; }
   const twr_sizes& sizes() const { return sizes_; }
   const double* g() const { return g_; }
@@ -83,7 +107,9 @@ class DeviceProblem {
   twr_sizes sizes_{};
   double *x_ = nullptr, *g_ = nullptr, *jac_ = nullptr;
   std::vector<double> lower_, upper_;
-  bool valid_ = false;
+  std::vector<twr_set_info> var_sets_;
+  int have_ = 0;   // TWR_EVAL_* bits that are valid for the x in x_
+  long n_value_evals_ = 0, n_jacobian_evals_ = 0;
 };
 
 class DeviceConstraintSet : public ifopt::ConstraintSet {
@@ -93,12 +119,7 @@ class DeviceConstraintSet : public ifopt::ConstraintSet {
     if (twr_structure_con_set(problem_->structure(), set_index, &info_) != TWR_OK)
       throw std::runtime_error(twr_last_error());
     SetRows(info_.size);
-    int n_sets = problem_->sizes().n_var_sets;
-    for (int i = 0; i < n_sets; ++i) {
-      twr_set_info v;
-      twr_structure_var_set(problem_->structure(), i, &v);
-      var_sets_.push_back(v);
-    }
+    var_sets_ = problem_->var_sets();
     // Where the values of (this set's row r) x (variable set v) sit in the CSR value array: the columns of a
     // row ascend and a variable set is a contiguous column range, so it is one sub-range per row, found once
     // here instead of re-walking the whole pattern on every FillJacobianBlock call.
@@ -116,8 +137,10 @@ class DeviceConstraintSet : public ifopt::ConstraintSet {
     }
   }
 
+  const DeviceProblem& problem() const { return *problem_; }
+
   VectorXd GetValues() const override {
-    problem_->Update(GetVariables()->GetValues());
+    problem_->Update(GetVariables(), TWR_EVAL_VALUES);
     return Eigen::Map<const VectorXd>(problem_->g() + info_.offset, info_.size);
   }
 
@@ -129,16 +152,20 @@ class DeviceConstraintSet : public ifopt::ConstraintSet {
   }
 
   void FillJacobianBlock(std::string var_set, Jacobian& jac) const override {
-    // The variable composite must be exactly the structure's sets (towr only adds "ee-schedule<ee>" when the durations
-    // are optimised, nlp_formulation.cc:88-92, and then TWR_SET_TOTAL_TIME puts them into the structure too).  A name
-    // the structure does not know is a mistyped or foreign set: a silent zero block would hide it from Ipopt's
-    // derivative test, so it throws -- before the evaluation, whose own check would only report a size mismatch.
+    // ifopt / towr convention: a constraint leaves the block of a variable set it does not depend on empty
+    // (time_discretization_constraint.cc:89-96 and every FillJacobianBlock of the reference test the name and fall
+    // through).  A host NLP may therefore hold variable sets of its own beside towr's: their blocks stay empty.  What
+    // must NOT pass silently is a towr-style name the structure does not know (a typo, or "ee-schedule<ee>" sets without
+    // TWR_SET_TOTAL_TIME): a zero block there would hide real derivatives from Ipopt, so that throws.
     size_t v = 0;
     while (v < var_sets_.size() && var_set != var_sets_[v].name) ++v;
-    if (v == var_sets_.size())
-      throw std::runtime_error("towr_amd: constraint set '" + std::string(info_.name) + "' asked for the Jacobian w.r.t. unknown variable set '" +
-                               var_set + "'");
-    problem_->Update(GetVariables()->GetValues());
+    if (v == var_sets_.size()) {
+      if (LooksLikeTowrSet(var_set))
+        throw std::runtime_error("towr_amd: constraint set '" + std::string(info_.name) + "' asked for the Jacobian w.r.t. unknown variable set '" +
+                                 var_set + "'");
+      return;
+    }
+    problem_->Update(GetVariables(), TWR_EVAL_JACOBIAN);
     const int32_t* col_idx = twr_structure_col_idx(problem_->structure());
     const double* val = problem_->jac();
     const int32_t* range = ranges_[v].data();
@@ -148,6 +175,13 @@ class DeviceConstraintSet : public ifopt::ConstraintSet {
   }
 
  private:
+  // towr's variable-set names (variable_names.h:47-54: "base-lin", "base-ang", "ee-motion_<ee>", "ee-force_<ee>",
+  // "ee-schedule<ee>"); anything that starts like one of them is meant to be one
+  static bool LooksLikeTowrSet(const std::string& name) {
+    for (const char* prefix : {"base-", "ee-"})
+      if (name.compare(0, std::strlen(prefix), prefix) == 0) return true;
+    return false;
+  }
   static std::string SetName(const DeviceProblem& p, int i) {
     twr_set_info s;
     if (twr_structure_con_set(p.structure(), i, &s) != TWR_OK) throw std::runtime_error(twr_last_error());

@@ -1407,7 +1407,7 @@ TWR_DEV void pdyn_issue_rec(uint64_t shared, uint64_t loc, int loc_stride, int c
 }
 template <int N>
 TWR_DEV void pdyn_wait_rec(ARec& a, PDynRec& r) {
-  asm volatile("s_waitcnt %6" : "+a"(a.sh), "+a"(a.q6), "+a"(a.lc[0]), "+a"(a.lc[1]), "+a"(a.lc[2]), "+a"(a.lc[3]) : "n"(vmcnt_imm(N)));
+  asm volatile("s_waitcnt %6" : "+a"(a.sh), "+a"(a.q6), "+a"(a.lc[0]), "+a"(a.lc[1]), "+a"(a.lc[2]), "+a"(a.lc[3]) : "n"(vmcnt_imm(N)) : "memory");
   static_assert(offsetof(DynLoc, xbase_m) == 32 && offsetof(DynLoc, slots_m) == 40 && offsetof(DynLoc, slots_f) == 48 &&
                 offsetof(DynLoc, im) == 56 && offsetof(DynLoc, cur) == 60, "DynLoc dwords");
   r.tb = pdyn_f64(a.sh.x, a.sh.y);
@@ -1445,7 +1445,7 @@ TWR_DEV void pdyn_issue_in(const PDynWork& w, const PDynRec& r, const double* __
 template <int N>
 TWR_DEV void pdyn_wait_in(AIn& a, PDynIn& in) {
   asm volatile("s_waitcnt %12" : "+a"(a.v[0]), "+a"(a.v[1]), "+a"(a.v[2]), "+a"(a.v[3]), "+a"(a.v[4]), "+a"(a.v[5]), "+a"(a.v[6]),
-               "+a"(a.v[7]), "+a"(a.v[8]), "+a"(a.v[9]), "+a"(a.v[10]), "+a"(a.v[11]) : "n"(vmcnt_imm(N)));
+               "+a"(a.v[7]), "+a"(a.v[8]), "+a"(a.v[9]), "+a"(a.v[10]), "+a"(a.v[11]) : "n"(vmcnt_imm(N)) : "memory");
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     in.bl[d] = a.v[d];
@@ -1471,7 +1471,7 @@ TWR_DEV void pdyn_issue_put(const PDynWork& w, const PDynRec& r, int lane, APut&
 }
 template <int N>
 TWR_DEV void pdyn_wait_put(APut& a, PDynPut& pu) {
-  asm volatile("s_waitcnt %6" : "+a"(a.pm), "+a"(a.pf[0]), "+a"(a.pf[1]), "+a"(a.pf[2]), "+a"(a.pe[0]), "+a"(a.pe[1]) : "n"(vmcnt_imm(N)));
+  asm volatile("s_waitcnt %6" : "+a"(a.pm), "+a"(a.pf[0]), "+a"(a.pf[1]), "+a"(a.pf[2]), "+a"(a.pe[0]), "+a"(a.pe[1]) : "n"(vmcnt_imm(N)) : "memory");
   pu.pm[0] = __float_as_uint(a.pm.x); pu.pm[1] = __float_as_uint(a.pm.y); pu.pm[2] = __float_as_uint(a.pm.z); pu.pm[3] = __float_as_uint(a.pm.w);
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
@@ -1979,7 +1979,7 @@ TWR_DEV void romp_issue_rec(uint64_t recs, int cnt, int lane, ARomRec& a) {
 }
 template <int N>
 TWR_DEV void romp_wait_rec(ARomRec& a, RomPRec& r) {
-  asm volatile("s_waitcnt %4" : "+a"(a.q[0]), "+a"(a.q[1]), "+a"(a.q[2]), "+a"(a.q[3]) : "n"(vmcnt_imm(N)));
+  asm volatile("s_waitcnt %4" : "+a"(a.q[0]), "+a"(a.q[1]), "+a"(a.q[2]), "+a"(a.q[3]) : "n"(vmcnt_imm(N)) : "memory");
   static_assert(offsetof(RomRec, q6) == 32 && offsetof(RomRec, meta) == 44 && offsetof(RomRec, slots) == 48 && offsetof(RomRec, pad) == 56,
                 "RomRec dwords");
   r.tb = pdyn_f64(a.q[0].x, a.q[0].y);
@@ -2011,7 +2011,7 @@ TWR_DEV void romp_issue_in(const RomPhaseWork& w, const RomPRec& r, const double
 template <int N>
 TWR_DEV void romp_wait_in(ARomIn& a, double in[9]) {
   asm volatile("s_waitcnt %9" : "+a"(a.v[0]), "+a"(a.v[1]), "+a"(a.v[2]), "+a"(a.v[3]), "+a"(a.v[4]), "+a"(a.v[5]), "+a"(a.v[6]),
-               "+a"(a.v[7]), "+a"(a.v[8]) : "n"(vmcnt_imm(N)));
+               "+a"(a.v[7]), "+a"(a.v[8]) : "n"(vmcnt_imm(N)) : "memory");
 #pragma unroll
   for (int q = 0; q < 9; ++q) in[q] = a.v[q];
 }

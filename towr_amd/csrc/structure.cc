@@ -834,6 +834,10 @@ void Structure::PackBlob() {
       }
       pt.row_rom[e] = row_rom[e];
       pt.nnz_rom[e] = nnz_rom[e];
+      // rom_phase_kernel assembles whole expanded time nodes in LDS: one node must fit the 160 KB of a CU
+      // (the dynamic set has the matching guard below; without it the batch is created and every evaluation fails to launch)
+      if (have_rom && pt.rom_node_vals[e] > 160 * 128)
+        throw std::runtime_error("optimised timings: a time node of rangeofmotion-" + std::to_string(e) + " has more than 20480 Jacobian values");
     }
     pt.o_tdyn = put(grid_dyn.data(), grid_dyn.size() * sizeof(double));
     pt.o_trom = put(grid_rom.data(), grid_rom.size() * sizeof(double));
@@ -1006,6 +1010,11 @@ void Structure::Build() {
   BuildTimeTables();
   BuildPattern();
   PackBlob();
+}
+void Structure::BuildSizes() {
+  BuildVariables();
+  BuildTimeTables();
+  BuildPattern();
 }
 
 // ------------------------------------------------------------------ terrain height (host, setup only)

@@ -86,6 +86,7 @@ struct Structure {
 
   const SetInfo* FindSet(const std::string& name) const;  // nullptr if the family is switched off
   void Build();            // throws std::runtime_error
+  void BuildSizes();       // variables, time tables and CSR pattern only (n_vars / n_rows / nnz): no device tables
   void InitialGuess(const double* lin0, const double* ang0, const double* lin1, const double* ang1,
                     const double* ee0, double* x) const;
   int SampleCount(double dt) const;  // fpowr GetTrajectory: samples while t <= T + 1e-5, t accumulated

@@ -45,29 +45,44 @@ def candidate_structures(model, cands, k_nodes=200, threads=0, grid=None, constr
 
 
 def candidate_weight(cand, k_nodes=200):
-    """Cheap byte weight of a candidate for sharding, without building it: the value array is dominated by
-    K time nodes x (dynamic + 4 rangeofmotion rows), whose lengths vary by < 0.2 % over the enumeration
-    (measured: nnz 102 779 .. 102 906 at K = 200), so the weight is the node count."""
+    """Cheap stand-in weight of ONE candidate without building anything: the time-node count (the value array is
+    dominated by K time nodes x (dynamic + 4 rangeofmotion rows)).  Good enough when every candidate has the same K and
+    constraint sets (nnz then varies by < 0.2 % over the enumeration); sweeps that mix either use candidate_bytes."""
     return float(k_nodes)
+
+
+def candidate_bytes(model, cands, k_nodes=200, threads=0, constraint_sets=None):
+    """Exact bytes per callback, 8 (n + m + nnz), of every candidate -- the weight SURVEY 8e shards by -- from the
+    library (twr_candidate_bytes: variable layout + time tables + CSR pattern only, multi-threaded, no device tables).
+    `k_nodes` may be one number or one per candidate.  Every rank computes the same list."""
+    import ctypes as C
+
+    from . import Params, Schedule, _check, lib
+
+    ks = [k_nodes] * len(cands) if np.isscalar(k_nodes) else list(k_nodes)
+    inputs = [candidate_inputs(model, c, k, constraint_sets) for c, k in zip(cands, ks)]
+    n = len(inputs)
+    sa = (Schedule * n)(*[i[0] for i in inputs])
+    pa = (Params * n)(*[i[1] for i in inputs])
+    out = np.zeros(n, dtype=np.int64)
+    _check(lib().twr_candidate_bytes(C.byref(model), sa, pa, n, int(threads), out.ctypes.data_as(C.POINTER(C.c_int64))))
+    return out
 
 
 def shard_bounds(weights, world):
     """Contiguous shards balanced by the prefix sum of `weights` (bytes per candidate):
-    rank r owns [bounds[r], bounds[r+1]).  Every candidate lands in exactly one shard."""
-    w = np.asarray(weights, dtype=np.float64)
+    rank r owns [bounds[r], bounds[r+1]).  Every candidate lands in exactly one shard, no shard is empty.
+    (twr_shard_bounds of the C ABI: the C++ caller, examples/sweep_multi_gpu.cc, cuts the same shards.)"""
+    import ctypes as C
+
+    from . import TowrError, lib
+
+    w = np.ascontiguousarray(weights, dtype=np.float64)
     if world < 1 or world > len(w):
         # every rank evaluates this with the same arguments, so all of them raise (no rank is left in a collective)
         raise ValueError("cannot shard %d candidates over %d ranks: every rank needs at least one" % (len(w), world))
-    csum = np.concatenate([[0.0], np.cumsum(w)])
-    total = csum[-1]
-    bounds = [0]
-    for r in range(1, world):
-        target = total * r / world
-        i = int(np.searchsorted(csum, target, side="left"))
-        # pick the boundary whose prefix sum is closest to the target
-        if i > 0 and abs(csum[i - 1] - target) <= abs(csum[min(i, len(w))] - target):
-            i -= 1
-        # never an empty shard: at least one candidate per rank, and leave one for every later rank
-        bounds.append(min(max(i, bounds[-1] + 1), len(w) - (world - r)))
-    bounds.append(len(w))
-    return bounds
+    out = np.zeros(world + 1, dtype=np.int32)
+    rc = lib().twr_shard_bounds(w.ctypes.data_as(C.POINTER(C.c_double)), len(w), int(world), out.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc != 0:
+        raise TowrError(lib().twr_last_error().decode())
+    return [int(b) for b in out]
