@@ -8,7 +8,7 @@ mkdir -p "$OUT/build"
 REF=${TOWR_REFERENCE_DIR:-/root/reference/towr}
 if [ ! -d "$REF/src" ]; then
   echo "unavailable: reference sources not present at $REF" > "$OUT/STATUS"
-elif cmake -S "$HERE" -B "$OUT/build" -DTOWR_REFERENCE_DIR="$REF" -DCMAKE_BUILD_TYPE=Release > "$OUT/configure.log" 2>&1 \
+elif cmake -S "$HERE" -B "$OUT/build" -DTOWR_REFERENCE_DIR="$REF" -DTOWR_AMD_ROOT="$HERE/../.." -DCMAKE_BUILD_TYPE=Release > "$OUT/configure.log" 2>&1 \
      && cmake --build "$OUT/build" -j4 > "$OUT/build.log" 2>&1; then
   cp "$OUT/build/ref_dump" "$OUT/ref_dump"
   echo "available" > "$OUT/STATUS"

@@ -35,3 +35,49 @@ def test_reference_build_recipe_reports_its_availability(tmp_path):
         rows = np.repeat(np.arange(P.m), np.diff(rp))
         assert np.array_equal(trip[:, 0].astype(int), rows) and np.array_equal(trip[:, 1].astype(int), ci)
         assert np.abs(trip[:, 2] - ov).max() <= 1e-9 * max(1.0, np.abs(ov).max())
+
+    # every golden fixture (tests/golden/mp_*.npz: the cases the oracle is pinned on, BASELINE sizes included): the
+    # fixture's schedule, discretisation and x go to the real reference as files; its g / Jacobian must equal the oracle's
+    import glob
+
+    from tests.test_oracle_golden import load_fixture
+
+    robots = {"monoped": 0, "biped": 1, "hyq": 2, "anymal": 3, "go1": 4}            # RobotModel::Robot, robot_model.h:66-71
+    terrains = {"flat": 0, "block": 1, "stairs": 2, "gap": 3, "slope": 4, "chimney": 5, "chimney_lr": 6}   # HeightMap::TerrainID
+    for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "mp_*.npz"))):
+        d, P = load_fixture(path)
+        sets = int(d["constraint_sets"]) if "constraint_sets" in d.files else 27
+        if sets & 128:
+            continue   # baseMotion's z bounds hang on the formulation's initial base height: covered by the built-in cases
+        prefix = str(tmp_path / os.path.basename(path)[:-4])
+        np.savetxt(prefix + "_xin.txt", d["x"], fmt="%.17g")
+        with open(prefix + "_phases.txt", "w") as f:
+            o = 0
+            for k, con in zip(d["n_phases"], d["contact_at_start"]):
+                f.write("%d %s\n" % (int(con), " ".join("%.17g" % v for v in d["phase_durations"][o:o + k])))
+                o += k
+        dt = [float(d["dt_dynamic"]), float(d["dt_rom"])] if "dt_dynamic" in d.files else [0.1, 0.08]
+        subprocess.check_call([os.path.join(REF, "ref_dump"), str(robots[str(d["robot"])]), str(terrains[str(d["terrain"])]), "0", "0",
+                               str(sets), prefix + "_xin.txt", "1.0", prefix, "--phases", prefix + "_phases.txt", "--dt", str(dt[0]), str(dt[1])])
+        g = np.loadtxt(prefix + "_g.txt")
+        trip = np.loadtxt(prefix + "_jac.txt")
+        og, rp, ci, ov = P.eval(d["x"])
+        rows = np.repeat(np.arange(P.m), np.diff(rp))
+        assert g.shape == og.shape and np.abs(g - og).max() <= 1e-9 * max(1.0, np.abs(og).max()), path
+        assert np.array_equal(trip[:, 0].astype(int), rows) and np.array_equal(trip[:, 1].astype(int), ci), path
+        assert np.abs(trip[:, 2] - ov).max() <= 1e-9 * max(1.0, np.abs(ov).max()), path
+
+
+@pytest.mark.gpu
+def test_towr_binding_against_the_real_reference(tmp_path):
+    """towr_amd/csrc/towr_binding.h compiled against the REAL towr / ifopt / Eigen headers (ref_dump --binding): the device
+    sets it returns for an NlpFormulation equal the reference's own sets on the same x.  Skips where the recipe cannot be
+    built (this image: no Eigen3, no ifopt)."""
+    status_file = os.path.join(REF, "STATUS")
+    if not os.path.exists(os.path.join(REF, "ref_dump")) or not os.path.exists(status_file) or open(status_file).read().strip() != "available":
+        pytest.skip("reference-native build unavailable on this box (needs Eigen3 + ifopt)")
+    for robot, terrain, combo, T, mask in ((0, 0, 2, 2.0, 63), (3, 3, 1, 2.0, 27), (3, 2, 0, 2.4, 127), (1, 4, 1, 1.6, 255)):
+        prefix = str(tmp_path / ("b%d_%d" % (robot, mask)))
+        r = subprocess.run([os.path.join(REF, "ref_dump"), str(robot), str(terrain), str(combo), str(T), str(mask), "guess", "1.0", prefix,
+                            "--binding"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "structure equal" in r.stdout, r.stdout + r.stderr

@@ -32,7 +32,6 @@ hipError_t launch_planes(const double* plan, const int32_t* counts, const double
                          int n_problems, int max_steps, int n_ee, int32_t* plane_index, hipStream_t stream);
 hipError_t launch_sample(const SampleWork* work, int n_work, const double* x, double* out, double dt, const double* times,
                          hipStream_t stream);
-int rom_stage_capacity();
 }  // namespace twr
 
 struct twr_structure {
@@ -150,40 +149,6 @@ void copy_set(const twr::SetInfo& s, twr_set_info* out) {
   out->nnz = s.nnz;
 }
 
-// Split the k range [0,K) of one constraint set into runs of at most max_cnt time nodes whose CSR
-// slice fits the LDS image of the kernel.  Returns (k0, cnt) pairs.
-std::vector<std::pair<int, int>> chunk(const std::vector<int32_t>& row_ptr, int row0, int rows_per_k, int K, int cap,
-                                       int max_cnt) {
-  // Balanced: the fewest runs that respect max_cnt and the capacity, of (nearly) equal length -- K = 200 gives 4 x 50
-  // rather than 64 + 64 + 64 + 8.  A kernel with a compile-time number of copy-out stores pays the full count for a
-  // short tail run too.
-  auto vals = [&](int k0, int k1) { return row_ptr[row0 + rows_per_k * k1] - row_ptr[row0 + rows_per_k * k0]; };
-  auto greedy = [&](int limit, std::vector<std::pair<int, int>>& out) {
-    out.clear();
-    for (int k0 = 0; k0 < K;) {
-      int k1 = k0;
-      while (k1 < K && k1 - k0 < limit && vals(k0, k1 + 1) <= cap) ++k1;
-      if (k1 == k0) throw std::runtime_error("one time node exceeds the LDS staging capacity");
-      out.push_back({k0, k1 - k0});
-      k0 = k1;
-    }
-  };
-  std::vector<std::pair<int, int>> out, best;
-  greedy(max_cnt, best);                                 // the minimum number of runs
-  static const bool balanced = [] { const char* e = getenv("TWR_ROM_BALANCED"); return !e || atoi(e) != 0; }();
-  if (balanced)
-    for (int limit = (K + (int)best.size() - 1) / (int)best.size(); limit < max_cnt; ++limit) {
-      greedy(limit, out);                                // the smallest run length that still needs no more runs
-      if (out.size() == best.size()) {
-        best = out;
-        break;
-      }
-    }
-  for (const auto& r : best)
-    // copy_out_fixed clamps its tail iterations to the last complete pair of the slice: a slice must hold one
-    if (vals(r.first, r.first + r.second) < 4) throw std::runtime_error("a time-node run with fewer than 4 Jacobian values cannot be staged");
-  return best;
-}
 }  // namespace
 
 extern "C" {
@@ -521,17 +486,8 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     std::vector<twr::RomPhaseWork> prom;
     size_t prec_bytes = 0;  // offsets into the scratch buffer are stored first and rebased after hipMalloc
     std::vector<int> dyn_first, rom_first;  // first work item of every problem (+ end)
-    static const int rom_nodes = [] { const char* e = getenv("TWR_ROM_NODES"); return e && atoi(e) > 0 ? std::min(64, atoi(e)) : 64; }();
-    // run lists are identical for problems that share a structure: build once per structure
-    std::vector<std::vector<std::vector<std::pair<int, int>>>> runs_rom(n_structs);
-    for (int i = 0; i < n_structs; ++i) {
-      const twr::Structure& S = structs[i]->s;
-      // families that are switched off (twr_params.constraint_sets) simply have no work items
-      if (S.timings) continue;  // optimised timings: PDynWork / LocWork / RomPhaseWork items below
-      for (int e = 0; e < S.n_ee; ++e)
-        if (const twr::SetInfo* rs = S.FindSet("rangeofmotion-" + std::to_string(e)))
-          runs_rom[i].push_back(chunk(S.row_ptr, rs->offset, 3, (int)S.grid_rom.size(), twr::rom_stage_capacity(), rom_nodes));
-    }
+    // (families that are switched off -- twr_params.constraint_sets -- simply have no work items; problems with
+    // optimised timings get PDynWork / LocWork / RomPhaseWork items instead of DynWork / RomWork)
     for (int p = 0; p < n_problems; ++p) {
       int si = struct_of_problem[p];
       if (si < 0 || si >= n_structs) throw std::runtime_error("struct_of_problem out of range");
@@ -566,19 +522,22 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
         w.nvals = sl.nvals;
         dyn.push_back(w);
       }
-      for (int e = 0; e < (int)runs_rom[si].size(); ++e) {
+      for (int e = 0; e < (int)S.rom_slices.size(); ++e) {   // fixed timings only (empty otherwise)
+        if (S.rom_slices[e].empty()) continue;
         const twr::SetInfo& rs = *S.FindSet("rangeofmotion-" + std::to_string(e));
-        for (auto& r : runs_rom[si][e]) {
+        for (const auto& sl : S.rom_slices[e]) {
           twr::RomWork w;
           std::memset(&w, 0, sizeof(w));
-          w.recs = blob + S.off_rom_recs[e] + sizeof(twr::RomRec) * (size_t)r.first;
+          w.nodes = blob + S.off_rom_nodes + sizeof(twr::RomNode) * (size_t)sl.k0;
+          w.segs = blob + sl.segs;
           w.x_off = b->x_off[p];
-          w.g_off = b->g_off[p] + rs.offset + 3 * r.first;
-          w.j_off = b->j_off[p] + S.row_ptr[rs.offset + 3 * r.first];
+          w.g_off = b->g_off[p] + rs.offset + 3 * sl.k0;
+          w.j_off = b->j_off[p] + S.row_ptr[rs.offset + 3 * sl.k0];
           w.off_lin = S.off_base_lin;
           w.off_ang = S.off_base_ang;
-          w.cnt = r.second;
-          w.nvals = S.row_ptr[rs.offset + 3 * (r.first + r.second)] - S.row_ptr[rs.offset + 3 * r.first];
+          w.cnt = sl.cnt;
+          w.nvals = sl.nvals;
+          std::memcpy(w.first, sl.first, sizeof(w.first));
           b->rom_max_vals = std::max(b->rom_max_vals, w.nvals);
           rom.push_back(w);
         }

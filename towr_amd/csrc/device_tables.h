@@ -31,7 +31,38 @@ struct PolyDesc {
   uint16_t cand[12];
 };
 
-// rangeofmotion-<ee>, one record per time node (64 B)
+// rangeofmotion-<ee>, fixed timings (rom_kernel).  What a lane (= one time node) needs is split by what it depends on, so
+// that a sweep -- every candidate its own tables, read from HBM exactly once per evaluation -- streams 10 KB per candidate
+// instead of the 51 KB of one 64-byte record per (time node, ee):
+//   RomNode  per time node, shared by the slices of all end-effectors: grid time and the base-spline lookup   (32 B)
+//   RomSeg   per (slice, polynomial of the ee-motion spline active inside the slice): everything that is constant while
+//            that polynomial stays active -- its start time, 1 / duration, variable range, where the segment's rows start (48 B)
+// The local time of the ee spline is t - t0 (t0 = the sum of the durations before the polynomial, accumulated like
+// Spline::GetSegmentID does, spline.cc:48-60); WHICH polynomial is active is still decided on the host by the reference's
+// rule (eps 1e-10, previous polynomial at a junction).  The reference subtracts the durations from t one by one
+// (spline.cc:62-78): t - t0 differs from that by rounding only (a few ulp of t), far inside the 1e-9 parity bar.
+constexpr int kRomStage = 4856;    // Jacobian values of one slice (LDS image, doubles); + 2 + 64 + 192 doubles = 40912 B
+constexpr int kRomMaxSeg = 8;      // polynomials of the ee spline per slice (a slice is cut earlier if it would span more)
+struct RomNode {
+  double t;           // global time of the node (TimeDiscretizationConstraint::dts_)
+  double tb, iTb;     // base spline: local time in the active polynomial, 1/duration
+  int32_t q6;         // 6 * (active base polynomial): offset of its first node in base-lin / base-ang
+  int32_t pad;
+};
+static_assert(sizeof(RomNode) == 32, "RomNode layout");
+struct RomSeg {
+  double t0, iTm;     // ee-motion polynomial: start time, 1/duration
+  uint32_t slots[2];  // 12 x 4 bit: slot of candidate c, 0xF = absent
+  int32_t xbase;      // first x index of the polynomial's variables
+  uint32_t meta;      // as PolyDesc::meta
+  int32_t voff0;      // CSR offset of the segment's first row relative to the slice's first value
+  int32_t kfirst;     // node (lane) of the slice at which the segment starts
+  int32_t node_vals;  // Jacobian values per time node inside the segment (68 + 3 nslots)
+  int32_t pad;
+};
+static_assert(sizeof(RomSeg) == 48, "RomSeg layout");
+
+// rangeofmotion-<ee> with optimised timings: one record per time node, written by the pre-pass (64 B)
 struct RomRec {
   double tb, iTb;     // base spline: local time in the active polynomial, 1/duration
   double tm, iTm;     // ee-motion spline
@@ -284,12 +315,14 @@ struct DynWork {          // cnt <= 16 time nodes of "dynamic"
 static_assert(sizeof(DynWork) == 80, "DynWork layout");
 
 struct RomWork {          // cnt <= 64 time nodes of "rangeofmotion-<ee>"
-  uint64_t recs;          // RomRec[k0..] of that ee
+  uint64_t nodes;         // RomNode[k0..]
+  uint64_t segs;          // RomSeg[] of this slice
   int64_t x_off, g_off, j_off;
   int32_t off_lin, off_ang;
   int32_t cnt, nvals;
+  uint8_t first[kRomMaxSeg];   // first[i] = first lane of segment i (first[0] = 0; 255 = no such segment)
 };
-static_assert(sizeof(RomWork) == 48, "RomWork layout");
+static_assert(sizeof(RomWork) == 64, "RomWork layout");
 
 struct NodeWork {         // all terrain-* and force-* sets of one problem
   uint64_t blob;

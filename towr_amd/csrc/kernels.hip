@@ -306,19 +306,46 @@ struct RomX {
   double bl[12], ba[12], m[12];
 };
 TWR_DEV uint64_t rom_slots(const RomRec& r) { return ((uint64_t)r.slots[1] << 32) | r.slots[0]; }
-TWR_DEV RomRec rom_load_rec(const RomWork& w, int lane) {
-  return gptr<RomRec>(w.recs)[min(lane, w.cnt - 1)];
+// What a lane of rom_kernel carries through the pipeline: its time node's record and its segment's record as loaded (raw:
+// nothing is computed from them at issue time, so the prefetch does not wait), and the lane's node index.
+struct RomLane {
+  RomNode nd;
+  RomSeg sg;
+  int k;
+};
+TWR_DEV RomLane rom_load_rec(const RomWork& w, int lane) {
+  RomLane L;
+  L.k = min(lane, w.cnt - 1);
+  int s = 0;   // segment of this node: the work item lists the first lane of every segment (wave-uniform bytes)
+#pragma unroll
+  for (int i = 1; i < kRomMaxSeg; ++i) s += (L.k >= (int)w.first[i]) ? 1 : 0;
+  L.nd = gptr<RomNode>(w.nodes)[L.k];
+  L.sg = gptr<RomSeg>(w.segs)[s];
+  return L;
 }
-TWR_DEV void rom_load_x(const RomWork& w, const RomRec& r, const double* __restrict__ x, RomX& X) {
+// the lane's view in the form the math is written for (fields of the optimised-timings record RomRec)
+TWR_DEV RomRec rom_rec_of(const RomLane& L) {
+  RomRec r;
+  r.tb = L.nd.tb; r.iTb = L.nd.iTb;
+  r.tm = L.nd.t - L.sg.t0; r.iTm = L.sg.iTm;
+  r.q6 = L.nd.q6;
+  r.xbase = L.sg.xbase;
+  r.voff = L.sg.voff0 + (L.k - L.sg.kfirst) * L.sg.node_vals;   // relative to the slice's first value
+  r.meta = L.sg.meta;
+  r.slots[0] = L.sg.slots[0]; r.slots[1] = L.sg.slots[1];
+  r.pad[0] = r.pad[1] = 0;
+  return r;
+}
+TWR_DEV void rom_load_x(const RomWork& w, const RomLane& L, const double* __restrict__ x, RomX& X) {
   const double* xp = x + w.x_off;
-  const double* xl = xp + w.off_lin + r.q6;
-  const double* xa = xp + w.off_ang + r.q6;
+  const double* xl = xp + w.off_lin + L.nd.q6;
+  const double* xa = xp + w.off_ang + L.nd.q6;
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
     X.bl[i] = xl[i];
     X.ba[i] = xa[i];
   }
-  gather12(xp, r.xbase, rom_slots(r), X.m);
+  gather12(xp, L.sg.xbase, ((uint64_t)L.sg.slots[1] << 32) | L.sg.slots[0], X.m);
 }
 TWR_DEV void rom_item(const RomWork& w, const RomRec& r, const RomX& X, double* __restrict__ gst, double* __restrict__ stage,
                       int par, int vbase, int trash, int lane, bool want_g, bool want_j) {
@@ -638,7 +665,7 @@ TWR_DEV void copy_out_fixed(double* __restrict__ dst, const double* __restrict__
 
 // LDS image sizes (doubles).  dynamic: 16 time nodes per wave (~170 values each at 4 ee) -> 22.5 KiB,
 // seven workgroups per CU; range of motion: 64 lanes x ~84 values -> 39 KiB, four per CU.
-constexpr int kRomStage = 4856;   // + 2 + 64 + 192 doubles = 40912 B
+// (kRomStage, the rom image: device_tables.h)
 
 // dynamic / range of motion: persistent workgroups, software pipelined over the strided work list.
 // Loop body for slice i (its record -- and for rom its x values -- were prefetched):
@@ -1040,7 +1067,7 @@ TWR_DEV void rom_body(const RomWork* __restrict__ work, int n_work, const double
   double* gst = stage + kRomStage + 2 + 64;
   if (i >= n_work) return;
   RomWork w0 = work[i], w1 = w0, w2 = w0;
-  RomRec r0 = rom_load_rec(w0, lane), r1 = r0;
+  RomLane r0 = rom_load_rec(w0, lane), r1 = r0;
   RomX X;
   if (i + stride < n_work) {
     w1 = work[i + stride];
@@ -1052,9 +1079,8 @@ TWR_DEV void rom_body(const RomWork* __restrict__ work, int n_work, const double
     if (has2) w2 = work[i + 2 * stride];
     double* dst = jac + w0.j_off;
     const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-    const int vbase = __builtin_amdgcn_readfirstlane(r0.voff);
-    if (lane < w0.cnt) rom_item(w0, r0, X, gst, stage, par, vbase, trash, lane, WANT_G, WANT_J);   // C
-    RomRec r2 = r1;
+    if (lane < w0.cnt) rom_item(w0, rom_rec_of(r0), X, gst, stage, par, 0, trash, lane, WANT_G, WANT_J);   // C
+    RomLane r2 = r1;
     if (has2) r2 = rom_load_rec(w2, lane);              // A (records first: the wait for x retires them too)
     if (has1) rom_load_x(w1, r1, x, X);
     if (WANT_J) copy_out_fixed<NIT, 13>(dst, stage, w0.nvals, par, lane);   // B
@@ -2749,7 +2775,6 @@ hipError_t prepare_phase_kernels(int pdyn_img_cap, int prom_img_cap) {
   }
   return st;
 }
-int rom_stage_capacity() { return kRomStage; }
 int dyn_dump_doubles() { return kDynImage + 2 + 96; }
 #endif  // !TWR_TU_ROM
 

@@ -737,8 +737,8 @@ void Structure::PackBlob() {
     off_dyn_gather = put(gather.data(), gather.size() * sizeof(DynGather));
     off_dyn_put = put(putv.data(), putv.size() * sizeof(DynPut));
   }
-  // --- per-lane records of the range-of-motion kernel
-  for (int e = 0; e < n_ee && have_rom; ++e) {
+  // --- rangeofmotion-<ee>, optimised timings: per-node record templates (the pre-pass fills in the x-dependent part)
+  for (int e = 0; e < n_ee && have_rom && timings; ++e) {
     std::vector<RomRec> rc(grid_rom.size());
     for (size_t k = 0; k < grid_rom.size(); ++k) {
       RomRec& R = rc[k];
@@ -758,6 +758,94 @@ void Structure::PackBlob() {
       R.slots[1] = (uint32_t)(slots >> 32);
     }
     off_rom_recs[e] = put(rc.data(), rc.size() * sizeof(RomRec));
+  }
+  // --- rangeofmotion-<ee>, fixed timings: per-node records shared by all ee, slices, per-(slice, polynomial) segments
+  rom_slices.assign(n_ee, {});
+  if (have_rom && !timings) {
+    const int K = (int)grid_rom.size();
+    std::vector<RomNode> nodes(K);
+    for (int k = 0; k < K; ++k) {
+      std::memset(&nodes[k], 0, sizeof(RomNode));
+      nodes[k].t = grid_rom[k];
+      nodes[k].tb = rom_base[k].t_local;
+      nodes[k].iTb = 1.0 / base.durations[rom_base[k].poly];
+      nodes[k].q6 = 6 * rom_base[k].poly;
+    }
+    off_rom_nodes = put(nodes.data(), nodes.size() * sizeof(RomNode));
+    for (int e = 0; e < n_ee; ++e) {
+      const int row0 = row_rom[e];
+      auto vals = [&](int k0, int k1) { return row_ptr[row0 + 3 * k1] - row_ptr[row0 + 3 * k0]; };
+      auto segs = [&](int k0, int k1) {   // polynomials of the ee spline active in nodes [k0, k1)
+        int n = 1;
+        for (int k = k0 + 1; k < k1; ++k) n += rom_motion[e][k].poly != rom_motion[e][k - 1].poly;
+        return n;
+      };
+      // Balanced runs: the fewest runs that respect the limits (<= 64 time nodes = lanes, the LDS image, kRomMaxSeg
+      // polynomials), of (nearly) equal length -- K = 200 gives 4 x 50 rather than 64 + 64 + 64 + 8: the kernel has a
+      // compile-time number of copy-out stores and pays the full count for a short tail run too.
+      auto greedy = [&](int limit, std::vector<std::pair<int, int>>& out) {
+        out.clear();
+        for (int k0 = 0; k0 < K;) {
+          int k1 = k0;
+          while (k1 < K && k1 - k0 < limit && vals(k0, k1 + 1) <= kRomStage && segs(k0, k1 + 1) <= kRomMaxSeg) ++k1;
+          if (k1 == k0) throw std::runtime_error("one time node exceeds the LDS staging capacity");
+          out.push_back({k0, k1 - k0});
+          k0 = k1;
+        }
+      };
+      std::vector<std::pair<int, int>> runs, best;
+      greedy(64, best);
+      for (int limit = (K + (int)best.size() - 1) / (int)best.size(); limit < 64; ++limit) {
+        greedy(limit, runs);   // the smallest run length that still needs no more runs
+        if (runs.size() == best.size()) {
+          best = runs;
+          break;
+        }
+      }
+      // t0 of every polynomial: the running sum Spline::GetSegmentID compares t against (spline.cc:52-57)
+      std::vector<double> t0(motion[e].durations.size() + 1, 0.0);
+      for (size_t q = 0; q < motion[e].durations.size(); ++q) t0[q + 1] = t0[q] + motion[e].durations[q];
+      for (const auto& r : best) {
+        RomSlice sl;
+        sl.k0 = r.first;
+        sl.cnt = r.second;
+        sl.nvals = vals(r.first, r.first + r.second);
+        // copy_out_fixed clamps its tail iterations to the last complete pair of the slice: a slice must hold one
+        if (sl.nvals < 4) throw std::runtime_error("a time-node run with fewer than 4 Jacobian values cannot be staged");
+        std::memset(sl.first, 255, sizeof(sl.first));
+        std::vector<RomSeg> sg;
+        for (int k = sl.k0; k < sl.k0 + sl.cnt; ++k) {
+          const int q = rom_motion[e][k].poly;
+          if (k > sl.k0 && q == rom_motion[e][k - 1].poly) continue;
+          const PolyDesc& mp = mpoly[e][q];
+          RomSeg S;
+          std::memset(&S, 0, sizeof(S));
+          S.t0 = t0[q];
+          S.iTm = mp.iT;
+          uint64_t slots = 0;
+          for (int c = 0; c < 12; ++c) slots |= (uint64_t)(mp.cand[c] & 0xF) << (4 * c);
+          S.slots[0] = (uint32_t)slots;
+          S.slots[1] = (uint32_t)(slots >> 32);
+          S.xbase = mp.xbase;
+          S.meta = mp.meta;
+          S.voff0 = row_ptr[row0 + 3 * k] - row_ptr[row0 + 3 * sl.k0];
+          S.kfirst = k - sl.k0;
+          S.node_vals = row_ptr[row0 + 3 * (k + 1)] - row_ptr[row0 + 3 * k];
+          if (S.node_vals != 68 + 3 * (int)(mp.meta & 0xF)) throw std::runtime_error("rangeofmotion row lengths inconsistent");
+          sl.first[sg.size()] = (uint8_t)(k - sl.k0);
+          sg.push_back(S);
+        }
+        // every node of a segment has the same row lengths: voff = voff0 + (k - kfirst) * node_vals (checked)
+        for (int k = sl.k0; k < sl.k0 + sl.cnt; ++k) {
+          size_t si = 0;
+          while (si + 1 < sg.size() && k - sl.k0 >= (int)sl.first[si + 1]) ++si;
+          if (row_ptr[row0 + 3 * k] - row_ptr[row0 + 3 * sl.k0] != sg[si].voff0 + (k - sl.k0 - sg[si].kfirst) * sg[si].node_vals)
+            throw std::runtime_error("rangeofmotion segment layout inconsistent");
+        }
+        sl.segs = put(sg.data(), sg.size() * sizeof(RomSeg));
+        rom_slices[e].push_back(sl);
+      }
+    }
   }
   // --- optimised timings: polynomial tables, set-wide counts, global grid times
   if (timings) {

@@ -82,7 +82,15 @@ struct Structure {
   };
   std::vector<DynSlice> dyn_slices;
   uint32_t off_dyn_nodes = 0, off_dyn_gather = 0, off_dyn_put = 0;
-  uint32_t off_rom_recs[kMaxEE] = {0, 0, 0, 0};
+  uint32_t off_rom_recs[kMaxEE] = {0, 0, 0, 0};   // optimised timings: RomRec[k] templates (base-spline part)
+  // fixed timings: slices of rangeofmotion-<ee> (device_tables.h RomNode / RomSeg)
+  struct RomSlice {
+    int k0, cnt, nvals;
+    uint32_t segs;               // byte offset of the slice's RomSeg records inside the blob
+    uint8_t first[kRomMaxSeg];   // first lane of every segment (255: none)
+  };
+  std::vector<std::vector<RomSlice>> rom_slices;   // [ee]
+  uint32_t off_rom_nodes = 0;
 
   const SetInfo* FindSet(const std::string& name) const;  // nullptr if the family is switched off
   void Build();            // throws std::runtime_error
