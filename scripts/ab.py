@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
-"""A/B of library builds on one box: scripts/ab.py lib1.so[:ENV=VAL,...] lib2.so ...  (kernel times of the default bench)."""
+"""A/B of library builds on one box: scripts/ab.py lib1.so[:ENV=VAL,...] lib2.so ... [-- bench.py arguments]
+(kernel times of the default bench, or of the workload the extra arguments select, e.g. -- --workload sweep --batch 1024)."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = sys.argv[1:]
+EXTRA = []
+if "--" in ARGS:
+    EXTRA = ARGS[ARGS.index("--") + 1:]
+    ARGS = ARGS[:ARGS.index("--")]
 for rep in range(2):
-    for spec in sys.argv[1:]:
+    for spec in ARGS:
         lib, _, envs = spec.partition(":")
         env = dict(os.environ, TWR_AMD_LIB=os.path.join(ROOT, "towr_amd", lib))
         for kv in filter(None, envs.split(",")):
             k, v = kv.split("=")
             env[k] = v
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "3", "--no-cpu-baseline",
-                            "--no-scale-c5", "--no-timings-c3"], env=env, capture_output=True, text=True)
+                            "--no-scale-c5", "--no-timings-c3"] + EXTRA, env=env, capture_output=True, text=True)
         try:
             d = json.loads(r.stdout.strip().splitlines()[-1])
             k = d["roofline"]["path"]["kernel_ms"]

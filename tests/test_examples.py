@@ -69,7 +69,16 @@ def _python_decision(n):
     batch.eval_device(xd.data_ptr(), g.data_ptr(), 0, ta.EVAL_VALUES, st)
     batch.score_device(g.data_ptr(), sc.data_ptr(), st)
     torch.cuda.synchronize()
-    return best_candidate(sc)
+    s = sc.cpu().numpy()
+    return best_candidate(sc), s[:, 0] + s[:, 2] + s[:, 6] + s[:, 8]
+
+
+def _same_decision(best_cpp, score_cpp, best_py, score_py, totals):
+    """The enumeration holds near-ties (candidates that differ in T only can violate the same bound by the same amount), and
+    the kernels are instantiated per output selection (values / values + Jacobian), which agree to rounding, not bit for bit:
+    the C++ caller must report the minimal score and a candidate that attains it to 1e-9."""
+    tol = 1e-9 * max(1.0, abs(score_py))
+    return abs(score_cpp - score_py) <= tol and abs(totals[best_cpp] - totals[best_py]) <= tol
 
 
 @pytest.mark.gpu
@@ -82,7 +91,7 @@ def test_cpp_multi_gpu_example_picks_the_python_paths_candidate():
 
     exe = _build_multi()
     n = 96
-    best_py, score_py = _python_decision(n)
+    (best_py, score_py), totals = _python_decision(n)
     runs = [[exe, str(n)], [exe, str(n), "--no-collective"], [exe, str(n), "--no-collective", "--devices", "0,0,0", "--jacobian"]]
     with tempfile.TemporaryDirectory() as tmp:
         runs.append([exe, str(n), "--rank", "0", "--world", "1", "--id-file", os.path.join(tmp, "rccl_id")])
@@ -92,8 +101,7 @@ def test_cpp_multi_gpu_example_picks_the_python_paths_candidate():
             assert r.returncode == 0, " ".join(cmd) + "\n" + r.stdout + r.stderr
             m = re.search(r"^best candidate (\d+) score ([0-9.eE+-]+)$", r.stdout, re.M)
             assert m, r.stdout
-            assert int(m.group(1)) == best_py and abs(float(m.group(2)) - score_py) <= 1e-9 * max(1.0, abs(score_py)), \
-                (cmd, r.stdout, best_py, score_py)
+            assert _same_decision(int(m.group(1)), float(m.group(2)), best_py, score_py, totals), (cmd, r.stdout, best_py, score_py)
             if "0,0,0" in cmd:
                 shards = re.findall(r"rank (\d): shard \[(\d+), (\d+)\)", r.stdout)
                 lo, hi = [int(s[1]) for s in shards], [int(s[2]) for s in shards]
@@ -129,7 +137,7 @@ def test_cpp_example_sweep_agrees_with_ctypes_path():
     s = sc.cpu().numpy()
     total = s[:, 0] + s[:, 2] + s[:, 6] + s[:, 8]
     best = int(np.argmin(total))
-    assert best == best_cpp and abs(total[best] - score_cpp) <= 1e-9 * max(1.0, abs(score_cpp))
+    assert _same_decision(best_cpp, score_cpp, best, total[best], total)
     # every foot in contact in the printed plan sits on one of the three regions (index 0..2), feet in the air are -1
     for line in states:
         for pair in line.split():

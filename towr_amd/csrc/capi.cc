@@ -511,8 +511,10 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
         twr::DynWork w;
         std::memset(&w, 0, sizeof(w));
         w.nodes = blob + S.off_dyn_nodes + sizeof(twr::DynNode) * (size_t)sl.k0;
-        w.gather = blob + S.off_dyn_gather + sizeof(twr::DynGather) * (size_t)sl.k0 * 4;
-        w.put = blob + S.off_dyn_put;   // (records are addressed through DynGather::put_off)
+        w.sel = blob + S.off_dyn_sel + sizeof(twr::DynSel) * (size_t)sl.k0 * 4;
+        w.tile = blob + S.off_dyn_tile;   // (records are addressed through DynSel::tile)
+        w.poly = blob + S.off_dyn_poly + sizeof(twr::DynPoly) * (size_t)sl.poly0;
+        w.dummy = blob + S.off_dyn_dummy;
         w.map = blob + sl.map;
         w.hdr = blob;
         w.x_off = b->x_off[p];

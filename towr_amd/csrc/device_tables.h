@@ -102,8 +102,21 @@ constexpr int kDynImage = TWR_DYN_IMAGE;    // Jacobian values of one slice (LDS
 constexpr int kDynNodes = 16;      // time nodes per slice: four lanes each
 constexpr int kDynG0 = kDynImage + 2;   // image + parity slack, then the constraint values of the slice (6 per node)
 constexpr int kDynXsCap = TWR_DYN_XS;     // staged doubles per slice (8-bit staging indices 2..255; 0/1 = the zero pair)
-// per time node, shared by the four lanes of the quad (32 B)
+// Tables of dyn_kernel, split by what they depend on (round 4: a sweep reads every candidate's tables from HBM exactly
+// once per evaluation, so their size is traffic -- 33-38 KB per K = 200 quadruped candidate now, 88-112 KB with one
+// 64-byte record per (time node, role) and one 128-byte offset record per (polynomial combination, role)):
+//   DynNode  per time node (40 B)             grid time, base-spline lookup, row offsets of the node
+//   DynSel   per (time node, role) (4 B)      WHICH tile / polynomial records the lane reads
+//   DynPoly  per polynomial of an ee spline   start time, 1 / duration, which of its twelve node values are variables and
+//            (80 B)                            in which slot, and the RANK of every tile value inside its tile
+//   DynTile  per (polynomial combination of a slice, role) (20 B)   where the role's two tiles start in each row, and
+//                                              where the polynomials' variables sit in the slice's staging area
+// A tile value goes to  node base + tile start in the row (DynTile) + 8 * rank (DynPoly);  the local time of an ee
+// spline is t - t0 (as in RomSeg: the active polynomial is still chosen on the host by the reference's rule, the
+// subtraction differs from the reference's one-by-one subtraction by rounding only).
+// per time node, shared by the four lanes of the quad
 struct DynNode {
+  double t;              // global time of the node (TimeDiscretizationConstraint::dts_)
   double tb, iTb;        // base spline: local time in the active polynomial, 1/duration
   uint16_t sb_lin;       // byte offset inside xs of the active base-lin polynomial's first node value ([p0 v0 p1 v1] x 3)
   uint16_t sb_ang;
@@ -111,26 +124,41 @@ struct DynNode {
   uint16_t rs1, rs2;     // byte offsets of rows AY, AZ relative to the node's first value (AX = 0)
   uint16_t rl[3];        // rows LX, LY, LZ
 };
-static_assert(sizeof(DynNode) == 32, "DynNode layout");
-// per (time node, role): what the front half needs (64 B).  Roles >= n_ee get a dummy record: every candidate reads
-// the zero slot and every store goes to the lane's trash pair.
-struct DynGather {
-  double tm, iTm, tf, iTf;
-  uint8_t idx_m[12], idx_f[12];  // staging index of candidate c = j*3+d (0 = constant zero)
-  uint32_t flags;                // bit 0: stance ee-motion polynomial (p1 shares p0's variable: w_p1 folds into w_p0)
-  uint32_t put_off;              // byte offset of this lane's DynPut record from DynWork::put
+static_assert(sizeof(DynNode) == 40, "DynNode layout");
+struct DynSel {
+  uint16_t tile;         // index of the lane's DynTile record (DynWork::tile)
+  uint8_t dm, df;        // ee-motion / ee-force polynomial: index of its DynPoly record relative to DynWork::poly,
+                         // 255 = the structure's dummy record (roles >= n_ee)
 };
-static_assert(sizeof(DynGather) == 64, "DynGather layout");
-// per (polynomial combination, role): where the end-effector tiles go (128 B).  Byte offsets relative to the node's
-// first value.  They depend only on WHICH polynomials are active (the row layout), so consecutive time nodes share a
-// record (DynGather::put_idx).  A candidate that is not a variable points at entry 8 + role of row AX -- a base-ang
-// value that the same wave writes later in program order (the tiles are stored first), so the garbage never leaves.
-struct DynPut {
-  uint16_t m[12][2];   // [f]x J_p : rows (d+1)%3 and (d+2)%3 of the angular block
-  uint16_t f[12][3];   // {[r]x J_f ; -J_f}: the same two angular rows, then linear row d
-  uint16_t pad[4];
+static_assert(sizeof(DynSel) == 4, "DynSel layout");
+constexpr int kDynPolyDummy = 255;
+// One polynomial of an ee-motion / ee-force spline.  Candidate c = j*3+d is node value (j, d), j in {p0,v0,p1,v1}.
+//   rel[c]   slot of the variable holding the candidate (its staging index is DynTile::s_m|s_f + rel), 0 when it is not a
+//            variable;  pres[c] = 0xFF / 0x00: the staging indices of four candidates are (S4 + rel4) & pres4, so a value that
+//            is not a variable reads the zero slot (index 0) without a select
+//   code     ee-motion: [c][2] = 8 * rank of the candidate's slot among the slots of rows (d+1)%3 and (d+2)%3 of the tile;
+//            ee-force:  [c][3] = the same two angular rows, then linear row d.
+//            A candidate that is NOT a variable carries the code of another candidate of the same d that IS one:
+//            ee-motion -> p0 (positions are always variables); the kernel stores j = 3, 2, 1 first and p0 last, so p0's
+//            value overwrites the garbage.  ee-force -> the node value of the OTHER node (a force node is either all
+//            variables or all constant); the kernel then stores that node's VALUE a second time (flags bits 1, 2), so no
+//            order is needed.  A polynomial without any variable has codes 0 and its tile starts are pointed at base-lin
+//            entries of its node, which the same wave overwrites later in program order (DynTile).
+struct DynPoly {
+  double t0, iT;         // start time (sum of the durations before it), 1 / duration
+  uint8_t rel[12];
+  uint8_t pres[12];
+  uint32_t flags;        // bit 0: stance ee-motion polynomial (p1 shares p0's variable: w_p1 folds into w_p0);
+                         // bit 1: first node constant (p0, v0 store p1's, v1's value); bit 2: second node constant
+  uint8_t code[36];
 };
-static_assert(sizeof(DynPut) == 128, "DynPut layout");
+static_assert(sizeof(DynPoly) == 80, "DynPoly layout");
+struct DynTile {
+  uint16_t base_m[3];    // byte offset, relative to the node's first value, of the role's ee-motion tile in rows AX, AY, AZ
+  uint16_t base_f[6];    // ee-force tile in rows AX, AY, AZ, LX, LY, LZ
+  uint8_t s_m, s_f;      // staging index of slot 0 of the active ee-motion / ee-force polynomial
+};
+static_assert(sizeof(DynTile) == 20, "DynTile layout");
 
 struct ForceNode {   // one non-constant ee-force node (force_constraint.cc:50-60)
   int32_t fidx;      // x index of the node's force px (py = +2, pz = +4)
@@ -302,17 +330,18 @@ struct DevStruct {
 // pointers / offsets are absolute so that a workgroup needs no header lookup.
 struct DynWork {          // cnt <= 16 time nodes of "dynamic"
   uint64_t nodes;         // DynNode[k0..]
-  uint64_t gather;        // DynGather[k0 * 4 ..]
-  uint64_t put;           // DynPut records of the structure (indexed through DynGather::put_off)
+  uint64_t sel;           // DynSel[k0 * 4 ..]
+  uint64_t tile;          // DynTile records of the structure (indexed by DynSel::tile)
+  uint64_t poly;          // the slice's first DynPoly record (DynSel::dm / df count from it)
+  uint64_t dummy;         // the structure's dummy DynPoly record
   uint64_t map;           // uint16_t[64][4]: lane l stages x[map[l][c]] at xs[2 + 64 c + l]
   uint64_t hdr;           // DevStruct (mass, gravity, inertia)
   int64_t x_off;          // problem's x
   int64_t g_off;          // first constraint value of the run (row 6*k0 of the set)
   int64_t j_off;          // first Jacobian value of the run
   int32_t cnt, nvals;     // time nodes, Jacobian values of the run
-  int64_t pad;
 };
-static_assert(sizeof(DynWork) == 80, "DynWork layout");
+static_assert(sizeof(DynWork) == 88, "DynWork layout");
 
 struct RomWork {          // cnt <= 64 time nodes of "rangeofmotion-<ee>"
   uint64_t nodes;         // RomNode[k0..]

@@ -704,18 +704,67 @@ TWR_DEV double lds_f64(const char* __restrict__ lds, uint32_t byte_off) {
   return *reinterpret_cast<const double*>(lds + byte_off);
 }
 TWR_DEV void lds_put(char* __restrict__ lds, uint32_t byte_off, double v) { *reinterpret_cast<double*>(lds + byte_off) = v; }
-// staged candidate c of a spline: xs[idx[c]]
-TWR_DEV void gather12s(const char* __restrict__ xs, const uint8_t idx[12], double v[12]) {
-  const uint32_t* w = reinterpret_cast<const uint32_t*>(idx);
+// staged candidate c of a spline: xs[idx[c]], idx = twelve bytes in three dwords
+TWR_DEV void gather12s(const char* __restrict__ xs, const uint32_t w[3], double v[12]) {
 #pragma unroll
   for (int c = 0; c < 12; ++c) v[c] = lds_f64(xs, ((w[c >> 2] >> (8 * (c & 3))) & 0xFFu) << 3);
 }
-TWR_DEV void dyn2_load_rec(const DynWork& w, int lane, DynNode& nd, DynGather& ga) {
+// What a lane needs of its records for the FRONT half of a slice (prefetched during the previous slice's back half) and
+// for the tile stores of the BACK half (the codes, loaded while the previous slice is copied out).  Whole dwords: no
+// sub-dword struct fields cross the loop back-edge (see the compiler note in DESIGN 6.0).
+struct DynFrontRec {
+  DynNode nd;
+  double t0m, iTm, t0f, iTf;
+  uint32_t relm[3], presm[3], relf[3], presf[3];
+  uint32_t flagsm, flagsf;
+  uint32_t tl[5];      // DynTile as five dwords: base_m[0..1] | base_m[2], base_f[0] | base_f[1..2] | base_f[3..4] | base_f[5], s_m, s_f
+};
+struct DynCodes {
+  uint32_t m[6];       // DynPoly::code of the ee-motion polynomial: [c][2]
+  uint32_t f[9];       // of the ee-force polynomial: [c][3]
+};
+TWR_DEV uint32_t dyn2_load_sel(const DynWork& w, int lane) {
   const int kk = min(lane >> 2, w.cnt - 1);
-  nd = gptr<DynNode>(w.nodes)[kk];
-  ga = gptr<DynGather>(w.gather)[kk * 4 + (lane & 3)];
+  return gptr<uint32_t>(w.sel)[kk * 4 + (lane & 3)];
 }
-TWR_DEV void dyn2_front(const DynNode& nd, const DynGather& ga, const char* __restrict__ xs, int lane, Dyn2Front& S) {
+TWR_DEV const TWR_GLOBAL char* dyn2_poly_addr(const DynWork& w, uint32_t d) {   // d = DynSel::dm or df
+  const uint64_t rec = w.poly + (uint64_t)d * sizeof(DynPoly);
+  return reinterpret_cast<const TWR_GLOBAL char*>(d == (uint32_t)kDynPolyDummy ? w.dummy : rec);
+}
+TWR_DEV void dyn2_load_front(const DynWork& w, uint32_t sel, int lane, DynFrontRec& r) {
+  const int kk = min(lane >> 2, w.cnt - 1);
+  r.nd = gptr<DynNode>(w.nodes)[kk];
+  const TWR_GLOBAL char* pm = dyn2_poly_addr(w, (sel >> 16) & 0xFFu);
+  const TWR_GLOBAL char* pf = dyn2_poly_addr(w, sel >> 24);
+  const TWR_GLOBAL uint32_t* tl = reinterpret_cast<const TWR_GLOBAL uint32_t*>(w.tile + (uint64_t)(sel & 0xFFFFu) * sizeof(DynTile));
+  static_assert(offsetof(DynPoly, rel) == 16 && offsetof(DynPoly, pres) == 28 && offsetof(DynPoly, flags) == 40 && offsetof(DynPoly, code) == 44,
+                "DynPoly dwords");
+  const TWR_GLOBAL double* dm = reinterpret_cast<const TWR_GLOBAL double*>(pm);
+  const TWR_GLOBAL double* df = reinterpret_cast<const TWR_GLOBAL double*>(pf);
+  const TWR_GLOBAL uint32_t* um = reinterpret_cast<const TWR_GLOBAL uint32_t*>(pm);
+  const TWR_GLOBAL uint32_t* uf = reinterpret_cast<const TWR_GLOBAL uint32_t*>(pf);
+  r.t0m = dm[0]; r.iTm = dm[1];
+  r.t0f = df[0]; r.iTf = df[1];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    r.relm[i] = um[4 + i]; r.presm[i] = um[7 + i];
+    r.relf[i] = uf[4 + i]; r.presf[i] = uf[7 + i];
+  }
+  r.flagsm = um[10];
+  r.flagsf = uf[10];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) r.tl[i] = tl[i];
+}
+TWR_DEV void dyn2_load_codes(const DynWork& w, uint32_t sel, DynCodes& c) {
+  const TWR_GLOBAL uint32_t* um = reinterpret_cast<const TWR_GLOBAL uint32_t*>(dyn2_poly_addr(w, (sel >> 16) & 0xFFu));
+  const TWR_GLOBAL uint32_t* uf = reinterpret_cast<const TWR_GLOBAL uint32_t*>(dyn2_poly_addr(w, sel >> 24));
+#pragma unroll
+  for (int i = 0; i < 6; ++i) c.m[i] = um[11 + i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) c.f[i] = uf[11 + i];
+}
+TWR_DEV void dyn2_front(const DynFrontRec& r, const char* __restrict__ xs, int lane, Dyn2Front& S) {
+  const DynNode& nd = r.nd;
   const int role = lane & 3;
   double wP[4], wV[4], wA[4];
   hermite_all(nd.tb, nd.iTb, wP, wV, wA);
@@ -739,12 +788,16 @@ TWR_DEV void dyn2_front(const DynNode& nd, const DynGather& ga, const char* __re
       S.edd[d] = wA[0] * ba[d] + wA[1] * ba[3 + d] + wA[2] * ba[6 + d] + wA[3] * ba[9 + d];
     }
   }
-  // this lane's end-effector: weights and spline points (absent candidates read the zero slot)
+  // staging indices of the twelve candidates of a spline, four at a time: (S4 + rel4) & pres4 -- a candidate that is not a
+  // variable reads index 0, the zero slot (no selects in the spline evaluation)
+  const uint32_t sm4 = ((r.tl[4] >> 16) & 0xFFu) * 0x01010101u, sf4 = (r.tl[4] >> 24) * 0x01010101u;
+  // this lane's end-effector: weights and spline points
   {
     double vm[12], p[3];
-    gather12s(xs, ga.idx_m, vm);
-    hermite_pos(ga.tm, ga.iTm, S.wm);
-    S.wm[0] += (ga.flags & 1) ? S.wm[2] : 0.0;   // stance polynomial: p1 is the same variable as p0
+    const uint32_t im[3] = {(sm4 + r.relm[0]) & r.presm[0], (sm4 + r.relm[1]) & r.presm[1], (sm4 + r.relm[2]) & r.presm[2]};
+    gather12s(xs, im, vm);
+    hermite_pos(nd.t - r.t0m, r.iTm, S.wm);
+    S.wm[0] += (r.flagsm & 1) ? S.wm[2] : 0.0;   // stance polynomial: p1 is the same variable as p0
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       p[d] = S.wm[0] * vm[d] + S.wm[1] * vm[3 + d] + S.wm[2] * vm[6 + d] + S.wm[3] * vm[9 + d];
@@ -753,8 +806,9 @@ TWR_DEV void dyn2_front(const DynNode& nd, const DynGather& ga, const char* __re
   }
   {
     double vf[12];
-    gather12s(xs, ga.idx_f, vf);
-    hermite_pos(ga.tf, ga.iTf, S.wf);
+    const uint32_t jf[3] = {(sf4 + r.relf[0]) & r.presf[0], (sf4 + r.relf[1]) & r.presf[1], (sf4 + r.relf[2]) & r.presf[2]};
+    gather12s(xs, jf, vf);
+    hermite_pos(nd.t - r.t0f, r.iTf, S.wf);
 #pragma unroll
     for (int d = 0; d < 3; ++d) S.f[d] = S.wf[0] * vf[d] + S.wf[1] * vf[3 + d] + S.wf[2] * vf[6 + d] + S.wf[3] * vf[9 + d];
   }
@@ -776,8 +830,9 @@ TWR_DEV void dyn2_front(const DynNode& nd, const DynGather& ga, const char* __re
 
 // Back half: Jacobian blocks and constraint values into the LDS image.  `img` is the byte address of the image
 // (parity shift included), node base and row offsets come from DynNode, tile offsets from DynPut.
-TWR_DEV void dyn2_back(const DynWork& w, const DynNode& nd, const DynPut& pu, const Dyn2Front& S, double* __restrict__ gst,
+TWR_DEV void dyn2_back(const DynWork& w, const DynFrontRec& rec, const DynCodes& cd, const Dyn2Front& S, double* __restrict__ gst,
                        char* __restrict__ img, int lane, bool want_g, bool want_j) {
+  const DynNode& nd = rec.nd;
   const int kk = lane >> 2, role = lane & 3;
   if (kk >= w.cnt) return;
   const double (&cdd)[3] = S.cdd, (&ed)[3] = S.ed, (&edd)[3] = S.edd;
@@ -785,24 +840,44 @@ TWR_DEV void dyn2_back(const DynWork& w, const DynNode& nd, const DynPut& pu, co
   const double sx = S.sx, cx = S.cx, sy = S.sy, cy = S.cy, sz = S.sz, cz = S.cz;
   char* nb = img + nd.nb;   // first value of this time node
   // --- ee-motion block [f]x J_p (:181-192) and ee-force block {[r]x J_f ; -J_f} (:167-179) of this lane's
-  // end-effector, BEFORE the base blocks: a candidate that is not a variable carries the offset of a base-ang entry
-  // of this node, which the base-ang code below overwrites
+  // end-effector, BEFORE the base blocks.  A value goes to  node base + tile start in its row (DynTile) + 8 * rank
+  // (DynPoly::code, one byte per value); see DynPoly for where the values of candidates that are not variables end up.
   if (want_j) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#define TWR_EE_TILE2(D, R1, R2)                                       \
-  {                                                                   \
-    lds_put(nb, pu.m[j * 3 + D][0], crs<R1, D>(f) * wm[j]);          \
-    lds_put(nb, pu.m[j * 3 + D][1], crs<R2, D>(f) * wm[j]);          \
-    lds_put(nb, pu.f[j * 3 + D][0], crs<R1, D>(rv) * wf[j]);         \
-    lds_put(nb, pu.f[j * 3 + D][1], crs<R2, D>(rv) * wf[j]);         \
-    lds_put(nb, pu.f[j * 3 + D][2], -wf[j]);                         \
+    char* rowm[3] = {nb + (rec.tl[0] & 0xFFFFu), nb + (rec.tl[0] >> 16), nb + (rec.tl[1] & 0xFFFFu)};
+    char* rowf[6] = {nb + (rec.tl[1] >> 16), nb + (rec.tl[2] & 0xFFFFu), nb + (rec.tl[2] >> 16),
+                     nb + (rec.tl[3] & 0xFFFFu), nb + (rec.tl[3] >> 16), nb + (rec.tl[4] & 0xFFFFu)};
+    // a force node that is constant stores the values of the polynomial's other node once more (same slots, same values)
+    const bool c0 = rec.flagsf & 2, c1 = rec.flagsf & 4;
+    const double wfp[4] = {c0 ? wf[2] : wf[0], c0 ? wf[3] : wf[1], c1 ? wf[0] : wf[2], c1 ? wf[1] : wf[3]};
+#define TWR_CODE_M(c, k) ((cd.m[(2 * (c) + (k)) >> 2] >> (8 * ((2 * (c) + (k)) & 3))) & 0xFFu)
+#define TWR_CODE_F(c, k) ((cd.f[(3 * (c) + (k)) >> 2] >> (8 * ((3 * (c) + (k)) & 3))) & 0xFFu)
+#define TWR_EE_TILE_M(J, D, R1, R2)                                              \
+  {                                                                              \
+    lds_put(rowm[R1], TWR_CODE_M((J) * 3 + D, 0), crs<R1, D>(f) * wm[J]);        \
+    lds_put(rowm[R2], TWR_CODE_M((J) * 3 + D, 1), crs<R2, D>(f) * wm[J]);        \
   }
-      TWR_EE_TILE2(0, 1, 2)
-      TWR_EE_TILE2(1, 2, 0)
-      TWR_EE_TILE2(2, 0, 1)
-#undef TWR_EE_TILE2
-    }
+#define TWR_EE_TILE_F(J, D, R1, R2)                                              \
+  {                                                                              \
+    lds_put(rowf[R1], TWR_CODE_F((J) * 3 + D, 0), crs<R1, D>(rv) * wfp[J]);      \
+    lds_put(rowf[R2], TWR_CODE_F((J) * 3 + D, 1), crs<R2, D>(rv) * wfp[J]);      \
+    lds_put(rowf[3 + D], TWR_CODE_F((J) * 3 + D, 2), -wfp[J]);                   \
+  }
+#define TWR_EE_TILES(J)      \
+  TWR_EE_TILE_M(J, 0, 1, 2)  \
+  TWR_EE_TILE_M(J, 1, 2, 0)  \
+  TWR_EE_TILE_M(J, 2, 0, 1)  \
+  TWR_EE_TILE_F(J, 0, 1, 2)  \
+  TWR_EE_TILE_F(J, 1, 2, 0)  \
+  TWR_EE_TILE_F(J, 2, 0, 1)
+    TWR_EE_TILES(3)   // (ee-motion: p0 LAST -- it overwrites what candidates without a variable left in its slots)
+    TWR_EE_TILES(2)
+    TWR_EE_TILES(1)
+    TWR_EE_TILES(0)
+#undef TWR_EE_TILES
+#undef TWR_EE_TILE_F
+#undef TWR_EE_TILE_M
+#undef TWR_CODE_F
+#undef TWR_CODE_M
   }
   // --- angular quantities (euler_converter.cc:58-83,133-166,207-221)
   double R[3][3];
@@ -937,13 +1012,15 @@ TWR_DEV void dyn2_back(const DynWork& w, const DynNode& nd, const DynPut& pu, co
 
 // Loop of one persistent single-wave workgroup over its strided slices.  State at the top of iteration i: xs holds
 // x(i); `xr` (registers) holds x(i+1), gathered one iteration ago; mapr holds the staging map of slice i+2;
-// the front records of slices i and i+1 are in registers.
-//   F  front(i): LDS reads of xs + the front record -> compact state
-//   P  issue the load of slice i's put record (needed by the back half only; it lands during the copy-out)
+// the front records of slice i and the record selectors (DynSel) of slices i and i+1 are in registers.
+//   F  front(i): LDS reads of xs + the front records -> compact state
+//   P  issue the loads of slice i's tile codes (needed by the back half only) and of slice i+1's front records (node,
+//      polynomial and tile records, addressed through its selector, which arrived an iteration ago); they land during
+//      the copy-out
 //   O  copy-out(i-1): image -> HBM (one phase late: the x gathers of the previous iteration were issued before
 //      these stores, so waiting for them never waits for a store)
 //   B  back(i): Jacobian blocks -> image
-//   S  xs <- xr (x(i+1));  then issue: front record of slice i+2, xr <- gather x(i+2), mapr <- map(i+3)
+//   S  xs <- xr (x(i+1));  then issue: selector of slice i+2, xr <- gather x(i+2), mapr <- map(i+3)
 // (`stage`: kDynLds doubles of LDS owned by this wave; the wave takes slices i, i + stride, ...)
 // WANT_G / WANT_J are compile-time, the first iteration copies the not-yet-filled image to a dump region instead of
 // skipping the copy-out, and no store sits in a divergent branch: the number of vector-memory instructions between a
@@ -986,19 +1063,17 @@ TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double
   double* pdst = dump;
   double* pg = dump + kDynImage + 2;
   DynWork w0 = wp, w1 = wp, w2 = wp;
-  DynNode nd0, nd1;
-  DynGather ga0, ga1;
+  DynFrontRec fr0;
   double xr[4];
   uint2 mapr = load_map(w0);
-  dyn2_load_rec(w0, lane, nd0, ga0);
+  uint32_t sel0 = dyn2_load_sel(w0, lane), sel1 = sel0;
+  dyn2_load_front(w0, sel0, lane, fr0);                  // (the only exposed record -> record dependency)
   gather_x(w0, mapr, xr);
   stage_x(xr);                                           // x(first slice): the only exposed gather
-  nd1 = nd0;
-  ga1 = ga0;
   if (i + stride < n_work) {
     w1 = work[i + stride];
     mapr = load_map(w1);
-    dyn2_load_rec(w1, lane, nd1, ga1);
+    sel1 = dyn2_load_sel(w1, lane);
     gather_x(w1, mapr, xr);
   }
   if (i + 2 * stride < n_work) {
@@ -1012,8 +1087,11 @@ TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double
     double* dst = jac + w0.j_off;
     const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
     Dyn2Front S;
-    dyn2_front(nd0, ga0, xs, lane, S);                                                       // F
-    const DynPut pu = *gptr<DynPut>(w0.put + ga0.put_off);                                   // P (earlier costs spills: slower)
+    dyn2_front(fr0, xs, lane, S);                                                            // F
+    DynCodes cd;
+    dyn2_load_codes(w0, sel0, cd);                                                           // P  (lands during the copy-out)
+    DynFrontRec fr1 = fr0;
+    if (has1) dyn2_load_front(w1, sel1, lane, fr1);                                          //    front records of slice i+1
     // (the copy-out runs at raised wave priority: with two waves per SIMD a wave in its store phase then gets its LDS
     // reads and stores issued ahead of its neighbour's math, which keeps the store stream of the CU steadier -- A/B on one
     // box 0.602-0.608 -> 0.591-0.596 ms; raised priority around the prefetches as well, or in rom_kernel, which runs one
@@ -1021,20 +1099,19 @@ TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double
     __builtin_amdgcn_s_setprio(3);
     copy_out(pdst, pg, wp.nvals, wp.cnt);                                                    // O
     __builtin_amdgcn_s_setprio(0);
-    dyn2_back(w0, nd0, pu, S, gst, reinterpret_cast<char*>(stage + par), lane, WANT_G, WANT_J);   // B
+    dyn2_back(w0, fr0, cd, S, gst, reinterpret_cast<char*>(stage + par), lane, WANT_G, WANT_J);   // B
     if (has1) stage_x(xr);                                                                   // S
-    DynNode nd2 = nd1;
-    DynGather ga2 = ga1;
+    uint32_t sel2 = sel1;
     if (has2) {
-      dyn2_load_rec(w2, lane, nd2, ga2);
+      sel2 = dyn2_load_sel(w2, lane);
       gather_x(w2, mapr, xr);
     }
     if (has3) mapr = load_map(w3);
     wp = w0;
     pdst = dst;
     pg = g + w0.g_off;
-    w0 = w1; nd0 = nd1; ga0 = ga1;
-    w1 = w2; nd1 = nd2; ga1 = ga2;
+    w0 = w1; fr0 = fr1; sel0 = sel1;
+    w1 = w2; sel1 = sel2;
     w2 = w3;
   }
   copy_out(pdst, pg, wp.nvals, wp.cnt);                 // last slice of this workgroup

@@ -618,14 +618,108 @@ void Structure::PackBlob() {
       return n;
     };
     auto nvals_of = [&](int k0, int k1) { return row_ptr[row_dyn + 6 * k1] - row_ptr[row_dyn + 6 * k0]; };
+    // --- DynPoly: one record per polynomial of every ee spline, ordered by start time, so that the records a slice
+    // (a short time window) reads sit next to each other and an 8-bit index relative to the slice's first record
+    // reaches all of them
+    struct PolyRef {
+      double t0;
+      int e, kind, q;   // kind 0: ee-motion, 1: ee-force
+    };
+    std::vector<PolyRef> order;
+    for (int e = 0; e < n_ee; ++e)
+      for (int kind = 0; kind < 2; ++kind) {
+        const std::vector<double>& dur = kind == 0 ? motion[e].durations : force[e].durations;
+        double t0 = 0.0;   // the running sum Spline::GetSegmentID compares t against (spline.cc:52-57)
+        for (size_t q = 0; q < dur.size(); ++q) {
+          order.push_back({t0, e, kind, (int)q});
+          t0 += dur[q];
+        }
+      }
+    std::stable_sort(order.begin(), order.end(), [](const PolyRef& a, const PolyRef& b) { return a.t0 < b.t0; });
+    std::vector<std::vector<int>> rec_of[2];   // [kind][ee][q] -> record index
+    for (int kind = 0; kind < 2; ++kind) {
+      rec_of[kind].resize(n_ee);
+      for (int e = 0; e < n_ee; ++e) rec_of[kind][e].resize(kind == 0 ? mpoly[e].size() : fpoly[e].size());
+    }
+    std::vector<DynPoly> polys(order.size() + 1);
+    for (size_t i = 0; i < order.size(); ++i) {
+      const PolyRef& pr = order[i];
+      rec_of[pr.kind][pr.e][pr.q] = (int)i;
+      const PolyDesc& pd = pr.kind == 0 ? mpoly[pr.e][pr.q] : fpoly[pr.e][pr.q];
+      DynPoly& P = polys[i];
+      std::memset(&P, 0, sizeof(P));
+      P.t0 = pr.t0;
+      P.iT = pd.iT;
+      int dim_of_slot[12] = {0}, slot_of[12];
+      for (int c = 0; c < 12; ++c) {
+        slot_of[c] = pd.cand[c] == 0xFFFF ? -1 : (pd.cand[c] & 0xF);
+        if (slot_of[c] >= 0) {
+          P.rel[c] = (uint8_t)slot_of[c];
+          P.pres[c] = 0xFF;
+          dim_of_slot[slot_of[c]] = c % 3;
+        }
+      }
+      const int nslots = pd.meta & 0xF;
+      auto rank = [&](int slot, int row_dim, bool equal) {   // position of the slot among the slots a row holds
+        int r = 0;
+        for (int s2 = 0; s2 < slot; ++s2) r += (dim_of_slot[s2] == row_dim) == equal;
+        return r;
+      };
+      if (pr.kind == 0) {
+        if ((pd.meta >> 16) & 1) P.flags |= 1;
+        for (int d = 0; d < 3; ++d)
+          if (slot_of[d] < 0) throw std::runtime_error("ee-motion node position that is not a variable");
+        for (int c = 0; c < 12; ++c) {
+          const int d = c % 3, src = slot_of[c] >= 0 ? c : d;   // not a variable: p0's slots (stored last by the kernel)
+          P.code[2 * c + 0] = (uint8_t)(8 * rank(slot_of[src], (d + 1) % 3, false));
+          P.code[2 * c + 1] = (uint8_t)(8 * rank(slot_of[src], (d + 2) % 3, false));
+        }
+      } else {
+        bool present[4];
+        for (int j = 0; j < 4; ++j) {
+          present[j] = slot_of[3 * j] >= 0;
+          for (int d = 1; d < 3; ++d)
+            if ((slot_of[3 * j + d] >= 0) != present[j]) throw std::runtime_error("ee-force node value that is a variable in some dimensions only");
+        }
+        if (present[0] != present[1] || present[2] != present[3]) throw std::runtime_error("ee-force node with a constant position or velocity only");
+        if (!present[0]) P.flags |= 2;
+        if (!present[2]) P.flags |= 4;
+        for (int c = 0; c < 12; ++c) {
+          const int d = c % 3, j = c / 3;
+          if (nslots == 0) continue;                      // no variables at all: codes 0, the tile starts point at trash
+          const int src = present[j] ? c : (j ^ 2) * 3 + d;   // constant node: the other node's value of the same kind
+          if (slot_of[src] < 0) throw std::runtime_error("ee-force polynomial layout not understood");
+          P.code[3 * c + 0] = (uint8_t)(8 * rank(slot_of[src], (d + 1) % 3, false));
+          P.code[3 * c + 1] = (uint8_t)(8 * rank(slot_of[src], (d + 2) % 3, false));
+          P.code[3 * c + 2] = (uint8_t)(8 * rank(slot_of[src], d, true));
+        }
+      }
+    }
+    {   // the dummy record of roles >= n_ee: every value reads the zero slot, finite weights, codes 0
+      DynPoly& P = polys.back();
+      std::memset(&P, 0, sizeof(P));
+      P.iT = 1.0;
+      P.flags = 2 | 4;
+    }
+    auto rec_span_ok = [&](int k0, int k1) {   // the 8-bit record indices of a slice (255 = dummy)
+      int lo = 1 << 30, hi = -1;
+      for (int e = 0; e < n_ee; ++e)
+        for (int k : {k0, k1 - 1}) {
+          lo = std::min({lo, rec_of[0][e][dyn_motion[e][k0].poly], rec_of[1][e][dyn_force[e][k0].poly]});
+          hi = std::max({hi, rec_of[0][e][dyn_motion[e][k].poly], rec_of[1][e][dyn_force[e][k].poly]});
+        }
+      return hi - lo < kDynPolyDummy;
+    };
     std::vector<DynNode> nodes(K);
-    std::vector<DynGather> gather((size_t)K * 4);
-    std::vector<DynPut> putv;   // one per (polynomial combination, role)
-    std::vector<int> combo_key, combo_first;   // active polynomial ids of the last combination
+    std::vector<DynSel> sel((size_t)K * 4);
+    std::vector<DynTile> tiles;   // four per (slice, polynomial combination)
+    std::vector<int> combo_key;   // active polynomial ids of the last combination
     dyn_slices.clear();
     for (int k0 = 0; k0 < K;) {
       int k1 = k0;
-      while (k1 < K && k1 - k0 < kDynNodes && nvals_of(k0, k1 + 1) <= kDynImage && stage_count(k0, k1 + 1) <= kDynXsCap) ++k1;
+      while (k1 < K && k1 - k0 < kDynNodes && nvals_of(k0, k1 + 1) <= kDynImage && stage_count(k0, k1 + 1) <= kDynXsCap &&
+             rec_span_ok(k0, k1 + 1))
+        ++k1;
       if (k1 == k0) throw std::runtime_error("one time node of the dynamic set exceeds the LDS staging capacity");
       if (nvals_of(k0, k1) < 16) throw std::runtime_error("a time-node run with fewer than 16 Jacobian values cannot be staged");
       // staging layout of the slice: xs index 2 + e
@@ -654,11 +748,16 @@ void Structure::PackBlob() {
       sl.cnt = k1 - k0;
       sl.nvals = nvals_of(k0, k1);
       sl.map = put(map.data(), map.size() * sizeof(uint16_t));
+      sl.poly0 = 1 << 30;
+      for (int e = 0; e < n_ee; ++e)
+        sl.poly0 = std::min({sl.poly0, rec_of[0][e][dyn_motion[e][k0].poly], rec_of[1][e][dyn_force[e][k0].poly]});
       dyn_slices.push_back(sl);
+      combo_key.clear();   // a new slice has its own staging layout: its first node opens a new combination
       for (int k = k0; k < k1; ++k) {
         const int row0 = row_dyn + 6 * k, v0 = row_ptr[row0];
         DynNode& N = nodes[k];
         std::memset(&N, 0, sizeof(N));
+        N.t = grid_dyn[k];
         N.tb = dyn_base[k].t_local;
         N.iTb = 1.0 / base.durations[dyn_base[k].poly];
         N.sb_lin = (uint16_t)(8 * (2 + 6 * (dyn_base[k].poly - qmin)));
@@ -668,6 +767,13 @@ void Structure::PackBlob() {
         N.rs1 = (uint16_t)(8 * (row_ptr[row0 + 1] - v0));
         N.rs2 = (uint16_t)(8 * (row_ptr[row0 + 2] - v0));
         for (int d = 0; d < 3; ++d) N.rl[d] = (uint16_t)(8 * (row_ptr[row0 + 3 + d] - v0));
+        // where a tile starts in a row, relative to the node's first value: the position of the polynomial's first
+        // variable in the CSR row (read off the pattern itself, so kernel and pattern cannot disagree)
+        auto tile_start = [&](int row, int col) -> int {
+          const int32_t* b = col_idx.data() + row_ptr[row0 + row];
+          const int32_t* e2 = col_idx.data() + row_ptr[row0 + row + 1];
+          return (int)(std::lower_bound(b, e2, col) - col_idx.data()) - v0;
+        };
         auto find = [&](int row, int col) -> int {  // position of `col` in row `row`, relative to the node's first value
           const int32_t* b = col_idx.data() + row_ptr[row0 + row];
           const int32_t* e2 = col_idx.data() + row_ptr[row0 + row + 1];
@@ -675,7 +781,7 @@ void Structure::PackBlob() {
           if (it == e2 || *it != col) throw std::runtime_error("dynamic pattern lacks an expected column");
           return (int)(it - col_idx.data()) - v0;
         };
-        // the put offsets depend on the node only through the active polynomials: one record set per combination
+        // the tile starts depend on the node only through the active polynomials: one record set per combination
         std::vector<int> key;
         for (int e = 0; e < n_ee; ++e) {
           key.push_back(dyn_motion[e][k].poly);
@@ -684,58 +790,68 @@ void Structure::PackBlob() {
         const bool new_combo = key != combo_key;
         if (new_combo) {
           combo_key = key;
-          putv.resize(putv.size() + 4);
+          tiles.resize(tiles.size() + 4);
         }
-        const size_t put0 = putv.size() - 4;
+        const size_t tile0 = tiles.size() - 4;
+        if (tile0 + 3 > 0xFFFF) throw std::runtime_error("too many polynomial combinations for 16-bit tile indices");
         for (int role = 0; role < 4; ++role) {
-          DynGather& G = gather[(size_t)k * 4 + role];
-          DynPut& P = putv[put0 + role];
-          DynPut Pold = P;
-          std::memset(&G, 0, sizeof(G));
-          G.put_off = (uint32_t)((put0 + role) * sizeof(DynPut));
-          const int trash = 8 * (8 + role);   // base-ang entry of row AX, rewritten after the tiles (see DynPut)
-          for (int c = 0; c < 12; ++c) {
-            P.m[c][0] = P.m[c][1] = (uint16_t)trash;
-            P.f[c][0] = P.f[c][1] = P.f[c][2] = (uint16_t)trash;
-          }
-          for (int i = 0; i < 4; ++i) P.pad[i] = 0;
-          G.tm = G.tf = 0.0;
-          G.iTm = G.iTf = 1.0;   // dummy roles evaluate finite weights on zeros
-          if (role >= n_ee) {
-            if (!new_combo && std::memcmp(&Pold, &P, sizeof(P)) != 0) throw std::runtime_error("dummy put record changed");
-            continue;
-          }
-          const int e = role;
-          const PolyDesc& mp = mpoly[e][dyn_motion[e][k].poly];
-          const PolyDesc& fp = fpoly[e][dyn_force[e][k].poly];
-          G.tm = dyn_motion[e][k].t_local; G.iTm = mp.iT;
-          G.tf = dyn_force[e][k].t_local;  G.iTf = fp.iT;
-          G.flags = (mp.meta >> 16) & 1;
-          for (int c = 0; c < 12; ++c) {
-            const int d = c % 3, r1 = (d + 1) % 3, r2 = (d + 2) % 3;
-            if (mp.cand[c] != 0xFFFF) {
-              const int col = mp.xbase + (mp.cand[c] & 0xF);
-              G.idx_m[c] = (uint8_t)(2 + mst[e] + col - mlo[e]);
-              P.m[c][0] = (uint16_t)(8 * find(r1, col));
-              P.m[c][1] = (uint16_t)(8 * find(r2, col));
+          DynSel& Sx = sel[(size_t)k * 4 + role];
+          DynTile T;
+          std::memset(&T, 0, sizeof(T));
+          Sx.tile = (uint16_t)(tile0 + role);
+          Sx.dm = Sx.df = (uint8_t)kDynPolyDummy;
+          // trash: base-lin entry `role` of every row (the rows' first four entries are base-lin values, which the same
+          // wave writes after the tiles); the dummy record's codes are 0
+          const int row_start[6] = {0, N.rs1, N.rs2, N.rl[0], N.rl[1], N.rl[2]};
+          for (int r = 0; r < 3; ++r) T.base_m[r] = (uint16_t)(row_start[r] + 8 * role);
+          for (int r = 0; r < 6; ++r) T.base_f[r] = (uint16_t)(row_start[r] + 8 * role);
+          if (role < n_ee) {
+            const int e = role;
+            const int qm = dyn_motion[e][k].poly, qf = dyn_force[e][k].poly;
+            const PolyDesc& mp = mpoly[e][qm];
+            const PolyDesc& fp = fpoly[e][qf];
+            Sx.dm = (uint8_t)(rec_of[0][e][qm] - sl.poly0);
+            Sx.df = (uint8_t)(rec_of[1][e][qf] - sl.poly0);
+            if (rec_of[0][e][qm] - sl.poly0 >= kDynPolyDummy || rec_of[1][e][qf] - sl.poly0 >= kDynPolyDummy || rec_of[0][e][qm] < sl.poly0 ||
+                rec_of[1][e][qf] < sl.poly0)
+              throw std::runtime_error("polynomial record index does not fit the slice");
+            T.s_m = (uint8_t)(2 + mst[e] + mp.xbase - mlo[e]);
+            if ((mp.meta & 0xF) == 0) throw std::runtime_error("ee-motion polynomial without variables");
+            for (int r = 0; r < 3; ++r) T.base_m[r] = (uint16_t)(8 * tile_start(r, mp.xbase));
+            if ((fp.meta & 0xF) != 0) {
+              T.s_f = (uint8_t)(2 + fst[e] + fp.xbase - flo[e]);
+              for (int r = 0; r < 6; ++r) T.base_f[r] = (uint16_t)(8 * tile_start(r, fp.xbase));
             }
-            if (fp.cand[c] != 0xFFFF) {
-              const int col = fp.xbase + (fp.cand[c] & 0xF);
-              G.idx_f[c] = (uint8_t)(2 + fst[e] + col - flo[e]);
-              P.f[c][0] = (uint16_t)(8 * find(r1, col));
-              P.f[c][1] = (uint16_t)(8 * find(r2, col));
-              P.f[c][2] = (uint16_t)(8 * find(3 + d, col));
+            // self-check of the decomposition  offset = tile start + 8 * rank  against the pattern, value by value
+            const DynPoly& PM = polys[rec_of[0][e][qm]];
+            const DynPoly& PF = polys[rec_of[1][e][qf]];
+            for (int c = 0; c < 12; ++c) {
+              const int d = c % 3, r1 = (d + 1) % 3, r2 = (d + 2) % 3;
+              if (mp.cand[c] != 0xFFFF) {
+                const int col = mp.xbase + (mp.cand[c] & 0xF);
+                if (T.base_m[r1] + PM.code[2 * c] != 8 * find(r1, col) || T.base_m[r2] + PM.code[2 * c + 1] != 8 * find(r2, col))
+                  throw std::runtime_error("ee-motion tile offsets disagree with the CSR pattern");
+              }
+              if (fp.cand[c] != 0xFFFF) {
+                const int col = fp.xbase + (fp.cand[c] & 0xF);
+                if (T.base_f[r1] + PF.code[3 * c] != 8 * find(r1, col) || T.base_f[r2] + PF.code[3 * c + 1] != 8 * find(r2, col) ||
+                    T.base_f[3 + d] + PF.code[3 * c + 2] != 8 * find(3 + d, col))
+                  throw std::runtime_error("ee-force tile offsets disagree with the CSR pattern");
+              }
             }
           }
-          if (!new_combo && std::memcmp(&Pold, &P, sizeof(P)) != 0)
-            throw std::runtime_error("put offsets differ inside one polynomial combination");
+          if (!new_combo && std::memcmp(&tiles[tile0 + role], &T, sizeof(T)) != 0)
+            throw std::runtime_error("tile starts differ inside one polynomial combination");
+          tiles[tile0 + role] = T;
         }
       }
       k0 = k1;
     }
     off_dyn_nodes = put(nodes.data(), nodes.size() * sizeof(DynNode));
-    off_dyn_gather = put(gather.data(), gather.size() * sizeof(DynGather));
-    off_dyn_put = put(putv.data(), putv.size() * sizeof(DynPut));
+    off_dyn_sel = put(sel.data(), sel.size() * sizeof(DynSel));
+    off_dyn_tile = put(tiles.data(), tiles.size() * sizeof(DynTile));
+    off_dyn_poly = put(polys.data(), polys.size() * sizeof(DynPoly));
+    off_dyn_dummy = off_dyn_poly + (uint32_t)((polys.size() - 1) * sizeof(DynPoly));
   }
   // --- rangeofmotion-<ee>, optimised timings: per-node record templates (the pre-pass fills in the x-dependent part)
   for (int e = 0; e < n_ee && have_rom && timings; ++e) {

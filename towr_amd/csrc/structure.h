@@ -79,9 +79,10 @@ struct Structure {
   struct DynSlice {
     int k0, cnt, nvals;
     uint32_t map;        // byte offset of the slice's staging map inside the blob
+    int poly0;           // index of the first DynPoly record the slice reads (DynSel::dm / df count from it)
   };
   std::vector<DynSlice> dyn_slices;
-  uint32_t off_dyn_nodes = 0, off_dyn_gather = 0, off_dyn_put = 0;
+  uint32_t off_dyn_nodes = 0, off_dyn_sel = 0, off_dyn_tile = 0, off_dyn_poly = 0, off_dyn_dummy = 0;
   uint32_t off_rom_recs[kMaxEE] = {0, 0, 0, 0};   // optimised timings: RomRec[k] templates (base-spline part)
   // fixed timings: slices of rangeofmotion-<ee> (device_tables.h RomNode / RomSeg)
   struct RomSlice {
