@@ -82,7 +82,10 @@ struct twr_batch {
   int node_families = 4;                     // 2 when no problem has more than terrain-* / force-* work for the node kernel
   int rom_max_vals = 0;                      // Jacobian values of the largest rom slice (picks the copy-out length)
   std::vector<int64_t> x_off, g_off, j_off;  // n_problems+1
-  std::vector<void*> blobs;                  // device blobs, one per distinct structure
+  std::vector<void*> blobs;                  // device blobs, one per distinct structure: addresses inside `arena`
+  void* arena = nullptr;                     // ONE allocation for the tables of all structures (a sweep has a thousand
+                                             // of them: one mapping with large pages instead of a thousand small ones,
+                                             // one upload instead of a thousand)
   std::vector<void*> grids;                  // device copies of the distinct gridded terrains
   // what twr_batch_sample needs of every problem (the structures need not outlive the batch)
   std::vector<uint64_t> blob_of_problem;     // device blob address
@@ -445,13 +448,18 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     b->n_problems = n_problems;
     b->n_ee = structs[0]->s.n_ee;
     std::vector<const twr::TerrainGrid*> host_grids;
+    std::vector<size_t> blob_off(n_structs + 1, 0);
     for (int i = 0; i < n_structs; ++i) {
       if (!structs[i]) throw std::runtime_error("null structure");
       if (structs[i]->s.n_ee != b->n_ee) throw std::runtime_error("all structures of a batch must share n_ee");
-      void* d = nullptr;
-      TWR_HIP(hipMalloc(&d, structs[i]->s.blob.size()));
-      b->blobs.push_back(d);
-      std::vector<char> blob = structs[i]->s.blob;
+      blob_off[i + 1] = blob_off[i] + (structs[i]->s.blob.size() + 255) / 256 * 256;   // every blob starts on a 256-byte line
+    }
+    TWR_HIP(hipMalloc(&b->arena, blob_off[n_structs]));
+    std::vector<char> host_arena(blob_off[n_structs], 0);
+    for (int i = 0; i < n_structs; ++i) {
+      b->blobs.push_back(static_cast<char*>(b->arena) + blob_off[i]);
+      char* blob = host_arena.data() + blob_off[i];
+      std::memcpy(blob, structs[i]->s.blob.data(), structs[i]->s.blob.size());
       if (structs[i]->s.grid) {  // gridded terrain: upload every distinct grid once, patch its address into the header
         const twr::TerrainGrid* tg = structs[i]->s.grid.get();
         void* dg = nullptr;
@@ -465,10 +473,10 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
           host_grids.push_back(tg);
           b->grids.push_back(dg);
         }
-        reinterpret_cast<twr::DevStruct*>(blob.data())->grid_ptr = reinterpret_cast<uint64_t>(dg);
+        reinterpret_cast<twr::DevStruct*>(blob)->grid_ptr = reinterpret_cast<uint64_t>(dg);
       }
-      TWR_HIP(hipMemcpy(d, blob.data(), blob.size(), hipMemcpyHostToDevice));
     }
+    TWR_HIP(hipMemcpy(b->arena, host_arena.data(), host_arena.size(), hipMemcpyHostToDevice));
     b->x_off.assign(n_problems + 1, 0);
     b->g_off.assign(n_problems + 1, 0);
     b->j_off.assign(n_problems + 1, 0);
@@ -717,7 +725,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
 void twr_batch_destroy(twr_batch* b) {
   if (!b) return;
   DeviceScope on(b->device);
-  for (void* d : b->blobs) (void)hipFree(d);
+  if (b->arena) (void)hipFree(b->arena);
   for (void* d : b->grids) (void)hipFree(d);
   if (b->d_dyn) (void)hipFree(b->d_dyn);
   if (b->d_rom) (void)hipFree(b->d_rom);

@@ -1058,40 +1058,37 @@ TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double
       pg[min(lane + 64, last)] = gst[min(lane + 64, last)];
     }
   };
+  // Every prefetch is issued unconditionally, with the slice index clamped to this workgroup's last slice (a repeated load
+  // of the last slice's records / x is harmless): no prefetched value goes through a phi or a conditional copy -- that is
+  // what makes the compiler wait for a load right where it is issued (see rom_body) -- and the number of vector-memory
+  // instructions per iteration is the same on every path.
+  const int last = i + (n_work - 1 - i) / stride * stride;
   DynWork wp = work[i];   // slice whose image is waiting to be copied out
   // (nothing is pending in the first iteration: its copy-out goes to the dump region, same instruction count)
   double* pdst = dump;
   double* pg = dump + kDynImage + 2;
-  DynWork w0 = wp, w1 = wp, w2 = wp;
+  DynWork w0 = wp, w1 = work[min(i + stride, last)], w2 = work[min(i + 2 * stride, last)];
   DynFrontRec fr0;
   double xr[4];
   uint2 mapr = load_map(w0);
-  uint32_t sel0 = dyn2_load_sel(w0, lane), sel1 = sel0;
+  uint32_t sel0 = dyn2_load_sel(w0, lane);
   dyn2_load_front(w0, sel0, lane, fr0);                  // (the only exposed record -> record dependency)
   gather_x(w0, mapr, xr);
   stage_x(xr);                                           // x(first slice): the only exposed gather
-  if (i + stride < n_work) {
-    w1 = work[i + stride];
-    mapr = load_map(w1);
-    sel1 = dyn2_load_sel(w1, lane);
-    gather_x(w1, mapr, xr);
-  }
-  if (i + 2 * stride < n_work) {
-    w2 = work[i + 2 * stride];
-    mapr = load_map(w2);
-  }
-  for (; i < n_work; i += stride) {
-    const bool has1 = i + stride < n_work, has2 = i + 2 * stride < n_work, has3 = i + 3 * stride < n_work;
-    DynWork w3 = w2;
-    if (has3) w3 = work[i + 3 * stride];
+  mapr = load_map(w1);
+  uint32_t sel1 = dyn2_load_sel(w1, lane);
+  gather_x(w1, mapr, xr);
+  mapr = load_map(w2);
+  for (; i <= last; i += stride) {
+    const DynWork w3 = work[min(i + 3 * stride, last)];
     double* dst = jac + w0.j_off;
     const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
     Dyn2Front S;
     dyn2_front(fr0, xs, lane, S);                                                            // F
     DynCodes cd;
     dyn2_load_codes(w0, sel0, cd);                                                           // P  (lands during the copy-out)
-    DynFrontRec fr1 = fr0;
-    if (has1) dyn2_load_front(w1, sel1, lane, fr1);                                          //    front records of slice i+1
+    DynFrontRec fr1;
+    dyn2_load_front(w1, sel1, lane, fr1);                                                    //    front records of slice i+1
     // (the copy-out runs at raised wave priority: with two waves per SIMD a wave in its store phase then gets its LDS
     // reads and stores issued ahead of its neighbour's math, which keeps the store stream of the CU steadier -- A/B on one
     // box 0.602-0.608 -> 0.591-0.596 ms; raised priority around the prefetches as well, or in rom_kernel, which runs one
@@ -1100,13 +1097,10 @@ TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double
     copy_out(pdst, pg, wp.nvals, wp.cnt);                                                    // O
     __builtin_amdgcn_s_setprio(0);
     dyn2_back(w0, fr0, cd, S, gst, reinterpret_cast<char*>(stage + par), lane, WANT_G, WANT_J);   // B
-    if (has1) stage_x(xr);                                                                   // S
-    uint32_t sel2 = sel1;
-    if (has2) {
-      sel2 = dyn2_load_sel(w2, lane);
-      gather_x(w2, mapr, xr);
-    }
-    if (has3) mapr = load_map(w3);
+    stage_x(xr);                                                                             // S
+    const uint32_t sel2 = dyn2_load_sel(w2, lane);
+    gather_x(w2, mapr, xr);
+    mapr = load_map(w3);
     wp = w0;
     pdst = dst;
     pg = g + w0.g_off;
@@ -1143,29 +1137,28 @@ TWR_DEV void rom_body(const RomWork* __restrict__ work, int n_work, const double
   const int trash = kRomStage + 2 + lane;
   double* gst = stage + kRomStage + 2 + 64;
   if (i >= n_work) return;
-  RomWork w0 = work[i], w1 = w0, w2 = w0;
-  RomLane r0 = rom_load_rec(w0, lane), r1 = r0;
+  // Every prefetch is issued unconditionally, with the slice index clamped to this workgroup's last slice (a repeated load
+  // of the last slice's records / x is harmless): no prefetched value goes through a phi or a conditional copy, which is
+  // what makes the compiler wait for a load right where it is issued (round 4: a `r2 = r1; if (has2) r2 = load` form of
+  // this loop waited with vmcnt(0) behind the record loads in every iteration -- +8 % with L2-resident tables, +17 % in a sweep).
+  const int last = i + (n_work - 1 - i) / stride * stride;
+  RomWork w0 = work[i], w1 = work[min(i + stride, last)];
+  RomLane r0 = rom_load_rec(w0, lane), r1 = rom_load_rec(w1, lane);
   RomX X;
-  if (i + stride < n_work) {
-    w1 = work[i + stride];
-    r1 = rom_load_rec(w1, lane);
-  }
   rom_load_x(w0, r0, x, X);
-  for (; i < n_work; i += stride) {
-    const bool has1 = i + stride < n_work, has2 = i + 2 * stride < n_work;
-    if (has2) w2 = work[i + 2 * stride];
+  for (; i <= last; i += stride) {
+    const RomWork w2 = work[min(i + 2 * stride, last)];
     double* dst = jac + w0.j_off;
     const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
     if (lane < w0.cnt) rom_item(w0, rom_rec_of(r0), X, gst, stage, par, 0, trash, lane, WANT_G, WANT_J);   // C
-    RomLane r2 = r1;
-    if (has2) r2 = rom_load_rec(w2, lane);              // A (records first: the wait for x retires them too)
-    if (has1) rom_load_x(w1, r1, x, X);
+    const RomLane r2 = rom_load_rec(w2, lane);          // A (records first: the wait for x retires them too)
+    rom_load_x(w1, r1, x, X);
     if (WANT_J) copy_out_fixed<NIT, 13>(dst, stage, w0.nvals, par, lane);   // B
     if (WANT_G) {                                       //   3 constraint values per time node, contiguous in g: clamped
       double* go = g + w0.g_off;                        //   lanes instead of predicates (see copy_out_fixed)
-      const int last = 3 * w0.cnt - 1;
+      const int last_g = 3 * w0.cnt - 1;
 #pragma unroll
-      for (int t = 0; t < 3; ++t) go[min(lane + 64 * t, last)] = gst[min(lane + 64 * t, last)];
+      for (int t = 0; t < 3; ++t) go[min(lane + 64 * t, last_g)] = gst[min(lane + 64 * t, last_g)];
     }
     w0 = w1; r0 = r1;
     w1 = w2; r1 = r2;
