@@ -331,6 +331,19 @@ int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_
  * followed by two copies: and gather x from them: 34 instead of 53 us for one quadruped problem (TWR_HOST_ZERO_COPY=0 switches it off). */
 int twr_batch_host_buffers(twr_batch* b, double** h_x, double** h_g, double** h_jac);
 
+/* Tuning knobs.  The DEFAULT build reads nothing from the environment: the values below are compiled in.  A build with
+ * -DTWR_TUNING_KNOBS (make -C towr_amd/csrc TUNING=1) reads them once per process, for A/B measurements (scripts/ab.py,
+ * DESIGN.md section 6); they never change results, only how the work is spread over the device:
+ *   TWR_DYN_BPC, TWR_ROM_BPC        persistent workgroups per CU of dyn_kernel / rom_kernel (8 / 4: their LDS images fill a CU)
+ *   TWR_PDYN_BPC, TWR_PROM_BPC      the same for dyn_phase_kernel / rom_phase_kernel (default: what their LDS images allow,
+ *                                   at most 4 / 8)
+ *   TWR_FUSED_MAX_ROM               rom slices up to which one fused launch replaces the three kernels (default: 8 rounds
+ *                                   of the rom residency = 8 x TWR_ROM_BPC x number of CUs)
+ *   TWR_FUSED_SPLIT                 eighths of the residency the fused launch gives the rom role when both roles do not fit
+ *                                   (default: 5 up to 25/8 rounds of rom slices, else no split)
+ *   TWR_HOST_ZERO_COPY[_X]=0        twr_batch_eval_host: copy through device buffers instead of letting the kernels store
+ *                                   into (gather x from) the page-locked host buffers */
+
 #ifdef __cplusplus
 }
 #endif

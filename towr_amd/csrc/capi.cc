@@ -605,8 +605,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
           if (!rs) continue;
           any_rom = true;
           const int K = (int)S.grid_rom.size(), nv = S.phase_tables.rom_node_vals[e];
-          static const int prom_nodes = [] { const char* e = getenv("TWR_PROM_NODES"); return e && atoi(e) > 0 ? std::min(16, atoi(e)) : 16; }();
-          const int run_max = std::max(1, std::min(prom_nodes, (160 * 128) / nv));   // time nodes per pass (four lanes each)
+          const int run_max = std::max(1, std::min(16, (160 * 128) / nv));   // time nodes per pass (four lanes each)
           const int n_pass = (K + run_max - 1) / run_max;
           const int run = (K + n_pass - 1) / n_pass;                  // balanced: no short tail pass (it pays the full copy-out)
           b->prom_img_cap = std::max(b->prom_img_cap, run * nv);
@@ -852,8 +851,12 @@ int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_
     if (!b->host_stream) TWR_HIP(hipStreamCreateWithFlags(&b->host_stream, hipStreamNonBlocking));
     hipStream_t hs = b->host_stream;
     // one stream-ordered chain on the batch's own stream and a single synchronisation (with page-locked buffers the copies are DMA)
+#ifdef TWR_TUNING_KNOBS   // (include/towr_amd.h, "Tuning knobs")
     static const bool zero_copy = [] { const char* e = getenv("TWR_HOST_ZERO_COPY"); return !e || atoi(e) != 0; }();
     static const bool zero_copy_x = [] { const char* e = getenv("TWR_HOST_ZERO_COPY_X"); return !e || atoi(e) != 0; }();
+#else
+    const bool zero_copy = true, zero_copy_x = true;
+#endif
     const bool zc = zero_copy && b->p_g && h_g == b->p_g && h_jac == b->p_j && nj * sizeof(double) <= (size_t)(32u << 20);
     const double* dx = b->d_x;
     if (zc && zero_copy_x && h_x == b->p_x) {   // x too: the kernels gather it straight from the page-locked buffer

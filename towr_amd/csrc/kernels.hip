@@ -2702,11 +2702,18 @@ hipError_t launch_check(int n_problems, const int64_t* g_off, const int64_t* j_o
 // over-reports it for the dynamic kernel (measured: 7 x 22.5 KB resident, an 8th starts a second
 // round), so the per-CU counts are fixed here and can be overridden for experiments.
 // (Running dyn and rom concurrently on two streams was measured and is slower than back to back.)
+// Tuning knobs (include/towr_amd.h, "Tuning knobs"): read from the environment ONLY in builds with -DTWR_TUNING_KNOBS
+// (make TUNING=1; what scripts/ab.py and the A/B notes of DESIGN 6 use); the default build has the measured optima compiled in.
 static int env_int(const char* name, int dflt) {
+#ifdef TWR_TUNING_KNOBS
   const char* e = getenv(name);
   if (!e) return dflt;
   int v = atoi(e);
   return v > 0 ? v : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
 }
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
                        int rom_max_vals, const NodeWork* node, int n_node, int node_families /* 2: terrain + force only; 4 */,
@@ -2717,11 +2724,13 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
   dim3 block(64);
   hipError_t st = hipSuccess;
   if (n_ee < 1 || n_ee > 4) return hipErrorInvalidValue;
-  // rom slices up to which the fused launch is used (round-3 re-tune on one box, ragged sweep, fused vs three launches:
-  // 320 / 400 / 512 candidates 75 / 98 / 126 vs 83 / 104 / 128 us per step, 768 / 1024: 187 / 250 vs 183 / 235)
-  static const int fused_max = env_int("TWR_FUSED_MAX_ROM", 8192);
+  // The fused launch is used while the rom role needs at most EIGHT rounds of its residency (rom_bpc workgroups per CU x
+  // n_cu: 8192 rom slices = 512 quadruped candidates of K = 200 on the 256 CUs of an MI355X; round-3 re-tune on one box,
+  // ragged sweep, fused vs three launches: 320 / 400 / 512 candidates 75 / 98 / 126 vs 83 / 104 / 128 us per step, 768 /
+  // 1024: 187 / 250 vs 183 / 235).  The thresholds are in units of the device's residency, not constants of one chip.
+  const int cap = rom_bpc * n_cu;
+  const int fused_max = env_int("TWR_FUSED_MAX_ROM", 8 * cap);
   if (!ev && n_pdyn == 0 && n_prom == 0 && n_rom > 0 && n_dyn > 0 && n_rom <= fused_max) {
-    const int cap = rom_bpc * n_cu;
     int g_rom = n_rom < cap ? n_rom : cap, g_dyn = (n_dyn + 1) / 2 < cap ? (n_dyn + 1) / 2 : cap;
     // When the two persistent roles do not fit the CUs together, the blocks of the later role only start as the earlier
     // ones retire, i.e. the roles run one after the other.  For up to 2560 rom slices (160 quadruped candidates of
@@ -2732,7 +2741,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
     static const int split_env = env_int("TWR_FUSED_SPLIT", 0);
     // (round 3: five eighths for rom up to 3200 slices -- 128 / 160 / 200 candidates 27.5 / 33.5 / 40.5 us against 27.7 / 33.9 /
     // 44.0 us with the round-2 rule "half each up to 2560"; from 256 candidates on unsplit is as good or better)
-    const int split = split_env > 0 ? split_env : (n_rom <= 3200 ? 5 : 8);
+    const int split = split_env > 0 ? split_env : (8 * n_rom <= 25 * cap ? 5 : 8);   // (3200 slices on 256 CUs)
     if (split < 8 && g_rom + g_dyn > cap) {
       const int r = cap * split / 8, d = cap - r;
       if (g_rom > r) g_rom = r;
