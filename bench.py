@@ -192,14 +192,21 @@ def traffic_from_profile(workload, kernel, problems_per_gpu):
         if t.get("workload") == "C3" and t.get("kernel_source_sha256") == kernel_source_hash():
             if workload == "C3" and t.get("problems_per_gpu") == problems_per_gpu:   # (kernel names carry template arguments)
                 return sum(v for k, v in t.get("hbm_bytes_per_launch", {}).items() if k.startswith(kernel)) or None
-            if workload == "C3+timings" and problems_per_gpu == 2048:   # the --sets timings --batch 2048 passes
-                per = t.get("timings_2048", {}).get("hbm_bytes_per_launch", {})
-                if kernel is None:
-                    return per
-                return sum(v for k, v in per.items() if k.startswith(kernel)) or None
+            for wl, key, count in (("C3+timings", "timings_2048", 2048), ("C3+all", "all_sets_8192", 8192)):
+                if workload == wl and problems_per_gpu == count:   # the --sets timings --batch 2048 / --sets all passes
+                    per = t.get(key, {}).get("hbm_bytes_per_launch", {})
+                    if kernel is None:
+                        return per
+                    return sum(v for k, v in per.items() if k.startswith(kernel)) or None
     except (OSError, ValueError):
         pass
     return None
+
+
+def traffic_source():
+    """Where roofline.traffic comes from: it is NOT measured by this run (PMC counters need rocprofv3 around the process);
+    it is the committed profile of the same kernels -- the hash ties it to the kernel sources of this tree."""
+    return "profiles/traffic.json@%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, scripts/profile_r04.sh)" % kernel_source_hash()
 
 
 def sweep_traffic_ratio(algorithmic_bytes):
@@ -317,6 +324,7 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
             # HBM traffic of the whole 1024-candidate sweep on ONE GPU over its algorithmic bytes (profiles/traffic.json,
             # rocprofv3 FETCH_SIZE / WRITE_SIZE passes): every candidate reads its own ~150 KB of tables
             "traffic_ratio": sweep_traffic_ratio(bytes_total) if world == 1 else None,
+            "traffic_source": traffic_source() if world == 1 else None,
             "planner": {"what": "values only -> twr_batch_score -> all-gather of 16 scores per candidate -> arg-min "
                                 "(host-synchronous: one decision per step)",
                         "steps": p_steps, "value": n_total * p_steps / p_elapsed, "unit": "candidates scored/s",
@@ -363,11 +371,11 @@ def timings_c3(ta, torch, dist, model, world, rank, dev, dev_index, backend, str
     kbytes = batch.kernel_bytes()
     dom = max(kern_ms, key=kern_ms.get)
     path_ms = sum(kern_ms.values())
-    traffic = traffic_from_profile("C3+timings", None, B) if timings else None
+    traffic = traffic_from_profile("C3+timings" if timings else "C3+all", None, B)
     dom_traffic = None
     if traffic:   # the dynamic interval holds the pre-pass and the kernel: both are charged
-        keys = {"dynamic": ["twr::dyn_phase_kernel", "twr::phase_locate_kernel"], "rangeofmotion": ["twr::rom_phase_kernel"],
-                "nodes": ["twr::node_kernel"]}[dom]
+        keys = {"dynamic": ["twr::dyn_phase_kernel", "twr::phase_locate_kernel"] if timings else ["twr::dyn_kernel"],
+                "rangeofmotion": ["twr::rom_phase_kernel" if timings else "twr::rom_kernel"], "nodes": ["twr::node_kernel"]}[dom]
         vals = [v for k, v in traffic.items() if any(k.startswith(q) for q in keys)]
         dom_traffic = sum(vals) if vals else None
     return {"workload": "C3 with %s: n=%d m=%d nnz=%d, %d problems/GPU"
@@ -376,6 +384,7 @@ def timings_c3(ta, torch, dist, model, world, rank, dev, dev_index, backend, str
             "ms_per_step": elapsed / steps * 1e3, "bytes_per_callback": S.algorithmic_bytes,
             "roofline": {"bound": "hbm", "achieved": kbytes[dom] / (kern_ms[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kbytes[dom] / (kern_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": dom_traffic,
+                         "traffic_source": traffic_source() if dom_traffic else None,
                          "kernel": names[dom], "kernel_ms": kern_ms[dom], "algorithmic_bytes_per_launch": kbytes[dom],
                          "path": {"achieved": batch.algorithmic_bytes / (path_ms * 1e-3) / 1e9,
                                   "frac": batch.algorithmic_bytes / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -518,6 +527,8 @@ def main():
                  "nodes": "twr::node_kernel2" if (args.workload != "c3" or args.sets == "hot") else "twr::node_kernel"}
         if args.workload == "c3" and args.sets == "timings":
             names.update(dynamic="twr::dyn_phase_kernel", rangeofmotion="twr::rom_phase_kernel")
+        main_traffic = (traffic_from_profile({"hot": "C3", "timings": "C3+timings", "all": "C3+all"}[args.sets], names[dom], B)
+                        if args.workload == "c3" else None)
         out = {
             "metric": "constraint+Jacobian evals/sec (full NLP callback), 4-EE SRBD",
             "value": callbacks / elapsed,
@@ -536,10 +547,10 @@ def main():
             "config": {"workload": workload, "problems_per_gpu": B, "bytes_per_callback": bytes_per_callback,
                        "setup_s": setup_s},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": (traffic_from_profile({"hot": "C3", "timings": "C3+timings"}[args.sets], names[dom], B)
-                                     if args.workload == "c3" and args.sets in ("hot", "timings") else None),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": main_traffic,
                          "kernel": names[dom], "kernel_ms": kern_ms[dom],
                          "algorithmic_bytes_per_launch": kbytes[dom],
+                         "traffic_source": traffic_source() if main_traffic else None,
                          # the whole callback = the three kernels back to back (SURVEY 8d figure 8*(n+m+nnz))
                          "path": {"achieved": path_achieved, "frac": path_achieved / HBM_PEAK_GBS,
                                   "kernel_ms": {names[k]: v for k, v in kern_ms.items()},

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Condense one scripts/profile_r03.sh run into the files that are committed under profiles/:
-<tag>_kernel_stats.csv, <tag>_timings_kernel_stats.csv, <tag>_pmc_summary.txt, traffic.json (+ the bench lines)."""
+"""Condense one scripts/profile_r04.sh run (or a round-3 profile_r03.sh run) into the files that are committed under
+profiles/: <tag>_kernel_stats.csv, <tag>_timings_kernel_stats.csv, <tag>_sweep_kernel_stats.csv, <tag>_all_sets_kernel_stats.csv,
+<tag>_pmc_summary.txt, traffic.json (+ the bench lines the traces were taken on)."""
 import collections
 import csv
 import glob
@@ -32,10 +33,15 @@ def keep_twr(src, dst):
                 w.writerow(row)
 
 
-keep_twr(find("ktrace", "*kernel_stats.csv"), os.path.join(prof, tag + "_kernel_stats.csv"))
-keep_twr(find("ktrace_t", "*kernel_stats.csv"), os.path.join(prof, tag + "_timings_kernel_stats.csv"))
-shutil.copy(os.path.join(out, "bench_under_rocprof.json"), os.path.join(prof, tag + "_bench_under_rocprof.json"))
-shutil.copy(os.path.join(out, "bench_timings_under_rocprof.json"), os.path.join(prof, tag + "_timings_bench_under_rocprof.json"))
+for d, name in (("ktrace", ""), ("ktrace_t", "_timings"), ("ktrace_s", "_sweep"), ("ktrace_a", "_all_sets")):
+    src = find(d, "*kernel_stats.csv")
+    if not src:
+        continue
+    keep_twr(src, os.path.join(prof, tag + name + "_kernel_stats.csv"))
+    for cand in ("bench_%s.json" % d, {"ktrace": "bench_under_rocprof.json", "ktrace_t": "bench_timings_under_rocprof.json"}.get(d, "")):
+        if cand and os.path.exists(os.path.join(out, cand)):
+            shutil.copy(os.path.join(out, cand), os.path.join(prof, tag + name + "_bench_under_rocprof.json"))
+            break
 
 
 def counters(d):
@@ -72,6 +78,17 @@ for d in ("tcc1_s", "tcc2_s"):
     swp.update(c)
     for k, v in sorted(c.items()):
         lines.append("%-22s %-26s %.6g" % (k[0], k[1], v))
+for d in ("sq1_s",):
+    c = counters(d)
+    for k, v in sorted(c.items()):
+        lines.append("%-22s %-26s %.6g" % (k[0], k[1], v))
+lines.append("# --sets all (towr's whole default constraint list, 8192 problems)")
+alls = {}
+for d in ("tcc1_a", "tcc2_a"):
+    c = counters(d)
+    alls.update(c)
+    for k, v in sorted(c.items()):
+        lines.append("%-22s %-26s %.6g" % (k[0], k[1], v))
 lines.append("# derived")
 for k, src in [(k_, allc) for k_ in sorted({k[0] for k in allc})] + [(k_, tim) for k_ in sorted({k[0] for k in tim})]:
     g = lambda n: src.get((k, n))
@@ -99,6 +116,7 @@ json.dump({"workload": "C3", "problems_per_gpu": 8192, "kernel_source_sha256": k
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = (WRITE_SIZE + 2*FETCH_SIZE) KiB",
            "hbm_bytes_per_launch": traffic(allc),
            "timings_2048": {"hbm_bytes_per_launch": traffic(tim)},
-           "sweep_1024": {"hbm_bytes_per_launch": traffic(swp)}},
+           "sweep_1024": {"hbm_bytes_per_launch": traffic(swp)},
+           "all_sets_8192": {"hbm_bytes_per_launch": traffic(alls)}},
           open(os.path.join(prof, "traffic.json"), "w"), indent=1)
 print("\n".join(lines[-12:]))

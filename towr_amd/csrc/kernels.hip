@@ -693,6 +693,9 @@ static_assert(kDynLds * 8 <= 20480, "dyn_kernel: eight workgroups of 20 KB per C
 #ifndef TWR_DYN_COPY_BATCH
 #define TWR_DYN_COPY_BATCH 8
 #endif
+#ifndef TWR_DYN_WAVES
+#define TWR_DYN_WAVES 2   // waves per SIMD dyn_kernel is compiled for (experiments: 3 with -DTWR_DYN_IMAGE=1362 -DTWR_DYN_XS=126)
+#endif
 
 constexpr int kDynCopyBatch = TWR_DYN_COPY_BATCH;   // LDS reads in flight before the first store of the copy-out
 struct Dyn2Front {   // (the base-spline weights are recomputed in the back half: 48 registers less across the copy-out)
@@ -1112,7 +1115,7 @@ TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double
 }
 
 template <bool WANT_G, bool WANT_J>
-__global__ __launch_bounds__(64, 2) void dyn_kernel(const DynWork* __restrict__ work, int n_work, const double* __restrict__ x,
+__global__ __launch_bounds__(64, TWR_DYN_WAVES) void dyn_kernel(const DynWork* __restrict__ work, int n_work, const double* __restrict__ x,
                                                     double* __restrict__ g, double* __restrict__ jac, double* __restrict__ dump) {
   __shared__ __attribute__((aligned(16))) double stage[kDynLds];
   dyn_body<WANT_G, WANT_J>(work, n_work, x, g, jac, dump, stage, threadIdx.x, blockIdx.x, gridDim.x);
