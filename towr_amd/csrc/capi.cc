@@ -17,7 +17,7 @@
 #include "structure.h"
 
 namespace twr {
-hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom, int rom_max_vals,
+hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dyn_map_chunks, const RomWork* rom, int n_rom, int rom_max_vals,
                        const NodeWork* node, int n_node, int node_families, const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap,
                        const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
                        double* g, double* jac, double* dump, int flags, hipStream_t stream, hipEvent_t* ev);
@@ -81,6 +81,7 @@ struct twr_batch {
   int n_dyn = 0, n_rom = 0, n_node = 0, n_cu = 0;
   int node_families = 4;                     // 2 when no problem has more than terrain-* / force-* work for the node kernel
   int rom_max_vals = 0;                      // Jacobian values of the largest rom slice (picks the copy-out length)
+  int dyn_map_chunks = 2;                    // 2: every dyn slice of the batch stages <= 128 doubles of x (256-byte staging maps), else 4
   std::vector<int64_t> x_off, g_off, j_off;  // n_problems+1
   std::vector<void*> blobs;                  // device blobs, one per distinct structure: addresses inside `arena`
   void* arena = nullptr;                     // ONE allocation for the tables of all structures (a sweep has a thousand
@@ -496,6 +497,8 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     std::vector<int> dyn_first, rom_first;  // first work item of every problem (+ end)
     // (families that are switched off -- twr_params.constraint_sets -- simply have no work items; problems with
     // optimised timings get PDynWork / LocWork / RomPhaseWork items instead of DynWork / RomWork)
+    for (int i = 0; i < n_structs; ++i)
+      if (structs[i]->s.dyn_staged_max > 128) b->dyn_map_chunks = 4;
     for (int p = 0; p < n_problems; ++p) {
       int si = struct_of_problem[p];
       if (si < 0 || si >= n_structs) throw std::runtime_error("struct_of_problem out of range");
@@ -523,7 +526,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
         w.tile = blob + S.off_dyn_tile;   // (records are addressed through DynSel::tile)
         w.poly = blob + S.off_dyn_poly + sizeof(twr::DynPoly) * (size_t)sl.poly0;
         w.dummy = blob + S.off_dyn_dummy;
-        w.map = blob + sl.map;
+        w.map = blob + (b->dyn_map_chunks == 2 ? sl.map2 : sl.map);
         w.hdr = blob;
         w.x_off = b->x_off[p];
         w.g_off = b->g_off[p] + ds.offset + 6 * sl.k0;
@@ -773,7 +776,7 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
   hipEvent_t* ev = nullptr;
   if (b->prof_count < b->prof_capacity) ev = b->prof_events.data() + 4 * b->prof_count++;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-  hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->d_rom, b->n_rom, b->rom_max_vals, b->d_node, b->n_node, b->node_families,
+  hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->dyn_map_chunks, b->d_rom, b->n_rom, b->rom_max_vals, b->d_node, b->n_node, b->node_families,
                                   b->d_pdyn, b->n_pdyn, b->pdyn_img_cap, b->d_ploc, b->n_ploc, b->d_prom, b->n_prom,
                                   b->prom_img_cap, d_x, d_g, d_jac, b->d_dump, flags & TWR_EVAL_BOTH, stream, ev);
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));

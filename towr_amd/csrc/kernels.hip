@@ -1030,25 +1030,36 @@ TWR_DEV void dyn2_back(const DynWork& w, const DynFrontRec& rec, const DynCodes&
 // prefetch and its use is then a constant on every path, and the compiler's counted waits stay counted.  (With run-time
 // flags and `if (pending)` it had to assume the shortest path -- no stores at all -- and the wait for the put record in
 // the middle of the loop drained the whole copy-out of the previous slice.)
-template <bool WANT_G, bool WANT_J>
+// XC = 64-entry chunks of the staging map the slices of the batch use (2: every slice stages at most 128 doubles of x --
+// true for all K = 200 problems, whose 12..15-node slices stage ~100 -- and reads the 256-byte form of its map; 4: the
+// general 512-byte form).  A compile-time count: the x gather is XC loads per lane, the same on every path.
+template <bool WANT_G, bool WANT_J, int XC>
 TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double* __restrict__ x, double* __restrict__ g,
                       double* __restrict__ jac, double* __restrict__ dump, double* stage, int lane, int i, int stride) {
+  static_assert(XC == 2 || XC == 4, "staging map chunks");
   double* gst = stage + kDynG0;
   char* xs = reinterpret_cast<char*>(stage + kDynX0);
   if (i >= n_work) return;
   constexpr int NIT = (kDynImage + 2 + 127) / 128;
   if (lane < 2) stage[kDynX0 + lane] = 0.0;   // the zero pair
-  auto load_map = [&](const DynWork& w) { return gptr<uint2>(w.map)[lane]; };   // four 16-bit x indices per lane
-  auto gather_x = [&](const DynWork& w, uint2 m, double xr[4]) {
+  auto load_map = [&](const DynWork& w) {   // XC 16-bit x indices per lane
+    uint2 m;
+    if (XC == 4) m = gptr<uint2>(w.map)[lane];
+    else m = make_uint2(gptr<uint32_t>(w.map)[lane], 0u);
+    return m;
+  };
+  auto gather_x = [&](const DynWork& w, uint2 m, double xr[XC]) {
     const double* xp = x + w.x_off;
     xr[0] = xp[m.x & 0xFFFFu];
     xr[1] = xp[m.x >> 16];
-    xr[2] = xp[m.y & 0xFFFFu];
-    xr[3] = xp[m.y >> 16];
+    if (XC == 4) {
+      xr[XC - 2] = xp[m.y & 0xFFFFu];
+      xr[XC - 1] = xp[m.y >> 16];
+    }
   };
-  auto stage_x = [&](const double xr[4]) {
+  auto stage_x = [&](const double xr[XC]) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < XC; ++c)
       if (64 * c + lane < kDynXsCap) stage[kDynX0 + 2 + 64 * c + lane] = xr[c];
   };
   // image -> HBM; the constraint values (6 per time node, contiguous in g) with clamped lanes instead of predicates
@@ -1072,7 +1083,7 @@ TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double
   double* pg = dump + kDynImage + 2;
   DynWork w0 = wp, w1 = work[min(i + stride, last)], w2 = work[min(i + 2 * stride, last)];
   DynFrontRec fr0;
-  double xr[4];
+  double xr[XC];
   uint2 mapr = load_map(w0);
   uint32_t sel0 = dyn2_load_sel(w0, lane);
   dyn2_load_front(w0, sel0, lane, fr0);                  // (the only exposed record -> record dependency)
@@ -1114,11 +1125,11 @@ TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double
   copy_out(pdst, pg, wp.nvals, wp.cnt);                 // last slice of this workgroup
 }
 
-template <bool WANT_G, bool WANT_J>
+template <bool WANT_G, bool WANT_J, int XC>
 __global__ __launch_bounds__(64, TWR_DYN_WAVES) void dyn_kernel(const DynWork* __restrict__ work, int n_work, const double* __restrict__ x,
                                                     double* __restrict__ g, double* __restrict__ jac, double* __restrict__ dump) {
   __shared__ __attribute__((aligned(16))) double stage[kDynLds];
-  dyn_body<WANT_G, WANT_J>(work, n_work, x, g, jac, dump, stage, threadIdx.x, blockIdx.x, gridDim.x);
+  dyn_body<WANT_G, WANT_J, XC>(work, n_work, x, g, jac, dump, stage, threadIdx.x, blockIdx.x, gridDim.x);
 }
 
 #endif  // !TWR_TU_ROM
@@ -1374,14 +1385,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4))) void n
 // and 40 KB: blocks [0, g_rom) take the rom role (wave 0 only; the image is 39 KB), the next g_dyn blocks the dyn role
 // (both waves, one 20-KB half each), the rest the node role (two families per block) -- the residency per CU of each
 // role is that of its own kernel, and blocks are dispatched in this order, so a later role starts as the earlier drains.
-template <int ROM_NIT, bool WANT_G, bool WANT_J>
+template <int ROM_NIT, bool WANT_G, bool WANT_J, int XC>
 __global__ __launch_bounds__(128, 2) void eval_fused_kernel(const RomWork* __restrict__ rom, int n_rom, int g_rom,
                                                             const DynWork* __restrict__ dyn, int n_dyn, int g_dyn,
                                                             const NodeWork* __restrict__ node, const double* __restrict__ x,
                                                             double* __restrict__ g, double* __restrict__ jac,
                                                             double* __restrict__ dump) {
-  static_assert(2 * kDynLds >= kRomLds && kDynLds >= kStageForce, "LDS of the fused kernel");
-  __shared__ __attribute__((aligned(16))) double stage[2 * kDynLds];
+  constexpr int kFusedLds = 2 * kDynLds >= kRomLds ? 2 * kDynLds : kRomLds;   // (the second case: experiment builds with small dyn images)
+  static_assert(kDynLds >= kStageForce, "LDS of the fused kernel");
+  __shared__ __attribute__((aligned(16))) double stage[kFusedLds];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   int b = blockIdx.x;
   if (b < g_rom) {
@@ -1390,7 +1402,7 @@ __global__ __launch_bounds__(128, 2) void eval_fused_kernel(const RomWork* __res
   }
   b -= g_rom;
   if (b < g_dyn) {
-    dyn_body<WANT_G, WANT_J>(dyn, n_dyn, x, g, jac, dump, stage + wave * kDynLds, lane, 2 * b + wave, 2 * g_dyn);
+    dyn_body<WANT_G, WANT_J, XC>(dyn, n_dyn, x, g, jac, dump, stage + wave * kDynLds, lane, 2 * b + wave, 2 * g_dyn);
     return;
   }
   b -= g_dyn;
@@ -2718,7 +2730,7 @@ static int env_int(const char* name, int dflt) {
   return dflt;
 #endif
 }
-hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const RomWork* rom, int n_rom,
+hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dyn_map_chunks /* 2 or 4 */, const RomWork* rom, int n_rom,
                        int rom_max_vals, const NodeWork* node, int n_node, int node_families /* 2: terrain + force only; 4 */,
                        const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap, const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
                        double* g, double* jac, double* dump /* kDynDump doubles */, int flags, hipStream_t stream,
@@ -2752,25 +2764,34 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, const 
     }
     const dim3 fgrid(g_rom + g_dyn + 2 * n_node);
     const int need = (rom_max_vals + 1 + 2 + 127) / 128;   // copy-out length of the rom role (see launch_rom_kernel)
-#define TWR_FUSED_LAUNCH(NIT)                                                                                                          \
+#define TWR_FUSED_LAUNCH(NIT, XC)                                                                                                      \
   {                                                                                                                                    \
     if ((flags & 3) == 3)                                                                                                              \
-      return twr_launch(eval_fused_kernel<NIT, true, true>, fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump);   \
+      return twr_launch(eval_fused_kernel<NIT, true, true, XC>, fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump);   \
     if (flags & 2)                                                                                                                     \
-      return twr_launch(eval_fused_kernel<NIT, false, true>, fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump);  \
-    return twr_launch(eval_fused_kernel<NIT, true, false>, fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump);    \
+      return twr_launch(eval_fused_kernel<NIT, false, true, XC>, fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump);  \
+    return twr_launch(eval_fused_kernel<NIT, true, false, XC>, fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump);    \
   }
-    if (need <= 34) TWR_FUSED_LAUNCH(34)
-    TWR_FUSED_LAUNCH(kRomNitMax)
+    if (dyn_map_chunks == 2) {
+      if (need <= 34) TWR_FUSED_LAUNCH(34, 2)
+      TWR_FUSED_LAUNCH(kRomNitMax, 2)
+    }
+    if (need <= 34) TWR_FUSED_LAUNCH(34, 4)
+    TWR_FUSED_LAUNCH(kRomNitMax, 4)
 #undef TWR_FUSED_LAUNCH
   }
   if (ev) (void)hipEventRecord(ev[0], stream);
   if (n_dyn > 0) {
     const int res = dyn_bpc * n_cu;
     dim3 grid(n_dyn < res ? n_dyn : res);
-    if ((flags & 3) == 3) st = twr_first(st, twr_launch(dyn_kernel<true, true>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, dump));
-    else if (flags & 2) st = twr_first(st, twr_launch(dyn_kernel<false, true>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, dump));
-    else st = twr_first(st, twr_launch(dyn_kernel<true, false>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, dump));
+#define TWR_DYN_LAUNCH(XC)                                                                                                              \
+  {                                                                                                                                      \
+    if ((flags & 3) == 3) st = twr_first(st, twr_launch(dyn_kernel<true, true, XC>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, dump));       \
+    else if (flags & 2) st = twr_first(st, twr_launch(dyn_kernel<false, true, XC>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, dump));        \
+    else st = twr_first(st, twr_launch(dyn_kernel<true, false, XC>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, dump));                       \
+  }
+    if (dyn_map_chunks == 2) TWR_DYN_LAUNCH(2) else TWR_DYN_LAUNCH(4)
+#undef TWR_DYN_LAUNCH
   }
   // optimised-timings problems: the pre-pass (segment lookup -> records), then the persistent kernels
   if (n_ploc > 0) st = twr_first(st, twr_launch(phase_locate_kernel, dim3(n_ploc), dim3(kLocateThreads), 0, stream, ploc, x));

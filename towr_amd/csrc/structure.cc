@@ -715,6 +715,7 @@ void Structure::PackBlob() {
     std::vector<DynTile> tiles;   // four per (slice, polynomial combination)
     std::vector<int> combo_key;   // active polynomial ids of the last combination
     dyn_slices.clear();
+    dyn_staged_max = 0;
     for (int k0 = 0; k0 < K;) {
       int k1 = k0;
       while (k1 < K && k1 - k0 < kDynNodes && nvals_of(k0, k1 + 1) <= kDynImage && stage_count(k0, k1 + 1) <= kDynXsCap &&
@@ -748,6 +749,13 @@ void Structure::PackBlob() {
       sl.cnt = k1 - k0;
       sl.nvals = nvals_of(k0, k1);
       sl.map = put(map.data(), map.size() * sizeof(uint16_t));
+      sl.map2 = sl.map;
+      dyn_staged_max = std::max(dyn_staged_max, (int)xidx.size());
+      if (xidx.size() <= 128) {   // the 256-byte form: lane l holds entries l and 64 + l (what a batch of such slices reads)
+        std::vector<uint16_t> m2(128, 0);
+        for (size_t e = 0; e < xidx.size(); ++e) m2[(e % 64) * 2 + e / 64] = (uint16_t)xidx[e];
+        sl.map2 = put(m2.data(), m2.size() * sizeof(uint16_t));
+      }
       sl.poly0 = 1 << 30;
       for (int e = 0; e < n_ee; ++e)
         sl.poly0 = std::min({sl.poly0, rec_of[0][e][dyn_motion[e][k0].poly], rec_of[1][e][dyn_force[e][k0].poly]});

@@ -78,10 +78,12 @@ struct Structure {
   // fixed timings: slices of the dynamic set and their tables (device_tables.h DynNode / DynGather / DynPut)
   struct DynSlice {
     int k0, cnt, nvals;
-    uint32_t map;        // byte offset of the slice's staging map inside the blob
+    uint32_t map;        // byte offset of the slice's staging map inside the blob: uint16[64][4], lane-transposed
+    uint32_t map2;       // the two-chunk form uint16[64][2] of the same map (slices that stage <= 128 doubles; else = map)
     int poly0;           // index of the first DynPoly record the slice reads (DynSel::dm / df count from it)
   };
   std::vector<DynSlice> dyn_slices;
+  int dyn_staged_max = 0;   // most doubles of x one slice stages (<= 128: the batch may use the two-chunk maps)
   uint32_t off_dyn_nodes = 0, off_dyn_sel = 0, off_dyn_tile = 0, off_dyn_poly = 0, off_dyn_dummy = 0;
   uint32_t off_rom_recs[kMaxEE] = {0, 0, 0, 0};   // optimised timings: RomRec[k] templates (base-spline part)
   // fixed timings: slices of rangeofmotion-<ee> (device_tables.h RomNode / RomSeg)
