@@ -366,8 +366,10 @@ def timings_c3(ta, torch, dist, model, world, rank, dev, dev_index, backend, str
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     timings = bool(constraint_sets & 64)
+    # (batches of >= 2048 problems with splineacc / swing rows and fixed timings: the persistent node_chunk_kernel)
     names = {"dynamic": "twr::phase_locate_kernel + twr::dyn_phase_kernel" if timings else "twr::dyn_kernel",
-             "rangeofmotion": "twr::rom_phase_kernel" if timings else "twr::rom_kernel", "nodes": "twr::node_kernel"}
+             "rangeofmotion": "twr::rom_phase_kernel" if timings else "twr::rom_kernel",
+             "nodes": "twr::node_kernel" if (timings or B < 2048) else "twr::node_chunk_kernel"}
     kbytes = batch.kernel_bytes()
     dom = max(kern_ms, key=kern_ms.get)
     path_ms = sum(kern_ms.values())
@@ -524,7 +526,8 @@ def main():
         path_achieved = alg_bytes / (path_ms * 1e-3) / 1e9
         names = {"dynamic": "twr::dyn_kernel", "rangeofmotion": "twr::rom_kernel",
                  # batches that carry the hot-path sets only run the two-family node kernel
-                 "nodes": "twr::node_kernel2" if (args.workload != "c3" or args.sets == "hot") else "twr::node_kernel"}
+                 "nodes": "twr::node_kernel2" if (args.workload != "c3" or args.sets == "hot") else
+                          ("twr::node_chunk_kernel" if (args.sets == "all" and B >= 2048) else "twr::node_kernel")}
         if args.workload == "c3" and args.sets == "timings":
             names.update(dynamic="twr::dyn_phase_kernel", rangeofmotion="twr::rom_phase_kernel")
         main_traffic = (traffic_from_profile({"hot": "C3", "timings": "C3+timings", "all": "C3+all"}[args.sets], names[dom], B)

@@ -73,6 +73,40 @@ def test_gpu_matches_mpmath_golden(path):
     assert_parity(S, g, j, rg, rj, os.path.basename(path))
 
 
+def test_large_ragged_batch_takes_the_persistent_node_kernel():
+    """Batches of >= 2048 problems evaluate their terrain / force / splineacc / swing rows with the persistent
+    node_chunk_kernel (per-family chunk lists, records two chunks ahead, x one chunk ahead) instead of one workgroup per
+    problem: 2304 problems over three ragged structures (towr's default constraint list on Gap and Stairs, a K = 90 one with
+    two splineacc chunks, the hot-path sets alone) against the oracle for a sample and against the SAME problems evaluated as
+    a 768-problem batch (node_kernel path) for every value; NaN-prefilled outputs: every element written."""
+    import torch
+    specs = [("anymal", "gap", 1, 2.0, dict(constraint_sets=63)), ("hyq", "stairs", 0, 2.4, dict(constraint_sets=63, **k_params(2.4, 90))),
+             ("go1", "slope", 3, 1.6, {})]
+    cases = [Case(r, t, ta.gait_combo(4, c, T), **kw) for r, t, c, T, kw in specs]
+    order = [p % 3 for p in range(2304)]
+    xs_of = [[c.x_wild(i) for i in range(6)] + [c.x_perturbed(i, 2.0) for i in range(2)] for c in cases]
+    xs = [xs_of[s][(p // 3) % 8] for p, s in enumerate(order)]
+    outs = []
+    for n in (2304, 768):
+        batch = ta.Batch([c.S for c in cases], order[:n], device=0)
+        x = torch.from_numpy(np.concatenate(xs[:n])).cuda()
+        g = torch.full((int(batch.g_off[-1]),), float("nan"), dtype=torch.float64, device="cuda")
+        j = torch.full((int(batch.jac_off[-1]),), float("nan"), dtype=torch.float64, device="cuda")
+        batch.profile_begin(1)   # per-kernel events: the separate launches (the fused launch has its own node role)
+        batch.eval_device(x.data_ptr(), g.data_ptr(), j.data_ptr(), ta.EVAL_BOTH, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        batch.profile_end()
+        outs.append((batch, g.cpu().numpy(), j.cpu().numpy()))
+    (b0, g0, j0), (b1, g1, j1) = outs
+    assert np.isfinite(g0).all() and np.isfinite(j0).all()
+    ng, nj = int(b1.g_off[-1]), int(b1.jac_off[-1])
+    assert np.abs(g0[:ng] - g1).max() <= 1e-13 * np.abs(g1).max() and np.abs(j0[:nj] - j1).max() <= 1e-13 * np.abs(j1).max()
+    for p in (0, 1, 2, 770, 1535, 2301, 2302, 2303):
+        rg, _, _, rj = cases[order[p]].P.eval(xs[p])
+        gd, jd = _split(b0, g0, j0, p)
+        assert_parity(cases[order[p]].S, gd, jd, rg, rj, "problem %d" % p, x=xs[p])
+
+
 def test_ragged_batch_of_distinct_structures():
     """Different gaits, horizons, terrains and robots in one launch (odd and even nnz offsets)."""
     specs = [("anymal", "gap", 0, 2.0, {}), ("anymal", "stairs", 1, 1.4, {}), ("hyq", "slope", 2, 2.4, {}),

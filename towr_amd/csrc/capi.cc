@@ -18,10 +18,12 @@
 
 namespace twr {
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dyn_map_chunks, const RomWork* rom, int n_rom, int rom_max_vals,
-                       const NodeWork* node, int n_node, int node_families, const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap,
+                       const NodeWork* node, int n_node, int node_families, const FamWork* const fam[4], const int n_fam[4],
+                       const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap,
                        const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
                        double* g, double* jac, double* dump, int flags, hipStream_t stream, hipEvent_t* ev);
 int dyn_dump_doubles();
+int node_force_chunk();
 hipError_t prepare_phase_kernels(int pdyn_img_cap, int prom_img_cap);
 hipError_t launch_check(int n_problems, const int64_t* g_off, const int64_t* j_off, const double* g, const double* jac,
                         int32_t* status, int flags, hipStream_t stream);
@@ -102,6 +104,8 @@ struct twr_batch {
   twr::DynWork* d_dyn = nullptr;
   twr::RomWork* d_rom = nullptr;
   twr::NodeWork* d_node = nullptr;
+  twr::FamWork* d_fam[4] = {nullptr, nullptr, nullptr, nullptr};   // chunk lists of node_chunk_kernel (large batches only)
+  int n_fam[4] = {0, 0, 0, 0};
   // optimised-timings problems have their own work lists
   twr::PDynWork* d_pdyn = nullptr;
   int pdyn_img_cap = 0, prom_img_cap = 0;    // doubles of the LDS images of dyn_phase_kernel / rom_phase_kernel (largest pass of the batch)
@@ -674,6 +678,49 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     upload(dyn.data(), dyn.size() * sizeof(twr::DynWork), reinterpret_cast<void**>(&b->d_dyn));
     upload(rom.data(), rom.size() * sizeof(twr::RomWork), reinterpret_cast<void**>(&b->d_rom));
     upload(node.data(), node.size() * sizeof(twr::NodeWork), reinterpret_cast<void**>(&b->d_node));
+    // Large batches whose node-based sets are terrain / force / splineacc / swing only: per-family chunk lists for the
+    // persistent node_chunk_kernel (baseMotion and totalduration rows, and small batches -- where the fused launch or the
+    // one-workgroup-per-problem kernel is as good -- stay with node_kernel).
+    {
+      // (hot-path batches -- terrain and force rows only -- are faster on node_kernel2: 0.041 vs 0.047 ms per 8192 C3 problems)
+      bool eligible = n_problems >= 2048 && b->node_families == 4;
+      for (int i = 0; i < n_structs && eligible; ++i)
+        if (structs[i]->s.params.constraint_sets & (TWR_SET_BASE_ROM | TWR_SET_TOTAL_TIME)) eligible = false;
+      if (eligible) {
+        std::vector<twr::FamWork> fam[4];
+        for (int p = 0; p < n_problems; ++p) {
+          const twr::Structure& S = structs[struct_of_problem[p]]->s;
+          const twr::DevStruct* H = reinterpret_cast<const twr::DevStruct*>(S.blob.data());
+          const uint64_t blob = b->blob_of_problem[p];
+          auto add = [&](int f, int count, uint32_t table_off, size_t rec_bytes, int row0, int rows_per, int nnz0, int vals_per) {
+            const int chunk = f == 1 ? twr::node_force_chunk() : 64;
+            for (int i0 = 0; i0 < count; i0 += chunk) {
+              twr::FamWork w;
+              std::memset(&w, 0, sizeof(w));
+              w.blob = blob;
+              w.table = blob + table_off + (f == 2 ? 0 : rec_bytes * (size_t)i0);
+              w.x_off = b->x_off[p];
+              w.g_off = b->g_off[p] + row0 + (int64_t)rows_per * i0;
+              w.j_off = b->j_off[p] + nnz0 + (int64_t)vals_per * i0;
+              w.cnt = std::min(chunk, count - i0);
+              w.i0 = f == 2 ? i0 : 0;
+              w.aux0 = 3 * H->n_junctions;
+              w.aux1 = H->off_base_ang;
+              w.inv_t_swing = H->inv_t_swing;
+              fam[f].push_back(w);
+            }
+          };
+          add(0, H->n_terrain_rows, H->o_terrain_rows, sizeof(twr::TerrainRow), H->row_terrain, 1, H->nnz_terrain, 3);
+          add(1, H->n_force_nodes, H->o_force_nodes, sizeof(twr::ForceNode), H->row_force, 5, H->nnz_force, 25);
+          add(2, 6 * H->n_junctions, H->o_acc, sizeof(twr::AccJunction), H->row_acc, 1, H->nnz_acc, 6);
+          add(3, H->n_swing_nodes, H->o_swing_nodes, sizeof(twr::SwingNode), H->row_swing, 4, H->nnz_swing, 12);
+        }
+        for (int f = 0; f < 4; ++f) {
+          b->n_fam[f] = (int)fam[f].size();
+          if (!fam[f].empty()) upload(fam[f].data(), fam[f].size() * sizeof(twr::FamWork), reinterpret_cast<void**>(&b->d_fam[f]));
+        }
+      }
+    }
     upload(b->g_off.data(), b->g_off.size() * sizeof(int64_t), reinterpret_cast<void**>(&b->d_goff));
     upload(b->j_off.data(), b->j_off.size() * sizeof(int64_t), reinterpret_cast<void**>(&b->d_joff));
     TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_dump), sizeof(double) * (size_t)twr::dyn_dump_doubles()));
@@ -732,6 +779,8 @@ void twr_batch_destroy(twr_batch* b) {
   if (b->d_dyn) (void)hipFree(b->d_dyn);
   if (b->d_rom) (void)hipFree(b->d_rom);
   if (b->d_node) (void)hipFree(b->d_node);
+  for (twr::FamWork* d : b->d_fam)
+    if (d) (void)hipFree(d);
   if (b->d_pdyn) (void)hipFree(b->d_pdyn);
   if (b->d_prom) (void)hipFree(b->d_prom);
   if (b->d_ploc) (void)hipFree(b->d_ploc);
@@ -776,7 +825,7 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
   hipEvent_t* ev = nullptr;
   if (b->prof_count < b->prof_capacity) ev = b->prof_events.data() + 4 * b->prof_count++;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-  hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->dyn_map_chunks, b->d_rom, b->n_rom, b->rom_max_vals, b->d_node, b->n_node, b->node_families,
+  hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->dyn_map_chunks, b->d_rom, b->n_rom, b->rom_max_vals, b->d_node, b->n_node, b->node_families, b->d_fam, b->n_fam,
                                   b->d_pdyn, b->n_pdyn, b->pdyn_img_cap, b->d_ploc, b->n_ploc, b->d_prom, b->n_prom,
                                   b->prom_img_cap, d_x, d_g, d_jac, b->d_dump, flags & TWR_EVAL_BOTH, stream, ev);
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));

@@ -359,6 +359,23 @@ struct NodeWork {         // all terrain-* and force-* sets of one problem
 };
 static_assert(sizeof(NodeWork) == 32, "NodeWork layout");
 
+// Node-based sets of LARGE batches (node_chunk_kernel): one work item = up to 64 items (spline nodes / rows) of ONE family of one
+// problem, everything the wave needs as absolute addresses / offsets, so that a persistent wave can prefetch the records of
+// the chunk two items ahead and its x values one item ahead.  Families: 0 terrain-* rows, 1 force-* nodes, 2 splineacc-base-*
+// rows, 3 swing-* nodes.  (baseMotion / totalduration rows and small batches stay with node_kernel / the fused kernel.)
+struct FamWork {
+  uint64_t blob;          // DevStruct (terrain constants / grid address: families 0, 1)
+  uint64_t table;         // first record of the chunk: TerrainRow / ForceNode / SwingNode; family 2: AccJunction[0]
+  int64_t x_off;          // problem's x
+  int64_t g_off;          // first constraint value of the chunk
+  int64_t j_off;          // first Jacobian value of the chunk
+  int32_t cnt;            // items of the chunk (<= 64, one per lane; force: <= 32)
+  int32_t i0;             // family 2: first row of the chunk inside splineacc-base-lin|ang; else 0
+  int32_t aux0, aux1;     // family 2: rows per set (3 x junctions), x offset of base-ang
+  double inv_t_swing;     // family 3: 1 / t_swing_avg_
+};
+static_assert(sizeof(FamWork) == 64, "FamWork layout");
+
 struct PDynWork {         // optimised timings: one pass = cnt <= 4 time nodes of "dynamic".  Everything the kernel
                           // needs is an absolute address or a value here: no dependent table lookups per pass.
   uint64_t hdr;           // DevStruct (mass, gravity, inertia)

@@ -536,10 +536,16 @@ TWR_DEV Terr terrain_eval(const DevStruct* __restrict__ S, int id, double flat_h
 
 // ForceConstraint::{GetValues, FillJacobianBlock} (force_constraint.cc:62-171) for one stance force
 // node; terrain basis and its "derivative" per height_map.cc:62-148 (component-wise product, as is).
+TWR_DEV void force_core(const DevStruct* __restrict__ S, const double f[3], double px, double py, double* __restrict__ g5,
+                        double* __restrict__ st25, bool want_g, bool want_j);
 TWR_DEV void force_item(const DevStruct* __restrict__ S, const ForceNode fn, const double* __restrict__ xp,
                         double* __restrict__ g5, double* __restrict__ st25, bool want_g, bool want_j) {
   const double f[3] = {xp[fn.fidx], xp[fn.fidx + 2], xp[fn.fidx + 4]};
-  const double px = xp[fn.hidx], py = xp[fn.hidx + 1];
+  force_core(S, f, xp[fn.hidx], xp[fn.hidx + 1], g5, st25, want_g, want_j);
+}
+// (f: the node's force, px / py: the stance foothold; the single body of the force rows for node_kernel and node_chunk_kernel)
+TWR_DEV void force_core(const DevStruct* __restrict__ S, const double f[3], double px, double py, double* __restrict__ g5,
+                        double* __restrict__ st25, bool want_g, bool want_j) {
   const Terr t = terrain_eval(S, S->terrain_id, S->flat_height, px, py);
   const double mu = S->mu;
   const double vb[3][3] = {{-t.hx, -t.hy, 1.0}, {1.0, 0.0, t.hx}, {0.0, 1.0, t.hy}};  // n, t1, t2 (height_map.cc:93-139)
@@ -1378,6 +1384,147 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4))) void n
   __shared__ __attribute__((aligned(16))) double stage_all[kStageTerrain + kStageForce];
   const int family = threadIdx.x >> 6;  // wave-uniform
   node_body(work[blockIdx.x], x, g, jac, flags, stage_all + kNodeStageOff[family], family, threadIdx.x & 63);
+}
+
+// ---------------------------------------------------------------- node-based sets of large batches: persistent chunks
+// node_kernel is one chain of dependent loads per wave (work item -> header -> records -> x) and lives on occupancy alone
+// (PMC: waiting 0.80-0.85 of the wave cycles).  For batches of more than a few thousand problems the same rows are evaluated
+// by PERSISTENT waves instead: one wave = one family, walking that family's chunk list (FamWork) with a stride, the
+// records of the chunk two items ahead and its x values one item ahead already in flight while the current chunk is
+// computed and streamed out.  Every prefetch is unconditional with a clamped index (no phi on in-flight values, see
+// rom_body).  Same arithmetic as node_body, statement by statement, so the same bits.
+template <int FAM>
+struct FamIn {
+  int32_t a[6];        // the lane's record: TerrainRow | ForceNode | (unused) | SwingNode
+  double c[6];         // family 2: the junction's six coefficients
+  double v[8];         // x values: 3 | 5 | 6 | 8
+};
+template <int FAM>
+TWR_DEV void fam_load_rec(const FamWork& w, int lane, FamIn<FAM>& in) {
+  const int i = min(lane, w.cnt - 1);
+  if (FAM == 0 || FAM == 1) {
+    const int2 r = gptr<int2>(w.table)[i];
+    in.a[0] = r.x; in.a[1] = r.y;
+  } else if (FAM == 2) {
+    const int rem = (w.i0 + i) % w.aux0;
+    const TWR_GLOBAL double* a = reinterpret_cast<const TWR_GLOBAL double*>(w.table) + 6 * (rem / 3);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) in.c[q] = a[q];
+  } else {
+    const TWR_GLOBAL int32_t* r = reinterpret_cast<const TWR_GLOBAL int32_t*>(w.table) + 6 * i;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) in.a[q] = r[q];
+  }
+}
+template <int FAM>
+TWR_DEV void fam_load_x(const FamWork& w, int lane, const double* __restrict__ x, FamIn<FAM>& in) {
+  const double* xp = x + w.x_off;
+  if (FAM == 0) {        // TerrainRow {idx, stride}
+    in.v[0] = xp[in.a[0]]; in.v[1] = xp[in.a[0] + in.a[1]]; in.v[2] = xp[in.a[0] + 2 * in.a[1]];
+  } else if (FAM == 1) { // ForceNode {fidx, hidx}
+    in.v[0] = xp[in.a[0]]; in.v[1] = xp[in.a[0] + 2]; in.v[2] = xp[in.a[0] + 4];
+    in.v[3] = xp[in.a[1]]; in.v[4] = xp[in.a[1] + 1];
+  } else if (FAM == 2) {
+    const int r = w.i0 + min(lane, w.cnt - 1);
+    const int which = r >= w.aux0, rem = r - which * w.aux0;
+    const int j = rem / 3, d = rem - 3 * j;
+    const double* xb = xp + (which ? w.aux1 : 0) + 6 * j + d;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) in.v[q] = xb[3 * q];
+  } else {               // SwingNode {cur, prev_x, prev_y, next_x, next_y}
+    in.v[0] = xp[in.a[1]]; in.v[1] = xp[in.a[3]]; in.v[2] = xp[in.a[0]]; in.v[3] = xp[in.a[0] + 1];
+    in.v[4] = xp[in.a[2]]; in.v[5] = xp[in.a[4]]; in.v[6] = xp[in.a[0] + 2]; in.v[7] = xp[in.a[0] + 3];
+  }
+}
+template <int FAM>
+TWR_DEV void fam_compute(const FamWork& w, const FamIn<FAM>& in, double* __restrict__ g, double* __restrict__ jac, double* stage,
+                         int lane, bool want_g, bool want_j) {
+  constexpr int kPer = FAM == 0 ? 3 : (FAM == 1 ? 25 : (FAM == 2 ? 6 : 12));    // Jacobian values per item
+  constexpr int kRows = FAM == 0 ? 1 : (FAM == 1 ? 5 : (FAM == 2 ? 1 : 4));     // constraint values per item
+  const DevStruct* S = reinterpret_cast<const DevStruct*>(w.blob);
+  double* dst = jac + w.j_off;
+  double* gp = g + w.g_off;
+  const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+  if (lane < w.cnt) {
+    if (FAM == 0) {
+      const Terr t = terrain_eval(S, S->terrain_id, S->flat_height, in.v[0], in.v[1]);
+      if (want_g) gp[lane] = in.v[2] - t.h;
+      if (want_j) {
+        stage[par + 3 * lane + 0] = -t.hx;
+        stage[par + 3 * lane + 1] = -t.hy;
+        stage[par + 3 * lane + 2] = 1.0;
+      }
+    } else if (FAM == 1) {
+      const double f[3] = {in.v[0], in.v[1], in.v[2]};
+      force_core(S, f, in.v[3], in.v[4], gp + 5 * lane, stage + par + 25 * lane, want_g, want_j);
+    } else if (FAM == 2) {
+      double v = 0.0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        v += in.c[q] * in.v[q];
+        if (want_j) stage[par + 6 * lane + q] = in.c[q];
+      }
+      if (want_g) gp[lane] = v;
+    } else {
+      const double it = w.inv_t_swing;
+#pragma unroll
+      for (int dim = 0; dim < 2; ++dim) {
+        const double prev = in.v[4 * dim], next = in.v[4 * dim + 1], pos = in.v[4 * dim + 2], vel = in.v[4 * dim + 3];
+        const double distance = next - prev;
+        if (want_g) {
+          gp[4 * lane + 2 * dim] = pos - (prev + 0.5 * distance);
+          gp[4 * lane + 2 * dim + 1] = vel - distance * it;
+        }
+        if (want_j) {
+          double* st = stage + par + 12 * lane + 6 * dim;
+          st[0] = -0.5; st[1] = 1.0; st[2] = -0.5;
+          st[3] = it;   st[4] = 1.0; st[5] = -it;
+        }
+      }
+    }
+  }
+  (void)kRows;
+  if (want_j) copy_out(dst, stage, kPer * w.cnt, par, lane);  // single wave: LDS accesses are ordered
+}
+template <int FAM>
+TWR_DEV void fam_body(const FamWork* __restrict__ work, int n_work, const double* __restrict__ x, double* __restrict__ g,
+                      double* __restrict__ jac, double* stage, int lane, int i, int stride, bool want_g, bool want_j) {
+  if (i >= n_work) return;
+  const int last = i + (n_work - 1 - i) / stride * stride;
+  FamWork w0 = work[i], w1 = work[min(i + stride, last)];
+  FamIn<FAM> in0, in1;
+  fam_load_rec<FAM>(w0, lane, in0);
+  fam_load_rec<FAM>(w1, lane, in1);
+  fam_load_x<FAM>(w0, lane, x, in0);
+  for (; i <= last; i += stride) {
+    const FamWork w2 = work[min(i + 2 * stride, last)];
+    FamIn<FAM> in2;
+    fam_load_rec<FAM>(w2, lane, in2);          // records two chunks ahead
+    fam_load_x<FAM>(w1, lane, x, in1);         // x one chunk ahead (its records arrived an iteration ago)
+    fam_compute<FAM>(w0, in0, g, jac, stage, lane, want_g, want_j);
+    w0 = w1; in0 = in1;
+    w1 = w2; in1 = in2;
+  }
+}
+// blocks [0, g0) walk the terrain chunks, the next g1 the force chunks, then splineacc, then swing (any count may be 0)
+constexpr int kForceChunk = 32;                                   // force nodes per chunk (25 values each)
+constexpr int kStageChunk = kForceChunk * 25 + 2;                // >= 64 x 12 + 2 (swing), 64 x 6 + 2, 64 x 3 + 2
+static_assert(kStageChunk >= kStageSwing && kStageChunk >= kStageAcc && kStageChunk >= kStageTerrain, "chunk image");
+__global__ __launch_bounds__(64, 4) void node_chunk_kernel(const FamWork* __restrict__ f0, int n0, int g0, const FamWork* __restrict__ f1,
+                                                        int n1, int g1, const FamWork* __restrict__ f2, int n2, int g2,
+                                                        const FamWork* __restrict__ f3, int n3, int g3, const double* __restrict__ x,
+                                                        double* __restrict__ g, double* __restrict__ jac, int flags) {
+  __shared__ __attribute__((aligned(16))) double stage[kStageChunk];
+  const int lane = threadIdx.x;
+  const bool want_g = flags & 1, want_j = flags & 2;
+  int b = blockIdx.x;
+  if (b < g0) return fam_body<0>(f0, n0, x, g, jac, stage, lane, b, g0, want_g, want_j);
+  b -= g0;
+  if (b < g1) return fam_body<1>(f1, n1, x, g, jac, stage, lane, b, g1, want_g, want_j);
+  b -= g1;
+  if (b < g2) return fam_body<2>(f2, n2, x, g, jac, stage, lane, b, g2, want_g, want_j);
+  b -= g2;
+  fam_body<3>(f3, n3, x, g, jac, stage, lane, b, g3, want_g, want_j);
 }
 
 // Small and mid-size batches: the three kernels above as ONE launch, so that their pipeline fills and drains overlap
@@ -2732,6 +2879,7 @@ static int env_int(const char* name, int dflt) {
 }
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dyn_map_chunks /* 2 or 4 */, const RomWork* rom, int n_rom,
                        int rom_max_vals, const NodeWork* node, int n_node, int node_families /* 2: terrain + force only; 4 */,
+                       const FamWork* const fam[4], const int n_fam[4] /* chunk lists of node_chunk_kernel; all 0: none */,
                        const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap, const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
                        double* g, double* jac, double* dump /* kDynDump doubles */, int flags, hipStream_t stream,
                        hipEvent_t* ev /* 4 events or nullptr */) {
@@ -2851,7 +2999,20 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
     st = twr_first(st, launch_rom_kernel((int)grid.x, stream, rom, n_rom, rom_max_vals, x, g, jac, flags));
   }
   if (ev) (void)hipEventRecord(ev[2], stream);
-  if (n_node > 0 && node_families == 2)
+  const int n_chunks = n_fam[0] + n_fam[1] + n_fam[2] + n_fam[3];
+  if (n_chunks > 0) {
+    // persistent waves per CU for ALL families together, shared out by their chunk counts
+    static const int node_bpc = env_int("TWR_NODE_BPC", 16);
+    const int res = node_bpc * n_cu;
+    int gf[4];
+    for (int f = 0; f < 4; ++f) {
+      gf[f] = n_fam[f] == 0 ? 0 : (int)((long long)res * n_fam[f] / n_chunks);
+      if (n_fam[f] > 0 && gf[f] < 1) gf[f] = 1;
+      if (gf[f] > n_fam[f]) gf[f] = n_fam[f];
+    }
+    st = twr_first(st, twr_launch(node_chunk_kernel, dim3(gf[0] + gf[1] + gf[2] + gf[3]), dim3(64), 0, stream, fam[0], n_fam[0], gf[0], fam[1],
+                                  n_fam[1], gf[1], fam[2], n_fam[2], gf[2], fam[3], n_fam[3], gf[3], x, g, jac, flags));
+  } else if (n_node > 0 && node_families == 2)
     st = twr_first(st, twr_launch(node_kernel2, dim3(n_node), dim3(128), 0, stream, node, x, g, jac, flags));
   else if (n_node > 0)
     st = twr_first(st, twr_launch(node_kernel, dim3(n_node), dim3(256), 0, stream, node, x, g, jac, flags));
@@ -2879,6 +3040,7 @@ hipError_t prepare_phase_kernels(int pdyn_img_cap, int prom_img_cap) {
   return st;
 }
 int dyn_dump_doubles() { return kDynImage + 2 + 96; }
+int node_force_chunk() { return kForceChunk; }
 #endif  // !TWR_TU_ROM
 
 }  // namespace twr
