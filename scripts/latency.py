@@ -46,5 +46,16 @@ for sets, name in ((27, "hot path"), (63, "default list"), (127, "default + timi
         pin_us = (time.perf_counter() - t0) / 100 * 1e6
         g2, j2 = batch.eval_host(xh)
         assert np.array_equal(g2, pg) and np.array_equal(j2, pj)
+        # what the ifopt adapter pays per Ipopt callback (page-locked buffers): eval_g = values only, eval_jac_g on a known
+        # x = Jacobian only, against one evaluation of both (what every new x cost before round 4)
+        per = {}
+        for what, flags in (("values", ta.EVAL_VALUES), ("jacobian", ta.EVAL_JACOBIAN)):
+            for _ in range(5):
+                batch.eval_host_pinned(flags)
+            t0 = time.perf_counter()
+            for _ in range(100):
+                batch.eval_host_pinned(flags)
+            per[what] = (time.perf_counter() - t0) / 100 * 1e6
         print("%-18s B=%-3d n=%d nnz=%d: back-to-back %.1f us/call, synchronised %.1f us/call, host buffers (H2D+eval+D2H) "
-              "pageable %.1f us/call, page-locked %.1f us/call" % (name, B, S.n, S.nnz, dev_us, sync_us, host_us, pin_us), flush=True)
+              "pageable %.1f us/call, page-locked %.1f us/call; page-locked eval_g (values only) %.1f us, eval_jac_g (Jacobian "
+              "only) %.1f us" % (name, B, S.n, S.nnz, dev_us, sync_us, host_us, pin_us, per["values"], per["jacobian"]), flush=True)

@@ -716,9 +716,25 @@ void Structure::PackBlob() {
     std::vector<int> combo_key;   // active polynomial ids of the last combination
     dyn_slices.clear();
     dyn_staged_max = 0;
+    // Slices that stage at most 128 doubles of x read the 256-byte form of their staging map and gather x with two loads per
+    // lane instead of four (dyn_body XC = 2) -- if EVERY slice of a batch does.  Fine discretisations do anyway (a 12..15-node
+    // slice of a K = 200 problem stages 90-130); where the general capacity would let a few slices stage a little more, they
+    // are cut at 128 instead, as long as that costs at most one more slice per eight.
+    auto count_slices = [&](int cap) {
+      int n = 0;
+      for (int k0 = 0; k0 < K; ++n) {
+        int k1 = k0;
+        while (k1 < K && k1 - k0 < kDynNodes && nvals_of(k0, k1 + 1) <= kDynImage && stage_count(k0, k1 + 1) <= cap && rec_span_ok(k0, k1 + 1)) ++k1;
+        if (k1 == k0) return 1 << 30;
+        k0 = k1;
+      }
+      return n;
+    };
+    const int n_general = count_slices(kDynXsCap), n_small = count_slices(std::min(kDynXsCap, 128));
+    const int xs_cap = n_small <= n_general + (n_general + 7) / 8 ? std::min(kDynXsCap, 128) : kDynXsCap;
     for (int k0 = 0; k0 < K;) {
       int k1 = k0;
-      while (k1 < K && k1 - k0 < kDynNodes && nvals_of(k0, k1 + 1) <= kDynImage && stage_count(k0, k1 + 1) <= kDynXsCap &&
+      while (k1 < K && k1 - k0 < kDynNodes && nvals_of(k0, k1 + 1) <= kDynImage && stage_count(k0, k1 + 1) <= xs_cap &&
              rec_span_ok(k0, k1 + 1))
         ++k1;
       if (k1 == k0) throw std::runtime_error("one time node of the dynamic set exceeds the LDS staging capacity");
