@@ -8,7 +8,8 @@ EXTRA = []
 if "--" in ARGS:
     EXTRA = ARGS[ARGS.index("--") + 1:]
     ARGS = ARGS[:ARGS.index("--")]
-for rep in range(2):
+REPS = int(os.environ.get("AB_REPS", "2"))   # AB_REPS=5: more alternations (run-to-run noise on one box is +-2 %)
+for rep in range(REPS):
     for spec in ARGS:
         lib, _, envs = spec.partition(":")
         env = dict(os.environ, TWR_AMD_LIB=os.path.join(ROOT, "towr_amd", lib))

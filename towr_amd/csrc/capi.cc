@@ -554,7 +554,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
           w.off_ang = S.off_base_ang;
           w.cnt = sl.cnt;
           w.nvals = sl.nvals;
-          std::memcpy(w.first, sl.first, sizeof(w.first));
+          w.ee = e;
           b->rom_max_vals = std::max(b->rom_max_vals, w.nvals);
           rom.push_back(w);
         }

@@ -34,7 +34,8 @@ struct PolyDesc {
 // rangeofmotion-<ee>, fixed timings (rom_kernel).  What a lane (= one time node) needs is split by what it depends on, so
 // that a sweep -- every candidate its own tables, read from HBM exactly once per evaluation -- streams 10 KB per candidate
 // instead of the 51 KB of one 64-byte record per (time node, ee):
-//   RomNode  per time node, shared by the slices of all end-effectors: grid time and the base-spline lookup   (32 B)
+//   RomNode  per time node, shared by the slices of all end-effectors: grid time, the base-spline lookup, and for every
+//            end-effector which RomSeg of its slice the node reads                                            (32 B)
 //   RomSeg   per (slice, polynomial of the ee-motion spline active inside the slice): everything that is constant while
 //            that polynomial stays active -- its start time, 1 / duration, variable range, where the segment's rows start (48 B)
 // The local time of the ee spline is t - t0 (t0 = the sum of the durations before the polynomial, accumulated like
@@ -47,7 +48,7 @@ struct RomNode {
   double t;           // global time of the node (TimeDiscretizationConstraint::dts_)
   double tb, iTb;     // base spline: local time in the active polynomial, 1/duration
   int32_t q6;         // 6 * (active base polynomial): offset of its first node in base-lin / base-ang
-  int32_t pad;
+  uint32_t seg;       // bits 3e .. 3e+2: which segment (RomSeg) of ee e's slice the node belongs to
 };
 static_assert(sizeof(RomNode) == 32, "RomNode layout");
 struct RomSeg {
@@ -349,7 +350,8 @@ struct RomWork {          // cnt <= 64 time nodes of "rangeofmotion-<ee>"
   int64_t x_off, g_off, j_off;
   int32_t off_lin, off_ang;
   int32_t cnt, nvals;
-  uint8_t first[kRomMaxSeg];   // first[i] = first lane of segment i (first[0] = 0; 255 = no such segment)
+  int32_t ee;             // the end-effector (which three bits of RomNode::seg are this slice's)
+  int32_t pad;
 };
 static_assert(sizeof(RomWork) == 64, "RomWork layout");
 

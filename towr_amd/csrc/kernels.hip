@@ -306,46 +306,34 @@ struct RomX {
   double bl[12], ba[12], m[12];
 };
 TWR_DEV uint64_t rom_slots(const RomRec& r) { return ((uint64_t)r.slots[1] << 32) | r.slots[0]; }
-// What a lane of rom_kernel carries through the pipeline: its time node's record and its segment's record as loaded (raw:
-// nothing is computed from them at issue time, so the prefetch does not wait), and the lane's node index.
-struct RomLane {
-  RomNode nd;
-  RomSeg sg;
-  int k;
-};
-TWR_DEV RomLane rom_load_rec(const RomWork& w, int lane) {
-  RomLane L;
-  L.k = min(lane, w.cnt - 1);
-  int s = 0;   // segment of this node: the work item lists the first lane of every segment (wave-uniform bytes)
-#pragma unroll
-  for (int i = 1; i < kRomMaxSeg; ++i) s += (L.k >= (int)w.first[i]) ? 1 : 0;
-  L.nd = gptr<RomNode>(w.nodes)[L.k];
-  L.sg = gptr<RomSeg>(w.segs)[s];
-  return L;
-}
+// What a lane of rom_kernel carries through the pipeline, as loaded (raw: nothing is computed from the records at issue
+// time, so a prefetch never waits): its time node's record -- fetched THREE slices ahead, because it also says which segment
+// record the lane reads -- and its segment's record, fetched two slices ahead.
+TWR_DEV RomNode rom_load_node(const RomWork& w, int lane) { return gptr<RomNode>(w.nodes)[min(lane, w.cnt - 1)]; }
+TWR_DEV RomSeg rom_load_seg(const RomWork& w, const RomNode& nd) { return gptr<RomSeg>(w.segs)[(nd.seg >> (3 * w.ee)) & 7u]; }
 // the lane's view in the form the math is written for (fields of the optimised-timings record RomRec)
-TWR_DEV RomRec rom_rec_of(const RomLane& L) {
+TWR_DEV RomRec rom_rec_of(const RomWork& w, const RomNode& nd, const RomSeg& sg, int lane) {
   RomRec r;
-  r.tb = L.nd.tb; r.iTb = L.nd.iTb;
-  r.tm = L.nd.t - L.sg.t0; r.iTm = L.sg.iTm;
-  r.q6 = L.nd.q6;
-  r.xbase = L.sg.xbase;
-  r.voff = L.sg.voff0 + (L.k - L.sg.kfirst) * L.sg.node_vals;   // relative to the slice's first value
-  r.meta = L.sg.meta;
-  r.slots[0] = L.sg.slots[0]; r.slots[1] = L.sg.slots[1];
+  r.tb = nd.tb; r.iTb = nd.iTb;
+  r.tm = nd.t - sg.t0; r.iTm = sg.iTm;
+  r.q6 = nd.q6;
+  r.xbase = sg.xbase;
+  r.voff = sg.voff0 + (min(lane, w.cnt - 1) - sg.kfirst) * sg.node_vals;   // relative to the slice's first value
+  r.meta = sg.meta;
+  r.slots[0] = sg.slots[0]; r.slots[1] = sg.slots[1];
   r.pad[0] = r.pad[1] = 0;
   return r;
 }
-TWR_DEV void rom_load_x(const RomWork& w, const RomLane& L, const double* __restrict__ x, RomX& X) {
+TWR_DEV void rom_load_x(const RomWork& w, const RomNode& nd, const RomSeg& sg, const double* __restrict__ x, RomX& X) {
   const double* xp = x + w.x_off;
-  const double* xl = xp + w.off_lin + L.nd.q6;
-  const double* xa = xp + w.off_ang + L.nd.q6;
+  const double* xl = xp + w.off_lin + nd.q6;
+  const double* xa = xp + w.off_ang + nd.q6;
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
     X.bl[i] = xl[i];
     X.ba[i] = xa[i];
   }
-  gather12(xp, L.sg.xbase, ((uint64_t)L.sg.slots[1] << 32) | L.sg.slots[0], X.m);
+  gather12(xp, sg.xbase, ((uint64_t)sg.slots[1] << 32) | sg.slots[0], X.m);
 }
 TWR_DEV void rom_item(const RomWork& w, const RomRec& r, const RomX& X, double* __restrict__ gst, double* __restrict__ stage,
                       int par, int vbase, int trash, int lane, bool want_g, bool want_j) {
@@ -1162,17 +1150,19 @@ TWR_DEV void rom_body(const RomWork* __restrict__ work, int n_work, const double
   // what makes the compiler wait for a load right where it is issued (round 4: a `r2 = r1; if (has2) r2 = load` form of
   // this loop waited with vmcnt(0) behind the record loads in every iteration -- +8 % with L2-resident tables, +17 % in a sweep).
   const int last = i + (n_work - 1 - i) / stride * stride;
-  RomWork w0 = work[i], w1 = work[min(i + stride, last)];
-  RomLane r0 = rom_load_rec(w0, lane), r1 = rom_load_rec(w1, lane);
+  RomWork w0 = work[i], w1 = work[min(i + stride, last)], w2 = work[min(i + 2 * stride, last)];
+  RomNode n0 = rom_load_node(w0, lane), n1 = rom_load_node(w1, lane), n2 = rom_load_node(w2, lane);
+  RomSeg s0 = rom_load_seg(w0, n0), s1 = rom_load_seg(w1, n1);
   RomX X;
-  rom_load_x(w0, r0, x, X);
+  rom_load_x(w0, n0, s0, x, X);
   for (; i <= last; i += stride) {
-    const RomWork w2 = work[min(i + 2 * stride, last)];
+    const RomWork w3 = work[min(i + 3 * stride, last)];
     double* dst = jac + w0.j_off;
     const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-    if (lane < w0.cnt) rom_item(w0, rom_rec_of(r0), X, gst, stage, par, 0, trash, lane, WANT_G, WANT_J);   // C
-    const RomLane r2 = rom_load_rec(w2, lane);          // A (records first: the wait for x retires them too)
-    rom_load_x(w1, r1, x, X);
+    if (lane < w0.cnt) rom_item(w0, rom_rec_of(w0, n0, s0, lane), X, gst, stage, par, 0, trash, lane, WANT_G, WANT_J);   // C
+    const RomNode n3 = rom_load_node(w3, lane);         // A: node records three slices ahead, segment records two ahead
+    const RomSeg s2 = rom_load_seg(w2, n2);             //    (records first: the wait for x retires them too)
+    rom_load_x(w1, n1, s1, x, X);
     if (WANT_J) copy_out_fixed<NIT, 13>(dst, stage, w0.nvals, par, lane);   // B
     if (WANT_G) {                                       //   3 constraint values per time node, contiguous in g: clamped
       double* go = g + w0.g_off;                        //   lanes instead of predicates (see copy_out_fixed)
@@ -1180,8 +1170,9 @@ TWR_DEV void rom_body(const RomWork* __restrict__ work, int n_work, const double
 #pragma unroll
       for (int t = 0; t < 3; ++t) go[min(lane + 64 * t, last_g)] = gst[min(lane + 64 * t, last_g)];
     }
-    w0 = w1; r0 = r1;
-    w1 = w2; r1 = r2;
+    w0 = w1; n0 = n1; s0 = s1;
+    w1 = w2; n1 = n2; s1 = s2;
+    w2 = w3; n2 = n3;
   }
 }
 

@@ -911,7 +911,6 @@ void Structure::PackBlob() {
       nodes[k].iTb = 1.0 / base.durations[rom_base[k].poly];
       nodes[k].q6 = 6 * rom_base[k].poly;
     }
-    off_rom_nodes = put(nodes.data(), nodes.size() * sizeof(RomNode));
     for (int e = 0; e < n_ee; ++e) {
       const int row0 = row_rom[e];
       auto vals = [&](int k0, int k1) { return row_ptr[row0 + 3 * k1] - row_ptr[row0 + 3 * k0]; };
@@ -982,10 +981,16 @@ void Structure::PackBlob() {
           if (row_ptr[row0 + 3 * k] - row_ptr[row0 + 3 * sl.k0] != sg[si].voff0 + (k - sl.k0 - sg[si].kfirst) * sg[si].node_vals)
             throw std::runtime_error("rangeofmotion segment layout inconsistent");
         }
+        for (int k = sl.k0; k < sl.k0 + sl.cnt; ++k) {   // which segment of this ee's slice node k reads: three bits per ee
+          uint32_t si = 0;
+          while (si + 1 < sg.size() && k - sl.k0 >= (int)sl.first[si + 1]) ++si;
+          nodes[k].seg |= si << (3 * e);
+        }
         sl.segs = put(sg.data(), sg.size() * sizeof(RomSeg));
         rom_slices[e].push_back(sl);
       }
     }
+    off_rom_nodes = put(nodes.data(), nodes.size() * sizeof(RomNode));   // (after the loop: it fills RomNode::seg)
   }
   // --- optimised timings: polynomial tables, set-wide counts, global grid times
   if (timings) {
