@@ -30,7 +30,7 @@ per = a[:, :5] / a[:, 7:8]
 names = ["F front (waits for last S's loads, LDS reads of xs, spline points, sincos)", "P issue codes + next front records",
          "O copy-out of the previous image", "B back (tile + base blocks -> image)", "S stage x, issue selector / gather / map"]
 tot = per.sum(axis=1).mean()
-print("dyn_kernel (stamped build) %.3f ms; workgroups %d, slices per workgroup %.1f, memtime ticks per slice %.0f (100 MHz: %.2f us)"
-      % (ms["dynamic"], len(a), a[:, 7].mean(), tot, tot / 100.0))
+print("dyn_kernel (stamped build) %.3f ms; workgroups %d, slices per workgroup %.1f, memtime ticks per slice %.0f"
+      % (ms["dynamic"], len(a), a[:, 7].mean(), tot))
 for n, v in zip(names, per.mean(axis=0)):
     print("  %-80s %9.0f  %5.1f %%" % (n, v, 100 * v / tot))
