@@ -10,9 +10,11 @@
 // NlpFormulation::GetConstraints in the reference.)  Nothing in towr changes; CPU Ipopt keeps driving the solve.
 //
 // COMPILE-GATED on <towr/nlp_formulation.h> and <ifopt/constraint_set.h> (this build image has neither, nor Eigen).  It is
-// compiled and run by oracle/ref_dump (ref_dump --binding: the REAL reference's constraint sets against these device
-// sets on the same NlpFormulation) on any box that has Eigen3 + ifopt; until then it is unverified by a compiler and says
-// so here.
+// compiled and RUN by oracle/ref_dump (ref_dump --binding: the REAL reference's constraint sets against these device
+// sets on the same NlpFormulation) on any box that has Eigen3 + ifopt.  In this image it is TYPE-CHECKED only
+// (tests/test_binding_syntax.py: g++ -fsyntax-only against the real towr headers with type-level stand-ins for the
+// Eigen / ifopt names they mention): every member, method and enum name of the reference used below exists with the
+// shape assumed; what the code computes is unverified until ref_dump --binding runs somewhere.
 //
 // What is read from where (all through PUBLIC members / virtual interfaces of the reference, no accessor is added to towr):
 //   robot      RobotModel::kinematic_model_ -> GetNominalStanceInBase / GetMaximumDeviationFromNominal
@@ -220,7 +222,7 @@ inline twr_params ToTwrParams(const towr::Parameters& params, const towr::BaseSt
       case towr::Parameters::BaseRom:
         p.constraint_sets |= TWR_SET_BASE_ROM;
         p.dt_base_motion = params.dt_constraint_base_motion_;
-        p.base_z_init = initial_base.lin.p().z();
+        p.base_z_init = initial_base.lin.p()(2);   // z
         break;
       default: throw std::runtime_error("constraint not defined!");   // as nlp_formulation.cc:224
     }
