@@ -39,3 +39,15 @@ def test_binding_header_type_checks_against_the_reference_headers(tmp_path):
             (tmp_path / n).write_text(open(os.path.join(ROOT, "towr_amd", "csrc", n)).read())
         r = _check(str(typo), tmp_path)
         assert r.returncode != 0 and bad in r.stderr, (good, r.stderr[-500:])
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference headers are not on this box")
+def test_ref_dump_driver_type_checks_too():
+    """oracle/ref_dump/ref_dump.cc (the driver of the real reference, incl. its --binding comparison) cannot be built here
+    either; the same type-level check keeps it honest against the reference's headers until a box with Eigen3 + ifopt
+    compiles it for real."""
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-DTWR_WITH_BINDING=1", "-I" + os.path.join(ROOT, "tests", "towr_syntax_stub"),
+                        "-I" + os.path.join(ROOT, "tests", "ifopt_stub"), "-I" + REF, "-I" + os.path.join(REF, "towr", "terrain"),
+                        "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "towr_amd", "csrc"),
+                        os.path.join(ROOT, "oracle", "ref_dump", "ref_dump.cc")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
