@@ -846,10 +846,11 @@ void Structure::PackBlob() {
               T.s_f = (uint8_t)(2 + fst[e] + fp.xbase - flo[e]);
               for (int r = 0; r < 6; ++r) T.base_f[r] = (uint16_t)(8 * tile_start(r, fp.xbase));
             }
-            // self-check of the decomposition  offset = tile start + 8 * rank  against the pattern, value by value
+            // self-check of the decomposition  offset = tile start + 8 * rank  against the pattern, value by value (once per
+            // polynomial combination: the nodes of a combination share their tile records, asserted below)
             const DynPoly& PM = polys[rec_of[0][e][qm]];
             const DynPoly& PF = polys[rec_of[1][e][qf]];
-            for (int c = 0; c < 12; ++c) {
+            for (int c = 0; c < 12 && new_combo; ++c) {
               const int d = c % 3, r1 = (d + 1) % 3, r2 = (d + 2) % 3;
               if (mp.cand[c] != 0xFFFF) {
                 const int col = mp.xbase + (mp.cand[c] & 0xF);
