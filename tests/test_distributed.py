@@ -32,8 +32,12 @@ hg = [None] * world
 dist.all_gather_object(hg, hashlib.sha256(b"".join(s_.col_idx.tobytes() for s_ in gs)).digest())
 assert all(x == hg[0] for x in hg)
 cands = sweep.enumerate_candidates(48)
-# SURVEY 8e: shard by a cheap weight, then every rank builds the structures of ITS shard only (threaded library call)
-weights = [int(sweep.candidate_weight(c)) for c in cands]
+# SURVEY 8e: shard by BYTES per callback -- every rank computes the same exact list without building device tables
+# (twr_candidate_bytes) -- then every rank builds the structures of ITS shard only (threaded library call)
+weights = [int(w) for w in sweep.candidate_bytes(model, cands, threads=2)]
+hw = [None] * world
+dist.all_gather_object(hw, weights)
+assert all(x == hw[0] for x in hw), "the ranks must cut the shards from identical weights"
 a, b = my_shard(weights, rank, world)
 structs_mine = sweep.candidate_structures(model, cands[a:b], threads=2)
 assert len(structs_mine) == b - a
@@ -42,6 +46,7 @@ if 7 not in structs:
     structs[7] = sweep.candidate_structure(model, cands[7])   # (one common candidate for the cross-rank pattern check)
 ref7 = sweep.candidate_structure(model, cands[a])
 assert np.array_equal(ref7.col_idx, structs[a].col_idx) and ref7.nnz == structs[a].nnz   # threaded == one by one
+assert weights[a] == ref7.algorithmic_bytes                                             # the weight IS 8 (n + m + nnz)
 mine = torch.tensor([a, b, sum(weights[a:b])], dtype=torch.int64)
 allr = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
 dist.all_gather(allr, mine)
