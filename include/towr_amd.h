@@ -230,6 +230,13 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
                      int n_problems, int device, twr_batch** out);
 void twr_batch_destroy(twr_batch* b);
 int twr_batch_num_problems(const twr_batch* b);
+/* Device memory of the batch's tables, in bytes (any pointer may be NULL): `resident` = what the batch holds for all its
+ * structures; `dyn_layout` = the layout tables of the "dynamic" set (index maps, CSR positions: everything that does not
+ * hold a time) as built, `dyn_layout_distinct` = what is left of them after the batch has merged byte-identical tables of
+ * different structures (candidates of a sweep that differ only in their total time share all of them), i.e. what one
+ * evaluation reads.  No reference counterpart: towr recomputes these indices inside every callback
+ * (towr/src/nodes_variables_phase_based.cc:210-298, spline.cc:48-78). */
+int twr_batch_table_bytes(const twr_batch* b, int64_t* resident, int64_t* dyn_layout, int64_t* dyn_layout_distinct);
 /* Ragged layout of the batch arrays, each n_problems+1 prefix sums in units of doubles:
  * problem p owns x[x_off[p]..x_off[p+1]), g[g_off[p]..), jac[jac_off[p]..). */
 int twr_batch_layout(const twr_batch* b, int64_t* x_off, int64_t* g_off, int64_t* jac_off);

@@ -643,6 +643,41 @@ def test_sweep_with_optimised_timings_ragged_multi_pass():
     assert {c[0] for c in cands} == {0, 1, 2, 3, 4}
 
 
+def test_layout_tables_are_shared_by_content():
+    """twr_batch_create stores byte-identical layout tables of the dynamic set once (device_tables.h): candidates that
+    differ in the total time only share all of them, candidates with different phase splits share none -- and sharing
+    changes no bit of the results (same slices, same instruction sequence, other addresses)."""
+    from towr_amd import sweep
+
+    model = ta.model_preset("anymal", "stairs")
+    # combo 1, swing scale 0.80, eight total times | combo 1, T = 2.0, six swing scales | one other combo
+    cands = [(1, 1.2 + 0.2 * i, 0.80) for i in range(8)] + [(1, 2.0, 0.80 + 0.016 * j) for j in range(1, 7)] + [(3, 2.0, 0.9)]
+    structs = sweep.candidate_structures(model, cands)
+    order = list(range(len(cands)))[::-1] + [0, 3, 9]      # problems in another order than the structures, some twice
+    batch = ta.Batch(structs, order, device=0)
+    tb = batch.table_bytes()
+    # 8 + 6 + 1 structures.  The eight T-siblings share what depends on the ee splines only (selectors, polynomial layout
+    # records, tile records: ~12 KB of ~30 KB each); the base splines keep their fixed 0.1-s polynomials whatever T is, so
+    # the variable offsets -- staging maps, base-polynomial offsets of the node records -- still differ.
+    assert tb["dyn_layout_distinct"] <= 0.85 * tb["dyn_layout"] and tb["dyn_layout_distinct"] >= 0.5 * tb["dyn_layout"], tb
+    assert tb["resident"] >= tb["dyn_layout"] > 0
+    xs = _sweep_inputs([structs[s] for s in order], model)
+    g, j = batch.eval_host(np.concatenate(xs))
+    for p, s in enumerate(order):
+        alone = ta.Batch([structs[s]], [0], device=0)     # nothing to share with
+        assert alone.table_bytes()["dyn_layout_distinct"] == alone.table_bytes()["dyn_layout"]
+        g1, j1 = alone.eval_host(xs[p])
+        gd, jd = _split(batch, g, j, p)
+        assert np.array_equal(gd, g1) and np.array_equal(jd, j1), "problem %d (structure %d)" % (p, s)
+        if p in (0, 7, 14, 16):
+            rg, _, _, rj = _oracle_for("anymal", "stairs", structs[s]).eval(xs[p])
+            assert_parity(structs[s], gd, jd, rg, rj, "problem %d (structure %d)" % (p, s))
+    # six different swing scales at one T: the phase splits differ, so which polynomial a time node falls into differs
+    # (selectors, tiles, most staging maps) -- the polynomial layout records, which know nothing of times, still coincide
+    six = ta.Batch(structs[8:14], list(range(6)), device=0).table_bytes()
+    assert 0.5 * six["dyn_layout"] <= six["dyn_layout_distinct"] < six["dyn_layout"], six
+
+
 @pytest.mark.parametrize("terrain", ["gap", "stairs"])
 def test_sweep_c4_64(terrain):
     """BASELINE config 4: batch of 64 enumerated candidate contact sequences on Gap / Stairs; all 64 checked."""

@@ -132,6 +132,7 @@ def lib():
         L.twr_batch_destroy.argtypes = [C.c_void_p]
         L.twr_batch_destroy.restype = None
         L.twr_batch_num_problems.argtypes = [C.c_void_p]
+        L.twr_batch_table_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.twr_batch_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.twr_batch_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.twr_batch_status.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
@@ -402,6 +403,13 @@ class Batch:
         """Asynchronous launch on raw device pointers (ints), e.g. torch tensors' data_ptr()."""
         _check(lib().twr_batch_eval(self._h, C.c_void_p(d_x), C.c_void_p(d_g), C.c_void_p(d_jac), flags,
                                     C.c_void_p(stream)))
+
+    def table_bytes(self):
+        """Device bytes of the batch's tables: resident, layout tables of the dynamic set as built, and what is left of them
+        after byte-identical tables of different structures were merged (twr_batch_table_bytes)."""
+        r, a, d = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _check(lib().twr_batch_table_bytes(self._h, C.byref(r), C.byref(a), C.byref(d)))
+        return dict(resident=r.value, dyn_layout=a.value, dyn_layout_distinct=d.value)
 
     def status(self, stream=0):
         """Per-problem non-finite flags of the last eval_device(..., flags | EVAL_CHECK): bit 0 g, bit 1 jac."""

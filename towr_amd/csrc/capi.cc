@@ -11,6 +11,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -89,6 +90,8 @@ struct twr_batch {
   void* arena = nullptr;                     // ONE allocation for the tables of all structures (a sweep has a thousand
                                              // of them: one mapping with large pages instead of a thousand small ones,
                                              // one upload instead of a thousand)
+  int64_t table_bytes = 0;                   // arena bytes
+  int64_t dyn_layout_bytes = 0, dyn_layout_distinct_bytes = 0;   // layout tables of dyn_kernel: as built / after sharing by content
   std::vector<void*> grids;                  // device copies of the distinct gridded terrains
   // what twr_batch_sample needs of every problem (the structures need not outlive the batch)
   std::vector<uint64_t> blob_of_problem;     // device blob address
@@ -482,6 +485,54 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
       }
     }
     TWR_HIP(hipMemcpy(b->arena, host_arena.data(), host_arena.size(), hipMemcpyHostToDevice));
+    b->table_bytes = (int64_t)host_arena.size();
+    // Layout tables of dyn_kernel (device_tables.h) are stored once per distinct CONTENT: a structure whose table is
+    // byte-identical to one of an earlier structure of the batch reads that one (its own copy stays in the arena, unread).
+    // Candidates of a sweep that differ in the total time only share all of them, and an evaluation then reads 24 B per
+    // time node + 16 B per polynomial of such a candidate instead of ~35 KB.  The model constants (DevStruct header) are
+    // taken from the first structure of the batch that has the same ones.
+    std::vector<std::unordered_map<uint32_t, uint64_t>> layout_at(n_structs);   // [structure][blob offset of the table] -> device address
+    std::vector<uint64_t> model_hdr(n_structs);
+    {
+      struct Seen {
+        const char* host;
+        uint32_t bytes;
+        uint64_t dev;
+      };
+      std::unordered_map<uint64_t, std::vector<Seen>> by_hash;
+      auto fnv = [](const char* p, size_t n) {
+        uint64_t h = 1469598103934665603ull;
+        for (size_t i = 0; i < n; ++i) h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
+        return h;
+      };
+      for (int i = 0; i < n_structs; ++i) {
+        const char* blob = host_arena.data() + blob_off[i];
+        for (const auto& tr : structs[i]->s.dyn_layout_tables) {
+          const char* src = blob + tr.off;
+          std::vector<Seen>& bucket = by_hash[fnv(src, tr.bytes) ^ tr.bytes];
+          uint64_t dev = 0;
+          for (const Seen& sn : bucket)
+            if (sn.bytes == tr.bytes && std::memcmp(sn.host, src, tr.bytes) == 0) dev = sn.dev;
+          if (!dev) {
+            dev = reinterpret_cast<uint64_t>(b->blobs[i]) + tr.off;
+            bucket.push_back({src, tr.bytes, dev});
+            b->dyn_layout_distinct_bytes += tr.bytes;
+          }
+          b->dyn_layout_bytes += tr.bytes;
+          layout_at[i][tr.off] = dev;
+        }
+        const twr::DevStruct* H = reinterpret_cast<const twr::DevStruct*>(blob);
+        model_hdr[i] = reinterpret_cast<uint64_t>(b->blobs[i]);
+        for (int q = 0; q < i; ++q) {
+          const twr::DevStruct* Q = reinterpret_cast<const twr::DevStruct*>(host_arena.data() + blob_off[q]);
+          if (model_hdr[q] == reinterpret_cast<uint64_t>(b->blobs[q]) && Q->mass == H->mass && Q->gravity == H->gravity &&
+              std::memcmp(Q->Ib, H->Ib, sizeof(H->Ib)) == 0) {
+            model_hdr[i] = model_hdr[q];
+            break;
+          }
+        }
+      }
+    }
     b->x_off.assign(n_problems + 1, 0);
     b->g_off.assign(n_problems + 1, 0);
     b->j_off.assign(n_problems + 1, 0);
@@ -525,13 +576,15 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
       for (const auto& sl : S.dyn_slices) {   // fixed timings only (empty otherwise)
         twr::DynWork w;
         std::memset(&w, 0, sizeof(w));
-        w.nodes = blob + S.off_dyn_nodes + sizeof(twr::DynNode) * (size_t)sl.k0;
-        w.sel = blob + S.off_dyn_sel + sizeof(twr::DynSel) * (size_t)sl.k0 * 4;
-        w.tile = blob + S.off_dyn_tile;   // (records are addressed through DynSel::tile)
-        w.poly = blob + S.off_dyn_poly + sizeof(twr::DynPoly) * (size_t)sl.poly0;
-        w.dummy = blob + S.off_dyn_dummy;
-        w.map = blob + (b->dyn_map_chunks == 2 ? sl.map2 : sl.map);
-        w.hdr = blob;
+        const auto& lay = layout_at[si];
+        w.nodes_t = blob + S.off_dyn_nodes_t + sizeof(twr::DynNodeT) * (size_t)sl.k0;
+        w.nodes_l = lay.at(S.off_dyn_nodes_l) + sizeof(twr::DynNodeL) * (size_t)sl.k0;
+        w.sel = lay.at(S.off_dyn_sel) + sizeof(twr::DynSel) * (size_t)sl.k0 * 4;
+        w.tile = lay.at(S.off_dyn_tile);   // (records are addressed through DynSel::tile)
+        w.poly_t = blob + S.off_dyn_poly_t + sizeof(twr::DynPolyT) * (size_t)sl.poly0;
+        w.poly_l = lay.at(S.off_dyn_poly_l) + sizeof(twr::DynPolyL) * (size_t)sl.poly0;
+        w.map = lay.at(b->dyn_map_chunks == 2 ? sl.map2 : sl.map);
+        w.hdr = model_hdr[si];
         w.x_off = b->x_off[p];
         w.g_off = b->g_off[p] + ds.offset + 6 * sl.k0;
         w.j_off = b->j_off[p] + S.row_ptr[ds.offset + 6 * sl.k0];
@@ -803,6 +856,14 @@ void twr_batch_destroy(twr_batch* b) {
 }
 
 int twr_batch_num_problems(const twr_batch* b) { return b ? b->n_problems : 0; }
+
+int twr_batch_table_bytes(const twr_batch* b, int64_t* resident, int64_t* dyn_layout, int64_t* dyn_layout_distinct) {
+  if (!b) return fail(TWR_ERR_INVALID, "null batch");
+  if (resident) *resident = b->table_bytes;
+  if (dyn_layout) *dyn_layout = b->dyn_layout_bytes;
+  if (dyn_layout_distinct) *dyn_layout_distinct = b->dyn_layout_distinct_bytes;
+  return TWR_OK;
+}
 
 int twr_batch_layout(const twr_batch* b, int64_t* x_off, int64_t* g_off, int64_t* jac_off) {
   if (!b) return fail(TWR_ERR_INVALID, "null batch");

@@ -104,32 +104,48 @@ constexpr int kDynNodes = 16;      // time nodes per slice: four lanes each
 constexpr int kDynG0 = kDynImage + 2;   // image + parity slack, then the constraint values of the slice (6 per node)
 constexpr int kDynXsCap = TWR_DYN_XS;     // staged doubles per slice (8-bit staging indices 2..255; 0/1 = the zero pair)
 // Tables of dyn_kernel, split by what they depend on (round 4: a sweep reads every candidate's tables from HBM exactly
-// once per evaluation, so their size is traffic -- 33-38 KB per K = 200 quadruped candidate now, 88-112 KB with one
-// 64-byte record per (time node, role) and one 128-byte offset record per (polynomial combination, role)):
-//   DynNode  per time node (40 B)             grid time, base-spline lookup, row offsets of the node
+// once per evaluation, so their size is traffic -- 33-38 KB per K = 200 quadruped candidate with these records whole,
+// 88-112 KB with one 64-byte record per (time node, role) and one 128-byte offset record per (polynomial combination,
+// role)) -- and, within a record, by whether the bytes hold TIMES or LAYOUT:
+//   DynNodeT per time node (24 B)             grid time, local time and 1 / duration of the active base polynomial
+//   DynNodeL per time node (16 B)             where the node's values sit: staging offsets of the base polynomials, row offsets
 //   DynSel   per (time node, role) (4 B)      WHICH tile / polynomial records the lane reads
-//   DynPoly  per polynomial of an ee spline   start time, 1 / duration, which of its twelve node values are variables and
-//            (80 B)                            in which slot, and the RANK of every tile value inside its tile
+//   DynPolyT per polynomial of an ee spline (16 B)   start time, 1 / duration
+//   DynPolyL per polynomial of an ee spline (64 B)   which of its twelve node values are variables and in which slot, and
+//                                              the RANK of every tile value inside its tile
 //   DynTile  per (polynomial combination of a slice, role) (20 B)   where the role's two tiles start in each row, and
 //                                              where the polynomials' variables sit in the slice's staging area
-// A tile value goes to  node base + tile start in the row (DynTile) + 8 * rank (DynPoly);  the local time of an ee
+// The layout tables (DynNodeL, DynSel, DynPolyL, DynTile, the staging maps) depend on the contact sequence and on WHICH
+// polynomial every time node falls into, not on the durations themselves: candidates of a sweep that differ in the total
+// time only (every duration and the time step scaled alike) have byte-identical layout tables, and a batch stores
+// byte-identical tables ONCE (twr_batch_create shares them by content; nothing here knows about sweeps).  Such a candidate
+// then owns 24 B per time node + 16 B per polynomial (~7 KB for a K = 200 quadruped).
+// A tile value goes to  node base + tile start in the row (DynTile) + 8 * rank (DynPolyL);  the local time of an ee
 // spline is t - t0 (as in RomSeg: the active polynomial is still chosen on the host by the reference's rule, the
 // subtraction differs from the reference's one-by-one subtraction by rounding only).
-// per time node, shared by the four lanes of the quad
-struct DynNode {
+struct DynNodeT {
   double t;              // global time of the node (TimeDiscretizationConstraint::dts_)
   double tb, iTb;        // base spline: local time in the active polynomial, 1/duration
+};
+static_assert(sizeof(DynNodeT) == 24, "DynNodeT layout");
+struct DynNodeL {
   uint16_t sb_lin;       // byte offset inside xs of the active base-lin polynomial's first node value ([p0 v0 p1 v1] x 3)
   uint16_t sb_ang;
   uint16_t nb;           // byte offset of the node's first Jacobian value inside the slice image
   uint16_t rs1, rs2;     // byte offsets of rows AY, AZ relative to the node's first value (AX = 0)
   uint16_t rl[3];        // rows LX, LY, LZ
 };
+static_assert(sizeof(DynNodeL) == 16, "DynNodeL layout");
+// per time node, shared by the four lanes of the quad: the two records as a lane holds them
+struct DynNode {
+  double t, tb, iTb;
+  uint16_t sb_lin, sb_ang, nb, rs1, rs2, rl[3];
+};
 static_assert(sizeof(DynNode) == 40, "DynNode layout");
 struct DynSel {
   uint16_t tile;         // index of the lane's DynTile record (DynWork::tile)
-  uint8_t dm, df;        // ee-motion / ee-force polynomial: index of its DynPoly record relative to DynWork::poly,
-                         // 255 = the structure's dummy record (roles >= n_ee)
+  uint8_t dm, df;        // ee-motion / ee-force polynomial: index of its DynPolyT / DynPolyL records relative to
+                         // DynWork::poly_t / poly_l, 255 = the dummy records (roles >= n_ee; constants of the kernel)
 };
 static_assert(sizeof(DynSel) == 4, "DynSel layout");
 constexpr int kDynPolyDummy = 255;
@@ -145,15 +161,18 @@ constexpr int kDynPolyDummy = 255;
 //            variables or all constant); the kernel then stores that node's VALUE a second time (flags bits 1, 2), so no
 //            order is needed.  A polynomial without any variable has codes 0 and its tile starts are pointed at base-lin
 //            entries of its node, which the same wave overwrites later in program order (DynTile).
-struct DynPoly {
+struct DynPolyT {
   double t0, iT;         // start time (sum of the durations before it), 1 / duration
+};
+static_assert(sizeof(DynPolyT) == 16, "DynPolyT layout");
+struct DynPolyL {
   uint8_t rel[12];
   uint8_t pres[12];
   uint32_t flags;        // bit 0: stance ee-motion polynomial (p1 shares p0's variable: w_p1 folds into w_p0);
                          // bit 1: first node constant (p0, v0 store p1's, v1's value); bit 2: second node constant
   uint8_t code[36];
 };
-static_assert(sizeof(DynPoly) == 80, "DynPoly layout");
+static_assert(sizeof(DynPolyL) == 64, "DynPolyL layout");
 struct DynTile {
   uint16_t base_m[3];    // byte offset, relative to the node's first value, of the role's ee-motion tile in rows AX, AY, AZ
   uint16_t base_f[6];    // ee-force tile in rows AX, AY, AZ, LX, LY, LZ
@@ -330,19 +349,20 @@ struct DevStruct {
 // Work items: one contiguous run of time nodes of one constraint set of one problem.  All
 // pointers / offsets are absolute so that a workgroup needs no header lookup.
 struct DynWork {          // cnt <= 16 time nodes of "dynamic"
-  uint64_t nodes;         // DynNode[k0..]
+  uint64_t nodes_t;       // DynNodeT[k0..]
+  uint64_t nodes_l;       // DynNodeL[k0..]                  (layout tables: possibly another structure's identical copy)
   uint64_t sel;           // DynSel[k0 * 4 ..]
   uint64_t tile;          // DynTile records of the structure (indexed by DynSel::tile)
-  uint64_t poly;          // the slice's first DynPoly record (DynSel::dm / df count from it)
-  uint64_t dummy;         // the structure's dummy DynPoly record
+  uint64_t poly_t;        // the slice's first DynPolyT record (DynSel::dm / df count from it)
+  uint64_t poly_l;        // the slice's first DynPolyL record
   uint64_t map;           // uint16_t[64][4]: lane l stages x[map[l][c]] at xs[2 + 64 c + l]
-  uint64_t hdr;           // DevStruct (mass, gravity, inertia)
+  uint64_t hdr;           // DevStruct (mass, gravity, inertia): of the first structure of the batch with these constants
   int64_t x_off;          // problem's x
   int64_t g_off;          // first constraint value of the run (row 6*k0 of the set)
   int64_t j_off;          // first Jacobian value of the run
   int32_t cnt, nvals;     // time nodes, Jacobian values of the run
 };
-static_assert(sizeof(DynWork) == 88, "DynWork layout");
+static_assert(sizeof(DynWork) == 96, "DynWork layout");
 
 struct RomWork {          // cnt <= 64 time nodes of "rangeofmotion-<ee>"
   uint64_t nodes;         // RomNode[k0..]

@@ -717,48 +717,62 @@ struct DynFrontRec {
   uint32_t tl[5];      // DynTile as five dwords: base_m[0..1] | base_m[2], base_f[0] | base_f[1..2] | base_f[3..4] | base_f[5], s_m, s_f
 };
 struct DynCodes {
-  uint32_t m[6];       // DynPoly::code of the ee-motion polynomial: [c][2]
+  uint32_t m[6];       // DynPolyL::code of the ee-motion polynomial: [c][2]
   uint32_t f[9];       // of the ee-force polynomial: [c][3]
 };
 TWR_DEV uint32_t dyn2_load_sel(const DynWork& w, int lane) {
   const int kk = min(lane >> 2, w.cnt - 1);
   return gptr<uint32_t>(w.sel)[kk * 4 + (lane & 3)];
 }
-TWR_DEV const TWR_GLOBAL char* dyn2_poly_addr(const DynWork& w, uint32_t d) {   // d = DynSel::dm or df
-  const uint64_t rec = w.poly + (uint64_t)d * sizeof(DynPoly);
-  return reinterpret_cast<const TWR_GLOBAL char*>(d == (uint32_t)kDynPolyDummy ? w.dummy : rec);
+// The records of roles >= n_ee (DynSel::dm / df = 255): every value reads the zero slot, finite weights, codes 0.  Constants of
+// the code object, the same for every structure.
+__device__ const DynPolyT g_dyn_dummy_t = {0.0, 1.0};
+__device__ const DynPolyL g_dyn_dummy_l = {{0}, {0}, 2u | 4u, {0}};
+TWR_DEV const TWR_GLOBAL char* dyn2_poly_t_addr(const DynWork& w, uint32_t d) {   // d = DynSel::dm or df
+  const uint64_t rec = w.poly_t + (uint64_t)d * sizeof(DynPolyT);
+  return reinterpret_cast<const TWR_GLOBAL char*>(d == (uint32_t)kDynPolyDummy ? reinterpret_cast<uint64_t>(&g_dyn_dummy_t) : rec);
+}
+TWR_DEV const TWR_GLOBAL char* dyn2_poly_l_addr(const DynWork& w, uint32_t d) {
+  const uint64_t rec = w.poly_l + (uint64_t)d * sizeof(DynPolyL);
+  return reinterpret_cast<const TWR_GLOBAL char*>(d == (uint32_t)kDynPolyDummy ? reinterpret_cast<uint64_t>(&g_dyn_dummy_l) : rec);
 }
 TWR_DEV void dyn2_load_front(const DynWork& w, uint32_t sel, int lane, DynFrontRec& r) {
   const int kk = min(lane >> 2, w.cnt - 1);
-  r.nd = gptr<DynNode>(w.nodes)[kk];
-  const TWR_GLOBAL char* pm = dyn2_poly_addr(w, (sel >> 16) & 0xFFu);
-  const TWR_GLOBAL char* pf = dyn2_poly_addr(w, sel >> 24);
+  const DynNodeT nt = gptr<DynNodeT>(w.nodes_t)[kk];
+  const uint4 nl = gptr<uint4>(w.nodes_l)[kk];
+  static_assert(sizeof(DynNodeL) == sizeof(uint4), "DynNodeL as four dwords");
+  r.nd.t = nt.t; r.nd.tb = nt.tb; r.nd.iTb = nt.iTb;
+  r.nd.sb_lin = (uint16_t)nl.x; r.nd.sb_ang = (uint16_t)(nl.x >> 16);
+  r.nd.nb = (uint16_t)nl.y;     r.nd.rs1 = (uint16_t)(nl.y >> 16);
+  r.nd.rs2 = (uint16_t)nl.z;    r.nd.rl[0] = (uint16_t)(nl.z >> 16);
+  r.nd.rl[1] = (uint16_t)nl.w;  r.nd.rl[2] = (uint16_t)(nl.w >> 16);
+  const uint32_t im = (sel >> 16) & 0xFFu, jf = sel >> 24;
+  const TWR_GLOBAL double* dm = reinterpret_cast<const TWR_GLOBAL double*>(dyn2_poly_t_addr(w, im));
+  const TWR_GLOBAL double* df = reinterpret_cast<const TWR_GLOBAL double*>(dyn2_poly_t_addr(w, jf));
+  const TWR_GLOBAL uint32_t* um = reinterpret_cast<const TWR_GLOBAL uint32_t*>(dyn2_poly_l_addr(w, im));
+  const TWR_GLOBAL uint32_t* uf = reinterpret_cast<const TWR_GLOBAL uint32_t*>(dyn2_poly_l_addr(w, jf));
   const TWR_GLOBAL uint32_t* tl = reinterpret_cast<const TWR_GLOBAL uint32_t*>(w.tile + (uint64_t)(sel & 0xFFFFu) * sizeof(DynTile));
-  static_assert(offsetof(DynPoly, rel) == 16 && offsetof(DynPoly, pres) == 28 && offsetof(DynPoly, flags) == 40 && offsetof(DynPoly, code) == 44,
-                "DynPoly dwords");
-  const TWR_GLOBAL double* dm = reinterpret_cast<const TWR_GLOBAL double*>(pm);
-  const TWR_GLOBAL double* df = reinterpret_cast<const TWR_GLOBAL double*>(pf);
-  const TWR_GLOBAL uint32_t* um = reinterpret_cast<const TWR_GLOBAL uint32_t*>(pm);
-  const TWR_GLOBAL uint32_t* uf = reinterpret_cast<const TWR_GLOBAL uint32_t*>(pf);
+  static_assert(offsetof(DynPolyL, rel) == 0 && offsetof(DynPolyL, pres) == 12 && offsetof(DynPolyL, flags) == 24 && offsetof(DynPolyL, code) == 28,
+                "DynPolyL dwords");
   r.t0m = dm[0]; r.iTm = dm[1];
   r.t0f = df[0]; r.iTf = df[1];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    r.relm[i] = um[4 + i]; r.presm[i] = um[7 + i];
-    r.relf[i] = uf[4 + i]; r.presf[i] = uf[7 + i];
+    r.relm[i] = um[i]; r.presm[i] = um[3 + i];
+    r.relf[i] = uf[i]; r.presf[i] = uf[3 + i];
   }
-  r.flagsm = um[10];
-  r.flagsf = uf[10];
+  r.flagsm = um[6];
+  r.flagsf = uf[6];
 #pragma unroll
   for (int i = 0; i < 5; ++i) r.tl[i] = tl[i];
 }
 TWR_DEV void dyn2_load_codes(const DynWork& w, uint32_t sel, DynCodes& c) {
-  const TWR_GLOBAL uint32_t* um = reinterpret_cast<const TWR_GLOBAL uint32_t*>(dyn2_poly_addr(w, (sel >> 16) & 0xFFu));
-  const TWR_GLOBAL uint32_t* uf = reinterpret_cast<const TWR_GLOBAL uint32_t*>(dyn2_poly_addr(w, sel >> 24));
+  const TWR_GLOBAL uint32_t* um = reinterpret_cast<const TWR_GLOBAL uint32_t*>(dyn2_poly_l_addr(w, (sel >> 16) & 0xFFu));
+  const TWR_GLOBAL uint32_t* uf = reinterpret_cast<const TWR_GLOBAL uint32_t*>(dyn2_poly_l_addr(w, sel >> 24));
 #pragma unroll
-  for (int i = 0; i < 6; ++i) c.m[i] = um[11 + i];
+  for (int i = 0; i < 6; ++i) c.m[i] = um[7 + i];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) c.f[i] = uf[11 + i];
+  for (int i = 0; i < 9; ++i) c.f[i] = uf[7 + i];
 }
 TWR_DEV void dyn2_front(const DynFrontRec& r, const char* __restrict__ xs, int lane, Dyn2Front& S) {
   const DynNode& nd = r.nd;
@@ -838,7 +852,7 @@ TWR_DEV void dyn2_back(const DynWork& w, const DynFrontRec& rec, const DynCodes&
   char* nb = img + nd.nb;   // first value of this time node
   // --- ee-motion block [f]x J_p (:181-192) and ee-force block {[r]x J_f ; -J_f} (:167-179) of this lane's
   // end-effector, BEFORE the base blocks.  A value goes to  node base + tile start in its row (DynTile) + 8 * rank
-  // (DynPoly::code, one byte per value); see DynPoly for where the values of candidates that are not variables end up.
+  // (DynPolyL::code, one byte per value); see DynPolyL for where the values of candidates that are not variables end up.
   if (want_j) {
     char* rowm[3] = {nb + (rec.tl[0] & 0xFFFFu), nb + (rec.tl[0] >> 16), nb + (rec.tl[1] & 0xFFFFu)};
     char* rowf[6] = {nb + (rec.tl[1] >> 16), nb + (rec.tl[2] & 0xFFFFu), nb + (rec.tl[2] >> 16),
@@ -2878,12 +2892,14 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
   dim3 block(64);
   hipError_t st = hipSuccess;
   if (n_ee < 1 || n_ee > 4) return hipErrorInvalidValue;
-  // The fused launch is used while the rom role needs at most EIGHT rounds of its residency (rom_bpc workgroups per CU x
-  // n_cu: 8192 rom slices = 512 quadruped candidates of K = 200 on the 256 CUs of an MI355X; round-3 re-tune on one box,
-  // ragged sweep, fused vs three launches: 320 / 400 / 512 candidates 75 / 98 / 126 vs 83 / 104 / 128 us per step, 768 /
-  // 1024: 187 / 250 vs 183 / 235).  The thresholds are in units of the device's residency, not constants of one chip.
+  // The fused launch is used while the rom role needs at most TEN rounds of its residency (rom_bpc workgroups per CU x
+  // n_cu; round-3 re-tune on one box, ragged sweep, fused vs three launches: 320 / 400 / 512 candidates 75 / 98 / 126 vs
+  // 83 / 104 / 128 us per step, 768 / 1024: 187 / 250 vs 183 / 235; round 4: 512 candidates 115 vs 124, 768 / 1024 equal).
+  // Ten, not eight: the 512 candidates of a two-GPU shard of the C5 sweep are ~8500 rom slices (the enumeration is ragged:
+  // 16.6 slices per candidate), 8.3 rounds on the 256 CUs of an MI355X.  The thresholds are in units of the device's
+  // residency, not constants of one chip.
   const int cap = rom_bpc * n_cu;
-  const int fused_max = env_int("TWR_FUSED_MAX_ROM", 8 * cap);
+  const int fused_max = env_int("TWR_FUSED_MAX_ROM", 10 * cap);
   if (!ev && n_pdyn == 0 && n_prom == 0 && n_rom > 0 && n_dyn > 0 && n_rom <= fused_max) {
     int g_rom = n_rom < cap ? n_rom : cap, g_dyn = (n_dyn + 1) / 2 < cap ? (n_dyn + 1) / 2 : cap;
     // When the two persistent roles do not fit the CUs together, the blocks of the later role only start as the earlier

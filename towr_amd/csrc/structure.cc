@@ -516,11 +516,19 @@ void Structure::PackBlob() {
   DevStruct h;
   std::memset(&h, 0, sizeof(h));
   std::vector<char> body;
-  auto put = [&](const void* src, size_t bytes) -> uint32_t {
-    size_t off = (sizeof(DevStruct) + body.size() + 15) / 16 * 16;
+  auto put_aligned = [&](const void* src, size_t bytes, size_t align) -> uint32_t {   // (a blob starts on a 256-byte line)
+    size_t off = (sizeof(DevStruct) + body.size() + align - 1) / align * align;
     body.resize(off - sizeof(DevStruct) + bytes);
     if (bytes) std::memcpy(body.data() + off - sizeof(DevStruct), src, bytes);
     return (uint32_t)off;
+  };
+  auto put = [&](const void* src, size_t bytes) -> uint32_t { return put_aligned(src, bytes, 16); };
+  // a layout table of dyn_kernel (device_tables.h): a batch stores byte-identical ones once
+  dyn_layout_tables.clear();
+  auto put_layout = [&](const void* src, size_t bytes) -> uint32_t {
+    const uint32_t off = put_aligned(src, bytes, 64);
+    dyn_layout_tables.push_back({off, (uint32_t)bytes});
+    return off;
   };
   h.n_ee = n_ee;
   h.terrain_id = model.terrain_id;
@@ -618,7 +626,7 @@ void Structure::PackBlob() {
       return n;
     };
     auto nvals_of = [&](int k0, int k1) { return row_ptr[row_dyn + 6 * k1] - row_ptr[row_dyn + 6 * k0]; };
-    // --- DynPoly: one record per polynomial of every ee spline, ordered by start time, so that the records a slice
+    // --- DynPolyT / DynPolyL: one record pair per polynomial of every ee spline, ordered by start time, so that the records a slice
     // (a short time window) reads sit next to each other and an 8-bit index relative to the slice's first record
     // reaches all of them
     struct PolyRef {
@@ -641,15 +649,16 @@ void Structure::PackBlob() {
       rec_of[kind].resize(n_ee);
       for (int e = 0; e < n_ee; ++e) rec_of[kind][e].resize(kind == 0 ? mpoly[e].size() : fpoly[e].size());
     }
-    std::vector<DynPoly> polys(order.size() + 1);
+    std::vector<DynPolyT> polys_t(order.size());
+    std::vector<DynPolyL> polys(order.size());
     for (size_t i = 0; i < order.size(); ++i) {
       const PolyRef& pr = order[i];
       rec_of[pr.kind][pr.e][pr.q] = (int)i;
       const PolyDesc& pd = pr.kind == 0 ? mpoly[pr.e][pr.q] : fpoly[pr.e][pr.q];
-      DynPoly& P = polys[i];
+      polys_t[i].t0 = pr.t0;
+      polys_t[i].iT = pd.iT;
+      DynPolyL& P = polys[i];
       std::memset(&P, 0, sizeof(P));
-      P.t0 = pr.t0;
-      P.iT = pd.iT;
       int dim_of_slot[12] = {0}, slot_of[12];
       for (int c = 0; c < 12; ++c) {
         slot_of[c] = pd.cand[c] == 0xFFFF ? -1 : (pd.cand[c] & 0xF);
@@ -695,12 +704,6 @@ void Structure::PackBlob() {
         }
       }
     }
-    {   // the dummy record of roles >= n_ee: every value reads the zero slot, finite weights, codes 0
-      DynPoly& P = polys.back();
-      std::memset(&P, 0, sizeof(P));
-      P.iT = 1.0;
-      P.flags = 2 | 4;
-    }
     auto rec_span_ok = [&](int k0, int k1) {   // the 8-bit record indices of a slice (255 = dummy)
       int lo = 1 << 30, hi = -1;
       for (int e = 0; e < n_ee; ++e)
@@ -710,7 +713,8 @@ void Structure::PackBlob() {
         }
       return hi - lo < kDynPolyDummy;
     };
-    std::vector<DynNode> nodes(K);
+    std::vector<DynNodeT> nodes_t(K);
+    std::vector<DynNodeL> nodes(K);
     std::vector<DynSel> sel((size_t)K * 4);
     std::vector<DynTile> tiles;   // four per (slice, polynomial combination)
     std::vector<int> combo_key;   // active polynomial ids of the last combination
@@ -764,13 +768,13 @@ void Structure::PackBlob() {
       sl.k0 = k0;
       sl.cnt = k1 - k0;
       sl.nvals = nvals_of(k0, k1);
-      sl.map = put(map.data(), map.size() * sizeof(uint16_t));
+      sl.map = put_layout(map.data(), map.size() * sizeof(uint16_t));
       sl.map2 = sl.map;
       dyn_staged_max = std::max(dyn_staged_max, (int)xidx.size());
       if (xidx.size() <= 128) {   // the 256-byte form: lane l holds entries l and 64 + l (what a batch of such slices reads)
         std::vector<uint16_t> m2(128, 0);
         for (size_t e = 0; e < xidx.size(); ++e) m2[(e % 64) * 2 + e / 64] = (uint16_t)xidx[e];
-        sl.map2 = put(m2.data(), m2.size() * sizeof(uint16_t));
+        sl.map2 = put_layout(m2.data(), m2.size() * sizeof(uint16_t));
       }
       sl.poly0 = 1 << 30;
       for (int e = 0; e < n_ee; ++e)
@@ -779,11 +783,11 @@ void Structure::PackBlob() {
       combo_key.clear();   // a new slice has its own staging layout: its first node opens a new combination
       for (int k = k0; k < k1; ++k) {
         const int row0 = row_dyn + 6 * k, v0 = row_ptr[row0];
-        DynNode& N = nodes[k];
+        DynNodeL& N = nodes[k];
         std::memset(&N, 0, sizeof(N));
-        N.t = grid_dyn[k];
-        N.tb = dyn_base[k].t_local;
-        N.iTb = 1.0 / base.durations[dyn_base[k].poly];
+        nodes_t[k].t = grid_dyn[k];
+        nodes_t[k].tb = dyn_base[k].t_local;
+        nodes_t[k].iTb = 1.0 / base.durations[dyn_base[k].poly];
         N.sb_lin = (uint16_t)(8 * (2 + 6 * (dyn_base[k].poly - qmin)));
         N.sb_ang = (uint16_t)(8 * (2 + nbase + 6 * (dyn_base[k].poly - qmin)));
         const int node_rel = v0 - row_ptr[row_dyn + 6 * k0];
@@ -848,8 +852,8 @@ void Structure::PackBlob() {
             }
             // self-check of the decomposition  offset = tile start + 8 * rank  against the pattern, value by value (once per
             // polynomial combination: the nodes of a combination share their tile records, asserted below)
-            const DynPoly& PM = polys[rec_of[0][e][qm]];
-            const DynPoly& PF = polys[rec_of[1][e][qf]];
+            const DynPolyL& PM = polys[rec_of[0][e][qm]];
+            const DynPolyL& PF = polys[rec_of[1][e][qf]];
             for (int c = 0; c < 12 && new_combo; ++c) {
               const int d = c % 3, r1 = (d + 1) % 3, r2 = (d + 2) % 3;
               if (mp.cand[c] != 0xFFFF) {
@@ -872,11 +876,13 @@ void Structure::PackBlob() {
       }
       k0 = k1;
     }
-    off_dyn_nodes = put(nodes.data(), nodes.size() * sizeof(DynNode));
-    off_dyn_sel = put(sel.data(), sel.size() * sizeof(DynSel));
-    off_dyn_tile = put(tiles.data(), tiles.size() * sizeof(DynTile));
-    off_dyn_poly = put(polys.data(), polys.size() * sizeof(DynPoly));
-    off_dyn_dummy = off_dyn_poly + (uint32_t)((polys.size() - 1) * sizeof(DynPoly));
+    // times first, then the layout tables (twr_batch_create stores byte-identical layout tables of a batch once)
+    off_dyn_nodes_t = put(nodes_t.data(), nodes_t.size() * sizeof(DynNodeT));
+    off_dyn_poly_t = put(polys_t.data(), polys_t.size() * sizeof(DynPolyT));
+    off_dyn_nodes_l = put_layout(nodes.data(), nodes.size() * sizeof(DynNodeL));
+    off_dyn_sel = put_layout(sel.data(), sel.size() * sizeof(DynSel));
+    off_dyn_tile = put_layout(tiles.data(), tiles.size() * sizeof(DynTile));
+    off_dyn_poly_l = put_layout(polys.data(), polys.size() * sizeof(DynPolyL));
   }
   // --- rangeofmotion-<ee>, optimised timings: per-node record templates (the pre-pass fills in the x-dependent part)
   for (int e = 0; e < n_ee && have_rom && timings; ++e) {

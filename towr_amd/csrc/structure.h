@@ -75,16 +75,21 @@ struct Structure {
   std::vector<char> blob;  // packed DevStruct + tables (device_tables.h)
   // byte offsets of the per-lane record arrays inside the blob
   uint32_t off_dyn_shared = 0, off_dyn_lanes = 0;   // optimised timings: DynShared[k] (base-spline part)
-  // fixed timings: slices of the dynamic set and their tables (device_tables.h DynNode / DynGather / DynPut)
+  // fixed timings: slices of the dynamic set and their tables (device_tables.h DynNodeT / DynNodeL / DynSel / DynPolyT / DynPolyL / DynTile)
   struct DynSlice {
     int k0, cnt, nvals;
     uint32_t map;        // byte offset of the slice's staging map inside the blob: uint16[64][4], lane-transposed
     uint32_t map2;       // the two-chunk form uint16[64][2] of the same map (slices that stage <= 128 doubles; else = map)
-    int poly0;           // index of the first DynPoly record the slice reads (DynSel::dm / df count from it)
+    int poly0;           // index of the first DynPolyT / DynPolyL record the slice reads (DynSel::dm / df count from it)
   };
   std::vector<DynSlice> dyn_slices;
   int dyn_staged_max = 0;   // most doubles of x one slice stages (<= 128: the batch may use the two-chunk maps)
-  uint32_t off_dyn_nodes = 0, off_dyn_sel = 0, off_dyn_tile = 0, off_dyn_poly = 0, off_dyn_dummy = 0;
+  uint32_t off_dyn_nodes_t = 0, off_dyn_nodes_l = 0, off_dyn_sel = 0, off_dyn_tile = 0, off_dyn_poly_t = 0, off_dyn_poly_l = 0;
+  struct TableRef {
+    uint32_t off, bytes;
+  };
+  std::vector<TableRef> dyn_layout_tables;   // the layout tables of dyn_kernel inside the blob (times excluded): what a batch may
+                                             // share between structures when the bytes are identical
   uint32_t off_rom_recs[kMaxEE] = {0, 0, 0, 0};   // optimised timings: RomRec[k] templates (base-spline part)
   // fixed timings: slices of rangeofmotion-<ee> (device_tables.h RomNode / RomSeg)
   struct RomSlice {
