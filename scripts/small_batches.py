@@ -14,6 +14,8 @@ structs_all = sweep.candidate_structures(model, cands)
 for B in sizes:
     structs = structs_all[:B]
     batch = ta.Batch(structs, list(range(B)), device=0)
+    tb = batch.table_bytes()
+    print("B=%4d  tables: %.1f MB resident, dyn layout %.1f MB built -> %.1f MB distinct" % (B, tb["resident"] / 1e6, tb["dyn_layout"] / 1e6, tb["dyn_layout_distinct"] / 1e6), flush=True)
     xh = np.concatenate([perturbed_inputs(s, model, 1, i)[0] for i, s in enumerate(structs)])
     x = torch.from_numpy(xh).cuda()
     g = torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device="cuda")
