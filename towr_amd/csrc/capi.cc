@@ -500,9 +500,16 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
         uint64_t dev;
       };
       std::unordered_map<uint64_t, std::vector<Seen>> by_hash;
-      auto fnv = [](const char* p, size_t n) {
+      auto fnv = [](const char* p, size_t n) {   // FNV-1a over 8-byte words (a bucket key only: equality is decided by memcmp)
         uint64_t h = 1469598103934665603ull;
-        for (size_t i = 0; i < n; ++i) h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+          uint64_t w;
+          std::memcpy(&w, p + i, 8);
+          h = (h ^ w) * 1099511628211ull;
+          h ^= h >> 29;
+        }
+        for (; i < n; ++i) h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
         return h;
       };
       for (int i = 0; i < n_structs; ++i) {
