@@ -1441,46 +1441,56 @@ TWR_DEV void fam_load_x(const FamWork& w, int lane, const double* __restrict__ x
     in.v[4] = xp[in.a[2]]; in.v[5] = xp[in.a[4]]; in.v[6] = xp[in.a[0] + 2]; in.v[7] = xp[in.a[0] + 3];
   }
 }
+// Items per chunk, Jacobian values and constraint values per item, store instructions of the copy-out (128 doubles each:
+// the largest chunk + parity shift), g store instructions (64 values each)
 template <int FAM>
-TWR_DEV void fam_compute(const FamWork& w, const FamIn<FAM>& in, double* __restrict__ g, double* __restrict__ jac, double* stage,
-                         int lane, bool want_g, bool want_j) {
-  constexpr int kPer = FAM == 0 ? 3 : (FAM == 1 ? 25 : (FAM == 2 ? 6 : 12));    // Jacobian values per item
-  constexpr int kRows = FAM == 0 ? 1 : (FAM == 1 ? 5 : (FAM == 2 ? 1 : 4));     // constraint values per item
+struct FamShape {
+  static constexpr int kItems = FAM == 1 ? 32 : 64;
+  static constexpr int kPer = FAM == 0 ? 3 : (FAM == 1 ? 25 : (FAM == 2 ? 6 : 12));
+  static constexpr int kRows = FAM == 0 ? 1 : (FAM == 1 ? 5 : (FAM == 2 ? 1 : 4));
+  static constexpr int kNit = (kItems * kPer + 1 + 2 + 127) / 128;
+  static constexpr int kGit = (kItems * kRows + 63) / 64;
+};
+// The chunk's values go to the LDS image (Jacobian) and to `gst` (constraint values); fam_store then streams both out with a
+// COMPILE-TIME number of store instructions and no store inside a divergent branch -- like rom_body / dyn_body, and for the
+// same reason: with the run-time copy-out loop and the lanes' own g stores of the first form of this kernel the compiler
+// could not count the stores behind the prefetched loads, and every chunk began with s_waitcnt vmcnt(0), i.e. with the
+// drain of the previous chunk's stores (A/B on one box with the work items three chunks ahead as well: 0.078 -> 0.069-0.074 ms per
+// 8192 problems with towr's default list).
+template <int FAM, bool WANT_G, bool WANT_J>
+TWR_DEV void fam_compute(const FamWork& w, const FamIn<FAM>& in, double* stage, double* gst, int par, int lane) {
   const DevStruct* S = reinterpret_cast<const DevStruct*>(w.blob);
-  double* dst = jac + w.j_off;
-  double* gp = g + w.g_off;
-  const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
   if (lane < w.cnt) {
     if (FAM == 0) {
       const Terr t = terrain_eval(S, S->terrain_id, S->flat_height, in.v[0], in.v[1]);
-      if (want_g) gp[lane] = in.v[2] - t.h;
-      if (want_j) {
+      if (WANT_G) gst[lane] = in.v[2] - t.h;
+      if (WANT_J) {
         stage[par + 3 * lane + 0] = -t.hx;
         stage[par + 3 * lane + 1] = -t.hy;
         stage[par + 3 * lane + 2] = 1.0;
       }
     } else if (FAM == 1) {
       const double f[3] = {in.v[0], in.v[1], in.v[2]};
-      force_core(S, f, in.v[3], in.v[4], gp + 5 * lane, stage + par + 25 * lane, want_g, want_j);
+      force_core(S, f, in.v[3], in.v[4], gst + 5 * lane, stage + par + 25 * lane, WANT_G, WANT_J);
     } else if (FAM == 2) {
       double v = 0.0;
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
         v += in.c[q] * in.v[q];
-        if (want_j) stage[par + 6 * lane + q] = in.c[q];
+        if (WANT_J) stage[par + 6 * lane + q] = in.c[q];
       }
-      if (want_g) gp[lane] = v;
+      if (WANT_G) gst[lane] = v;
     } else {
       const double it = w.inv_t_swing;
 #pragma unroll
       for (int dim = 0; dim < 2; ++dim) {
         const double prev = in.v[4 * dim], next = in.v[4 * dim + 1], pos = in.v[4 * dim + 2], vel = in.v[4 * dim + 3];
         const double distance = next - prev;
-        if (want_g) {
-          gp[4 * lane + 2 * dim] = pos - (prev + 0.5 * distance);
-          gp[4 * lane + 2 * dim + 1] = vel - distance * it;
+        if (WANT_G) {
+          gst[4 * lane + 2 * dim] = pos - (prev + 0.5 * distance);
+          gst[4 * lane + 2 * dim + 1] = vel - distance * it;
         }
-        if (want_j) {
+        if (WANT_J) {
           double* st = stage + par + 12 * lane + 6 * dim;
           st[0] = -0.5; st[1] = 1.0; st[2] = -0.5;
           st[3] = it;   st[4] = 1.0; st[5] = -it;
@@ -1488,48 +1498,84 @@ TWR_DEV void fam_compute(const FamWork& w, const FamIn<FAM>& in, double* __restr
       }
     }
   }
-  (void)kRows;
-  if (want_j) copy_out(dst, stage, kPer * w.cnt, par, lane);  // single wave: LDS accesses are ordered
 }
+template <int FAM, bool WANT_G, bool WANT_J>
+TWR_DEV void fam_store(const FamWork& w, double* __restrict__ g, double* __restrict__ jac, const double* stage, const double* gst,
+                       int par, int lane) {
+  typedef FamShape<FAM> Sh;
+  if (WANT_J) copy_out_fixed<Sh::kNit, Sh::kNit>(jac + w.j_off, stage, Sh::kPer * w.cnt, par, lane);   // single wave: LDS accesses are ordered
+  if (WANT_G) {   // clamped lanes instead of predicates (see copy_out_fixed)
+    double* gp = g + w.g_off;
+    const int last_g = Sh::kRows * w.cnt - 1;
+#pragma unroll
+    for (int t = 0; t < Sh::kGit; ++t) gp[min(lane + 64 * t, last_g)] = gst[min(lane + 64 * t, last_g)];
+  }
+}
+// A use of every loaded value of the prologue that the compiler can see: it then waits for the prologue's loads IN the prologue
+// and the loop is entered with none in flight.  (Otherwise the one wait in front of a chunk's math has to serve both ways
+// into the loop header -- from the prologue, where the x loads of the first chunk are the youngest loads, and from the
+// latch, where a counted number of stores is behind them -- and becomes s_waitcnt vmcnt(0): the store drain again.)
 template <int FAM>
+TWR_DEV void fam_pin(FamIn<FAM>& in, bool with_x) {
+  constexpr int kA = FAM == 2 ? 0 : (FAM == 3 ? 5 : 2), kC = FAM == 2 ? 6 : 0, kV = FAM == 0 ? 3 : (FAM == 1 ? 5 : (FAM == 2 ? 6 : 8));
+#pragma unroll
+  for (int q = 0; q < kA; ++q) asm volatile("" : "+v"(in.a[q]));
+#pragma unroll
+  for (int q = 0; q < kC; ++q) asm volatile("" : "+v"(in.c[q]));
+  if (with_x) {
+#pragma unroll
+    for (int q = 0; q < kV; ++q) asm volatile("" : "+v"(in.v[q]));
+  }
+}
+template <int FAM, bool WANT_G, bool WANT_J>
 TWR_DEV void fam_body(const FamWork* __restrict__ work, int n_work, const double* __restrict__ x, double* __restrict__ g,
-                      double* __restrict__ jac, double* stage, int lane, int i, int stride, bool want_g, bool want_j) {
+                      double* __restrict__ jac, double* stage, double* gst, int lane, int i, int stride) {
   if (i >= n_work) return;
   const int last = i + (n_work - 1 - i) / stride * stride;
-  FamWork w0 = work[i], w1 = work[min(i + stride, last)];
+  FamWork w0 = work[i], w1 = work[min(i + stride, last)], w2 = work[min(i + 2 * stride, last)];
   FamIn<FAM> in0, in1;
   fam_load_rec<FAM>(w0, lane, in0);
   fam_load_rec<FAM>(w1, lane, in1);
   fam_load_x<FAM>(w0, lane, x, in0);
+  fam_pin<FAM>(in0, true);
+  fam_pin<FAM>(in1, false);
   for (; i <= last; i += stride) {
-    const FamWork w2 = work[min(i + 2 * stride, last)];
+    const FamWork w3 = work[min(i + 3 * stride, last)];   // work item three chunks ahead (the list is a cold stream: a scalar
+                                                          // load that is used in the iteration it is issued in costs its HBM latency)
     FamIn<FAM> in2;
     fam_load_rec<FAM>(w2, lane, in2);          // records two chunks ahead
     fam_load_x<FAM>(w1, lane, x, in1);         // x one chunk ahead (its records arrived an iteration ago)
-    fam_compute<FAM>(w0, in0, g, jac, stage, lane, want_g, want_j);
+    const int par = (int)((reinterpret_cast<uintptr_t>(jac + w0.j_off) >> 3) & 1);
+    fam_compute<FAM, WANT_G, WANT_J>(w0, in0, stage, gst, par, lane);
+    fam_store<FAM, WANT_G, WANT_J>(w0, g, jac, stage, gst, par, lane);
     w0 = w1; in0 = in1;
     w1 = w2; in1 = in2;
+    w2 = w3;
   }
 }
 // blocks [0, g0) walk the terrain chunks, the next g1 the force chunks, then splineacc, then swing (any count may be 0)
 constexpr int kForceChunk = 32;                                   // force nodes per chunk (25 values each)
 constexpr int kStageChunk = kForceChunk * 25 + 2;                // >= 64 x 12 + 2 (swing), 64 x 6 + 2, 64 x 3 + 2
+constexpr int kStageChunkG = 64 * 4;                             // constraint values of a chunk: <= 64 x 4 (swing), 32 x 5 (force)
 static_assert(kStageChunk >= kStageSwing && kStageChunk >= kStageAcc && kStageChunk >= kStageTerrain, "chunk image");
+static_assert(FamShape<1>::kItems == kForceChunk && FamShape<0>::kNit * 128 <= kStageChunk + 127 && FamShape<1>::kNit * 128 <= kStageChunk + 127 &&
+              FamShape<2>::kNit * 128 <= kStageChunk + 127 && FamShape<3>::kNit * 128 <= kStageChunk + 127, "chunk copy-out inside the image");
+template <bool WANT_G, bool WANT_J>
 __global__ __launch_bounds__(64, 4) void node_chunk_kernel(const FamWork* __restrict__ f0, int n0, int g0, const FamWork* __restrict__ f1,
                                                         int n1, int g1, const FamWork* __restrict__ f2, int n2, int g2,
                                                         const FamWork* __restrict__ f3, int n3, int g3, const double* __restrict__ x,
-                                                        double* __restrict__ g, double* __restrict__ jac, int flags) {
-  __shared__ __attribute__((aligned(16))) double stage[kStageChunk];
+                                                        double* __restrict__ g, double* __restrict__ jac) {
+  __shared__ __attribute__((aligned(16))) double stage[kStageChunk + kStageChunkG];
+  double* gst = stage + kStageChunk;
   const int lane = threadIdx.x;
-  const bool want_g = flags & 1, want_j = flags & 2;
   int b = blockIdx.x;
-  if (b < g0) return fam_body<0>(f0, n0, x, g, jac, stage, lane, b, g0, want_g, want_j);
+  if (b < g0) return fam_body<0, WANT_G, WANT_J>(f0, n0, x, g, jac, stage, gst, lane, b, g0);
   b -= g0;
-  if (b < g1) return fam_body<1>(f1, n1, x, g, jac, stage, lane, b, g1, want_g, want_j);
+  if (b < g1) return fam_body<1, WANT_G, WANT_J>(f1, n1, x, g, jac, stage, gst, lane, b, g1);
   b -= g1;
-  if (b < g2) return fam_body<2>(f2, n2, x, g, jac, stage, lane, b, g2, want_g, want_j);
+  if (b < g2) return fam_body<2, WANT_G, WANT_J>(f2, n2, x, g, jac, stage, gst, lane, b, g2);
   b -= g2;
-  fam_body<3>(f3, n3, x, g, jac, stage, lane, b, g3, want_g, want_j);
+  fam_body<3, WANT_G, WANT_J>(f3, n3, x, g, jac, stage, gst, lane, b, g3);
 }
 
 // Small and mid-size batches: the three kernels above as ONE launch, so that their pipeline fills and drains overlap
@@ -3008,7 +3054,8 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
   if (ev) (void)hipEventRecord(ev[2], stream);
   const int n_chunks = n_fam[0] + n_fam[1] + n_fam[2] + n_fam[3];
   if (n_chunks > 0) {
-    // persistent waves per CU for ALL families together, shared out by their chunk counts
+    // persistent waves per CU for ALL families together, shared out by their chunk counts (by count, not by bytes: an iteration
+    // costs about the same whatever the family -- weighting the force chunks 1.5 x ... 3 x was 4-15 % slower)
     static const int node_bpc = env_int("TWR_NODE_BPC", 16);
     const int res = node_bpc * n_cu;
     int gf[4];
@@ -3017,8 +3064,13 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
       if (n_fam[f] > 0 && gf[f] < 1) gf[f] = 1;
       if (gf[f] > n_fam[f]) gf[f] = n_fam[f];
     }
-    st = twr_first(st, twr_launch(node_chunk_kernel, dim3(gf[0] + gf[1] + gf[2] + gf[3]), dim3(64), 0, stream, fam[0], n_fam[0], gf[0], fam[1],
-                                  n_fam[1], gf[1], fam[2], n_fam[2], gf[2], fam[3], n_fam[3], gf[3], x, g, jac, flags));
+#define TWR_CHUNK_LAUNCH(WG, WJ)                                                                                                              \
+  st = twr_first(st, twr_launch(node_chunk_kernel<WG, WJ>, dim3(gf[0] + gf[1] + gf[2] + gf[3]), dim3(64), 0, stream, fam[0], n_fam[0], gf[0],   \
+                                fam[1], n_fam[1], gf[1], fam[2], n_fam[2], gf[2], fam[3], n_fam[3], gf[3], x, g, jac))
+    if ((flags & 3) == 3) TWR_CHUNK_LAUNCH(true, true);
+    else if (flags & 2) TWR_CHUNK_LAUNCH(false, true);
+    else TWR_CHUNK_LAUNCH(true, false);
+#undef TWR_CHUNK_LAUNCH
   } else if (n_node > 0 && node_families == 2)
     st = twr_first(st, twr_launch(node_kernel2, dim3(n_node), dim3(128), 0, stream, node, x, g, jac, flags));
   else if (n_node > 0)
