@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../towr_amd/csrc/structure.h"
@@ -99,7 +100,57 @@ static void one_case(int robot, int terrain, int combo, double T, int sets, doub
   orc_destroy(P);
 }
 
+// twr::ShareLayoutTables (what twr_batch_create merges): T-siblings of a sweep at K = 200 share selector / polynomial-layout /
+// tile tables, every reference points at bytes identical to the structure's own table, owners own themselves, and the
+// byte counts add up.
+static void sharing_case() {
+  twr_model m;
+  twr::ModelPreset(2, 4, &m);
+  std::vector<twr::Structure> ss(11);
+  for (int i = 0; i < 11; ++i) {
+    const double T = i < 8 ? 1.2 + 0.2 * i : 2.0;
+    const double scale = i < 8 ? 0.80 : 0.80 + 0.016 * (i - 7);
+    twr::GaitCombo(m.n_ee, i == 10 ? 3 : 1, T, scale, &ss[i].schedule);
+    twr_params p;
+    p.dt_dynamic = p.dt_rom = T / (200 - 1.5);
+    p.duration_base_poly = 0.1;
+    p.polys_per_swing = 2;
+    p.polys_per_stance_force = 3;
+    p.constraint_sets = 27;
+    p.reserved_ = 0;
+    p.dt_base_motion = 0.025;
+    p.base_z_init = -m.nominal_stance[0][2];
+    ss[i].model = m;
+    ss[i].params = p;
+    ss[i].Build();
+  }
+  std::vector<const twr::Structure*> sp;
+  for (const auto& s : ss) sp.push_back(&s);
+  sp.push_back(&ss[3]);   // the same structure twice: shares everything with its first occurrence
+  const twr::LayoutShare sh = twr::ShareLayoutTables(sp);
+  int64_t built = 0, distinct = 0;
+  for (size_t i = 0; i < sp.size(); ++i) {
+    const auto& tabs = sp[i]->dyn_layout_tables;
+    CHECK(sh.of[i].size() == tabs.size() && !tabs.empty(), "sharing: table count of structure %zu", i);
+    for (size_t t = 0; t < tabs.size(); ++t) {
+      const twr::LayoutShare::Ref r = sh.of[i][t];
+      CHECK(r.owner >= 0 && r.owner <= (int)i, "sharing: owner after its user");
+      const twr::Structure& O = *sp[r.owner];
+      CHECK((size_t)r.off + tabs[t].bytes <= O.blob.size() && std::memcmp(O.blob.data() + r.off, sp[i]->blob.data() + tabs[t].off, tabs[t].bytes) == 0,
+            "sharing: structure %zu table %zu reads other bytes", i, t);
+      built += tabs[t].bytes;
+      if (r.owner == (int)i && r.off == tabs[t].off) distinct += tabs[t].bytes;
+    }
+  }
+  CHECK(built == sh.bytes_built && distinct == sh.bytes_distinct, "sharing: byte counts %lld / %lld vs %lld / %lld", (long long)built,
+        (long long)distinct, (long long)sh.bytes_built, (long long)sh.bytes_distinct);
+  CHECK(sh.bytes_distinct < sh.bytes_built * 85 / 100 && sh.bytes_distinct > sh.bytes_built / 3, "sharing: %lld of %lld bytes distinct",
+        (long long)sh.bytes_distinct, (long long)sh.bytes_built);
+  for (size_t t = 0; t < sh.of[11].size(); ++t) CHECK(sh.of[11][t].owner <= 3, "sharing: a repeated structure owns a table");
+}
+
 int main() {
+  sharing_case();
   int cases = 0;
   const int masks[] = {27, 63, 127, 255, 2, 8 | 64, 1 | 16};
   for (int robot = 0; robot < 5; ++robot) {

@@ -494,41 +494,18 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     std::vector<std::unordered_map<uint32_t, uint64_t>> layout_at(n_structs);   // [structure][blob offset of the table] -> device address
     std::vector<uint64_t> model_hdr(n_structs);
     {
-      struct Seen {
-        const char* host;
-        uint32_t bytes;
-        uint64_t dev;
-      };
-      std::unordered_map<uint64_t, std::vector<Seen>> by_hash;
-      auto fnv = [](const char* p, size_t n) {   // FNV-1a over 8-byte words (a bucket key only: equality is decided by memcmp)
-        uint64_t h = 1469598103934665603ull;
-        size_t i = 0;
-        for (; i + 8 <= n; i += 8) {
-          uint64_t w;
-          std::memcpy(&w, p + i, 8);
-          h = (h ^ w) * 1099511628211ull;
-          h ^= h >> 29;
-        }
-        for (; i < n; ++i) h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
-        return h;
-      };
+      std::vector<const twr::Structure*> sp(n_structs);
+      for (int i = 0; i < n_structs; ++i) sp[i] = &structs[i]->s;
+      const twr::LayoutShare share = twr::ShareLayoutTables(sp);   // (host logic: structure.cc)
+      b->dyn_layout_bytes = share.bytes_built;
+      b->dyn_layout_distinct_bytes = share.bytes_distinct;
       for (int i = 0; i < n_structs; ++i) {
-        const char* blob = host_arena.data() + blob_off[i];
-        for (const auto& tr : structs[i]->s.dyn_layout_tables) {
-          const char* src = blob + tr.off;
-          std::vector<Seen>& bucket = by_hash[fnv(src, tr.bytes) ^ tr.bytes];
-          uint64_t dev = 0;
-          for (const Seen& sn : bucket)
-            if (sn.bytes == tr.bytes && std::memcmp(sn.host, src, tr.bytes) == 0) dev = sn.dev;
-          if (!dev) {
-            dev = reinterpret_cast<uint64_t>(b->blobs[i]) + tr.off;
-            bucket.push_back({src, tr.bytes, dev});
-            b->dyn_layout_distinct_bytes += tr.bytes;
-          }
-          b->dyn_layout_bytes += tr.bytes;
-          layout_at[i][tr.off] = dev;
+        const auto& tabs = structs[i]->s.dyn_layout_tables;
+        for (size_t t = 0; t < tabs.size(); ++t) {
+          const twr::LayoutShare::Ref& r = share.of[i][t];
+          layout_at[i][tabs[t].off] = reinterpret_cast<uint64_t>(b->blobs[r.owner]) + r.off;
         }
-        const twr::DevStruct* H = reinterpret_cast<const twr::DevStruct*>(blob);
+        const twr::DevStruct* H = reinterpret_cast<const twr::DevStruct*>(host_arena.data() + blob_off[i]);
         model_hdr[i] = reinterpret_cast<uint64_t>(b->blobs[i]);
         for (int q = 0; q < i; ++q) {
           const twr::DevStruct* Q = reinterpret_cast<const twr::DevStruct*>(host_arena.data() + blob_off[q]);

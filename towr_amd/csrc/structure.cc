@@ -8,6 +8,7 @@
 #include <limits>
 #include <numeric>
 #include <stdexcept>
+#include <unordered_map>
 
 namespace twr {
 
@@ -1603,6 +1604,52 @@ void GaitCombo(int n_ee, int combo, double t_total, double swing_scale, twr_sche
     out->in_contact_at_start[e] = (contacts.front() >> e) & 1;  // IsInContactAtStart :107-111
     for (size_t i = 0; i < foot[e].size(); ++i) out->phase_durations[e][i] = (foot[e][i] / total) * t_total;
   }
+}
+
+LayoutShare ShareLayoutTables(const std::vector<const Structure*>& structs) {
+  struct Seen {
+    const char* bytes;
+    uint32_t n;
+    LayoutShare::Ref ref;
+  };
+  auto hash = [](const char* p, size_t n) {   // FNV-1a over 8-byte words (a bucket key only: equality is decided by memcmp)
+    uint64_t h = 1469598103934665603ull;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+      uint64_t w;
+      std::memcpy(&w, p + i, 8);
+      h = (h ^ w) * 1099511628211ull;
+      h ^= h >> 29;
+    }
+    for (; i < n; ++i) h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
+    return h;
+  };
+  LayoutShare out;
+  out.of.resize(structs.size());
+  std::unordered_map<uint64_t, std::vector<Seen>> by_hash;
+  for (size_t i = 0; i < structs.size(); ++i) {
+    const Structure& S = *structs[i];
+    for (const Structure::TableRef& tr : S.dyn_layout_tables) {
+      if ((size_t)tr.off + tr.bytes > S.blob.size()) throw std::runtime_error("layout table outside its blob");
+      const char* src = S.blob.data() + tr.off;
+      std::vector<Seen>& bucket = by_hash[hash(src, tr.bytes) ^ tr.bytes];
+      LayoutShare::Ref ref{(int)i, tr.off};
+      bool found = false;
+      for (const Seen& sn : bucket)
+        if (sn.n == tr.bytes && std::memcmp(sn.bytes, src, tr.bytes) == 0) {
+          ref = sn.ref;
+          found = true;
+          break;
+        }
+      if (!found) {
+        bucket.push_back({src, tr.bytes, ref});
+        out.bytes_distinct += tr.bytes;
+      }
+      out.bytes_built += tr.bytes;
+      out.of[i].push_back(ref);
+    }
+  }
+  return out;
 }
 
 }  // namespace twr

@@ -117,6 +117,18 @@ struct Structure {
 };
 
 // gait tables
+// Layout tables of dyn_kernel stored once per distinct CONTENT (device_tables.h): for every structure and every entry of its
+// dyn_layout_tables, which structure's copy a batch reads -- the first one of the list with the same bytes (itself if none).
+// Host logic only (no device): twr_batch_create turns {owner, offset} into device addresses.
+struct LayoutShare {
+  struct Ref {
+    int owner;          // index into the structure list
+    uint32_t off;       // byte offset of the table inside the OWNER's blob
+  };
+  std::vector<std::vector<Ref>> of;     // [structure][i] for dyn_layout_tables[i]
+  int64_t bytes_built = 0, bytes_distinct = 0;
+};
+LayoutShare ShareLayoutTables(const std::vector<const Structure*>& structs);
 void GaitCombo(int n_ee, int combo, double t_total, double swing_scale, twr_schedule* out);
 void ModelPreset(int robot, int terrain, twr_model* out);
 double TerrainHeightHost(const twr_model& m, const TerrainGrid* grid, double x, double y);
