@@ -217,7 +217,7 @@ static_assert(sizeof(PhasePoly) == 64, "PhasePoly layout");
 // dynamic with optimised timings: where the values of ONE polynomial's candidates go inside a time node's expanded
 // rows.  The rows hold all variables of every ee set, so the row layout is a constant of the structure and the byte
 // offset (relative to the node's first value) of a candidate depends on its end-effector and polynomial only: one
-// record per (ee, polynomial), read off the CSR pattern like DynPut.  A candidate that is not a variable points at
+// record per (ee, polynomial), read off the CSR pattern like DynTile.  A candidate that is not a variable points at
 // entry 8 + ee of row AX (a base-ang value the same wave writes afterwards).
 struct PhasePutM {
   uint16_t off[4][8];    // [j][2 D + r]  [f]x J_p of candidate (j, D): rows (D+1)%3 and (D+2)%3 of the angular block

@@ -678,7 +678,7 @@ TWR_DEV void copy_out_fixed(double* __restrict__ dst, const double* __restrict__
 #ifndef TWR_TU_ROM
 // ---------------------------------------------------------------- dynamic, fixed timings (dyn_kernel)
 // DynamicConstraint + SingleRigidBodyDynamics + EulerConverter for one time node on a quad of lanes (see above); every
-// index is an LDS byte offset prepared on the host (device_tables.h DynNode / DynGather / DynPut): the slice's part of x
+// index is an LDS byte offset prepared on the host (device_tables.h DynNodeL / DynSel / DynPolyL / DynTile): the slice's part of x
 // sits in LDS ("xs"), values that are not optimisation variables read its zero slot, and a Jacobian value is stored at
 // node base + a 16-bit offset from the record.
 constexpr int kDynX0 = kDynG0 + 96;        // xs: zero pair, then <= kDynXsCap staged doubles of x
@@ -840,7 +840,7 @@ TWR_DEV void dyn2_front(const DynFrontRec& r, const char* __restrict__ xs, int l
 }
 
 // Back half: Jacobian blocks and constraint values into the LDS image.  `img` is the byte address of the image
-// (parity shift included), node base and row offsets come from DynNode, tile offsets from DynPut.
+// (parity shift included), node base and row offsets come from DynNodeL, tile offsets from DynTile + DynPolyL::code.
 TWR_DEV void dyn2_back(const DynWork& w, const DynFrontRec& rec, const DynCodes& cd, const Dyn2Front& S, double* __restrict__ gst,
                        char* __restrict__ img, int lane, bool want_g, bool want_j) {
   const DynNode& nd = rec.nd;
