@@ -237,6 +237,11 @@ int twr_batch_num_problems(const twr_batch* b);
  * evaluation reads.  No reference counterpart: towr recomputes these indices inside every callback
  * (towr/src/nodes_variables_phase_based.cc:210-298, spline.cc:48-78). */
 int twr_batch_table_bytes(const twr_batch* b, int64_t* resident, int64_t* dyn_layout, int64_t* dyn_layout_distinct);
+/* 1 when the batch's Jacobian values leave the dynamic / range-of-motion kernels with non-temporal stores, else 0.  Chosen by
+ * twr_batch_create from the shape of the batch alone (fewer than four problems per structure on average AND more than
+ * 256 MB of output per evaluation: a sweep whose candidates all bring their own tables); the values written are the
+ * same bits either way. */
+int twr_batch_streaming_stores(const twr_batch* b);
 /* Ragged layout of the batch arrays, each n_problems+1 prefix sums in units of doubles:
  * problem p owns x[x_off[p]..x_off[p+1]), g[g_off[p]..), jac[jac_off[p]..). */
 int twr_batch_layout(const twr_batch* b, int64_t* x_off, int64_t* g_off, int64_t* jac_off);

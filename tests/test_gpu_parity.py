@@ -678,6 +678,22 @@ def test_layout_tables_are_shared_by_content():
     assert 0.5 * six["dyn_layout"] <= six["dyn_layout_distinct"] < six["dyn_layout"], six
 
 
+def test_mid_size_sweep_streams_non_temporal_through_the_fused_launch():
+    """384 enumerated candidates (every 2nd of the first 768: all gait combos of the enumeration's first four): 330 MB of
+    output per evaluation and one structure per problem, so the batch streams its Jacobian values with non-temporal
+    stores (twr_batch_streaming_stores), and ~6400 rom slices, so it goes through the FUSED launch -- the nt
+    instantiation of eval_fused_kernel.  All candidates against the oracle.  Smaller or single-structure batches keep plain stores."""
+    cands = _run_sweep("anymal", "stairs", 384, list(range(384)), stride=2)
+    assert {c[0] for c in cands} == {0, 1, 2, 3}
+    from towr_amd import sweep
+
+    model = ta.model_preset("anymal", "stairs")
+    structs = sweep.candidate_structures(model, sweep.enumerate_candidates(768)[::2])
+    assert ta.Batch(structs, list(range(384)), device=0).streaming_stores()
+    assert not ta.Batch(structs[:64], list(range(64)), device=0).streaming_stores()        # 55 MB of output
+    assert not ta.Batch(structs[:1], [0] * 2048, device=0).streaming_stores()              # one structure for all problems
+
+
 @pytest.mark.parametrize("terrain", ["gap", "stairs"])
 def test_sweep_c4_64(terrain):
     """BASELINE config 4: batch of 64 enumerated candidate contact sequences on Gap / Stairs; all 64 checked."""

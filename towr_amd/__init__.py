@@ -133,6 +133,7 @@ def lib():
         L.twr_batch_destroy.restype = None
         L.twr_batch_num_problems.argtypes = [C.c_void_p]
         L.twr_batch_table_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.twr_batch_streaming_stores.argtypes = [C.c_void_p]
         L.twr_batch_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.twr_batch_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.twr_batch_status.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
@@ -410,6 +411,10 @@ class Batch:
         r, a, d = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         _check(lib().twr_batch_table_bytes(self._h, C.byref(r), C.byref(a), C.byref(d)))
         return dict(resident=r.value, dyn_layout=a.value, dyn_layout_distinct=d.value)
+
+    def streaming_stores(self):
+        """True when the batch streams its Jacobian values out with non-temporal stores (twr_batch_streaming_stores)."""
+        return bool(lib().twr_batch_streaming_stores(self._h))
 
     def status(self, stream=0):
         """Per-problem non-finite flags of the last eval_device(..., flags | EVAL_CHECK): bit 0 g, bit 1 jac."""

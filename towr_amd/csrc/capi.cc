@@ -22,7 +22,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
                        const NodeWork* node, int n_node, int node_families, const FamWork* const fam[4], const int n_fam[4],
                        const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap,
                        const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
-                       double* g, double* jac, double* dump, int flags, hipStream_t stream, hipEvent_t* ev);
+                       double* g, double* jac, double* dump, int flags, bool stream_nt, hipStream_t stream, hipEvent_t* ev);
 int dyn_dump_doubles();
 int node_force_chunk();
 hipError_t prepare_phase_kernels(int pdyn_img_cap, int prom_img_cap);
@@ -84,6 +84,7 @@ struct twr_batch {
   int n_dyn = 0, n_rom = 0, n_node = 0, n_cu = 0;
   int node_families = 4;                     // 2 when no problem has more than terrain-* / force-* work for the node kernel
   int rom_max_vals = 0;                      // Jacobian values of the largest rom slice (picks the copy-out length)
+  bool stream_nt = false;                    // non-temporal copy-out stores in dyn_kernel / rom_kernel / the fused kernel (set by twr_batch_create)
   int dyn_map_chunks = 2;                    // 2: every dyn slice of the batch stages <= 128 doubles of x (256-byte staging maps), else 4
   std::vector<int64_t> x_off, g_off, j_off;  // n_problems+1
   std::vector<void*> blobs;                  // device blobs, one per distinct structure: addresses inside `arena`
@@ -704,6 +705,23 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     interleave(rom, rom_first);
     b->n_dyn = (int)dyn.size();
     b->n_rom = (int)rom.size();
+    // Store policy of the copy-out (kernels.hip copy_out_fixed): non-temporal when the batch is SWEEP-LIKE -- fewer than four
+    // problems per structure on average, so every evaluation re-reads tables (and x) that only that problem uses -- AND one
+    // evaluation writes more than the Infinity Cache holds (256 MB on an MI355X), so that plain stores would flush those
+    // tables out of it between two evaluations.  Measured (one box, no per-kernel events): the C5 sweep at 512 /
+    // 1024 candidates 116-118 / 223-224 -> 99 / 209-211 us per step; at 256 candidates (220 MB of output, absorbed by the
+    // Infinity Cache as it is) 52 -> 55 us, and 8192 problems of ONE structure lose 15 % in rom_kernel -- hence the two conditions.
+    {
+      std::vector<char> used(n_structs, 0);
+      int n_used = 0;
+      for (int p = 0; p < n_problems; ++p)
+        if (!used[struct_of_problem[p]]) {
+          used[struct_of_problem[p]] = 1;
+          ++n_used;
+        }
+      const int64_t out_bytes = 8 * (b->g_off[n_problems] + b->j_off[n_problems]);
+      b->stream_nt = (int64_t)n_used * 4 > n_problems && out_bytes > (int64_t)256 << 20;
+    }
     b->n_node = (int)node.size();
     b->node_families = 2;
     for (int i = 0; i < n_structs; ++i)
@@ -841,6 +859,8 @@ void twr_batch_destroy(twr_batch* b) {
 
 int twr_batch_num_problems(const twr_batch* b) { return b ? b->n_problems : 0; }
 
+int twr_batch_streaming_stores(const twr_batch* b) { return b && b->stream_nt ? 1 : 0; }
+
 int twr_batch_table_bytes(const twr_batch* b, int64_t* resident, int64_t* dyn_layout, int64_t* dyn_layout_distinct) {
   if (!b) return fail(TWR_ERR_INVALID, "null batch");
   if (resident) *resident = b->table_bytes;
@@ -872,7 +892,7 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->dyn_map_chunks, b->d_rom, b->n_rom, b->rom_max_vals, b->d_node, b->n_node, b->node_families, b->d_fam, b->n_fam,
                                   b->d_pdyn, b->n_pdyn, b->pdyn_img_cap, b->d_ploc, b->n_ploc, b->d_prom, b->n_prom,
-                                  b->prom_img_cap, d_x, d_g, d_jac, b->d_dump, flags & TWR_EVAL_BOTH, stream, ev);
+                                  b->prom_img_cap, d_x, d_g, d_jac, b->d_dump, flags & TWR_EVAL_BOTH, b->stream_nt, stream, ev);
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   if (flags & TWR_EVAL_CHECK) {
     e = twr::launch_check(b->n_problems, b->d_goff, b->d_joff, d_g, d_jac, b->d_status, flags & TWR_EVAL_BOTH, stream);

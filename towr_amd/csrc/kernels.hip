@@ -619,7 +619,11 @@ TWR_DEV void copy_out(double* __restrict__ dst, const double* __restrict__ stage
 // counted s_waitcnt vmcnt(N) when the persistent loop next touches its prefetched loads (on gfx9
 // loads and stores retire through one in-order counter; an unknown store count would force
 // vmcnt(0), i.e. a full store drain per slice).
-template <int NIT, int kBatch>
+// NT: the 16-byte stores carry the non-temporal hint (global_store_dwordx4 ... nt): the values stream to HBM without
+// displacing what the kernels RE-READ -- a sweep's per-candidate tables and x -- from the XCD's L2 and the Infinity Cache.
+// Chosen per batch (twr_batch_create): worth 5-15 % of a step whose candidates all bring their own tables and
+// whose output exceeds the Infinity Cache; it COSTS rom_kernel 10-15 % when one structure serves thousands of problems.
+template <int NIT, int kBatch, bool NT = false>
 TWR_DEV void copy_out_fixed(double* __restrict__ dst, const double* __restrict__ stage, int n, int par, int lane) {
   // byte offsets as unsigned 32-bit values: one VGPR addresses both the LDS read and the global store (wave-uniform
   // base + 32-bit offset), two VALU instructions per store instead of a 64-bit address computation
@@ -646,7 +650,15 @@ TWR_DEV void copy_out_fixed(double* __restrict__ dst, const double* __restrict__
       }
 #pragma unroll
     for (int b = 0; b < kBatch; ++b)
-      if (it0 + b < NIT) *reinterpret_cast<double2*>(al + off[b]) = v[b];
+      if (it0 + b < NIT) {
+        if (NT) {
+          typedef double twr_d2 __attribute__((ext_vector_type(2)));
+          const twr_d2 vv = {v[b].x, v[b].y};
+          __builtin_nontemporal_store(vv, reinterpret_cast<twr_d2*>(al + off[b]));
+        } else {
+          *reinterpret_cast<double2*>(al + off[b]) = v[b];
+        }
+      }
   }
   // first and last value of the slice (they sit in half pairs when the slice starts / ends on an odd index): stored by
   // every lane, whatever the parity -- two more store instructions that are ALWAYS issued.  A store inside a divergent
@@ -1041,7 +1053,7 @@ TWR_DEV void dyn2_back(const DynWork& w, const DynFrontRec& rec, const DynCodes&
 // XC = 64-entry chunks of the staging map the slices of the batch use (2: every slice stages at most 128 doubles of x --
 // true for all K = 200 problems, whose 12..15-node slices stage ~100 -- and reads the 256-byte form of its map; 4: the
 // general 512-byte form).  A compile-time count: the x gather is XC loads per lane, the same on every path.
-template <bool WANT_G, bool WANT_J, int XC>
+template <bool WANT_G, bool WANT_J, int XC, bool NT>
 TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double* __restrict__ x, double* __restrict__ g,
                       double* __restrict__ jac, double* __restrict__ dump, double* stage, int lane, int i, int stride) {
   static_assert(XC == 2 || XC == 4, "staging map chunks");
@@ -1073,7 +1085,9 @@ TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double
   // image -> HBM; the constraint values (6 per time node, contiguous in g) with clamped lanes instead of predicates
   auto copy_out = [&](double* pdst, double* pg, int nvals, int cnt) {
     const int ppar = (int)((reinterpret_cast<uintptr_t>(pdst) >> 3) & 1);
-    if (WANT_J) copy_out_fixed<NIT, kDynCopyBatch>(pdst, stage, nvals, ppar, lane);
+    // (NT: batches of two -- with the non-temporal builtin the LDS reads of a batch keep registers of their own, and eight of
+    // them in flight put 12 VGPRs into scratch; the plain form ends up serialised through one quad whatever the batch is)
+    if (WANT_J) copy_out_fixed<NIT, NT ? 2 : kDynCopyBatch, NT>(pdst, stage, nvals, ppar, lane);
     if (WANT_G) {
       const int last = 6 * cnt - 1;
       pg[min(lane, last)] = gst[min(lane, last)];
@@ -1133,11 +1147,11 @@ TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double
   copy_out(pdst, pg, wp.nvals, wp.cnt);                 // last slice of this workgroup
 }
 
-template <bool WANT_G, bool WANT_J, int XC>
+template <bool WANT_G, bool WANT_J, int XC, bool NT>
 __global__ __launch_bounds__(64, TWR_DYN_WAVES) void dyn_kernel(const DynWork* __restrict__ work, int n_work, const double* __restrict__ x,
                                                     double* __restrict__ g, double* __restrict__ jac, double* __restrict__ dump) {
   __shared__ __attribute__((aligned(16))) double stage[kDynLds];
-  dyn_body<WANT_G, WANT_J, XC>(work, n_work, x, g, jac, dump, stage, threadIdx.x, blockIdx.x, gridDim.x);
+  dyn_body<WANT_G, WANT_J, XC, NT>(work, n_work, x, g, jac, dump, stage, threadIdx.x, blockIdx.x, gridDim.x);
 }
 
 #endif  // !TWR_TU_ROM
@@ -1152,7 +1166,7 @@ constexpr int kRomLds = kRomStage + 2 + 64 + 192;   // doubles: image, per-lane 
 // (The hand-scheduled form of dyn_phase_kernel -- asm loads into AGPRs, one counted wait behind the copy-out -- was built
 // for this loop too and is SLOWER here, 0.98 vs 0.90 ms on one box: the compiler's clause-oriented schedule of the 28
 // loads with scalar bases and immediate offsets beats 28 separate asm loads with per-lane 64-bit addresses.)
-template <int NIT, bool WANT_G, bool WANT_J>
+template <int NIT, bool WANT_G, bool WANT_J, bool NT>
 TWR_DEV void rom_body(const RomWork* __restrict__ work, int n_work, const double* __restrict__ x, double* __restrict__ g,
                       double* __restrict__ jac, double* stage, int lane, int i, int stride) {
   static_assert(NIT * 128 <= kRomStage + 2 + 127, "copy-out longer than the image");
@@ -1177,7 +1191,7 @@ TWR_DEV void rom_body(const RomWork* __restrict__ work, int n_work, const double
     const RomNode n3 = rom_load_node(w3, lane);         // A: node records three slices ahead, segment records two ahead
     const RomSeg s2 = rom_load_seg(w2, n2);             //    (records first: the wait for x retires them too)
     rom_load_x(w1, n1, s1, x, X);
-    if (WANT_J) copy_out_fixed<NIT, 13>(dst, stage, w0.nvals, par, lane);   // B
+    if (WANT_J) copy_out_fixed<NIT, 13, NT>(dst, stage, w0.nvals, par, lane);   // B
     if (WANT_G) {                                       //   3 constraint values per time node, contiguous in g: clamped
       double* go = g + w0.g_off;                        //   lanes instead of predicates (see copy_out_fixed)
       const int last_g = 3 * w0.cnt - 1;
@@ -1192,23 +1206,25 @@ TWR_DEV void rom_body(const RomWork* __restrict__ work, int n_work, const double
 
 constexpr int kRomNitMax = (kRomStage + 2 + 127) / 128;   // 38
 #ifdef TWR_TU_ROM
-template <int NIT, bool WANT_G, bool WANT_J>
+template <int NIT, bool WANT_G, bool WANT_J, bool NT>
 __global__ __launch_bounds__(64, 1) void rom_kernel(const RomWork* __restrict__ work, int n_work, const double* __restrict__ x,
                                                     double* __restrict__ g, double* __restrict__ jac) {
   __shared__ __attribute__((aligned(16))) double stage[kRomLds];
-  rom_body<NIT, WANT_G, WANT_J>(work, n_work, x, g, jac, stage, threadIdx.x, blockIdx.x, gridDim.x);
+  rom_body<NIT, WANT_G, WANT_J, NT>(work, n_work, x, g, jac, stage, threadIdx.x, blockIdx.x, gridDim.x);
 }
 
 // max_vals: Jacobian values of the largest slice of the batch
 hipError_t launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, int max_vals, const double* x, double* g,
-                             double* jac, int flags) {
+                             double* jac, int flags, bool nt) {
   const bool wg = flags & 1, wj = flags & 2;
   const int need = (max_vals + 1 + 2 + 127) / 128;   // (+ parity shift, rounded up to whole store instructions)
 #define TWR_ROM_LAUNCH(NIT)                                                                                                  \
   {                                                                                                                          \
-    if (wg && wj) return twr_launch(rom_kernel<NIT, true, true>, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac);    \
-    if (wj) return twr_launch(rom_kernel<NIT, false, true>, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac);         \
-    return twr_launch(rom_kernel<NIT, true, false>, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac);                 \
+    if (wg && wj && nt) return twr_launch(rom_kernel<NIT, true, true, true>, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac);    \
+    if (wg && wj) return twr_launch(rom_kernel<NIT, true, true, false>, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac);         \
+    if (wj && nt) return twr_launch(rom_kernel<NIT, false, true, true>, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac);         \
+    if (wj) return twr_launch(rom_kernel<NIT, false, true, false>, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac);              \
+    return twr_launch(rom_kernel<NIT, true, false, false>, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g, jac);                      \
   }
   if (need <= 26) TWR_ROM_LAUNCH(26)
   if (need <= 30) TWR_ROM_LAUNCH(30)
@@ -1218,7 +1234,7 @@ hipError_t launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, i
 }
 #else   // !TWR_TU_ROM
 hipError_t launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, int max_vals, const double* x, double* g,
-                             double* jac, int flags);
+                             double* jac, int flags, bool nt);
 
 // all terrain-ee-motion_e (terrain_constraint.cc:57-108), force-ee-force_e, splineacc-base-* and
 // swing-ee-motion_e sets of one problem.  One workgroup of four waves per problem, one wave per family
@@ -1503,7 +1519,8 @@ template <int FAM, bool WANT_G, bool WANT_J>
 TWR_DEV void fam_store(const FamWork& w, double* __restrict__ g, double* __restrict__ jac, const double* stage, const double* gst,
                        int par, int lane) {
   typedef FamShape<FAM> Sh;
-  if (WANT_J) copy_out_fixed<Sh::kNit, Sh::kNit>(jac + w.j_off, stage, Sh::kPer * w.cnt, par, lane);   // single wave: LDS accesses are ordered
+  // (non-temporal: A/B on one box, towr's default list, 8192 problems of one structure: 0.067 -> 0.063 ms)
+  if (WANT_J) copy_out_fixed<Sh::kNit, Sh::kNit, true>(jac + w.j_off, stage, Sh::kPer * w.cnt, par, lane);   // single wave: LDS accesses are ordered
   if (WANT_G) {   // clamped lanes instead of predicates (see copy_out_fixed)
     double* gp = g + w.g_off;
     const int last_g = Sh::kRows * w.cnt - 1;
@@ -1583,7 +1600,7 @@ __global__ __launch_bounds__(64, 4) void node_chunk_kernel(const FamWork* __rest
 // and 40 KB: blocks [0, g_rom) take the rom role (wave 0 only; the image is 39 KB), the next g_dyn blocks the dyn role
 // (both waves, one 20-KB half each), the rest the node role (two families per block) -- the residency per CU of each
 // role is that of its own kernel, and blocks are dispatched in this order, so a later role starts as the earlier drains.
-template <int ROM_NIT, bool WANT_G, bool WANT_J, int XC>
+template <int ROM_NIT, bool WANT_G, bool WANT_J, int XC, bool NT>
 __global__ __launch_bounds__(128, 2) void eval_fused_kernel(const RomWork* __restrict__ rom, int n_rom, int g_rom,
                                                             const DynWork* __restrict__ dyn, int n_dyn, int g_dyn,
                                                             const NodeWork* __restrict__ node, const double* __restrict__ x,
@@ -1595,12 +1612,12 @@ __global__ __launch_bounds__(128, 2) void eval_fused_kernel(const RomWork* __res
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   int b = blockIdx.x;
   if (b < g_rom) {
-    if (wave == 0) rom_body<ROM_NIT, WANT_G, WANT_J>(rom, n_rom, x, g, jac, stage, lane, b, g_rom);
+    if (wave == 0) rom_body<ROM_NIT, WANT_G, WANT_J, NT>(rom, n_rom, x, g, jac, stage, lane, b, g_rom);
     return;
   }
   b -= g_rom;
   if (b < g_dyn) {
-    dyn_body<WANT_G, WANT_J, XC>(dyn, n_dyn, x, g, jac, dump, stage + wave * kDynLds, lane, 2 * b + wave, 2 * g_dyn);
+    dyn_body<WANT_G, WANT_J, XC, NT>(dyn, n_dyn, x, g, jac, dump, stage + wave * kDynLds, lane, 2 * b + wave, 2 * g_dyn);
     return;
   }
   b -= g_dyn;
@@ -2932,8 +2949,8 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
                        int rom_max_vals, const NodeWork* node, int n_node, int node_families /* 2: terrain + force only; 4 */,
                        const FamWork* const fam[4], const int n_fam[4] /* chunk lists of node_chunk_kernel; all 0: none */,
                        const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap, const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
-                       double* g, double* jac, double* dump /* kDynDump doubles */, int flags, hipStream_t stream,
-                       hipEvent_t* ev /* 4 events or nullptr */) {
+                       double* g, double* jac, double* dump /* kDynDump doubles */, int flags, bool stream_nt /* non-temporal copy-out of
+                       dyn / rom (copy_out_fixed) */, hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */) {
   static const int dyn_bpc = env_int("TWR_DYN_BPC", 8), rom_bpc = env_int("TWR_ROM_BPC", 4);
   dim3 block(64);
   hipError_t st = hipSuccess;
@@ -2965,13 +2982,14 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
     }
     const dim3 fgrid(g_rom + g_dyn + 2 * n_node);
     const int need = (rom_max_vals + 1 + 2 + 127) / 128;   // copy-out length of the rom role (see launch_rom_kernel)
-#define TWR_FUSED_LAUNCH(NIT, XC)                                                                                                      \
-  {                                                                                                                                    \
-    if ((flags & 3) == 3)                                                                                                              \
-      return twr_launch(eval_fused_kernel<NIT, true, true, XC>, fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump);   \
-    if (flags & 2)                                                                                                                     \
-      return twr_launch(eval_fused_kernel<NIT, false, true, XC>, fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump);  \
-    return twr_launch(eval_fused_kernel<NIT, true, false, XC>, fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump);    \
+#define TWR_FUSED_ARGS fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump
+#define TWR_FUSED_LAUNCH(NIT, XC)                                                                              \
+  {                                                                                                            \
+    if ((flags & 3) == 3 && stream_nt) return twr_launch(eval_fused_kernel<NIT, true, true, XC, true>, TWR_FUSED_ARGS);    \
+    if ((flags & 3) == 3) return twr_launch(eval_fused_kernel<NIT, true, true, XC, false>, TWR_FUSED_ARGS);                \
+    if ((flags & 2) && stream_nt) return twr_launch(eval_fused_kernel<NIT, false, true, XC, true>, TWR_FUSED_ARGS);        \
+    if (flags & 2) return twr_launch(eval_fused_kernel<NIT, false, true, XC, false>, TWR_FUSED_ARGS);                      \
+    return twr_launch(eval_fused_kernel<NIT, true, false, XC, false>, TWR_FUSED_ARGS);                                     \
   }
     if (dyn_map_chunks == 2) {
       if (need <= 34) TWR_FUSED_LAUNCH(34, 2)
@@ -2980,19 +2998,24 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
     if (need <= 34) TWR_FUSED_LAUNCH(34, 4)
     TWR_FUSED_LAUNCH(kRomNitMax, 4)
 #undef TWR_FUSED_LAUNCH
+#undef TWR_FUSED_ARGS
   }
   if (ev) (void)hipEventRecord(ev[0], stream);
   if (n_dyn > 0) {
     const int res = dyn_bpc * n_cu;
     dim3 grid(n_dyn < res ? n_dyn : res);
-#define TWR_DYN_LAUNCH(XC)                                                                                                              \
-  {                                                                                                                                      \
-    if ((flags & 3) == 3) st = twr_first(st, twr_launch(dyn_kernel<true, true, XC>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, dump));       \
-    else if (flags & 2) st = twr_first(st, twr_launch(dyn_kernel<false, true, XC>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, dump));        \
-    else st = twr_first(st, twr_launch(dyn_kernel<true, false, XC>, grid, block, 0, stream, dyn, n_dyn, x, g, jac, dump));                       \
+#define TWR_DYN_ARGS grid, block, 0, stream, dyn, n_dyn, x, g, jac, dump
+#define TWR_DYN_LAUNCH(XC)                                                                                                   \
+  {                                                                                                                           \
+    if ((flags & 3) == 3 && stream_nt) st = twr_first(st, twr_launch(dyn_kernel<true, true, XC, true>, TWR_DYN_ARGS));        \
+    else if ((flags & 3) == 3) st = twr_first(st, twr_launch(dyn_kernel<true, true, XC, false>, TWR_DYN_ARGS));               \
+    else if ((flags & 2) && stream_nt) st = twr_first(st, twr_launch(dyn_kernel<false, true, XC, true>, TWR_DYN_ARGS));       \
+    else if (flags & 2) st = twr_first(st, twr_launch(dyn_kernel<false, true, XC, false>, TWR_DYN_ARGS));                     \
+    else st = twr_first(st, twr_launch(dyn_kernel<true, false, XC, false>, TWR_DYN_ARGS));                                    \
   }
     if (dyn_map_chunks == 2) TWR_DYN_LAUNCH(2) else TWR_DYN_LAUNCH(4)
 #undef TWR_DYN_LAUNCH
+#undef TWR_DYN_ARGS
   }
   // optimised-timings problems: the pre-pass (segment lookup -> records), then the persistent kernels
   if (n_ploc > 0) st = twr_first(st, twr_launch(phase_locate_kernel, dim3(n_ploc), dim3(kLocateThreads), 0, stream, ploc, x));
@@ -3049,7 +3072,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
   if (n_rom > 0) {
     const int res = rom_bpc * n_cu;
     dim3 grid(n_rom < res ? n_rom : res);
-    st = twr_first(st, launch_rom_kernel((int)grid.x, stream, rom, n_rom, rom_max_vals, x, g, jac, flags));
+    st = twr_first(st, launch_rom_kernel((int)grid.x, stream, rom, n_rom, rom_max_vals, x, g, jac, flags, stream_nt));
   }
   if (ev) (void)hipEventRecord(ev[2], stream);
   const int n_chunks = n_fam[0] + n_fam[1] + n_fam[2] + n_fam[3];
