@@ -2962,7 +2962,10 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
   // 16.6 slices per candidate), 8.3 rounds on the 256 CUs of an MI355X.  The thresholds are in units of the device's
   // residency, not constants of one chip.
   const int cap = rom_bpc * n_cu;
-  const int fused_max = env_int("TWR_FUSED_MAX_ROM", 10 * cap);
+  // With non-temporal stores (sweep-like batches) the fused launch stays ahead for longer -- 768 / 896 / 1024 candidates of the
+  // C5 sweep (12.7 / 14.9 / 17 thousand rom slices): 160-165 / 179 / 210 us as three launches, 148 / 166 / 202 us fused -- twenty
+  // rounds there (the enumeration ends at 1040 candidates; nothing larger was measured).
+  const int fused_max = env_int("TWR_FUSED_MAX_ROM", (stream_nt ? 20 : 10) * cap);
   if (!ev && n_pdyn == 0 && n_prom == 0 && n_rom > 0 && n_dyn > 0 && n_rom <= fused_max) {
     int g_rom = n_rom < cap ? n_rom : cap, g_dyn = (n_dyn + 1) / 2 < cap ? (n_dyn + 1) / 2 : cap;
     // When the two persistent roles do not fit the CUs together, the blocks of the later role only start as the earlier
