@@ -234,7 +234,10 @@ def sweep_traffic_ratio(algorithmic_bytes):
             t = json.load(f)
         per = t.get("sweep_1024", {}).get("hbm_bytes_per_launch", {})
         if t.get("kernel_source_sha256") == kernel_source_hash() and per:
-            return sum(per.values()) / algorithmic_bytes
+            # the profiled run holds both forms of a step: the fused launch (what this leg's event-free steps run at 1024
+            # candidates) and the three separate kernels (the steps with per-kernel events)
+            fused = [v for k, v in per.items() if k.startswith("twr::eval_fused_kernel")]
+            return (sum(fused) if fused else sum(per.values())) / algorithmic_bytes
     except (OSError, ValueError):
         pass
     return None

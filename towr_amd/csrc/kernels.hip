@@ -1617,7 +1617,13 @@ __global__ __launch_bounds__(128, 2) void eval_fused_kernel(const RomWork* __res
   }
   b -= g_rom;
   if (b < g_dyn) {
-    dyn_body<WANT_G, WANT_J, XC, NT>(dyn, n_dyn, x, g, jac, dump, stage + wave * kDynLds, lane, 2 * b + wave, 2 * g_dyn);
+    // Which slices a block's two waves take: the work list is ordered so that position j wants XCD j % 8 (all slices of one
+    // problem on one XCD, capi.cc), and blocks are dealt round-robin over the XCDs -- so block 8 q + r takes positions
+    // 16 q + r and 16 q + 8 + r: every position a block ever visits is r modulo 8.  (With positions 2 b, 2 b + 1 the
+    // slices of a problem ran on two XCDs, and its x and tables were fetched by both.)  Needs g_dyn to be a multiple
+    // of 8 (the launcher rounds it down); tiny grids keep the plain mapping.
+    const int first = (g_dyn & 7) == 0 ? ((b >> 3) << 4) + (wave << 3) + (b & 7) : 2 * b + wave;
+    dyn_body<WANT_G, WANT_J, XC, NT>(dyn, n_dyn, x, g, jac, dump, stage + wave * kDynLds, lane, first, 2 * g_dyn);
     return;
   }
   b -= g_dyn;
@@ -2983,6 +2989,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
       if (g_rom > r) g_rom = r;
       if (g_dyn > d) g_dyn = d;
     }
+    if (g_dyn >= 8) g_dyn &= ~7;   // (the XCD-aware slice mapping of the dyn role, eval_fused_kernel)
     const dim3 fgrid(g_rom + g_dyn + 2 * n_node);
     const int need = (rom_max_vals + 1 + 2 + 127) / 128;   // copy-out length of the rom role (see launch_rom_kernel)
 #define TWR_FUSED_ARGS fgrid, dim3(128), 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, x, g, jac, dump
