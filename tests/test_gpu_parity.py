@@ -689,7 +689,26 @@ def test_mid_size_sweep_streams_non_temporal_through_the_fused_launch():
 
     model = ta.model_preset("anymal", "stairs")
     structs = sweep.candidate_structures(model, sweep.enumerate_candidates(768)[::2])
-    assert ta.Batch(structs, list(range(384)), device=0).streaming_stores()
+    import torch
+
+    batch = ta.Batch(structs, list(range(384)), device=0)
+    assert batch.streaming_stores()
+    # the same batch through the three separate kernels (per-kernel events on): the nt instantiations of dyn_kernel /
+    # rom_kernel, bit for bit what the fused launch wrote
+    x = torch.from_numpy(np.concatenate(_sweep_inputs(structs, model))).cuda()
+    outs = []
+    for profiled in (False, True):
+        g = torch.full((int(batch.g_off[-1]),), float("nan"), dtype=torch.float64, device="cuda")
+        j = torch.full((int(batch.jac_off[-1]),), float("nan"), dtype=torch.float64, device="cuda")
+        if profiled:
+            batch.profile_begin(1)
+        batch.eval_device(x.data_ptr(), g.data_ptr(), j.data_ptr(), ta.EVAL_BOTH, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        if profiled:
+            assert batch.profile_end()[1] == 1
+        outs.append((g, j))
+    assert bool(torch.isfinite(outs[0][1]).all()) and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    del outs, x
     assert not ta.Batch(structs[:64], list(range(64)), device=0).streaming_stores()        # 55 MB of output
     assert not ta.Batch(structs[:1], [0] * 2048, device=0).streaming_stores()              # one structure for all problems
 
