@@ -354,6 +354,7 @@ int twr_batch_host_buffers(twr_batch* b, double** h_x, double** h_g, double** h_
  *                                   stream their output with non-temporal stores, twr_batch_streaming_stores)
  *   TWR_FUSED_SPLIT                 eighths of the residency the fused launch gives the rom role when both roles do not fit
  *                                   (default: 5 up to 25/8 rounds of rom slices, else no split)
+ *   TWR_STREAM_NT=0|1               overrides the store policy twr_batch_create picks (twr_batch_streaming_stores)
  *   TWR_HOST_ZERO_COPY[_X]=0        twr_batch_eval_host: copy through device buffers instead of letting the kernels store
  *                                   into (gather x from) the page-locked host buffers */
 
