@@ -34,6 +34,9 @@ def dist_on(world):
     return world > 1 or bool(os.environ.get("TWR_BENCH_FORCE_DIST"))
 
 
+LEG_WARMUP_S = 0.25   # device_power_warmup before the untimed warm-up steps of the extra legs (timings_c3, all_sets_c3, scale_c5)
+
+
 def device_power_warmup(torch, dev, seconds):
     """Brings the GPU out of its idle power state BEFORE the W warm-up steps: plain HBM writes (torch.fill_ of a 1-GiB
     scratch buffer) until `seconds` have passed.  It is not a step of the path and nothing of it is timed.  Why: the set-up
@@ -268,6 +271,7 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
     x = torch.from_numpy(x_host).to(dev)
     g = torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device=dev)
     jac = torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev)
+    device_power_warmup(torch, dev, LEG_WARMUP_S)   # (the CPU-baseline leg and the structure builds left the device idle)
     for _ in range(10):
         batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)
     torch.cuda.synchronize()
@@ -367,6 +371,7 @@ def timings_c3(ta, torch, dist, model, world, rank, dev, dev_index, backend, str
     x = torch.from_numpy(np.tile(base, ((B + base.shape[0] - 1) // base.shape[0], 1))[:B].reshape(-1)).to(dev)
     g = torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device=dev)
     jac = torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev)
+    device_power_warmup(torch, dev, LEG_WARMUP_S)
     for _ in range(3):
         batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)
     batch.profile_begin(steps)
@@ -511,6 +516,8 @@ def main():
     def step():
         batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)
 
+    global LEG_WARMUP_S
+    LEG_WARMUP_S = min(LEG_WARMUP_S, args.device_warmup_s)   # (--device-warmup-s 0 switches every such warm-up off)
     warm_s = device_power_warmup(torch, dev, args.device_warmup_s)
     for _ in range(args.warmup):
         step()
