@@ -149,8 +149,21 @@ static void sharing_case() {
   for (size_t t = 0; t < sh.of[11].size(); ++t) CHECK(sh.of[11][t].owner <= 3, "sharing: a repeated structure owns a table");
 }
 
+// the store policy of a batch (structure.h): the measured cases of DESIGN 6.R4
+static void policy_case() {
+  const int64_t per = 859216;   // bytes per callback of a K = 200 quadruped candidate
+  CHECK(twr::StreamNonTemporal(1024, 1024, 1024 * per), "policy: the 1024-candidate sweep streams");
+  CHECK(twr::StreamNonTemporal(384, 384, 384 * per), "policy: 384 candidates stream");
+  CHECK(!twr::StreamNonTemporal(256, 256, 256 * per), "policy: 256 candidates (220 MB) keep plain stores");
+  CHECK(!twr::StreamNonTemporal(64, 64, 64 * per), "policy: 64 candidates keep plain stores");
+  CHECK(!twr::StreamNonTemporal(1, 8192, 8192 * per), "policy: one structure for 8192 problems keeps plain stores");
+  CHECK(!twr::StreamNonTemporal(1024, 4096, 4096 * per), "policy: four problems per structure keep plain stores");
+  CHECK(twr::StreamNonTemporal(1024, 2048, 2048 * per), "policy: two problems per structure stream");
+}
+
 int main() {
   sharing_case();
+  policy_case();
   int cases = 0;
   const int masks[] = {27, 63, 127, 255, 2, 8 | 64, 1 | 16};
   for (int robot = 0; robot < 5; ++robot) {

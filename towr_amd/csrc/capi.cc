@@ -720,7 +720,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
           ++n_used;
         }
       const int64_t out_bytes = 8 * (b->g_off[n_problems] + b->j_off[n_problems]);
-      b->stream_nt = (int64_t)n_used * 4 > n_problems && out_bytes > (int64_t)256 << 20;
+      b->stream_nt = twr::StreamNonTemporal(n_used, n_problems, out_bytes);
 #ifdef TWR_TUNING_KNOBS   // (include/towr_amd.h, "Tuning knobs")
       if (const char* e = getenv("TWR_STREAM_NT")) b->stream_nt = atoi(e) != 0;
 #endif

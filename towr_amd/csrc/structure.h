@@ -129,6 +129,13 @@ struct LayoutShare {
   int64_t bytes_built = 0, bytes_distinct = 0;
 };
 LayoutShare ShareLayoutTables(const std::vector<const Structure*>& structs);
+// Store policy of a batch (kernels.hip copy_out_fixed): non-temporal stores for SWEEP-LIKE batches -- fewer than
+// four problems per structure on average, so that every evaluation re-reads tables and x that only one problem uses -- whose
+// evaluation writes more than the Infinity Cache holds, so that plain stores would flush those tables out of it.
+constexpr int64_t kInfinityCacheBytes = (int64_t)256 << 20;   // MI355X
+inline bool StreamNonTemporal(int structures_used, int n_problems, int64_t output_bytes_per_evaluation) {
+  return (int64_t)structures_used * 4 > n_problems && output_bytes_per_evaluation > kInfinityCacheBytes;
+}
 void GaitCombo(int n_ee, int combo, double t_total, double swing_scale, twr_schedule* out);
 void ModelPreset(int robot, int terrain, twr_model* out);
 double TerrainHeightHost(const twr_model& m, const TerrainGrid* grid, double x, double y);
