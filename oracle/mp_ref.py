@@ -242,8 +242,86 @@ def cross(a, b):
     return [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]
 
 
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+class GridMapTerrain:
+    """The `Grid` height map fpowr hands the solver (towr/include/towr/terrain/grid_height_map.h:15-60,
+    fpowr/src/footstep_plan_server.cc:155), written from that header -- NOT from oracle/towr_oracle.cc:
+      GetHeight            = (double)(float) map_.atPosition("elevation", (x, y), INTER_LINEAR); out_of_range -> FLT_MAX  (:30-46)
+      GetHeightDerivWrtX/Y = (float(h(+eps)) - float(h(-eps))) / (2 eps), the difference taken in FLOAT, eps = resolution / 6  (:23,48-60)
+    The second height derivatives are not overridden (height_map.h: 0), so the reference's force rows carry explicit
+    ZEROS in their foothold columns on this terrain.
+    grid_map itself is third party and absent from /root/reference (unpinned distro package, Dockerfile); its half is
+    restated here from the published grid_map_core algorithm (GridMap::atPosition / atPositionLinearInterpolated /
+    getIndexFromPosition / getPositionFromIndex / checkIfPositionWithinMap), start index (0, 0):
+      cell (i, j) centre = position + length / 2 - ((i, j) + 1/2) * resolution      (x falls with i, y falls with j)
+      index of a position = trunc(-(p - length / 2 - position) / resolution), valid iff 0 <= length/2 - (p - position) < length
+      bilinear over the cell of p and its neighbours TOWARDS p; a neighbour outside the buffer -> nearest cell; p outside
+      the map -> std::out_of_range.
+    elevation[i, j] is float32 (grid_map::Matrix = Eigen::MatrixXf)."""
+
+    def __init__(self, elevation, resolution, position):
+        self.e = np.asarray(elevation, dtype=np.float32)
+        self.res = float(resolution)
+        self.pos = (float(position[0]), float(position[1]))
+        self.size = self.e.shape
+        self.length = (self.size[0] * self.res, self.size[1] * self.res)
+        self.eps = self.res / 6.0
+
+    def _index(self, p):
+        idx, inside = [], True
+        for a in (0, 1):
+            v = (p[a] - 0.5 * self.length[a] - self.pos[a]) / self.res
+            idx.append(int(-v))                       # Eigen cast<int>: truncation towards zero
+            t = -(p[a] - self.pos[a] - 0.5 * self.length[a])
+            inside = inside and (0.0 <= t < self.length[a])
+            inside = inside and (0 <= idx[a] < self.size[a])
+        return idx, inside
+
+    def _centre(self, idx):
+        return [self.pos[a] + 0.5 * self.length[a] - (idx[a] + 0.5) * self.res for a in (0, 1)]
+
+    def at_position(self, x, y):
+        """float32 value of atPosition(INTER_LINEAR), or None for std::out_of_range."""
+        p = (float(x), float(y))
+        i0, inside = self._index(p)
+        c0 = self._centre(i0)
+        # the three other corners lie towards p: index - 1 where p >= centre (positions fall with the index)
+        step = [-1 if p[a] >= c0[a] else +1 for a in (0, 1)]
+        lo = [min(i0[a], i0[a] + step[a]) for a in (0, 1)]   # the corner with the LARGEST position has the smallest index
+        corners = [(lo[0] + di, lo[1] + dj) for di in (0, 1) for dj in (0, 1)]
+        n = self.size[0] * self.size[1]
+        # grid_map's own range test is on the LINEAR index of each corner (column-major, i + j * size_x) against the buffer
+        lin = [c[0] + c[1] * self.size[0] for c in corners]
+        if all(0 <= l <= n for l in lin) and all(0 <= c[0] < self.size[0] and 0 <= c[1] < self.size[1] for c in corners) and inside:
+            # weights from the corner with the largest position: u, v in [0, 1] measured DOWN from it
+            top = self._centre(lo)
+            u = (mpf(top[0]) - mpf(p[0])) / mpf(self.res)
+            v = (mpf(top[1]) - mpf(p[1])) / mpf(self.res)
+            f = lambda di, dj: mpf(float(self.e[lo[0] + di, lo[1] + dj]))
+            val = f(0, 0) * (1 - u) * (1 - v) + f(1, 0) * u * (1 - v) + f(0, 1) * (1 - u) * v + f(1, 1) * u * v
+            return np.float32(float(val))
+        if inside:
+            return self.e[i0[0], i0[1]]               # INTER_NEAREST fall-back
+        return None
+
+    def height(self, x, y):
+        v = self.at_position(x, y)
+        return np.float32(FLT_MAX) if v is None else np.float32(v)
+
+    def h_hx_hy(self, x, y):
+        x, y = float(x), float(y)
+        h = float(self.height(x, y))
+        hx = float(np.float32(self.height(x + self.eps, y) - self.height(x - self.eps, y))) / (2 * self.eps)
+        hy = float(np.float32(self.height(x, y + self.eps) - self.height(x, y - self.eps))) / (2 * self.eps)
+        return mpf(h), mpf(hx), mpf(hy)
+
+
 def terrain_h(tid, x, y):
     """height and slopes (height_map_examples.{h,cc}); x,y are mpf, comparisons as in the reference."""
+    if isinstance(tid, GridMapTerrain):
+        return tid.h_hx_hy(x, y)
     z = mpf(0)
     if tid == "flat":
         return z, z, z
@@ -344,10 +422,11 @@ def swing_rows(L, ee, x, t_swing_avg=0.3):
     return out
 
 
-def constraints(L, terrain, x, fn_max=1000.0, sets=HOT_PATH):
+def constraints(L, terrain, x, fn_max=1000.0, sets=HOT_PATH, xt=None):
     """g(x) stacked in reference order (parameters.cc:55-60): terrain-*, dynamic, splineacc-base-{lin,ang},
-    rangeofmotion-*, force-*, swing-*; `sets` is the bit mask of oracle/towr_oracle.h."""
-    parts = _constraint_parts(L, terrain, x, fn_max)
+    rangeofmotion-*, force-*, swing-*; `sets` is the bit mask of oracle/towr_oracle.h.  `xt`: the point whose footholds
+    the TERRAIN is sampled at (default x; the gridded terrain is differentiated with the terrain frozen, see generate)."""
+    parts = _constraint_parts(L, terrain, x, fn_max, xt)
     g = []
     if sets & 1:
         g += parts["terrain"]
@@ -371,8 +450,9 @@ def constraints(L, terrain, x, fn_max=1000.0, sets=HOT_PATH):
     return g
 
 
-def _constraint_parts(L, terrain, x, fn_max=1000.0):
+def _constraint_parts(L, terrain, x, fn_max=1000.0, xt=None):
     rb = L.rb
+    xt = x if xt is None else xt
     parts = {}
     g = []
     # terrain_constraint.cc:57-70 : one row per ee-motion node id>=1
@@ -380,7 +460,7 @@ def _constraint_parts(L, terrain, x, fn_max=1000.0):
         s = L.splines["ee-motion_%d" % ee]
         for nid in range(1, len(s["nodes"])):
             p = [x[s["nodes"][nid][(0, dm)]] for dm in range(3)]
-            g.append(p[2] - terrain_h(terrain, p[0], p[1])[0])
+            g.append(p[2] - terrain_h(terrain, xt[s["nodes"][nid][(0, 0)]], xt[s["nodes"][nid][(0, 1)]])[0])
     parts["terrain"], g = g, []
     # dynamic_constraint.cc:59-64 + single_rigid_body_dynamics.cc:76-101
     Ixx, Iyy, Izz, Ixy, Ixz, Iyz = [mpf(v) for v in rb["I"]]
@@ -425,7 +505,7 @@ def _constraint_parts(L, terrain, x, fn_max=1000.0):
             adj = 0 if nid == 0 else nid - 1  # first adjacent polynomial -> its phase
             phase = sf["polys"][adj][0]
             start = next(i for i, pl in enumerate(sm["polys"]) if pl[0] == phase)
-            px, py = x[sm["nodes"][start][(0, 0)]], x[sm["nodes"][start][(0, 1)]]
+            px, py = xt[sm["nodes"][start][(0, 0)]], xt[sm["nodes"][start][(0, 1)]]
             _, hx, hy = terrain_h(terrain, px, py)
             n = unit([-hx, -hy, mpf(1)])
             t1 = unit([mpf(1), mpf(0), hx])
@@ -486,7 +566,28 @@ def cases():
         "c2_biped_walk_flat_k100": dict(robot="biped", terrain="flat", phases=_gait(2, 0, 2.0), seed=24, k_nodes=100),
         "c3_anymal_trot_flat_k200": dict(robot="anymal", terrain="flat", phases=_gait(4, 1, 2.0), seed=25, k_nodes=200),
         "c5_anymal_walk_stairs_k200": dict(robot="anymal", terrain="stairs", phases=_sweep_candidate(30), seed=26, k_nodes=200),
+        # (round 5) BASELINE C4 on the one analytic terrain with curvature, at K = 200: candidate 60 of the enumeration
+        # (walk, T = 1.6, swing scale 0.928) on the Gap -- the non-chain-rule quirk of height_map.cc:80-91 at BASELINE size
+        "c4_anymal_gap_k200": dict(robot="anymal", terrain="gap", phases=_sweep_candidate(60), seed=27, k_nodes=200),
+        # (round 5) fpowr's production formulation (fpowr/src/footstep_plan_server.cc:147-200): Go1, `Grid` height map over a
+        # grid_map elevation layer, gait combo C1, TIME_HORIZON = 2 s (:31), default discretisation, towr's default
+        # constraint list (parameters.cc:55-60)
+        "fpowr_go1_grid_c1": dict(robot="go1", terrain="grid_map", phases=_gait(4, 1, 2.0), seed=28, sets=TOWR_DEFAULT,
+                                  grid_map=step_patch(seed=28)),
     }
+
+
+def step_patch(seed, size=(100, 100), res=0.04, pos=(1.5, 0.0)):
+    """A perception-style elevation layer (float32 [size_x, size_y], grid_map cell order: x falls with i, y with j): three
+    8-cm steps across x with edges that wander a little in y, a gentle cross slope and +-3 mm of seeded sensor noise."""
+    rng = np.random.default_rng(seed)
+    i, j = np.meshgrid(np.arange(size[0]), np.arange(size[1]), indexing="ij")
+    cx = pos[0] + 0.5 * size[0] * res - (i + 0.5) * res
+    cy = pos[1] + 0.5 * size[1] * res - (j + 0.5) * res
+    h = 0.02 * cy + 0.003 * rng.uniform(-1, 1, size=size)
+    for k, edge in enumerate((0.9, 1.4, 1.9)):
+        h = h + 0.08 * (cx > edge + 0.05 * np.sin(2.0 * cy + k))
+    return h.astype(np.float32), res, pos
 
 
 def make_x(L, seed):
@@ -520,8 +621,12 @@ def _col(j):
     xm = list(x)
     xp[j] += h
     xm[j] -= h
-    gp = constraints(L, terrain, xp, sets=sets)
-    gm = constraints(L, terrain, xm, sets=sets)
+    # a gridded terrain is rounded to float (grid_height_map.h:37-45): g is not differentiable through it, and the
+    # reference does not pretend it is -- its terrain entries are DEFINED (central float differences over eps, zeros for
+    # the basis derivatives).  So the terrain stays frozen at x here and generate() adds the defined entries.
+    xt = x if isinstance(terrain, GridMapTerrain) else None
+    gp = constraints(L, terrain, xp, sets=sets, xt=xt)
+    gm = constraints(L, terrain, xm, sets=sets, xt=xt)
     col = [(a - b) / (2 * h) for a, b in zip(gp, gm)]
     return j, [(i, float(v)) for i, v in enumerate(col) if abs(v) > mpf(10) ** (-25)]
 
@@ -540,8 +645,13 @@ def generate(name, spec, outdir, procs=8):
     x64 = make_x(L, spec["seed"])
     x = [mpf(float(v)) for v in x64]
     sets = spec.get("sets", HOT_PATH)
-    _CTX.update(L=L, terrain=spec["terrain"], x=x, sets=sets)
-    g = constraints(L, spec["terrain"], x, sets=sets)
+    terrain, extra = spec["terrain"], {}
+    if terrain == "grid_map":
+        el, res, pos = spec["grid_map"]
+        terrain = GridMapTerrain(el, res, pos)
+        extra = dict(grid_elevation=terrain.e, grid_resolution=np.float64(res), grid_position=np.array(pos, dtype=np.float64))
+    _CTX.update(L=L, terrain=terrain, x=x, sets=sets)
+    g = constraints(L, terrain, x, sets=sets)
     with Pool(procs) as pool:
         cols = pool.map(_col, range(L.n), chunksize=4)
     rows, cidx, vals = [], [], []
@@ -550,12 +660,32 @@ def generate(name, spec, outdir, procs=8):
             rows.append(i)
             cidx.append(j)
             vals.append(v)
+    if isinstance(terrain, GridMapTerrain):
+        # terrain_constraint.cc:97-103: row of node id >= 1 carries -dh/dx, -dh/dy in the node's x / y columns, with the
+        # reference's dh = Grid::GetHeightDerivWrtX/Y.  (The force rows' foothold columns are zeros in the reference:
+        # nothing to add, the test reads a missing entry as 0.)
+        assert sets & 1
+        row = 0
+        for ee in range(L.n_ee):
+            s = L.splines["ee-motion_%d" % ee]
+            for nid in range(1, len(s["nodes"])):
+                cx, cy = s["nodes"][nid][(0, 0)], s["nodes"][nid][(0, 1)]
+                for q in (x64[cx] - terrain.eps, x64[cx] + terrain.eps):   # every sample well inside the map
+                    assert abs(q - terrain.pos[0]) < 0.5 * terrain.length[0] - 2 * terrain.res
+                for q in (x64[cy] - terrain.eps, x64[cy] + terrain.eps):
+                    assert abs(q - terrain.pos[1]) < 0.5 * terrain.length[1] - 2 * terrain.res
+                _, hx, hy = terrain.h_hx_hy(x64[cx], x64[cy])
+                for c, v in ((cx, -float(hx)), (cy, -float(hy))):
+                    rows.append(row)
+                    cidx.append(c)
+                    vals.append(v)
+                row += 1
     np.savez_compressed(
         os.path.join(outdir, "mp_%s.npz" % name), robot=spec["robot"], terrain=spec["terrain"],
         n_phases=np.array([len(p) for p in pd]), phase_durations=np.concatenate([np.array(p) for p in pd]),
         contact_at_start=np.array(con), constraint_sets=np.int32(sets), x=x64, g=np.array([float(v) for v in g]),
         jac_row=np.array(rows, dtype=np.int32), jac_col=np.array(cidx, dtype=np.int32), jac_val=np.array(vals),
-        dt_dynamic=np.float64(dts.get("dt_dyn", 0.1)), dt_rom=np.float64(dts.get("dt_rom", 0.08)))
+        dt_dynamic=np.float64(dts.get("dt_dyn", 0.1)), dt_rom=np.float64(dts.get("dt_rom", 0.08)), **extra)
     print(name, "n", L.n, "m", len(g), "nnz(true)", len(vals), flush=True)
 
 

@@ -59,3 +59,19 @@ for sets, name in ((27, "hot path"), (63, "default list"), (127, "default + timi
         print("%-18s B=%-3d n=%d nnz=%d: back-to-back %.1f us/call, synchronised %.1f us/call, host buffers (H2D+eval+D2H) "
               "pageable %.1f us/call, page-locked %.1f us/call; page-locked eval_g (values only) %.1f us, eval_jac_g (Jacobian "
               "only) %.1f us" % (name, B, S.n, S.nnz, dev_us, sync_us, host_us, pin_us, per["values"], per["jacobian"]), flush=True)
+
+
+# The ifopt boundary seen from the host: ANYmal, towr's default list, 19 constraint sets x 10 variable
+# sets = 209 GetValues / FillJacobianBlock requests per Ipopt iteration, variable sets with the cost shape of towr's
+# NodesVariables::GetValues (nodes_variables.cc:52-62: a map lookup + a vector copy per index).  Host microseconds spent
+# finding out whether x moved and reading it, beside the device microseconds (twr_batch_eval_host, page-locked buffers).
+import json, subprocess
+from tests.test_ifopt_adapter import EXE, _build
+_build()
+for mode in ("push", "loose", "poll"):
+    r = subprocess.run([EXE, "--quadruped", mode, "200"], capture_output=True, text=True, timeout=300)
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    print("ifopt adapter, ANYmal default list, x-change %-28s: %5.1f variable-set reads, host %7.1f us, device (upload + kernels + "
+          "download) %6.1f us per iteration; one read of all of x %.1f us, i.e. round 4's read-on-every-request rule %.0f us"
+          % (rep["mode"], rep["variable_set_reads_per_iteration"], rep["host_change_detection_us_per_iteration"],
+             rep["device_eval_host_us_per_iteration"], rep["read_all_sets_once_us"], rep["round4_rule_us_per_iteration"]), flush=True)

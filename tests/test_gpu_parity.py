@@ -51,8 +51,10 @@ def test_gpu_matches_mpmath_golden(path):
     if sets & 64 and not getattr(ta, "SUPPORTS_OPTIMISED_TIMINGS", False):
         pytest.skip("optimised timings (SURVEY 8f #2): oracle and fixtures exist, the device path is next")
     dts = dict(dt_dynamic=float(d["dt_dynamic"]), dt_rom=float(d["dt_rom"])) if "dt_dynamic" in d.files else {}
+    # (the fpowr fixture: Go1 on the `Grid` terrain, with its grid_map elevation layer)
+    gm = dict(grid=(d["grid_elevation"], float(d["grid_resolution"]), tuple(d["grid_position"]))) if "grid_elevation" in d.files else {}
     case = Case(str(d["robot"]), str(d["terrain"]), ta.schedule(pd, list(d["contact_at_start"])), constraint_sets=sets,
-                base_z_init=0.6, **dts)
+                base_z_init=0.6, **dts, **gm)
     S = case.S
     batch, g, j = _eval_case(case, [d["x"]])
     assert np.abs(g - d["g"]).max() <= 1e-12 * np.abs(d["g"]).max()

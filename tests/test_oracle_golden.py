@@ -26,8 +26,10 @@ def load_fixture(path):
     sets = int(d["constraint_sets"]) if "constraint_sets" in d.files else ob.SETS_HOT_PATH
     # (fixtures at BASELINE sizes carry their discretisation; the older ones use the reference defaults 0.1 / 0.08)
     dts = dict(dt_dynamic=float(d["dt_dynamic"]), dt_rom=float(d["dt_rom"])) if "dt_dynamic" in d.files else {}
+    # (the fpowr fixture runs on the `Grid` terrain: it carries its grid_map elevation layer)
+    gm = dict(grid_map=(d["grid_elevation"], float(d["grid_resolution"]), tuple(d["grid_position"]))) if "grid_elevation" in d.files else {}
     P = ob.OracleProblem(str(d["robot"]), str(d["terrain"]), pd, list(d["contact_at_start"]), constraint_sets=sets,
-                         base_z_init=0.6, **dts)
+                         base_z_init=0.6, **dts, **gm)
     return d, P
 
 

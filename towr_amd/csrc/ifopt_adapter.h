@@ -24,7 +24,10 @@
 #if __has_include(<ifopt/constraint_set.h>)
 #include <ifopt/constraint_set.h>
 
+#include <algorithm>
+#include <chrono>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -34,8 +37,9 @@
 
 namespace towr_amd {
 
-// One problem on one GPU.  All adapter sets of a problem share it; x is uploaded and the kernels run once per new x and
-// kind of result (ifopt calls GetValues / FillJacobianBlock once per set and per variable set).
+// One problem on one GPU.  All adapter sets of a problem share it; x is read from the variable sets once per new x
+// (see "x changed" below), uploaded, and the kernels run once per new x and kind of result (ifopt calls GetValues /
+// FillJacobianBlock once per set and per variable set).
 class DeviceProblem {
  public:
   // `grid`: the gridded terrain for model.terrain_id == TWR_TERRAIN_GRID_MAP (the `Grid` height map fpowr hands
@@ -55,6 +59,9 @@ class DeviceProblem {
       twr_set_info v;
       Check(twr_structure_var_set(structure_, i, &v));
       var_sets_.push_back(v);
+      VarSet s;
+      s.info = v;
+      vars_.push_back(s);
     }
   }
   ~DeviceProblem() {
@@ -64,29 +71,115 @@ class DeviceProblem {
   DeviceProblem(const DeviceProblem&) = delete;
   DeviceProblem& operator=(const DeviceProblem&) = delete;
 
+  // ---- "x changed" -------------------------------------------------------------------------------------------------
+  // The reference PUSHES: NodesVariables::SetVariables -> UpdateObservers -> NodesObserver::UpdateNodes
+  // (nodes_variables.cc:64-79, nodes_observer.h:52-68; PhaseDurations likewise, phase_durations.cc:52-103), so its splines
+  // never ask whether x moved.  ifopt itself has no such channel (a ConstraintSet only ever sees GetVariables()), and
+  // ifopt calls FillJacobianBlock once per (constraint set x variable set): 190 calls + 19 GetValues per Ipopt iteration
+  // for the quadruped default list.  Re-reading all of x on each of them (rounds 3-4) is O(sets^2 * n) host work per
+  // iteration -- ~10 ms with towr's allocating NodesVariables::GetValues (nodes_variables.cc:52-62) against 33 us on the
+  // device.  So:
+  //  * Link() (from InitVariableDependedQuantities, the pattern of force_constraint.cc:50-54) resolves every variable set
+  //    ONCE, by walking the composite; a missing set is a std::runtime_error that names it.
+  //  * a variable set that can push (towr's: towr_binding.h registers a NodesObserver / PhaseDurationsObserver on it
+  //    through the link hook; any host: call MarkDirty) is read when its flag is set, i.e. once per SetVariables.
+  //  * a set that cannot is POLLED once per SWEEP: ifopt asks every (set, block) exactly once per eval_g / eval_jac_g, so
+  //    a request that was already served since the last read starts a new sweep and triggers one read of the polled
+  //    sets.  In between, every request re-reads ONE polled set (the smallest, "sentinel") and compares it, so that an x
+  //    that moved between two requests of one sweep (a caller that is not ifopt::Problem) is still noticed; a solver
+  //    that only drives the sets through ifopt::Problem can switch that off (set_strict_polling(false)).
+  using VariablesPtr = ifopt::ConstraintSet::VariablesPtr;
+  using LinkHook = std::function<void(DeviceProblem&, const std::vector<ifopt::Component::Ptr>&)>;
+
+  // Called with the resolved variable sets (in the structure's order) at the end of every Link(); it may register
+  // change notifications on them and reports each set that now pushes with EnablePush(index).
+  void SetLinkHook(LinkHook hook) { link_hook_ = std::move(hook); }
+  void EnablePush(int var_set) { vars_.at(static_cast<size_t>(var_set)).push = true; }
+  // keeps whatever the hook registered (observer objects) alive as long as this problem
+  void KeepAlive(std::shared_ptr<void> p) { keep_.push_back(std::move(p)); }
+  // The push entry point: variable set `var_set` (index in the structure's order; -1 = all) has new values.
+  void MarkDirty(int var_set = -1) {
+    if (var_set < 0)
+      for (auto& v : vars_) v.dirty = true;
+    else
+      vars_.at(static_cast<size_t>(var_set)).dirty = true;
+  }
+  void set_strict_polling(bool on) { strict_ = on; }
+
+  void Link(const VariablesPtr& vars) {
+    if (!vars) throw std::runtime_error("towr_amd: LinkWithVariables(nullptr)");
+    if (linked_ == vars.get()) return;   // every set of the problem links with the same composite
+    const auto comps = vars->GetComponents();
+    std::vector<ifopt::Component::Ptr> found;
+    for (auto& v : vars_) {
+      ifopt::Component::Ptr c;
+      for (const auto& k : comps)
+        if (k->GetName() == v.info.name) c = k;
+      if (!c) throw std::runtime_error(std::string("towr_amd: the NLP has no variable set '") + v.info.name + "' (the structure needs it)");
+      if (c->GetRows() != v.info.size)
+        throw std::runtime_error(std::string("towr_amd: variable set '") + v.info.name + "' has another size than the structure's");
+      v.comp = c.get();   // ifopt's variable composite owns the set and outlives its constraint sets' calls
+      v.push = false;
+      v.dirty = true;
+      found.push_back(c);
+    }
+    linked_ = vars.get();
+    keep_.clear();
+    have_ = 0;
+    have_x_ = false;
+    if (link_hook_) link_hook_(*this, found);
+    sentinel_ = -1;
+    for (size_t i = 0; i < vars_.size(); ++i)
+      if (!vars_[i].push && (sentinel_ < 0 || vars_[i].info.size < vars_[static_cast<size_t>(sentinel_)].info.size)) sentinel_ = static_cast<int>(i);
+  }
+
   // Brings the device results for the current x up to date, evaluating ONLY what is asked for (the reference's sets do the
   // same: GetValues computes values, FillJacobianBlock derivatives -- time_discretization_constraint.cc:65-96).  Ipopt
   // calls eval_g far more often than eval_jac_g (every line-search trial point), and a values-only evaluation does not
   // move the 8 * nnz bytes of the Jacobian over PCIe.  `want` = TWR_EVAL_VALUES or TWR_EVAL_JACOBIAN: a new x evaluates
   // just that; the first FillJacobianBlock on an x whose values are already there adds the Jacobian alone.
-  // x is gathered set by set, BY NAME, from the variable composite (Composite::GetComponent), so a host NLP may hold
-  // further variable sets of its own, in any position: they are simply not read.
-  void Update(const ifopt::ConstraintSet::VariablesPtr& vars, int want) {
-    bool same = have_ != 0;
-    for (const twr_set_info& v : var_sets_) {
-      const Eigen::VectorXd xv = vars->GetComponent(v.name)->GetValues();
-      if (static_cast<int>(xv.size()) != v.size) throw std::runtime_error(std::string("towr_amd: variable set '") + v.name + "' has another size than the structure's");
-      if (same && std::memcmp(xv.data(), x_ + v.offset, sizeof(double) * v.size) != 0) same = false;
-      if (!same) std::memcpy(x_ + v.offset, xv.data(), sizeof(double) * v.size);
+  // `request` identifies who asks (constraint set, values or which block) for the sweep rule above.
+  // x is read set by set, BY NAME (resolved in Link), so a host NLP may hold further variable sets of its own, in any
+  // position: they are simply not read.
+  void Update(const VariablesPtr& vars, int want, size_t request) {
+    const auto t0 = std::chrono::steady_clock::now();
+    Link(vars);
+    bool changed = !have_x_, read = false;
+    for (auto& v : vars_)
+      if (v.push && v.dirty) {
+        changed |= Read(v);
+        read = true;
+      }
+    if (sentinel_ >= 0) {
+      if (request >= served_.size()) served_.resize(request + 1, 0);
+      bool poll = !have_x_ || served_[request];
+      if (!poll && strict_) poll = Differs(vars_[static_cast<size_t>(sentinel_)]);
+      if (poll) {
+        for (auto& v : vars_)
+          if (!v.push) changed |= Read(v);
+        read = true;
+      }
     }
-    if (!same) have_ = 0;
+    if (read) std::fill(served_.begin(), served_.end(), 0);
+    if (request < served_.size()) served_[request] = 1;
+    have_x_ = true;
+    if (changed) have_ = 0;
     const int need = want & ~have_;
+    const auto t1 = std::chrono::steady_clock::now();
+    read_seconds_ += std::chrono::duration<double>(t1 - t0).count();
     if (!need) return;
     Check(twr_batch_eval_host(batch_, x_, g_, jac_, need));
+    eval_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
     have_ |= need;
     n_value_evals_ += (need & TWR_EVAL_VALUES) != 0;
     n_jacobian_evals_ += (need & TWR_EVAL_JACOBIAN) != 0;
   }
+  // VariableSet::GetValues calls made so far (tests, scripts/latency.py: the host cost of the boundary is this count
+  // times what the host's GetValues costs)
+  long variable_reads() const { return n_reads_; }
+  // wall time spent so far deciding whether x moved + reading it, and inside twr_batch_eval_host (upload, kernels, download)
+  double read_seconds() const { return read_seconds_; }
+  double eval_seconds() const { return eval_seconds_; }
   // evaluations launched so far (tests; a solver log can show the eval_g : eval_jac_g ratio with them)
   long value_evaluations() const { return n_value_evals_; }
   long jacobian_evaluations() const { return n_jacobian_evals_; }
@@ -102,20 +195,50 @@ class DeviceProblem {
   static void Check(int rc) {
     if (rc != TWR_OK) throw std::runtime_error(std::string("towr_amd: ") + twr_last_error());
   }
+  struct VarSet {
+    twr_set_info info{};
+    const ifopt::Component* comp = nullptr;   // resolved by Link()
+    bool push = false;                        // the set reports its changes through MarkDirty
+    bool dirty = true;
+  };
+  // reads one variable set into the page-locked x; true if its values differ from what was there
+  bool Read(VarSet& v) {
+    const Eigen::VectorXd xv = v.comp->GetValues();
+    ++n_reads_;
+    v.dirty = false;
+    if (static_cast<int>(xv.size()) != v.info.size) throw std::runtime_error(std::string("towr_amd: variable set '") + v.info.name + "' changed its size");
+    if (have_x_ && std::memcmp(xv.data(), x_ + v.info.offset, sizeof(double) * v.info.size) == 0) return false;
+    std::memcpy(x_ + v.info.offset, xv.data(), sizeof(double) * v.info.size);
+    return true;
+  }
+  bool Differs(const VarSet& v) {
+    const Eigen::VectorXd xv = v.comp->GetValues();
+    ++n_reads_;
+    return static_cast<int>(xv.size()) != v.info.size || std::memcmp(xv.data(), x_ + v.info.offset, sizeof(double) * v.info.size) != 0;
+  }
   twr_structure* structure_ = nullptr;
   twr_batch* batch_ = nullptr;
   twr_sizes sizes_{};
   double *x_ = nullptr, *g_ = nullptr, *jac_ = nullptr;
   std::vector<double> lower_, upper_;
   std::vector<twr_set_info> var_sets_;
+  std::vector<VarSet> vars_;
+  const void* linked_ = nullptr;        // the variable composite vars_[].comp were resolved in
+  LinkHook link_hook_;
+  std::vector<std::shared_ptr<void>> keep_;
+  std::vector<char> served_;            // requests answered since x was last read (polled sets only)
+  int sentinel_ = -1;                   // smallest polled set, -1 when every set pushes
+  bool strict_ = true;
+  bool have_x_ = false;
   int have_ = 0;   // TWR_EVAL_* bits that are valid for the x in x_
-  long n_value_evals_ = 0, n_jacobian_evals_ = 0;
+  long n_value_evals_ = 0, n_jacobian_evals_ = 0, n_reads_ = 0;
+  double read_seconds_ = 0.0, eval_seconds_ = 0.0;
 };
 
 class DeviceConstraintSet : public ifopt::ConstraintSet {
  public:
   DeviceConstraintSet(std::shared_ptr<DeviceProblem> problem, int set_index)
-      : ifopt::ConstraintSet(kSpecifyLater, SetName(*problem, set_index)), problem_(std::move(problem)) {
+      : ifopt::ConstraintSet(kSpecifyLater, SetName(*problem, set_index)), problem_(std::move(problem)), set_index_(set_index) {
     if (twr_structure_con_set(problem_->structure(), set_index, &info_) != TWR_OK)
       throw std::runtime_error(twr_last_error());
     SetRows(info_.size);
@@ -138,9 +261,14 @@ class DeviceConstraintSet : public ifopt::ConstraintSet {
   }
 
   const DeviceProblem& problem() const { return *problem_; }
+  DeviceProblem& problem() { return *problem_; }
+
+  // ifopt::ConstraintSet::LinkWithVariables -> here (the reference's sets look their variable sets up at this point too:
+  // force_constraint.cc:50-54, terrain_constraint.cc:44-47)
+  void InitVariableDependedQuantities(const VariablesPtr& x) override { problem_->Link(x); }
 
   VectorXd GetValues() const override {
-    problem_->Update(GetVariables(), TWR_EVAL_VALUES);
+    problem_->Update(GetVariables(), TWR_EVAL_VALUES, Request(0));
     return Eigen::Map<const VectorXd>(problem_->g() + info_.offset, info_.size);
   }
 
@@ -165,7 +293,7 @@ class DeviceConstraintSet : public ifopt::ConstraintSet {
                                  var_set + "'");
       return;
     }
-    problem_->Update(GetVariables(), TWR_EVAL_JACOBIAN);
+    problem_->Update(GetVariables(), TWR_EVAL_JACOBIAN, Request(1 + v));
     const int32_t* col_idx = twr_structure_col_idx(problem_->structure());
     const double* val = problem_->jac();
     const int32_t* range = ranges_[v].data();
@@ -187,17 +315,23 @@ class DeviceConstraintSet : public ifopt::ConstraintSet {
     if (twr_structure_con_set(p.structure(), i, &s) != TWR_OK) throw std::runtime_error(twr_last_error());
     return s.name;
   }
+  // one id per thing ifopt asks of this set: its values, or its block w.r.t. variable set v
+  size_t Request(size_t what) const { return static_cast<size_t>(set_index_) * (var_sets_.size() + 1) + what; }
   std::shared_ptr<DeviceProblem> problem_;
+  int set_index_ = 0;
   twr_set_info info_{};
   std::vector<twr_set_info> var_sets_;
   std::vector<std::vector<int32_t>> ranges_;  // [variable set][2 * row + {begin, end}] into the CSR value array
 };
 
-// All device sets of one problem (twr_params.constraint_sets), in the reference's relative order.
+// All device sets of one problem (twr_params.constraint_sets), in the reference's relative order.  `problem_out`: the
+// shared DeviceProblem behind them (to install a link hook / call MarkDirty / read the counters).
 inline std::vector<ifopt::ConstraintSet::Ptr> MakeDeviceConstraints(const twr_model& model, const twr_schedule& schedule,
                                                                     const twr_params& params, int device = 0,
-                                                                    const twr_terrain_grid* grid = nullptr) {
+                                                                    const twr_terrain_grid* grid = nullptr,
+                                                                    std::shared_ptr<DeviceProblem>* problem_out = nullptr) {
   auto problem = std::make_shared<DeviceProblem>(model, schedule, params, device, grid);
+  if (problem_out) *problem_out = problem;
   std::vector<ifopt::ConstraintSet::Ptr> sets;
   for (int i = 0; i < problem->sizes().n_con_sets; ++i) sets.push_back(std::make_shared<DeviceConstraintSet>(problem, i));
   return sets;

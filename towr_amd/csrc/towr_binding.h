@@ -1,6 +1,8 @@
 // towr-side binding: turns the objects a towr::NlpFormulation holds into the PODs of include/towr_amd.h and returns the
 // device constraint sets in place of the reference's Eigen ones -- the code a maintainer includes, not a sketch.
 //
+// STATUS: EXPERIMENTAL until `ref_dump --binding` has run on a box with Eigen3 + ifopt.
+//
 //   #include <towr_amd/csrc/towr_binding.h>
 //   ...
 //   for (auto c : formulation.GetVariableSets(solution)) nlp.AddVariableSet(c);
@@ -37,6 +39,10 @@
 #include <towr/models/single_rigid_body_dynamics.h>
 #include <towr/nlp_formulation.h>
 #include <towr/terrain/examples/height_map_examples.h>
+#include <towr/variables/nodes_observer.h>
+#include <towr/variables/nodes_variables.h>
+#include <towr/variables/phase_durations.h>
+#include <towr/variables/phase_durations_observer.h>
 
 #include <cmath>
 #include <cstring>
@@ -75,6 +81,9 @@ inline std::shared_ptr<twr_terrain_grid> OwnGrid(twr_terrain_grid* g) {
 // Throws for every other subclass, including the gridded ones (use GridTerrain / CsvTerrain for those).
 inline DeviceTerrain ToTwrTerrain(const towr::HeightMap& t) {
   DeviceTerrain d;
+  // the device path carries height_map.h:136's friction coefficient as a model constant (twr_model.friction, set to 0.5
+  // in ToTwrModel); a terrain that says otherwise -- whichever subclass -- would be another problem
+  if (t.GetFrictionCoeff() != 0.5) throw std::runtime_error("towr_amd: friction coefficient other than height_map.h:136's 0.5");
   if (dynamic_cast<const towr::FlatGround*>(&t)) {
     d.id = TWR_TERRAIN_FLAT;
     d.flat_height = t.GetHeight(0.0, 0.0);   // FlatGround(height), height_map_examples.h:45-52
@@ -91,7 +100,6 @@ inline DeviceTerrain ToTwrTerrain(const towr::HeightMap& t) {
         "towr_amd: this HeightMap subclass has no device counterpart.  Gridded maps: pass GridTerrain(map) / "
         "CsvTerrain(path) to MakeDeviceConstraints; anything else: keep the CPU constraint sets for it, or add its "
         "height function to terrain_eval in kernels.hip");
-  if (t.GetFrictionCoeff() != 0.5) throw std::runtime_error("towr_amd: friction coefficient other than height_map.h:136's 0.5");
   return d;
 }
 
@@ -247,6 +255,52 @@ inline const char* ComponentPrefix(towr::Parameters::ConstraintName name) {
   }
 }
 
+// "x changed" as a PUSH, the reference's own mechanism: NodesVariables::SetVariables -> UpdateObservers ->
+// NodesObserver::UpdateNodes (nodes_variables.cc:64-79, nodes_observer.h:52-68; the reference's NodeSpline is such an
+// observer, node_spline.cc:45-54), PhaseDurations::SetVariables -> UpdatePolynomialDurations (phase_durations.cc:77-103,
+// phase_durations_observer.h:52).  One observer per variable set flips that set's flag in the DeviceProblem; the next
+// GetValues / FillJacobianBlock reads exactly the flagged sets -- once per Problem::SetVariables, never per call.
+// The base-class constructors register `this` with the subject (nodes_observer.cc:36-42, phase_durations_observer.cc:37-43);
+// subjects hold RAW observer pointers and never drop them, so -- exactly like the reference's splines -- the device sets
+// (which own these observers through DeviceProblem::KeepAlive) must live as long as anybody calls SetVariables on the
+// variable sets they were linked with.  ifopt::Problem holds both and destroys them together.
+class NodesDirtyObserver final : public towr::NodesObserver {
+ public:
+  NodesDirtyObserver(towr::NodesVariables* subject, DeviceProblem* problem, int var_set)
+      : towr::NodesObserver(subject), problem_(problem), var_set_(var_set) {}
+  void UpdateNodes() override { problem_->MarkDirty(var_set_); }
+
+ private:
+  DeviceProblem* problem_;
+  int var_set_;
+};
+
+class DurationsDirtyObserver final : public towr::PhaseDurationsObserver {
+ public:
+  DurationsDirtyObserver(towr::PhaseDurations* subject, DeviceProblem* problem, int var_set)
+      : towr::PhaseDurationsObserver(subject), problem_(problem), var_set_(var_set) {}
+  void UpdatePolynomialDurations() override { problem_->MarkDirty(var_set_); }
+
+ private:
+  DeviceProblem* problem_;
+  int var_set_;
+};
+
+// The link hook (DeviceProblem::SetLinkHook): runs once, when the first device set is linked with the variable composite
+// -- where the reference's sets take their x->GetComponent<NodesVariablesPhaseBased>(name) (force_constraint.cc:50-54).
+// A variable set of another type (a host's own) stays polled.
+inline void RegisterTowrObservers(DeviceProblem& problem, const std::vector<ifopt::Component::Ptr>& sets) {
+  for (size_t i = 0; i < sets.size(); ++i) {
+    if (auto nodes = std::dynamic_pointer_cast<towr::NodesVariables>(sets[i])) {
+      problem.KeepAlive(std::make_shared<NodesDirtyObserver>(nodes.get(), &problem, static_cast<int>(i)));
+      problem.EnablePush(static_cast<int>(i));
+    } else if (auto durations = std::dynamic_pointer_cast<towr::PhaseDurations>(sets[i])) {
+      problem.KeepAlive(std::make_shared<DurationsDirtyObserver>(durations.get(), &problem, static_cast<int>(i)));
+      problem.EnablePush(static_cast<int>(i));
+    }
+  }
+}
+
 // NlpFormulation::GetConstraints (nlp_formulation.cc:200-209) on the device: the sets of every name in
 // params_.constraints_, in the caller's order of names, per name in the reference's creation order (per end-effector).
 // `terrain`: leave empty for the analytic maps (formulation.terrain_ is asked what it is); pass GridTerrain(map) /
@@ -262,7 +316,9 @@ inline towr::NlpFormulation::ContraintPtrVec MakeDeviceConstraints(const towr::N
   if (sched.n_ee != model.n_ee) throw std::runtime_error("towr_amd: schedule and robot disagree on the leg count");
   const twr_params prm = ToTwrParams(f.params_, f.initial_base_);
   // (the batch uploads its own copy of a gridded terrain's cells, so `t.grid` may go once the sets exist)
-  const std::vector<ifopt::ConstraintSet::Ptr> all = MakeDeviceConstraints(model, sched, prm, device, t.grid.get());
+  std::shared_ptr<DeviceProblem> problem;
+  const std::vector<ifopt::ConstraintSet::Ptr> all = MakeDeviceConstraints(model, sched, prm, device, t.grid.get(), &problem);
+  problem->SetLinkHook(RegisterTowrObservers);
   towr::NlpFormulation::ContraintPtrVec out;
   for (auto name : f.params_.constraints_) {
     const std::string prefix = ComponentPrefix(name);
