@@ -303,21 +303,35 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
     per_rank_ms = [float(t_[0]) for t_ in per_rank]
     per_rank_setup = [float(t_[1]) for t_ in per_rank]
     # Planner-style step (optional exchange): constraint values only, scored on the device, one all-gather of
-    # the 16 scores per candidate, arg-min on every rank -- what a sweep that wants ONE decision does per iterate.
+    # the 16 scores per candidate, arg-min ON THE DEVICE (twr_batch_best) -- what a sweep that wants ONE decision does per
+    # iterate.  The step is stream-ordered; the decision reaches the host as one 16-byte copy.
     from towr_amd.dist import best_candidate, gather_scores
     sizes = [bounds[r + 1] - bounds[r] for r in range(world)]
     scores = torch.empty((len(mine), 16), dtype=torch.float64, device=dev)
+    best_d = torch.zeros(2, dtype=torch.float64, device=dev)
+    best_h = torch.zeros(2, dtype=torch.float64).pin_memory()
 
-    def planner_step():
+    def planner_enqueue():
         batch.eval_device(x.data_ptr(), g.data_ptr(), 0, ta.EVAL_VALUES, stream)
         batch.score_device(g.data_ptr(), scores.data_ptr(), stream)
         table = scores
         if dist_on(world):
             table = gather_scores(scores if backend == "nccl" else scores.cpu(), sizes)
-        return best_candidate(table)
+            if backend != "nccl":
+                table = table.to(dev)
+        batch.best_device(table.data_ptr(), table.shape[0], best_d.data_ptr(), stream=stream)
+        return table
+
+    def planner_step():   # one decision per step ON THE HOST: the 16-byte copy and its synchronisation are part of the step
+        table = planner_enqueue()
+        best_h.copy_(best_d, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return int(best_h[0]), float(best_h[1]), table
 
     for _ in range(3):
         best = planner_step()
+    # the device's decision is the host rule's (towr_amd.dist.best_candidate) on the same table
+    assert (best[0], best[1]) == best_candidate(best[2]), (best[:2], best_candidate(best[2]))
     torch.cuda.synchronize()
     if dist_on(world):
         dist.barrier()
@@ -329,9 +343,20 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
     if dist_on(world):
         dist.barrier()
     p_elapsed = torch.tensor([time.perf_counter() - t3], dtype=torch.float64, device=dev if backend == "nccl" else None)
+    # ... and back to back, the decision left on the device (a solver loop that consumes it there; one copy at the end)
+    t4 = time.perf_counter()
+    for _ in range(p_steps):
+        planner_enqueue()
+    best_h.copy_(best_d, non_blocking=True)
+    torch.cuda.synchronize()
+    if dist_on(world):
+        dist.barrier()
+    q_elapsed = torch.tensor([time.perf_counter() - t4], dtype=torch.float64, device=dev if backend == "nccl" else None)
     if dist_on(world):
         dist.all_reduce(p_elapsed, op=dist.ReduceOp.MAX)
-    p_elapsed = float(p_elapsed[0])
+        dist.all_reduce(q_elapsed, op=dist.ReduceOp.MAX)
+    p_elapsed, q_elapsed = float(p_elapsed[0]), float(q_elapsed[0])
+    curve = shard_curve(ta, torch, sweep, m5, cands, mine, x_host, dev, dev_index, stream, elapsed / steps, threads) if world == 1 else None
     return {"workload": "C5 sweep: %d enumerated ANYmal candidates (combo x T x swing scale) on Stairs, K=200, ragged"
                         % n_total,
             "candidates": n_total, "scaling": "strong", "steps": steps,
@@ -351,10 +376,122 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
             # rocprofv3 FETCH_SIZE / WRITE_SIZE passes): every candidate reads its own ~150 KB of tables
             "traffic_ratio": sweep_traffic_ratio(bytes_total) if world == 1 else None,
             "traffic_source": traffic_source() if world == 1 else None,
-            "planner": {"what": "values only -> twr_batch_score -> all-gather of 16 scores per candidate -> arg-min "
-                                "(host-synchronous: one decision per step)",
+            "planner": {"what": "values only -> twr_batch_score -> all-gather of 16 scores per candidate -> twr_batch_best "
+                                "(device arg-min) -> one 16-byte copy to the host + synchronisation per step",
                         "steps": p_steps, "value": n_total * p_steps / p_elapsed, "unit": "candidates scored/s",
-                        "ms_per_step": p_elapsed / p_steps * 1e3, "best_candidate": int(best[0])}}
+                        "ms_per_step": p_elapsed / p_steps * 1e3,
+                        "ms_per_step_decision_left_on_device": q_elapsed / p_steps * 1e3, "best_candidate": int(best[0])},
+            # what ONE GPU can say about north_star's strong-scaling curve (no collective on the evaluation path)
+            "shard_curve": curve}
+
+
+def shard_curve(ta, torch, sweep, m5, cands, structs, x_host, dev, dev_index, stream, step_s_1024, threads, steps=400):
+    """The shards an N-rank run of the 1024-candidate sweep cuts (byte-balanced, twr_shard_bounds), each evaluated ON THIS
+    GPU, event-free: rank 0's shard and the largest one for N = 2, 4, 8 -- microseconds per step, TB/s, fraction of 8 TB/s
+    -- and what the sweep's speed-up would be if nothing but the slowest shard's step mattered.  A PROJECTION from one
+    device (no second GPU, no collective, no host contention between ranks), not a scaling measurement."""
+    weights = sweep.candidate_bytes(m5, cands, threads=threads)
+    x_off = np.concatenate([[0], np.cumsum([s_.n for s_ in structs])])
+    out = {"what": "byte-balanced shards of the 1024 candidates for world = 2, 4, 8, each timed on this one GPU (event-free "
+                   "steps); projected_speedup_no_overhead = step(1024) / step(slowest of the shards timed) -- a projection, "
+                   "not a scaling measurement", "steps": steps, "step_us_1024": step_s_1024 * 1e6, "world": {}}
+    for world in (2, 4, 8):
+        bounds = sweep.shard_bounds(weights, world)
+        sizes = [sum(weights[bounds[r]:bounds[r + 1]]) for r in range(world)]
+        picks = sorted({0, int(np.argmax(sizes))})
+        rows = []
+        for r in picks:
+            lo, hi = bounds[r], bounds[r + 1]
+            batch = ta.Batch(structs[lo:hi], list(range(hi - lo)), device=dev_index)
+            x = torch.from_numpy(x_host[x_off[lo]:x_off[hi]].copy()).to(dev)
+            g = torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device=dev)
+            jac = torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev)
+            for _ in range(20):
+                batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            assert bool(torch.isfinite(g).all()) and bool(torch.isfinite(jac).all())
+            rows.append({"rank": r, "candidates": hi - lo, "bytes": int(batch.algorithmic_bytes), "us_per_step": dt * 1e6,
+                         "TBps": batch.algorithmic_bytes / dt / 1e12, "frac": batch.algorithmic_bytes / dt / 1e9 / HBM_PEAK_GBS,
+                         "largest": r == int(np.argmax(sizes))})
+            del batch, x, g, jac
+        slowest = max(r_["us_per_step"] for r_ in rows)
+        out["world"][str(world)] = {"shards": rows, "projected_speedup_no_overhead": step_s_1024 * 1e6 / slowest}
+    return out
+
+
+def values_c3(ta, torch, model, dev, dev_index, stream, steps=50, B=8192):
+    """What Ipopt calls most (every line-search trial point is an eval_g): the C3 callback with TWR_EVAL_VALUES at batch
+    size, per-kernel events.  Algorithmic bytes = 8 (n + m) per problem: x read once, g written once -- 36 KB against the
+    859 KB of the full callback, so neither HBM nor the FP64 pipe is the bound; the leg says how far from both it runs."""
+    m = ta.Model.from_buffer_copy(bytes(model))
+    m.terrain_id = ta.TERRAINS["flat"]
+    sched, params, S = build_case(ta, m)
+    batch = ta.Batch([S], [0] * B, device=dev_index)
+    base = perturbed_inputs(S, m, min(B, 256), first_seed=0)
+    x = torch.from_numpy(np.tile(base, ((B + base.shape[0] - 1) // base.shape[0], 1))[:B].reshape(-1)).to(dev)
+    g = torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device=dev)
+    device_power_warmup(torch, dev, LEG_WARMUP_S)
+    for _ in range(5):
+        batch.eval_device(x.data_ptr(), g.data_ptr(), 0, ta.EVAL_VALUES, stream)
+    batch.profile_begin(steps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.eval_device(x.data_ptr(), g.data_ptr(), 0, ta.EVAL_VALUES, stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms, n_prof = batch.profile_end()
+    assert n_prof == steps and bool(torch.isfinite(g).all())
+    # event-free (what a solver loop sees)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.eval_device(x.data_ptr(), g.data_ptr(), 0, ta.EVAL_VALUES, stream)
+    torch.cuda.synchronize()
+    free_ms = (time.perf_counter() - t0) / steps * 1e3
+    names = {"dynamic": "twr::dyn_kernel<values>", "rangeofmotion": "twr::rom_kernel<values>", "nodes": "twr::node_kernel2<values>"}
+    bytes_values = 8 * (S.n + S.m) * B
+    path_ms = sum(kern_ms.values())
+    # FP64 vector peak: 256 CUs x 4 SIMDs x 16 FP64 lanes/clk x 2 (FMA) x 2.4 GHz = 78.6 TFLOP/s = half the guide's FP32
+    # vector rate (157.3 TF); VALU instructions per launch from the committed PMC pass (profiles/traffic.json,
+    # SQ_INSTS_VALU), each charged as a 4-cycle wave64 FP64 issue -- an UPPER bound of the pipe's occupancy
+    valu = valu_from_profile(B)
+    issue_peak = 256 * 4 * 2.4e9 / 4.0   # wave64 FP64 instructions per second, chip-wide
+    valu_frac = {names[k]: valu[k] / (kern_ms[k] * 1e-3) / issue_peak for k in kern_ms if valu and k in valu} or None
+    return {"workload": "C3 values only (TWR_EVAL_VALUES): n=%d m=%d, %d problems/GPU" % (S.n, S.m, B), "problems_per_gpu": B,
+            "steps": steps, "value": B * steps / elapsed, "unit": "callbacks/s", "ms_per_step": elapsed / steps * 1e3,
+            "ms_per_step_without_events": free_ms, "bytes_per_callback": 8 * (S.n + S.m),
+            "kernel_ms": {names[k]: v for k, v in kern_ms.items()},
+            "hbm": {"achieved": bytes_values / (path_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": bytes_values / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "fp64_valu": {"peak_TFLOPs": 78.6, "issue_frac_upper_bound": valu_frac,
+                          "source": "SQ_INSTS_VALU of profiles/traffic.json values_8192 (rocprofv3 --pmc), 4 cycles per wave64 instruction"
+                                    if valu_frac else None},
+            "bound": "latency: neither HBM (frac above) nor the FP64 VALU pipe (issue fraction) is near its roof -- a values-only "
+                     "slice is one dependent chain (records -> x -> spline points -> sin/cos -> SRBD) per wave with "
+                     "two to four waves per SIMD to hide it"}
+
+
+def valu_from_profile(problems_per_gpu):
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        v = t.get("values_8192", {})
+        if t.get("kernel_source_sha256") == kernel_source_hash() and v.get("problems_per_gpu") == problems_per_gpu:
+            per = v.get("valu_insts_per_launch", {})
+            out = {}
+            for role, key in (("dynamic", "twr::dyn_kernel"), ("rangeofmotion", "twr::rom_kernel"), ("nodes", "twr::node_kernel")):
+                vals = [c for k, c in per.items() if k.startswith(key)]
+                if vals:
+                    out[role] = sum(vals)
+            return out or None
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 def timings_c3(ta, torch, dist, model, world, rank, dev, dev_index, backend, stream, steps=20, B=2048, constraint_sets=127):
@@ -438,6 +575,7 @@ def main():
                     help="seconds of plain HBM writes before the W warm-up steps, to leave the idle power state (0: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scale-c5", action="store_true", help="skip the strong-scaling C5 leg of the default run")
+    ap.add_argument("--no-values-c3", action="store_true", help="skip the values-only leg of the default run")
     ap.add_argument("--no-timings-c3", action="store_true",
                     help="skip the optimised-timings and the whole-default-list legs of the default run")
     args = ap.parse_args()
@@ -535,6 +673,26 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms, n_prof = batch.profile_end()
     assert n_prof == args.steps
+    # measurement hygiene: the same timed region twice more (same K steps, same per-kernel events, barriers on both
+    # sides).  The headline stays the FIRST region (the contract's K steps); the repeats show its run-to-run spread.
+    repeats = [elapsed]
+    for _ in range(2):
+        batch.profile_begin(args.steps)
+        torch.cuda.synchronize()
+        if dist_on(world):
+            dist.barrier()
+        t_r = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if dist_on(world):
+            dist.barrier()
+        repeats.append(time.perf_counter() - t_r)
+        batch.profile_end()
+    if dist_on(world):
+        t_rep = torch.tensor(repeats, dtype=torch.float64, device=dev if backend == "nccl" else None)
+        dist.all_reduce(t_rep, op=dist.ReduceOp.MAX)
+        repeats = [float(v) for v in t_rep]
 
     per_rank_ms = [elapsed / args.steps * 1e3]
     if dist_on(world):
@@ -575,6 +733,8 @@ def main():
             "warmup": args.warmup,
             "device_warmup_s": warm_s,   # plain HBM writes before the W warm-up steps (idle power state), not steps of the path
             "ms_per_step": elapsed / args.steps * 1e3,
+            # the timed region three times in this process (max over ranks each); [0] is the headline's region
+            "ms_per_step_repeats": [r_ / args.steps * 1e3 for r_ in repeats],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -597,9 +757,11 @@ def main():
     # north_star's strong-scaling claim rides on the same command: 1024 sweep candidates over all ranks
     c5 = t3 = None
     default_run = args.workload == "c3" and args.sets == "hot"
-    if default_run and not (args.no_scale_c5 and args.no_timings_c3):
+    if default_run and not (args.no_scale_c5 and args.no_timings_c3 and args.no_values_c3):
         del x, g, jac, batch
-    a3 = None
+    a3 = v3 = None
+    if default_run and not args.no_values_c3 and world == 1:
+        v3 = values_c3(ta, torch, model, dev, dev_index, stream)
     if default_run and not args.no_timings_c3:
         t3 = timings_c3(ta, torch, dist, model, world, rank, dev, dev_index, backend, stream)
         a3 = timings_c3(ta, torch, dist, model, world, rank, dev, dev_index, backend, stream, B=8192, constraint_sets=63)
@@ -609,6 +771,8 @@ def main():
         if t3 is not None:
             out["timings_c3"] = t3
             out["all_sets_c3"] = a3
+        if v3 is not None:
+            out["values_c3"] = v3
         if c5 is not None:
             out["scale_c5"] = c5
         print(json.dumps(out), flush=True)

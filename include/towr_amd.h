@@ -293,6 +293,17 @@ int twr_batch_initial_guess(twr_batch* b, const double* d_x, const double* d_tim
  * (0 for families the structure does not build; NaN if a constraint value of the family is NaN).  d_g is the output of
  * twr_batch_eval with TWR_EVAL_VALUES.  Asynchronous on hip_stream. */
 int twr_batch_score(twr_batch* b, const double* d_g, double* d_scores /* 16 * n_problems */, void* hip_stream);
+/* The planner's decision without leaving the device: the candidate with the smallest SUM over the chosen constraint
+ * families (bit f of `families` = family f of twr_batch_score, i.e. the TWR_SET_* bit) of the inf-norm violations
+ * d_scores[16 c + 2 f], c < n_candidates.  The table may be longer than this batch (after an all-gather of every rank's
+ * score rows it holds the whole sweep; `b` only names the device and owns the scratch).  A NaN total loses, the first
+ * index wins a tie.  d_best[0] = index (as a double), d_best[1] = its total; one 16-byte copy brings the decision to the
+ * host.  Asynchronous on hip_stream, capturable; one call per batch in flight at a time.
+ * Replaces the host arg-min of a sweep driver over time_discretization_constraint.cc:65-75-style constraint values
+ * (fpowr runs ONE candidate, footstep_plan_server.cc:193-195; a sweep over gait_generator.cc:54-105 candidates needs the
+ * choice). */
+int twr_batch_best(twr_batch* b, const double* d_scores, int32_t n_candidates, uint32_t families, double* d_best /* 2 */,
+                   void* hip_stream);
 /* fpowr::ExtractFootstepPlan (fpowr/include/fpowr/footstep_plan_extractor.h:69-133) for every problem of the batch,
  * up to the nearest-plane lookup (twr_batch_contact_planes below): the solution x sampled every dt
  * (GetTrajectory, :19-53), a footstep state at the first sample and wherever HasEndEffectorContactChanged (:55-67)

@@ -68,7 +68,7 @@ for sets, name in ((27, "hot path"), (63, "default list"), (127, "default + timi
 import json, subprocess
 from tests.test_ifopt_adapter import EXE, _build
 _build()
-for mode in ("push", "loose", "poll"):
+for mode in ("push", "poll", "strict"):
     r = subprocess.run([EXE, "--quadruped", mode, "200"], capture_output=True, text=True, timeout=300)
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     print("ifopt adapter, ANYmal default list, x-change %-28s: %5.1f variable-set reads, host %7.1f us, device (upload + kernels + "

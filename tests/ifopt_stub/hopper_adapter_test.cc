@@ -4,13 +4,13 @@
 // EvalNonzerosOfJacobian(x, values), GetBoundsOnConstraints -- with towr_amd's device sets behind
 // ifopt::ConstraintSet (towr_amd/csrc/ifopt_adapter.h).  Compiled against tests/ifopt_stub (this image has neither
 // ifopt nor Eigen).  The result must equal a direct twr_batch_eval_host call bit for bit, in ifopt's stacking order.
-//   hopper_adapter_test --gpu <sets> [gridmap|flat] [poll|loose|push]
+//   hopper_adapter_test --gpu <sets> [gridmap|flat] [poll|strict|push]
 //                                  -> needs a GPU, exit 0 on success; `gridmap`: on the `Grid` terrain fpowr hands the
 //                                     solver (a grid_map elevation layer) instead of flat ground; how the adapter learns
-//                                     that x moved: polled with the sentinel check (default), polled once per sweep
-//                                     only, or pushed by the variable sets' observers (what towr_binding.h does with
-//                                     towr's NodesObserver / PhaseDurationsObserver)
-//   hopper_adapter_test --quadruped [poll|loose|push] [iterations]
+//                                     that x moved: polled once per sweep (default), polled on every request, or
+//                                     pushed by the variable sets' observers (what towr_binding.h does with towr's
+//                                     NodesObserver / PhaseDurationsObserver)
+//   hopper_adapter_test --quadruped [poll|strict|push] [iterations]
 //                                  -> needs a GPU: ANYmal flying trot, towr's default list (19 constraint sets x 10
 //                                     variable sets), one JSON line with the host and device microseconds per Ipopt
 //                                     iteration (eval_g + eval_jac_g on a new x); scripts/latency.py prints it
@@ -92,15 +92,16 @@ void RegisterObservers(towr_amd::DeviceProblem& problem, const std::vector<ifopt
       problem.EnablePush(static_cast<int>(i));
     }
 }
-enum Mode { kPoll, kLoose, kPush };
+enum Mode { kPoll, kStrict, kPush };
 Mode ParseMode(const char* s) {
   if (std::string(s) == "push") return kPush;
-  if (std::string(s) == "loose") return kLoose;
+  if (std::string(s) == "strict") return kStrict;
   return kPoll;
 }
+const char* ModeName(Mode m) { return m == kPush ? "push" : m == kStrict ? "poll on every request" : "poll per sweep"; }
 void Configure(towr_amd::DeviceProblem& p, Mode mode) {
   if (mode == kPush) p.SetLinkHook(RegisterObservers);
-  if (mode == kLoose) p.set_strict_polling(false);
+  if (mode == kStrict) p.set_polling(towr_amd::DeviceProblem::Polling::kEveryRequest);
 }
 int fails = 0;
 void expect(bool ok, const char* what) {
@@ -166,14 +167,15 @@ int Quadruped(Mode mode, int iterations) {
               "\"requests_per_iteration\": %d, \"variable_set_reads_per_iteration\": %.1f, \"host_change_detection_us_per_iteration\": %.1f, "
               "\"device_eval_host_us_per_iteration\": %.1f, \"wall_us_per_iteration_incl_stub_sparse_fill\": %.1f, \"read_all_sets_once_us\": %.2f, "
               "\"round4_rule_us_per_iteration\": %.1f, \"value_evals\": %ld, \"jacobian_evals\": %ld, \"iterations\": %d}\n",
-              mode == kPush ? "push" : mode == kLoose ? "poll_per_sweep" : "poll_per_sweep_plus_sentinel", sz.n_con_sets, sz.n_var_sets, sz.n_vars, sz.nnz,
+              mode == kPush ? "push" : mode == kStrict ? "poll_on_every_request" : "poll_per_sweep", sz.n_con_sets, sz.n_var_sets, sz.n_vars, sz.nnz,
               requests, double(dp->variable_reads() - reads0) / iterations, (dp->read_seconds() - rs0) / iterations * 1e6,
               (dp->eval_seconds() - es0) / iterations * 1e6, wall_us, read_all_us, read_all_us * requests, dp->value_evaluations() - v0,
               dp->jacobian_evaluations() - j0, iterations);
   const bool ok = dp->value_evaluations() - v0 == iterations && dp->jacobian_evaluations() - j0 == iterations && sink == sink;
-  // reads per iteration: push = one per set and SetVariables (2 per iteration); polled = one per set and sweep (+ sentinel)
+  // reads per iteration: push = one per set and SetVariables (2 per iteration); polled = one per set and sweep (2 sweeps);
+  // on every request = round 4's rule
   const double per_it = double(dp->variable_reads() - reads0) / iterations;
-  const double bound = mode == kPoll ? 2.0 * sz.n_var_sets + requests : 2.0 * sz.n_var_sets;
+  const double bound = mode == kStrict ? double(requests + sz.n_var_sets) * sz.n_var_sets : (mode == kPoll ? 3.0 : 2.0) * sz.n_var_sets;
   if (!ok || per_it > bound) {
     std::fprintf(stderr, "FAILED: %g reads per iteration (bound %g), evaluations %ld / %ld\n", per_it, bound, dp->value_evaluations() - v0,
                  dp->jacobian_evaluations() - j0);
@@ -326,10 +328,16 @@ int main(int argc, char** argv) {
     nlp.EvalNonzerosOfJacobian(xb.data(), vals.data());             // again: nothing to do
     (void)nlp.EvaluateConstraints(xb.data());
     expect(dp.value_evaluations() == v0 + 2 && dp.jacobian_evaluations() == j0 + 1, "same x again: no evaluation");
+    expect(twr_batch_eval_host(B, xb.data(), g_ref.data(), nullptr, TWR_EVAL_VALUES) == TWR_OK, "twr_batch_eval_host");
+    expect(twr_batch_eval_host(B, xb.data(), nullptr, j_ref.data(), TWR_EVAL_JACOBIAN) == TWR_OK, "twr_batch_eval_host");
+    double d2 = 0;
+    for (int i = 0; i < sz.n_rows; ++i) d2 = std::fmax(d2, std::fabs(gb[i] - g_ref[i]));
+    for (int k = 0; k < sz.nnz; ++k) d2 = std::fmax(d2, std::fabs(vals[k] - j_ref[k]));
+    expect(d2 == 0.0, "the adapter's values-only + Jacobian-only evaluations equal the direct ones");
     // ... and x is READ once per new x, not once per request.  A sweep = what one Problem call asks:
     // n_con_sets requests for eval_g, n_con_sets * n_var_sets for eval_jac_g.  Pushed: exactly one read per variable set
     // and Problem::SetVariables (the flag of every set is raised by it, nodes_variables.cc:64-79).  Polled: one read per
-    // set and sweep, plus -- with the sentinel check -- one read of the smallest set per further request.
+    // set and sweep.  (kEveryRequest is round 4's rule: one read per set and request.)
     {
       const int nv = sz.n_var_sets, nc = sz.n_con_sets;
       std::vector<double> xc = x;
@@ -348,8 +356,10 @@ int main(int argc, char** argv) {
         worst_j = std::max(worst_j, dp.variable_reads() - r0);
       }
       if (mode == kPush) expect(worst_g == nv && worst_j == nv, "pushed: one read per variable set and SetVariables");
-      if (mode == kLoose) expect(worst_g <= nv && worst_j <= nv, "polled per sweep: at most one read per variable set and sweep");
-      if (mode == kPoll) expect(worst_g <= nv + nc && worst_j <= nv + nc * nv, "polled + sentinel: one read per set and sweep + one sentinel read per request");
+      // (Composite::GetJacobian asks its FIRST component twice -- once for the column count --, so the first set's blocks
+      // repeat inside an eval_jac_g sweep and a polled problem reads x twice there)
+      if (mode == kPoll) expect(worst_g == nv && worst_j <= 2 * nv, "polled per sweep: one read per variable set and sweep");
+      if (mode == kStrict) expect(worst_g == nv * nc && worst_j >= nv * nc * nv, "polled on every request: one read per set and request");
       // nobody but the adapter's counted reads touched the variable sets in those sweeps
       expect(PlainVariables::reads > 0, "the stand-in counts GetValues");
       std::vector<double> g_chk(sz.n_rows);
@@ -360,8 +370,8 @@ int main(int argc, char** argv) {
       expect(d3 == 0.0, "the Jacobian after three iterations equals the direct evaluation");
     }
     // an x that moves BETWEEN two requests of one sweep (a caller that is not ifopt::Problem): noticed when the sets push
-    // or the sentinel check is on; the per-sweep-only rule documents that it relies on ifopt's calling pattern
-    if (mode != kLoose) {
+    // or every request polls; the per-sweep rule's contract excludes it (ifopt_adapter.h, "x changed")
+    if (mode != kPoll) {
       std::vector<double> xm = xb;
       (void)nlp.EvaluateConstraints(xm.data());
       xm[2] += 5e-3;
@@ -375,12 +385,6 @@ int main(int argc, char** argv) {
       for (int i = 0; i < c.size; ++i) d4 = std::fmax(d4, std::fabs(g_last[i] - g_ref[c.offset + i]));
       expect(d4 == 0.0, "a mid-sweep change of x is noticed");
     }
-    expect(twr_batch_eval_host(B, xb.data(), g_ref.data(), nullptr, TWR_EVAL_VALUES) == TWR_OK, "twr_batch_eval_host");
-    expect(twr_batch_eval_host(B, xb.data(), nullptr, j_ref.data(), TWR_EVAL_JACOBIAN) == TWR_OK, "twr_batch_eval_host");
-    double d2 = 0;
-    for (int i = 0; i < sz.n_rows; ++i) d2 = std::fmax(d2, std::fabs(gb[i] - g_ref[i]));
-    for (int k = 0; k < sz.nnz; ++k) d2 = std::fmax(d2, std::fabs(vals[k] - j_ref[k]));
-    expect(d2 == 0.0, "the adapter's values-only + Jacobian-only evaluations equal the direct ones");
   }
 
   // a host NLP with a variable set of its own (ifopt convention: constraints leave the blocks of sets they do not depend on
@@ -462,8 +466,7 @@ int main(int argc, char** argv) {
     expect(threw, "FillJacobianBlock throws on an unknown towr-style variable set name");
   }
 
-  std::printf("x-change detection: %s, %ld variable-set reads in all\n", mode == kPush ? "push" : mode == kLoose ? "poll per sweep" : "poll per sweep + sentinel",
-              shared_problem->variable_reads());
+  std::printf("x-change detection: %s, %ld variable-set reads in all\n", ModeName(mode), shared_problem->variable_reads());
   std::printf("hopper through ifopt%s: n=%d m=%d nnz=%d sets=%d  max|dg|=%g max|dJ|=%g  %s\n", gridmap ? " on a grid_map terrain" : "",
               sz.n_vars, sz.n_rows, sz.nnz, sz.n_con_sets, dg, dj, fails ? "FAILED" : "ok");
   twr_batch_destroy(B);

@@ -866,6 +866,41 @@ def test_grid_map_sweep_through_create_many():
         assert_parity(S, *_split(batch, g, j, p), rg, rj, "grid_map sweep candidate %d" % p, x=xs[p])
 
 
+def test_device_arg_min_matches_the_host_decision():
+    """twr_batch_best (the planner's decision on the device) against towr_amd.dist.best_candidate on the same score table:
+    NaN totals lose, the first index wins a tie, an all-NaN table answers 0; table sizes from one row to several blocks
+    (the table may be longer than the batch: after an all-gather it holds every rank's candidates); replayed calls reuse
+    the scratch."""
+    import torch
+
+    from towr_amd.dist import best_candidate
+
+    case = Case("anymal", "flat", ta.gait_combo(4, 1, 2.0))
+    batch = ta.Batch([case.S], [0, 0], device=0)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    best = torch.zeros(2, dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 63, 64, 65, 1000, 1024, 1025, 4097, 300001):
+        for variant in ("plain", "ties", "nans", "all_nan", "inf"):
+            t = rng.uniform(0.0, 10.0, size=(n, 16))
+            if variant == "ties":
+                t[:, :] = np.round(t, 0)      # many equal totals
+            if variant == "nans":
+                t[rng.uniform(size=n) < 0.3, 2] = np.nan
+            if variant == "all_nan":
+                t[:, 0] = np.nan
+            if variant == "inf":
+                t[:, 8] = np.inf
+                t[n // 2, 8] = 1.0
+            table = torch.from_numpy(t).to(dev)
+            for fam in ((0, 1, 3, 4), (1,), (0, 1, 2, 3, 4, 5, 6, 7)):
+                batch.best_device(table.data_ptr(), n, best.data_ptr(), families=fam, stream=st)
+                got = best.cpu().numpy()
+                idx, total = best_candidate(table, families=fam)
+                assert int(got[0]) == idx and (got[1] == total or (np.isinf(got[1]) and np.isinf(total))), (n, variant, fam, got, idx, total)
+
+
 def test_candidate_scores_and_contact_plans():
     """Sweep post-processing on the device: per-family bound violations (twr_batch_score) against numpy on the oracle's
     g and bounds, and fpowr::ExtractFootstepPlan (footstep_plan_extractor.h:69-133, minus the plane lookup) against

@@ -37,9 +37,9 @@ def test_adapter_compiles_warning_free_and_fails_loudly_without_a_gpu():
 @pytest.mark.gpu
 @pytest.mark.parametrize("sets,terrain,mode",
                          [(63, "flat", "poll"), (127, "flat", "poll"), (27, "flat", "poll"), (63, "gridmap", "poll"), (127, "gridmap", "poll"),
-                          (63, "flat", "push"), (127, "gridmap", "push"), (63, "flat", "loose")],
+                          (63, "flat", "push"), (127, "gridmap", "push"), (63, "flat", "strict")],
                          ids=["towr_default", "optimised_timings", "hot_path", "grid_map_terrain", "grid_map_optimised_timings",
-                              "towr_default_pushed", "grid_map_optimised_timings_pushed", "towr_default_polled_per_sweep"])
+                              "towr_default_pushed", "grid_map_optimised_timings_pushed", "towr_default_polled_on_every_request"])
 def test_hopper_through_the_ifopt_surface(sets, terrain, mode):
     """MakeDeviceConstraints -> GetValues / GetBounds / GetJacobian of every set == twr_batch_eval_host, stacked; on flat
     ground (hopper_example.cc) and on the `Grid` terrain fpowr hands the solver (footstep_plan_server.cc:155); an unknown
@@ -52,11 +52,11 @@ def test_hopper_through_the_ifopt_surface(sets, terrain, mode):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "max|dg|=0 max|dJ|=0" in r.stdout and " ok" in r.stdout, r.stdout
     assert ("grid_map terrain" in r.stdout) == (terrain == "gridmap")
-    assert "x-change detection: " + {"poll": "poll per sweep + sentinel", "loose": "poll per sweep", "push": "push"}[mode] in r.stdout
+    assert "x-change detection: " + {"poll": "poll per sweep", "strict": "poll on every request", "push": "push"}[mode] in r.stdout
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["push", "loose", "poll"])
+@pytest.mark.parametrize("mode", ["push", "poll", "strict"])
 def test_quadruped_default_list_host_cost_per_iteration(mode):
     """ANYmal, towr's default list: 19 constraint sets x 10 variable sets = 209 requests per Ipopt iteration.
     The adapter reads x at most once per variable set and SetVariables (push) / sweep (polled), evaluates values once and
@@ -69,7 +69,7 @@ def test_quadruped_default_list_host_cost_per_iteration(mode):
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["n_con_sets"] == 19 and rep["n_var_sets"] == 10 and rep["requests_per_iteration"] == 209
     assert rep["value_evals"] == 40 and rep["jacobian_evals"] == 40
-    if mode != "poll":
-        assert rep["variable_set_reads_per_iteration"] <= 20.0
+    if mode != "strict":
+        assert rep["variable_set_reads_per_iteration"] <= (20.0 if mode == "push" else 30.0)
         # the host side of the boundary stays well below what re-reading x on every request cost (round 4)
         assert rep["host_change_detection_us_per_iteration"] < 0.25 * rep["round4_rule_us_per_iteration"]

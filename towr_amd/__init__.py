@@ -142,6 +142,7 @@ def lib():
         L.twr_batch_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int64, C.c_void_p]
         L.twr_batch_initial_guess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
         L.twr_batch_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.twr_batch_best.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.twr_structure_contact_steps_max.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.twr_planes_create.argtypes = [_dp, _dp, C.POINTER(C.c_int32), C.c_int32, C.c_int, C.POINTER(C.c_void_p)]
         L.twr_planes_destroy.argtypes = [C.c_void_p]
@@ -462,6 +463,14 @@ class Batch:
     def score_device(self, d_g, d_scores, stream=0):
         """twr_batch_score: d_scores[16 p + 2 f + {0: inf-norm, 1: 1-norm}] of the bound violation per family f."""
         _check(lib().twr_batch_score(self._h, C.c_void_p(d_g), C.c_void_p(d_scores), C.c_void_p(stream)))
+
+    def best_device(self, d_scores, n_candidates, d_best, families=(0, 1, 3, 4), stream=0):
+        """twr_batch_best: device arg-min of the summed inf-norm violations of `families` (indices into FAMILIES) over a
+        score table of n_candidates rows (this batch's, or the all-gathered one); d_best = 2 doubles [index, total]."""
+        mask = 0
+        for f in families:
+            mask |= 1 << int(f)
+        _check(lib().twr_batch_best(self._h, C.c_void_p(d_scores), int(n_candidates), mask, C.c_void_p(d_best), C.c_void_p(stream)))
 
     def contact_plan_device(self, d_x, dt, time_horizon, d_out, max_steps, d_counts, stream=0):
         """twr_batch_contact_plan (fpowr ExtractFootstepPlan without the plane lookup)."""

@@ -29,6 +29,8 @@ hipError_t prepare_phase_kernels(int pdyn_img_cap, int prom_img_cap);
 hipError_t launch_check(int n_problems, const int64_t* g_off, const int64_t* j_off, const double* g, const double* jac,
                         int32_t* status, int flags, hipStream_t stream);
 hipError_t launch_score(const NodeWork* work, int n_problems, const double* g, double* scores, hipStream_t stream);
+int best_max_blocks();
+hipError_t launch_best(const double* scores, int n, unsigned families, double* partial, unsigned* counter, double* best, hipStream_t stream);
 hipError_t launch_contact_plan(const NodeWork* work, int n_problems, const double* x, double* out, int32_t* counts, double dt,
                                double time_horizon, int n_samples_max, int max_steps, hipStream_t stream);
 hipError_t launch_planes(const double* plan, const int32_t* counts, const double* poly_xy, const int32_t* poly_start, int n_polys,
@@ -118,6 +120,7 @@ struct twr_batch {
   int64_t *d_goff = nullptr, *d_joff = nullptr;  // device copies of g_off / j_off (TWR_EVAL_CHECK)
   int32_t* d_status = nullptr;                    // per-problem non-finite flags of the last checked evaluation
   double* d_dump = nullptr; // where dyn_kernel's first (empty) copy-out of every workgroup goes
+  double* d_best = nullptr; // twr_batch_best: per-block results (2 doubles each) + the block counter behind them
   void* d_precs = nullptr;  // scratch: x-dependent DynLoc / RomRec records of the optimised-timings problems
   int n_pdyn = 0, n_ploc = 0, n_prom = 0;
   // lazily sized scratch for twr_batch_eval_host
@@ -783,6 +786,8 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     upload(b->j_off.data(), b->j_off.size() * sizeof(int64_t), reinterpret_cast<void**>(&b->d_joff));
     TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_dump), sizeof(double) * (size_t)twr::dyn_dump_doubles()));
     TWR_HIP(hipMemset(b->d_dump, 0, sizeof(double) * (size_t)twr::dyn_dump_doubles()));
+    TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_best), sizeof(double) * (2 * (size_t)twr::best_max_blocks() + 1)));
+    TWR_HIP(hipMemset(b->d_best, 0, sizeof(double) * (2 * (size_t)twr::best_max_blocks() + 1)));
     TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_status), sizeof(int32_t) * (size_t)n_problems));
     TWR_HIP(hipMemset(b->d_status, 0, sizeof(int32_t) * (size_t)n_problems));
     b->n_pdyn = (int)pdyn.size();
@@ -847,6 +852,7 @@ void twr_batch_destroy(twr_batch* b) {
   if (b->d_joff) (void)hipFree(b->d_joff);
   if (b->d_status) (void)hipFree(b->d_status);
   if (b->d_dump) (void)hipFree(b->d_dump);
+  if (b->d_best) (void)hipFree(b->d_best);
   if (b->d_swork) (void)hipFree(b->d_swork);
   if (b->d_gwork) (void)hipFree(b->d_gwork);
   for (hipEvent_t e : b->prof_events) (void)hipEventDestroy(e);
@@ -1172,6 +1178,18 @@ int twr_batch_score(twr_batch* b, const double* d_g, double* d_scores, void* hip
   DeviceScope on(b->device);
   if (on.status != hipSuccess) return fail(TWR_ERR_HIP, "hipSetDevice failed");
   hipError_t e = twr::launch_score(b->d_node, b->n_problems, d_g, d_scores, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  return TWR_OK;
+}
+
+int twr_batch_best(twr_batch* b, const double* d_scores, int32_t n_candidates, uint32_t families, double* d_best, void* hip_stream) {
+  if (!b || !d_scores || !d_best) return fail(TWR_ERR_INVALID, "null argument");
+  if (n_candidates < 1) return fail(TWR_ERR_INVALID, "twr_batch_best needs at least one candidate");
+  if (!(families & 0xffu) || (families & ~0xffu)) return fail(TWR_ERR_INVALID, "families must be a non-empty mask of the eight TWR_SET_* bits");
+  DeviceScope on(b->device);
+  if (on.status != hipSuccess) return fail(TWR_ERR_HIP, "hipSetDevice failed");
+  unsigned* counter = reinterpret_cast<unsigned*>(b->d_best + 2 * (size_t)twr::best_max_blocks());
+  hipError_t e = twr::launch_best(d_scores, n_candidates, families, b->d_best, counter, d_best, static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   return TWR_OK;
 }

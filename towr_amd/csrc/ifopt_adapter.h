@@ -83,11 +83,16 @@ class DeviceProblem {
   //    ONCE, by walking the composite; a missing set is a std::runtime_error that names it.
   //  * a variable set that can push (towr's: towr_binding.h registers a NodesObserver / PhaseDurationsObserver on it
   //    through the link hook; any host: call MarkDirty) is read when its flag is set, i.e. once per SetVariables.
-  //  * a set that cannot is POLLED once per SWEEP: ifopt asks every (set, block) exactly once per eval_g / eval_jac_g, so
-  //    a request that was already served since the last read starts a new sweep and triggers one read of the polled
-  //    sets.  In between, every request re-reads ONE polled set (the smallest, "sentinel") and compares it, so that an x
-  //    that moved between two requests of one sweep (a caller that is not ifopt::Problem) is still noticed; a solver
-  //    that only drives the sets through ifopt::Problem can switch that off (set_strict_polling(false)).
+  //  * a set that cannot is POLLED once per SWEEP.  ifopt::Problem asks every set for its values once per eval_g
+  //    (Composite::GetValues) and for every block once per eval_jac_g (ConstraintSet::GetJacobian), each right after ONE
+  //    SetVariables.  So a new sweep -- the only moment x can have moved -- shows as a request that was already served
+  //    since the last read, or as a change of kind (values after blocks, blocks after values); that request reads the
+  //    polled sets, the others of the sweep read nothing.  Contract of this default (kPerSweep): x does not move between
+  //    two requests of the same kind unless one of them repeats.  A caller that cannot promise that (it moves x and asks
+  //    ANOTHER set for the same kind of result) selects kEveryRequest -- every request re-reads the polled sets, always
+  //    right, O(requests * n) -- or calls MarkDirty() when it moves x.
+  enum class Polling { kPerSweep, kEveryRequest };
+  void set_polling(Polling p) { polling_ = p; }
   using VariablesPtr = ifopt::ConstraintSet::VariablesPtr;
   using LinkHook = std::function<void(DeviceProblem&, const std::vector<ifopt::Component::Ptr>&)>;
 
@@ -104,7 +109,6 @@ class DeviceProblem {
     else
       vars_.at(static_cast<size_t>(var_set)).dirty = true;
   }
-  void set_strict_polling(bool on) { strict_ = on; }
 
   void Link(const VariablesPtr& vars) {
     if (!vars) throw std::runtime_error("towr_amd: LinkWithVariables(nullptr)");
@@ -128,9 +132,8 @@ class DeviceProblem {
     have_ = 0;
     have_x_ = false;
     if (link_hook_) link_hook_(*this, found);
-    sentinel_ = -1;
-    for (size_t i = 0; i < vars_.size(); ++i)
-      if (!vars_[i].push && (sentinel_ < 0 || vars_[i].info.size < vars_[static_cast<size_t>(sentinel_)].info.size)) sentinel_ = static_cast<int>(i);
+    n_polled_ = 0;
+    for (const auto& v : vars_) n_polled_ += !v.push;
   }
 
   // Brings the device results for the current x up to date, evaluating ONLY what is asked for (the reference's sets do the
@@ -150,10 +153,9 @@ class DeviceProblem {
         changed |= Read(v);
         read = true;
       }
-    if (sentinel_ >= 0) {
+    if (n_polled_ > 0) {
       if (request >= served_.size()) served_.resize(request + 1, 0);
-      bool poll = !have_x_ || served_[request];
-      if (!poll && strict_) poll = Differs(vars_[static_cast<size_t>(sentinel_)]);
+      const bool poll = !have_x_ || polling_ == Polling::kEveryRequest || served_[request] || want != last_want_;
       if (poll) {
         for (auto& v : vars_)
           if (!v.push) changed |= Read(v);
@@ -162,6 +164,7 @@ class DeviceProblem {
     }
     if (read) std::fill(served_.begin(), served_.end(), 0);
     if (request < served_.size()) served_[request] = 1;
+    last_want_ = want;
     have_x_ = true;
     if (changed) have_ = 0;
     const int need = want & ~have_;
@@ -211,11 +214,6 @@ class DeviceProblem {
     std::memcpy(x_ + v.info.offset, xv.data(), sizeof(double) * v.info.size);
     return true;
   }
-  bool Differs(const VarSet& v) {
-    const Eigen::VectorXd xv = v.comp->GetValues();
-    ++n_reads_;
-    return static_cast<int>(xv.size()) != v.info.size || std::memcmp(xv.data(), x_ + v.info.offset, sizeof(double) * v.info.size) != 0;
-  }
   twr_structure* structure_ = nullptr;
   twr_batch* batch_ = nullptr;
   twr_sizes sizes_{};
@@ -227,8 +225,9 @@ class DeviceProblem {
   LinkHook link_hook_;
   std::vector<std::shared_ptr<void>> keep_;
   std::vector<char> served_;            // requests answered since x was last read (polled sets only)
-  int sentinel_ = -1;                   // smallest polled set, -1 when every set pushes
-  bool strict_ = true;
+  int n_polled_ = 0;                    // variable sets that do not push
+  Polling polling_ = Polling::kPerSweep;
+  int last_want_ = 0;                   // kind of the previous request (TWR_EVAL_VALUES / TWR_EVAL_JACOBIAN)
   bool have_x_ = false;
   int have_ = 0;   // TWR_EVAL_* bits that are valid for the x in x_
   long n_value_evals_ = 0, n_jacobian_evals_ = 0, n_reads_ = 0;

@@ -2729,6 +2729,78 @@ hipError_t launch_score(const NodeWork* work, int n_problems, const double* g, d
   return twr_launch(score_kernel, dim3(n_problems), dim3(64), 0, stream, work, g, scores);
 }
 
+// twr_batch_best: the planner's decision on the device -- arg-min over a score table of the summed inf-norm violations of
+// the chosen constraint families (the table may be longer than this batch: after an all-gather it holds the candidates of
+// every rank).  Same rule as towr_amd.dist.best_candidate: families summed in ascending order, NaN loses, first index wins
+// a tie.  One launch: every block reduces its stride of candidates, the last block to finish reduces the blocks' results
+// (threadfence + counter, reset for the next call) and writes best[0] = index, best[1] = its total.
+__device__ __forceinline__ void best_of(double& v, int& i, double ov, int oi) {
+  if (ov < v || (ov == v && oi < i)) {
+    v = ov;
+    i = oi;
+  }
+}
+__global__ __launch_bounds__(256) void best_kernel(const double* __restrict__ scores, int n, unsigned families, double* __restrict__ partial,
+                                                   unsigned* __restrict__ counter, double* __restrict__ best) {
+  __shared__ double s_v[4];
+  __shared__ int s_i[4];
+  __shared__ bool s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double bv = __builtin_inf();
+  int bi = 0x7fffffff;
+  for (int c = blockIdx.x * 256 + tid; c < n; c += gridDim.x * 256) {
+    const double* row = scores + 16 * (size_t)c;
+    double t = 0.0;
+    bool first = true;
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+      if (families >> f & 1u) {
+        t = first ? row[2 * f] : t + row[2 * f];
+        first = false;
+      }
+    if (t != t) t = __builtin_inf();
+    best_of(bv, bi, t, c);
+  }
+  auto block_reduce = [&]() {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best_of(bv, bi, __shfl_xor(bv, o), __shfl_xor(bi, o));
+    if (lane == 0) {
+      s_v[wave] = bv;
+      s_i[wave] = bi;
+    }
+    __syncthreads();
+    if (tid == 0)
+      for (int w = 1; w < 4; ++w) best_of(bv, bi, s_v[w], s_i[w]);
+  };
+  block_reduce();
+  if (tid == 0) {
+    partial[2 * blockIdx.x] = bv;
+    partial[2 * blockIdx.x + 1] = (double)bi;
+    __threadfence();
+    s_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  bv = __builtin_inf();
+  bi = 0x7fffffff;
+  for (int k = tid; k < (int)gridDim.x; k += 256)
+    best_of(bv, bi, __builtin_nontemporal_load(partial + 2 * k), (int)__builtin_nontemporal_load(partial + 2 * k + 1));
+  __syncthreads();
+  block_reduce();
+  if (tid == 0) {
+    best[0] = (double)(bi == 0x7fffffff ? 0 : bi);
+    best[1] = bv;
+    *counter = 0u;
+  }
+}
+int best_max_blocks() { return 256; }
+hipError_t launch_best(const double* scores, int n, unsigned families, double* partial, unsigned* counter, double* best, hipStream_t stream) {
+  int blocks = (n + 1023) / 1024;   // >= four candidates per thread before another block pays
+  blocks = blocks < 1 ? 1 : (blocks > best_max_blocks() ? best_max_blocks() : blocks);
+  return twr_launch(best_kernel, dim3(blocks), dim3(256), 0, stream, scores, n, families, partial, counter, best);
+}
+
 // ---------------------------------------------------------------- contact plan
 // fpowr::ExtractFootstepPlan (fpowr/include/fpowr/footstep_plan_extractor.h:69-133) minus the nearest-plane lookup
 // (boost::geometry over ROS messages, left to the caller): the solution is sampled every dt like GetTrajectory
