@@ -738,6 +738,15 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     };
     upload(dyn.data(), dyn.size() * sizeof(twr::DynWork), reinterpret_cast<void**>(&b->d_dyn));
     upload(rom.data(), rom.size() * sizeof(twr::RomWork), reinterpret_cast<void**>(&b->d_rom));
+    {  // one entry past the end carries the totals: a kernel reads a problem's row count as work[p + 1].g_off - work[p].g_off
+       // from the work list alone (score_kernel requests g before the structure's header has arrived)
+      twr::NodeWork end;
+      end.blob = 0;
+      end.x_off = b->x_off[b->n_problems];
+      end.g_off = b->g_off[b->n_problems];
+      end.j_off = b->j_off[b->n_problems];
+      node.push_back(end);
+    }
     upload(node.data(), node.size() * sizeof(twr::NodeWork), reinterpret_cast<void**>(&b->d_node));
     // Large batches whose node-based sets are terrain / force / splineacc / swing only: per-family chunk lists for the
     // persistent node_chunk_kernel (baseMotion and totalduration rows, and small batches -- where the fused launch or the

@@ -300,15 +300,27 @@ struct SampleWork {       // cnt <= 64 samples of one problem from sample s0
 };
 static_assert(sizeof(SampleWork) == 32, "SampleWork layout");
 
-// Candidate scoring (twr_batch_score): the bounds of every row and which constraint family a set belongs to.
+// Candidate scoring (twr_batch_score): per row the constraint family and the bounds.  The bounds of a structure take a
+// handful of distinct (lower, upper) values (dynamic: 0 / 0; rangeofmotion-e: nominal +- deviation per dimension; force-*:
+// five; terrain-*: two; ...), so a row carries 16 bits -- family << 12 | index of its pair among the DISTINCT pairs -- instead
+// of two doubles: 2 bytes per row next to the 8 bytes of g the kernel reads it for (round 4: 16 bytes, 62 KB per K = 200
+// quadruped candidate).  "family" in a meta word is a SLOT: the families of a structure numbered in the order of their
+// first row, so that the slot never falls along the rows (a thread of score_kernel walks ascending rows and keeps ONE
+// running pair of accumulators, handing it over when the slot moves on); slot_of_family maps back.  Layout in the blob,
+// one record:
+//     [ meta: uint16[n_rows], padded to 16 bytes ][ ScoreTables ][ pairs: (lower, upper) x n_pairs ][ zero padding ]
+// DevStruct::o_score points at the ScoreTables; the meta words END there (the kernel knows n_rows from its work list, so it
+// requests them together with the head of the record, before any field of it has arrived), and at least kScoreHeadBytes
+// bytes follow o_score, so that the head can be requested without knowing n_pairs.
 constexpr int kMaxConSets = 24;   // 4 terrain + dynamic + 2 splineacc + 4 rangeofmotion + 4 force + 4 swing + baseMotion + 4 totalduration
+constexpr int kScoreHeadBytes = 2048;
+constexpr int kScoreMaxPairs = 256;     // distinct pairs per structure (12-bit index; score_kernel keeps them all in LDS).  A real
+                                        // structure has a few dozen: twr_structure_create rejects one with more
 struct ScoreTables {
-  int32_t n_sets, n_rows;
-  uint32_t o_lower, o_upper;       // double[n_rows] (twr_structure_bounds)
-  struct {
-    int32_t row0, row1, family, pad;   // family = bit index of the set's TWR_SET_* flag (0 terrain .. 7 baseMotion, 6 totalduration)
-  } sets[kMaxConSets];
+  int32_t n_rows, n_pairs;
+  int8_t slot_of_family[8];        // -1: the structure has no set of that family
 };
+static_assert(sizeof(ScoreTables) == 16, "ScoreTables layout");
 
 // Blob header: model constants + what the node kernel needs.  The terrain-ee-motion_e sets are
 // adjacent in g / jac, and so are the force-ee-force_e sets, so each family is one flat node list.

@@ -36,6 +36,9 @@
 namespace twr {
 
 #define TWR_DEV __device__ __forceinline__
+#ifndef TWR_VALUES_WAVES
+#define TWR_VALUES_WAVES 3   // waves per SIMD the values-only kernels (dyn_values_kernel, rom_values_kernel) are compiled for
+#endif
 constexpr int TWR_MAX_PHASES_DEV = 32;  // = TWR_MAX_PHASES of include/towr_amd.h
 
 template <typename T>
@@ -1057,11 +1060,13 @@ template <bool WANT_G, bool WANT_J, int XC, bool NT>
 TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double* __restrict__ x, double* __restrict__ g,
                       double* __restrict__ jac, double* __restrict__ dump, double* stage, int lane, int i, int stride) {
   static_assert(XC == 2 || XC == 4, "staging map chunks");
-  double* gst = stage + kDynG0;
-  char* xs = reinterpret_cast<char*>(stage + kDynX0);
+  // (values only: no image -- the wave's LDS is g + xs, kDynValuesLds doubles, see dyn_values_kernel)
+  constexpr int kG0 = WANT_J ? kDynG0 : 0, kX0 = kG0 + 96;
+  double* gst = stage + kG0;
+  char* xs = reinterpret_cast<char*>(stage + kX0);
   if (i >= n_work) return;
   constexpr int NIT = (kDynImage + 2 + 127) / 128;
-  if (lane < 2) stage[kDynX0 + lane] = 0.0;   // the zero pair
+  if (lane < 2) stage[kX0 + lane] = 0.0;   // the zero pair
   auto load_map = [&](const DynWork& w) {   // XC 16-bit x indices per lane
     uint2 m;
     if (XC == 4) m = gptr<uint2>(w.map)[lane];
@@ -1080,7 +1085,7 @@ TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double
   auto stage_x = [&](const double xr[XC]) {
 #pragma unroll
     for (int c = 0; c < XC; ++c)
-      if (64 * c + lane < kDynXsCap) stage[kDynX0 + 2 + 64 * c + lane] = xr[c];
+      if (64 * c + lane < kDynXsCap) stage[kX0 + 2 + 64 * c + lane] = xr[c];
   };
   // image -> HBM; the constraint values (6 per time node, contiguous in g) with clamped lanes instead of predicates
   auto copy_out = [&](double* pdst, double* pg, int nvals, int cnt) {
@@ -1154,6 +1159,17 @@ __global__ __launch_bounds__(64, TWR_DYN_WAVES) void dyn_kernel(const DynWork* _
   dyn_body<WANT_G, WANT_J, XC, NT>(work, n_work, x, g, jac, dump, stage, threadIdx.x, blockIdx.x, gridDim.x);
 }
 
+// Values only (TWR_EVAL_VALUES: what Ipopt's eval_g and a planner's scoring step ask for): the same body, but a wave then
+// owns 2.6 KB of LDS instead of 20 KB (no image) and the kernel is compiled for more waves per SIMD -- a values-only slice is
+// one chain of dependent loads and FP64 latencies per wave, so waves in flight are what it runs on.
+constexpr int kDynValuesLds = 96 + 2 + kDynXsCap;
+template <int XC>
+__global__ __launch_bounds__(64, TWR_VALUES_WAVES) void dyn_values_kernel(const DynWork* __restrict__ work, int n_work, const double* __restrict__ x,
+                                                                          double* __restrict__ g, double* __restrict__ dump) {
+  __shared__ __attribute__((aligned(16))) double stage[kDynValuesLds];
+  dyn_body<true, false, XC, false>(work, n_work, x, g, nullptr, dump, stage, threadIdx.x, blockIdx.x, gridDim.x);
+}
+
 #endif  // !TWR_TU_ROM
 
 // rom_kernel is compiled in its own translation unit (rom_tu.hip) with a different instruction scheduling
@@ -1171,7 +1187,7 @@ TWR_DEV void rom_body(const RomWork* __restrict__ work, int n_work, const double
                       double* __restrict__ jac, double* stage, int lane, int i, int stride) {
   static_assert(NIT * 128 <= kRomStage + 2 + 127, "copy-out longer than the image");
   const int trash = kRomStage + 2 + lane;
-  double* gst = stage + kRomStage + 2 + 64;
+  double* gst = stage + (WANT_J ? kRomStage + 2 + 64 : 0);   // (values only: the wave's LDS is the 192 constraint values alone)
   if (i >= n_work) return;
   // Every prefetch is issued unconditionally, with the slice index clamped to this workgroup's last slice (a repeated load
   // of the last slice's records / x is harmless): no prefetched value goes through a phi or a conditional copy, which is
@@ -1213,6 +1229,16 @@ __global__ __launch_bounds__(64, 1) void rom_kernel(const RomWork* __restrict__ 
   rom_body<NIT, WANT_G, WANT_J, NT>(work, n_work, x, g, jac, stage, threadIdx.x, blockIdx.x, gridDim.x);
 }
 
+// values only: 1.5 KB of LDS per wave instead of 40 KB, compiled for more waves per SIMD (see dyn_values_kernel)
+__global__ __launch_bounds__(64, TWR_VALUES_WAVES) void rom_values_kernel(const RomWork* __restrict__ work, int n_work, const double* __restrict__ x,
+                                                                          double* __restrict__ g) {
+  __shared__ __attribute__((aligned(16))) double stage[192];
+  rom_body<26, true, false, false>(work, n_work, x, g, nullptr, stage, threadIdx.x, blockIdx.x, gridDim.x);
+}
+hipError_t launch_rom_values_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, const double* x, double* g) {
+  return twr_launch(rom_values_kernel, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g);
+}
+
 // max_vals: Jacobian values of the largest slice of the batch
 hipError_t launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, int max_vals, const double* x, double* g,
                              double* jac, int flags, bool nt) {
@@ -1235,6 +1261,7 @@ hipError_t launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, i
 #else   // !TWR_TU_ROM
 hipError_t launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, int max_vals, const double* x, double* g,
                              double* jac, int flags, bool nt);
+hipError_t launch_rom_values_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, const double* x, double* g);
 
 // all terrain-ee-motion_e (terrain_constraint.cc:57-108), force-ee-force_e, splineacc-base-* and
 // swing-ee-motion_e sets of one problem.  One workgroup of four waves per problem, one wave per family
@@ -1629,6 +1656,27 @@ __global__ __launch_bounds__(128, 2) void eval_fused_kernel(const RomWork* __res
   b -= g_dyn;
   const int family = 2 * (b & 1) + wave;
   node_body(node[b >> 1], x, g, jac, (WANT_G ? 1 : 0) | (WANT_J ? 2 : 0), stage + wave * kDynLds, family, lane);
+}
+
+// Values only, one launch: blocks [0, g_rom) take the rom role, the next g_dyn the dyn role, the rest one node family of
+// one problem each -- single-wave blocks with the small LDS of the values-only bodies (no image), compiled for
+// TWR_VALUES_WAVES waves per SIMD.  The three roles are latency chains of different shape; in one launch their heads and
+// tails overlap (a planner step at 128 ... 1024 candidates is 10 ... 50 us of it).
+constexpr int kValuesLds = kDynValuesLds > 192 ? kDynValuesLds : 192;
+template <int XC>
+__global__ __launch_bounds__(64, TWR_VALUES_WAVES) void eval_values_kernel(const RomWork* __restrict__ rom, int n_rom, int g_rom,
+                                                                           const DynWork* __restrict__ dyn, int n_dyn, int g_dyn,
+                                                                           const NodeWork* __restrict__ node, int node_families,
+                                                                           const double* __restrict__ x, double* __restrict__ g,
+                                                                           double* __restrict__ dump) {
+  __shared__ __attribute__((aligned(16))) double stage[kValuesLds];
+  const int lane = threadIdx.x;
+  int b = blockIdx.x;
+  if (b < g_rom) return rom_body<26, true, false, false>(rom, n_rom, x, g, nullptr, stage, lane, b, g_rom);
+  b -= g_rom;
+  if (b < g_dyn) return dyn_body<true, false, XC, false>(dyn, n_dyn, x, g, nullptr, dump, stage, lane, b, g_dyn);
+  b -= g_dyn;
+  node_body(node[b / node_families], x, g, nullptr, 1, stage, b % node_families, lane);   // (values only: the node image is not touched)
 }
 
 // ---------------------------------------------------------------- optimised timings (PhaseSpline) kernels
@@ -2678,55 +2726,106 @@ hipError_t launch_sample(const SampleWork* work, int n_work, const double* x, do
 // ---------------------------------------------------------------- candidate scoring
 // twr_batch_score: per problem and constraint family the inf- and 1-norm of the bound violation
 // max(lower - g, g - upper, 0) over the family's rows (bounds of ConstraintSet::GetBounds, twr_structure_bounds).
-// One wave per problem; a sweep then returns 16 doubles per candidate instead of its Jacobian.
-__global__ __launch_bounds__(64) void score_kernel(const NodeWork* __restrict__ work, const double* __restrict__ g,
-                                                   double* __restrict__ scores) {
+// A sweep then returns 16 doubles per candidate instead of its Jacobian.
+// (round 5: 256 threads per problem, row r = 256 k + thread, sixteen rows per thread; family slot and bounds of a row come
+// from its 16-bit meta word and the structure's short table of distinct (lower, upper) pairs, device_tables.h ScoreTables.)
+// Three dependent round trips: (1) the work item and its successor (row count = difference of their g offsets; the list
+// carries an end entry), (2) the rows of g AND the structure's header, (3) the meta words of the rows AND the head of the
+// score record (2 KB requested on spec: the pair table) -> LDS.  The slot of a thread's rows never falls, so it keeps one
+// running (max, sum) pair and hands it to its LDS cell when the slot moves on.  Round 4's kernel fetched a cold candidate's
+// fields one s_load at a time and 16 bytes of bounds per row: 25 us for 128 candidates, 43 us for 1024.
+TWR_DEV double nan_max(double a, double b) { return (a != a || b != b) ? (a != a ? a : b) : fmax(a, b); }
+__global__ __launch_bounds__(256) void score_kernel(const NodeWork* __restrict__ work, const double* __restrict__ g,
+                                                    double* __restrict__ scores) {
+  constexpr int kHeadDwords = kScoreHeadBytes / 4, kTabDwords = (int)(sizeof(ScoreTables) / 4);
+  static_assert(kHeadDwords == 512 && kTabDwords + 4 * kScoreMaxPairs <= 2 * kHeadDwords + 4 * 256, "record head: two loads per thread (+ four for a full table)");
+  __shared__ __attribute__((aligned(16))) int32_t s_tab[kTabDwords + 4 * kScoreMaxPairs];   // the record as in the blob
+  __shared__ double red[256 * 16 + 16 * 16];   // cell (2 slot + {max, sum}, thread), then the partial results of the fold
+  const int tid = threadIdx.x;
   const NodeWork w = work[blockIdx.x];
+  const int n_rows = (int)(work[blockIdx.x + 1].g_off - w.g_off);
+  const double* gp = g + w.g_off;
   const char* blob = reinterpret_cast<const char*>(w.blob);
   const DevStruct* S = reinterpret_cast<const DevStruct*>(blob);
-  const ScoreTables* T = tbl<ScoreTables>(blob, S->o_score);
-  const double* lo = tbl<double>(blob, T->o_lower);
-  const double* up = tbl<double>(blob, T->o_upper);
-  const double* gp = g + w.g_off;
-  const int lane = threadIdx.x;
-  double fmax8[8], fsum8[8];
 #pragma unroll
-  for (int f = 0; f < 8; ++f) fmax8[f] = fsum8[f] = 0.0;
-  for (int s = 0; s < T->n_sets; ++s) {
-    double vmax = 0.0, vsum = 0.0;
-    for (int r = T->sets[s].row0 + lane; r < T->sets[s].row1; r += 64) {
-      const double v = gp[r];
-      // NaN-propagating: a non-finite constraint value makes the family's scores NaN instead of hiding in a max()
-      double viol = fmax(fmax(lo[r] - v, v - up[r]), 0.0);
-      if (v != v) viol = v;
-      vmax = (viol != viol || vmax != vmax) ? (viol != viol ? viol : vmax) : fmax(vmax, viol);
-      vsum += viol;
-    }
+  for (int c = 0; c < 16; ++c) red[c * 256 + tid] = 0.0;   // (a cell is written at most once more; own cells only: no barrier)
+  int cur = 0;
+  double cm = 0.0, cs = 0.0;
+  for (int base = 0; base < n_rows; base += 16 * 256) {   // (one trip for structures of up to 4096 rows)
+    double v[16];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const double om = __shfl_xor(vmax, o), os = __shfl_xor(vsum, o);
-      vmax = (om != om || vmax != vmax) ? (om != om ? om : vmax) : fmax(vmax, om);
-      vsum += os;
-    }
-    const int fam = T->sets[s].family;   // wave-uniform
+    for (int k = 0; k < 16; ++k) v[k] = gp[min(base + 256 * k + tid, n_rows - 1)];
+    const int32_t* Tw = reinterpret_cast<const int32_t*>(tbl<ScoreTables>(blob, S->o_score));
+    const uint16_t* meta = reinterpret_cast<const uint16_t*>(Tw) - n_rows;   // the meta words end where the record starts
+    uint32_t m[16];
 #pragma unroll
-    for (int f = 0; f < 8; ++f)
-      if (f == fam) {
-        fmax8[f] = (vmax != vmax || fmax8[f] != fmax8[f]) ? (vmax != vmax ? vmax : fmax8[f]) : fmax(fmax8[f], vmax);
-        fsum8[f] += vsum;
+    for (int k = 0; k < 16; ++k) m[k] = meta[min(base + 256 * k + tid, n_rows - 1)];
+    if (base == 0) {
+      const int32_t a = Tw[tid], c = Tw[tid + 256];
+      s_tab[tid] = a;
+      s_tab[tid + 256] = c;
+      __syncthreads();
+      const int n_pairs = min(__builtin_amdgcn_readfirstlane(s_tab[1]), kScoreMaxPairs);   // (never more: twr_structure_create)
+      if (kTabDwords + 4 * n_pairs > kHeadDwords) {   // uniform; more pairs than the head held
+        for (int d = kHeadDwords + tid; d < kTabDwords + 4 * n_pairs; d += 256) s_tab[d] = Tw[d];
+        __syncthreads();
       }
-  }
-  if (lane == 0) {
-    double* o = scores + 16 * (size_t)blockIdx.x;
-#pragma unroll
-    for (int f = 0; f < 8; ++f) {
-      o[2 * f] = fmax8[f];
-      o[2 * f + 1] = fsum8[f];
     }
+    const double* s_pairs = reinterpret_cast<const double*>(s_tab + kTabDwords);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (base + 256 * k < n_rows) {   // uniform
+        const bool live = base + 256 * k + tid < n_rows;
+        const int slot = (int)(m[k] >> 12), q = (int)(m[k] & 0xFFFu);
+        const double lo = s_pairs[2 * q], up = s_pairs[2 * q + 1], val = v[k];
+        // NaN-propagating: a non-finite constraint value makes the family's scores NaN instead of hiding in a max()
+        double viol = fmax(fmax(lo - val, val - up), 0.0);
+        if (val != val) viol = val;
+        if (live && slot != cur) {   // the slot moved on: hand over the running pair (rare: a few times per thread)
+          red[(2 * cur) * 256 + tid] = cm;
+          red[(2 * cur + 1) * 256 + tid] = cs;
+          cm = cs = 0.0;
+          cur = slot;
+        }
+        if (live) {
+          cm = nan_max(cm, viol);
+          cs += viol;
+        }
+      }
+    }
+  }
+  red[(2 * cur) * 256 + tid] = cm;
+  red[(2 * cur + 1) * 256 + tid] = cs;
+  // 256 threads x 16 cells -> 16 values, transposed: thread 16 c + j folds column j of threads c, c + 16, ..., then sixteen
+  // threads fold the sixteen partial results of their column and store it at its FAMILY's place
+  __syncthreads();
+  {
+    const int j = tid & 15, c = tid >> 4;   // column j (even: an inf-norm, odd: a 1-norm)
+    double acc = red[j * 256 + c];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) {
+      const double o = red[j * 256 + c + 16 * i];
+      acc = (j & 1) ? acc + o : nan_max(acc, o);
+    }
+    red[256 * 16 + c * 16 + j] = acc;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const int slot = reinterpret_cast<const int8_t*>(s_tab + 2)[tid >> 1];   // ScoreTables::slot_of_family[family tid / 2]
+    double acc = 0.0;
+    if (slot >= 0) {
+      const int j = 2 * slot + (tid & 1);
+      acc = red[256 * 16 + j];
+      for (int c = 1; c < 16; ++c) {
+        const double o = red[256 * 16 + c * 16 + j];
+        acc = (tid & 1) ? acc + o : nan_max(acc, o);
+      }
+    }
+    scores[16 * (size_t)blockIdx.x + tid] = acc;
   }
 }
 hipError_t launch_score(const NodeWork* work, int n_problems, const double* g, double* scores, hipStream_t stream) {
-  return twr_launch(score_kernel, dim3(n_problems), dim3(64), 0, stream, work, g, scores);
+  return twr_launch(score_kernel, dim3(n_problems), dim3(256), 0, stream, work, g, scores);
 }
 
 // twr_batch_best: the planner's decision on the device -- arg-min over a score table of the summed inf-norm violations of
@@ -3023,6 +3122,7 @@ static int env_int(const char* name, int dflt) {
   return dflt;
 #endif
 }
+static int n_chunks_of(const int n_fam[4]) { return n_fam[0] + n_fam[1] + n_fam[2] + n_fam[3]; }
 hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dyn_map_chunks /* 2 or 4 */, const RomWork* rom, int n_rom,
                        int rom_max_vals, const NodeWork* node, int n_node, int node_families /* 2: terrain + force only; 4 */,
                        const FamWork* const fam[4], const int n_fam[4] /* chunk lists of node_chunk_kernel; all 0: none */,
@@ -3039,7 +3139,73 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
   // Ten, not eight: the 512 candidates of a two-GPU shard of the C5 sweep are ~8500 rom slices (the enumeration is ragged:
   // 16.6 slices per candidate), 8.3 rounds on the 256 CUs of an MI355X.  The thresholds are in units of the device's
   // residency, not constants of one chip.
+  auto launch_nodes = [&]() {   // the node-based sets (terrain-*, force-*, splineacc-*, swing-*, ...): last launch of every path
+    const int n_chunks = n_fam[0] + n_fam[1] + n_fam[2] + n_fam[3];
+    if (n_chunks > 0) {
+      // persistent waves per CU for ALL families together, shared out by their chunk counts (by count, not by bytes: an iteration
+      // costs about the same whatever the family -- weighting the force chunks 1.5 x ... 3 x was 4-15 % slower)
+      static const int node_bpc = env_int("TWR_NODE_BPC", 16);
+      const int res = node_bpc * n_cu;
+      int gf[4];
+      for (int f = 0; f < 4; ++f) {
+        gf[f] = n_fam[f] == 0 ? 0 : (int)((long long)res * n_fam[f] / n_chunks);
+        if (n_fam[f] > 0 && gf[f] < 1) gf[f] = 1;
+        if (gf[f] > n_fam[f]) gf[f] = n_fam[f];
+      }
+  #define TWR_CHUNK_LAUNCH(WG, WJ)                                                                                                              \
+    st = twr_first(st, twr_launch(node_chunk_kernel<WG, WJ>, dim3(gf[0] + gf[1] + gf[2] + gf[3]), dim3(64), 0, stream, fam[0], n_fam[0], gf[0],   \
+                                  fam[1], n_fam[1], gf[1], fam[2], n_fam[2], gf[2], fam[3], n_fam[3], gf[3], x, g, jac))
+      if ((flags & 3) == 3) TWR_CHUNK_LAUNCH(true, true);
+      else if (flags & 2) TWR_CHUNK_LAUNCH(false, true);
+      else TWR_CHUNK_LAUNCH(true, false);
+  #undef TWR_CHUNK_LAUNCH
+    } else if (n_node > 0 && node_families == 2)
+      st = twr_first(st, twr_launch(node_kernel2, dim3(n_node), dim3(128), 0, stream, node, x, g, jac, flags));
+    else if (n_node > 0)
+      st = twr_first(st, twr_launch(node_kernel, dim3(n_node), dim3(256), 0, stream, node, x, g, jac, flags));
+  };
   const int cap = rom_bpc * n_cu;
+  // Values only (no Jacobian): the dedicated high-occupancy kernels, except for batches so small that one launch matters
+  // more than waves in flight (the fused launch below).
+  static const int values_min_rom = env_int("TWR_VALUES_MIN_ROM", 1);
+  if (!(flags & 2) && (flags & 1) && n_pdyn == 0 && n_prom == 0 && n_ploc == 0 && n_rom >= values_min_rom && n_dyn > 0) {
+    static const int vw = env_int("TWR_VALUES_WPC", 4 * TWR_VALUES_WAVES);   // workgroups (= waves) per CU
+    static const int values_fused = env_int("TWR_VALUES_FUSED", 1);
+    if (!ev && values_fused && n_node > 0 && n_chunks_of(n_fam) == 0) {
+      // one launch; the residency is shared out by the roles' slice counts (a rom slice and a dyn slice cost about the same
+      // here), whole multiples of 8 so that a role's block r still takes the list positions r modulo 8 (one problem, one XCD)
+      const int res = vw * n_cu;
+      int g_rom = n_rom, g_dyn = n_dyn;
+      if (g_rom + g_dyn > res) {
+        g_rom = (int)((long long)res * n_rom / (n_rom + n_dyn));
+        g_dyn = res - g_rom;
+        if (g_rom > n_rom) g_rom = n_rom;
+        if (g_dyn > n_dyn) g_dyn = n_dyn;
+      }
+      if (g_rom >= 8) g_rom &= ~7;
+      if (g_dyn >= 8) g_dyn &= ~7;
+      const dim3 vgrid(g_rom + g_dyn + node_families * n_node);
+      if (dyn_map_chunks == 2)
+        return twr_launch(eval_values_kernel<2>, vgrid, block, 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, node_families, x, g, dump);
+      return twr_launch(eval_values_kernel<4>, vgrid, block, 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, node_families, x, g, dump);
+    }
+    if (ev) (void)hipEventRecord(ev[0], stream);
+    {
+      const int res = vw * n_cu;
+      dim3 grid(n_dyn < res ? n_dyn : res);
+      if (dyn_map_chunks == 2) st = twr_first(st, twr_launch(dyn_values_kernel<2>, grid, block, 0, stream, dyn, n_dyn, x, g, dump));
+      else st = twr_first(st, twr_launch(dyn_values_kernel<4>, grid, block, 0, stream, dyn, n_dyn, x, g, dump));
+    }
+    if (ev) (void)hipEventRecord(ev[1], stream);
+    {
+      const int res = vw * n_cu;
+      st = twr_first(st, launch_rom_values_kernel(n_rom < res ? n_rom : res, stream, rom, n_rom, x, g));
+    }
+    if (ev) (void)hipEventRecord(ev[2], stream);
+    launch_nodes();
+    if (ev) (void)hipEventRecord(ev[3], stream);
+    return st;
+  }
   // With non-temporal stores (sweep-like batches) the fused launch stays ahead for longer -- 768 / 896 / 1024 candidates of the
   // C5 sweep (12.7 / 14.9 / 17 thousand rom slices): 160-165 / 179 / 210 us as three launches, 148 / 166 / 202 us fused -- twenty
   // rounds there (the enumeration ends at 1040 candidates; nothing larger was measured).
@@ -3157,29 +3323,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
     st = twr_first(st, launch_rom_kernel((int)grid.x, stream, rom, n_rom, rom_max_vals, x, g, jac, flags, stream_nt));
   }
   if (ev) (void)hipEventRecord(ev[2], stream);
-  const int n_chunks = n_fam[0] + n_fam[1] + n_fam[2] + n_fam[3];
-  if (n_chunks > 0) {
-    // persistent waves per CU for ALL families together, shared out by their chunk counts (by count, not by bytes: an iteration
-    // costs about the same whatever the family -- weighting the force chunks 1.5 x ... 3 x was 4-15 % slower)
-    static const int node_bpc = env_int("TWR_NODE_BPC", 16);
-    const int res = node_bpc * n_cu;
-    int gf[4];
-    for (int f = 0; f < 4; ++f) {
-      gf[f] = n_fam[f] == 0 ? 0 : (int)((long long)res * n_fam[f] / n_chunks);
-      if (n_fam[f] > 0 && gf[f] < 1) gf[f] = 1;
-      if (gf[f] > n_fam[f]) gf[f] = n_fam[f];
-    }
-#define TWR_CHUNK_LAUNCH(WG, WJ)                                                                                                              \
-  st = twr_first(st, twr_launch(node_chunk_kernel<WG, WJ>, dim3(gf[0] + gf[1] + gf[2] + gf[3]), dim3(64), 0, stream, fam[0], n_fam[0], gf[0],   \
-                                fam[1], n_fam[1], gf[1], fam[2], n_fam[2], gf[2], fam[3], n_fam[3], gf[3], x, g, jac))
-    if ((flags & 3) == 3) TWR_CHUNK_LAUNCH(true, true);
-    else if (flags & 2) TWR_CHUNK_LAUNCH(false, true);
-    else TWR_CHUNK_LAUNCH(true, false);
-#undef TWR_CHUNK_LAUNCH
-  } else if (n_node > 0 && node_families == 2)
-    st = twr_first(st, twr_launch(node_kernel2, dim3(n_node), dim3(128), 0, stream, node, x, g, jac, flags));
-  else if (n_node > 0)
-    st = twr_first(st, twr_launch(node_kernel, dim3(n_node), dim3(256), 0, stream, node, x, g, jac, flags));
+  launch_nodes();
   if (ev) (void)hipEventRecord(ev[3], stream);
   return st;
 }
