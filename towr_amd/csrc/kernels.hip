@@ -3209,7 +3209,9 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
   // With non-temporal stores (sweep-like batches) the fused launch stays ahead for longer -- 768 / 896 / 1024 candidates of the
   // C5 sweep (12.7 / 14.9 / 17 thousand rom slices): 160-165 / 179 / 210 us as three launches, 148 / 166 / 202 us fused -- twenty
   // rounds there (the enumeration ends at 1040 candidates; nothing larger was measured).
-  const int fused_max = env_int("TWR_FUSED_MAX_ROM", (stream_nt ? 20 : 10) * cap);
+  // (round 5, with the roles always co-resident: batches that share one structure, plain stores, 640 / 1024 / 2048 problems
+  // 129.5 / 193.5 / 365 us as three launches, 120 / 188 / 376 us fused -- twenty rounds for both store policies)
+  const int fused_max = env_int("TWR_FUSED_MAX_ROM", 20 * cap);
   if (!ev && n_pdyn == 0 && n_prom == 0 && n_rom > 0 && n_dyn > 0 && n_rom <= fused_max) {
     int g_rom = n_rom < cap ? n_rom : cap, g_dyn = (n_dyn + 1) / 2 < cap ? (n_dyn + 1) / 2 : cap;
     // When the two persistent roles do not fit the CUs together, the blocks of the later role only start as the earlier
@@ -3220,12 +3222,21 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
     // TWR_FUSED_SPLIT = eighths of the residency given to rom (experiments; 8 = never split).
     static const int split_env = env_int("TWR_FUSED_SPLIT", 0);
     // (round 3: five eighths for rom up to 3200 slices -- 128 / 160 / 200 candidates 27.5 / 33.5 / 40.5 us against 27.7 / 33.9 /
-    // 44.0 us with the round-2 rule "half each up to 2560"; from 256 candidates on unsplit is as good or better)
-    const int split = split_env > 0 ? split_env : (8 * n_rom <= 25 * cap ? 5 : 8);   // (3200 slices on 256 CUs)
+    // 44.0 us with the round-2 rule "half each up to 2560"; from 256 candidates on unsplit was as good or better THEN.)
+    // Round 5, re-measured with the round-4 kernels (split tables, nt stores; scripts/r05_split_exp.sh, one box, ragged
+    // sweep, us per step unsplit -> split): 256 candidates 53.8 -> 47.2 (five eighths; 48.6 at four), 320: 69.3 -> 62.5 (four),
+    // 384: 81.7 -> 74.5, 512: 100.9 -> 92.6, 768: 155.8 -> 145.9, 1024: 206.0 -> 194.1; six eighths loses everywhere.  The two
+    // roles are ALWAYS co-resident now: the latency-bound dyn waves fill the holes of the store-bound rom stream.
+    const int split = split_env > 0 ? split_env : (8 * n_rom <= 34 * cap ? 5 : 4);   // (4352 slices on 256 CUs)
     if (split < 8 && g_rom + g_dyn > cap) {
       const int r = cap * split / 8, d = cap - r;
       if (g_rom > r) g_rom = r;
       if (g_dyn > d) g_dyn = d;
+    }
+    {   // experiments (make TUNING=1): explicit grids of the two roles
+      static const int e_rom = env_int("TWR_FUSED_GROM", 0), e_dyn = env_int("TWR_FUSED_GDYN", 0);
+      if (e_rom > 0) g_rom = e_rom < n_rom ? e_rom : n_rom;
+      if (e_dyn > 0) g_dyn = e_dyn < (n_dyn + 1) / 2 ? e_dyn : (n_dyn + 1) / 2;
     }
     if (g_dyn >= 8) g_dyn &= ~7;   // (the XCD-aware slice mapping of the dyn role, eval_fused_kernel)
     const dim3 fgrid(g_rom + g_dyn + 2 * n_node);
