@@ -36,6 +36,22 @@
 namespace twr {
 
 #define TWR_DEV __device__ __forceinline__
+#ifdef TWR_DIAG_NOCONFLICT
+// DIAGNOSTIC BUILD ONLY (make DIAG=-DTWR_DIAG_NOCONFLICT; wrong results on purpose): every scattered 8-byte store into the LDS
+// image of dyn_kernel / rom_kernel goes to `8 * lane + a constant of the call site` instead of its CSR position -- the sixteen
+// lanes of a ds_write_b64 group then hit sixteen different bank pairs (MI355X_MICROARCH.md: 4 x 16 contiguous lanes, bank =
+// (a / 4) mod 32), with the same number of stores and no address arithmetic at all: an UPPER bound of what removing the bank
+// conflicts of the image scatter can buy.
+template <int N>
+TWR_DEV void diag_put(double v) {
+  const uint32_t a = (threadIdx.x & 63u) << 3;
+  asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(a), "v"(v), "n"((N % 30) * 512));
+}
+#define lds_put(l, o, ...) diag_put<__COUNTER__>(__VA_ARGS__)
+#define TWR_ROM_PUT(idx, ...) diag_put<__COUNTER__>(__VA_ARGS__)
+#else
+#define TWR_ROM_PUT(idx, ...) stage[idx] = (__VA_ARGS__)
+#endif
 #ifndef TWR_VALUES_WAVES
 #define TWR_VALUES_WAVES 3   // waves per SIMD the values-only kernels (dyn_values_kernel, rom_values_kernel) are compiled for
 #endif
@@ -384,19 +400,19 @@ TWR_DEV void rom_item(const RomWork& w, const RomRec& r, const RomX& X, double* 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
-      for (int d = 0; d < 3; ++d) stage[rs[row] + 3 * j + d] = -ro.R[d][row] * wP[j];  // -R^T J_c
+      for (int d = 0; d < 3; ++d) TWR_ROM_PUT(rs[row] + 3 * j + d, -ro.R[d][row] * wP[j]);  // -R^T J_c
       if (row == 0) {  // row 0 of R^T v does not depend on roll
-        stage[rs[0] + 12 + 2 * j + 0] = wP[j] * uy[0];
-        stage[rs[0] + 12 + 2 * j + 1] = wP[j] * uz[0];
+        TWR_ROM_PUT(rs[0] + 12 + 2 * j + 0, wP[j] * uy[0]);
+        TWR_ROM_PUT(rs[0] + 12 + 2 * j + 1, wP[j] * uz[0]);
       } else {
-        stage[rs[row] + 12 + 3 * j + 0] = wP[j] * ux[row];
-        stage[rs[row] + 12 + 3 * j + 1] = wP[j] * uy[row];
-        stage[rs[row] + 12 + 3 * j + 2] = wP[j] * uz[row];
+        TWR_ROM_PUT(rs[row] + 12 + 3 * j + 0, wP[j] * ux[row]);
+        TWR_ROM_PUT(rs[row] + 12 + 3 * j + 1, wP[j] * uy[row]);
+        TWR_ROM_PUT(rs[row] + 12 + 3 * j + 2, wP[j] * uz[row]);
       }
 #pragma unroll
       for (int d = 0; d < 3; ++d) {  // R^T J_p
         const int sl = (int)((slots >> (4 * (j * 3 + d))) & 0xF);
-        stage[sl != 0xF ? rs[row] + mo[row] + sl : trash] = ro.R[d][row] * wm[j];
+        TWR_ROM_PUT(sl != 0xF ? rs[row] + mo[row] + sl : trash, ro.R[d][row] * wm[j]);
       }
     }
   }
@@ -715,7 +731,10 @@ struct Dyn2Front {   // (the base-spline weights are recomputed in the back half
 TWR_DEV double lds_f64(const char* __restrict__ lds, uint32_t byte_off) {
   return *reinterpret_cast<const double*>(lds + byte_off);
 }
+#ifndef TWR_DIAG_NOCONFLICT
 TWR_DEV void lds_put(char* __restrict__ lds, uint32_t byte_off, double v) { *reinterpret_cast<double*>(lds + byte_off) = v; }
+#endif
+
 // staged candidate c of a spline: xs[idx[c]], idx = twelve bytes in three dwords
 TWR_DEV void gather12s(const char* __restrict__ xs, const uint32_t w[3], double v[12]) {
 #pragma unroll
