@@ -12,8 +12,14 @@
 //   --no-collective: the same sweep without RCCL at all -- the threads of one process share host memory, so the model is
 //        a plain struct copy and the scores are copied device -> host into one table ("one process, N
 //        devices").  Also the way to rehearse several ranks on ONE device (--devices 0,0).
-//   --rank R --world N --id-file PATH: one PROCESS per device instead (ncclCommInitRank; rank 0 writes the ncclUniqueId to
-//        PATH, the others wait for it) -- for launchers that start one process per GPU.
+//   --rank R --world N --id-file PATH [--run-id S]: one PROCESS per device instead (ncclCommInitRank; rank 0 writes the
+//        ncclUniqueId to PATH[.S], the others wait for it) -- for launchers that start one process per GPU.  A launcher
+//        should pass a fresh --run-id (its pid, a timestamp) to every rank: the id file of an EARLIER run can then never be
+//        mistaken for this one's.  Without it ranks > 0 only accept a file that is younger than their own start (minus a
+//        minute of launcher skew); rank 0 removes the file once ncclCommInitRank has returned (every rank has read it by then).
+//   A rank that fails (out of memory, a HIP error, ...) while its peers sit in a collective: its thread aborts EVERY
+//        communicator (ncclCommAbort), so the peers' collectives return an error instead of waiting for ever, and the
+//        process exits non-zero.
 //
 // Build:  hipcc -std=c++17 -O2 -I include examples/sweep_multi_gpu.cc -L towr_amd -ltowr_amd -lrccl -pthread \
 //               -Wl,-rpath,$PWD/towr_amd -o sweep_multi_gpu
@@ -23,6 +29,9 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <sys/stat.h>
+
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -60,8 +69,9 @@ struct Options {
   std::vector<int> devices;    // one rank per entry (thread mode)
   bool collective = true, jacobian = false;
   int steps = 0;               // timed evaluations per rank after the decision (0: none)
+  int fail_rank = -1;          // fault injection (tests)
   int rank = -1, world = 0;    // process mode
-  std::string id_file;
+  std::string id_file, run_id;
 };
 
 struct Decision {
@@ -110,6 +120,8 @@ void ArgMin(const std::vector<double>& table, int n, Decision& d) {
 void RunRank(const Options& opt, int rank, int world, int device, ncclComm_t comm, const twr_model* shared_model,
              std::vector<double>* shared_table, Decision& out) {
   const auto t_start = std::chrono::steady_clock::now();
+  // test hook: --fail-rank R makes rank R fail before its first collective (what an out-of-memory batch would do)
+  if (opt.fail_rank == rank) throw Fail{"injected failure (--fail-rank)"};
   HIP(hipSetDevice(device));
   hipStream_t stream;
   HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -231,6 +243,8 @@ int main(int argc, char** argv) {
     else if (a == "--rank" && i + 1 < argc) opt.rank = std::atoi(argv[++i]);
     else if (a == "--world" && i + 1 < argc) opt.world = std::atoi(argv[++i]);
     else if (a == "--id-file" && i + 1 < argc) opt.id_file = argv[++i];
+    else if (a == "--run-id" && i + 1 < argc) opt.run_id = argv[++i];
+    else if (a == "--fail-rank" && i + 1 < argc) opt.fail_rank = std::atoi(argv[++i]);
     else if (a[0] != '-') opt.n_cand = std::atoi(argv[i]);
     else {
       std::fprintf(stderr, "unknown option %s\n", argv[i]);
@@ -248,25 +262,37 @@ int main(int argc, char** argv) {
       if (opt.world < 1 || opt.rank >= opt.world || opt.id_file.empty()) throw Fail{"--rank needs --world and --id-file"};
       const int device = opt.devices.empty() ? opt.rank % n_dev : opt.devices[0];
       HIP(hipSetDevice(device));
+      const time_t started = time(nullptr);
+      const std::string id_path = opt.run_id.empty() ? opt.id_file : opt.id_file + "." + opt.run_id;
       ncclUniqueId id;
       if (opt.rank == 0) {
+        (void)std::remove(id_path.c_str());   // whatever an earlier run left behind
         NCCL(ncclGetUniqueId(&id));
-        std::ofstream f(opt.id_file + ".tmp", std::ios::binary);
+        std::ofstream f(id_path + ".tmp", std::ios::binary);
         f.write(reinterpret_cast<const char*>(&id), sizeof(id));
         f.close();
-        if (std::rename((opt.id_file + ".tmp").c_str(), opt.id_file.c_str()) != 0) throw Fail{"cannot publish the RCCL id"};
+        if (std::rename((id_path + ".tmp").c_str(), id_path.c_str()) != 0) throw Fail{"cannot publish the RCCL id"};
       } else {
         for (int tries = 0;; ++tries) {
-          std::ifstream f(opt.id_file, std::ios::binary);
-          if (f.read(reinterpret_cast<char*>(&id), sizeof(id))) break;
-          if (tries > 600) throw Fail{"no RCCL id after 60 s"};
+          struct stat st;
+          // without a --run-id the name may be an earlier run's: only a file written around this run's start counts
+          const bool fresh = stat(id_path.c_str(), &st) == 0 && (!opt.run_id.empty() || st.st_mtime >= started - 60);
+          std::ifstream f(id_path, std::ios::binary);
+          if (fresh && f.read(reinterpret_cast<char*>(&id), sizeof(id))) break;
+          if (tries > 600) throw Fail{"no RCCL id after 60 s (" + id_path + ")"};
           std::this_thread::sleep_for(std::chrono::milliseconds(100));
         }
       }
       ncclComm_t comm;
       NCCL(ncclCommInitRank(&comm, opt.world, id, opt.rank));
+      if (opt.rank == 0) (void)std::remove(id_path.c_str());   // init is collective: every rank has read it
       Decision d;
-      RunRank(opt, opt.rank, opt.world, device, comm, nullptr, nullptr, d);
+      try {
+        RunRank(opt, opt.rank, opt.world, device, comm, nullptr, nullptr, d);
+      } catch (const Fail&) {
+        (void)ncclCommAbort(comm);   // peers blocked in a collective with this rank get an error, not a hang
+        throw;
+      }
       NCCL(ncclCommDestroy(comm));
       std::printf("rank %d: shard [%d, %d) on device %d, setup %.3f s\n", opt.rank, d.lo, d.hi, device, d.setup_s);
       std::printf("best candidate %d score %.12e\n", d.best, d.score);
@@ -290,17 +316,27 @@ int main(int argc, char** argv) {
     }
     std::vector<Decision> dec(world);
     std::vector<std::thread> pool;
+    std::atomic<bool> failed{false};
     for (int r = 0; r < world; ++r)
       pool.emplace_back([&, r] {
         try {
           RunRank(opt, r, world, opt.devices[r], comms[r], &shared_model, &shared_table, dec[r]);
         } catch (const Fail& f) {
           dec[r].error = f.what;
+          // The peers may be sitting in ncclBroadcast / ncclAllGather (or in the stream synchronisation behind one) waiting
+          // for this rank: abort every communicator, once, so that they come back with an error and join() returns.
+          if (!failed.exchange(true))
+            for (ncclComm_t c : comms)
+              if (c) (void)ncclCommAbort(c);
         }
       });
     for (auto& t : pool) t.join();
-    for (ncclComm_t c : comms)
-      if (c) (void)ncclCommDestroy(c);
+    if (!failed.load())
+      for (ncclComm_t c : comms)
+        if (c) (void)ncclCommDestroy(c);   // (an aborted communicator is already gone)
+    // the first failure is the cause; the errors of the aborted peers are its consequence
+    for (int r = 0; r < world; ++r)
+      if (!dec[r].error.empty() && dec[r].error.find("nccl") == std::string::npos) throw Fail{"rank " + std::to_string(r) + ": " + dec[r].error};
     for (int r = 0; r < world; ++r)
       if (!dec[r].error.empty()) throw Fail{"rank " + std::to_string(r) + ": " + dec[r].error};
     if (!opt.collective)

@@ -256,7 +256,12 @@ int twr_batch_layout(const twr_batch* b, int64_t* x_off, int64_t* g_off, int64_t
  * returns; it neither reads nor clears the thread's sticky HIP error (every launch returns its own status, which is
  * what a TWR_ERR_HIP result reports).  At most ONE evaluation of a given batch may
  * be in flight at a time (batches with optimised timings keep per-batch scratch records; the profiling
- * counters are per batch too): serialise evaluations of one batch on one stream, use one batch per stream. */
+ * counters are per batch too): serialise evaluations of one batch on one stream, use one batch per stream.
+ * REPRODUCIBILITY: for a FIXED value of `flags` a given x gives bit-identical g / Jacobian values wherever the problem sits
+ * in a batch, on every device and rank.  The kernels are instantiated per output selection, and the selections (values
+ * only / Jacobian only / both) agree with each other to rounding (<= 1e-13 of the set scale), NOT bit for bit.  A sweep
+ * that compares candidates across ranks or calls must therefore score all of them with the SAME flags (near-tied
+ * candidates could otherwise be ranked differently); twr_batch_score / twr_batch_best are deterministic given g. */
 int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, int flags, void* hip_stream);
 /* Failure detection (the reference only has Release-mode-silent asserts, spline.cc:52,65): after an evaluation with
  * TWR_EVAL_CHECK, h_status[p] has bit 0 set if a constraint value of problem p is NaN/Inf and bit 1 if a Jacobian

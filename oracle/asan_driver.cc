@@ -159,6 +159,13 @@ static void policy_case() {
   CHECK(!twr::StreamNonTemporal(1, 8192, 8192 * per), "policy: one structure for 8192 problems keeps plain stores");
   CHECK(!twr::StreamNonTemporal(1024, 4096, 4096 * per), "policy: four problems per structure keep plain stores");
   CHECK(twr::StreamNonTemporal(1024, 2048, 2048 * per), "policy: two problems per structure stream");
+  // the threshold is the device's memory-side cache, by architecture name: MI355X / MI300X 256 MB, a CPX
+  // partition its share, an unknown device eight times its L2 -- where a 384-candidate sweep keeps plain stores
+  CHECK(twr::MemorySideCacheBytes("gfx950:sramecc+:xnack-", 4 << 20) == ((int64_t)256 << 20), "cache: gfx950");
+  CHECK(twr::MemorySideCacheBytes("gfx942", 4 << 20, 8) == ((int64_t)32 << 20), "cache: a CPX partition of gfx942");
+  CHECK(twr::MemorySideCacheBytes("gfx90a", 8 << 20) == ((int64_t)64 << 20), "cache: unknown architecture");
+  CHECK(twr::StreamNonTemporal(128, 128, 128 * per, twr::MemorySideCacheBytes("gfx90a", 8 << 20)), "policy: follows the device's cache");
+  CHECK(!twr::StreamNonTemporal(256, 256, 256 * per, twr::MemorySideCacheBytes("gfx950", 4 << 20)), "policy: MI355X as measured");
 }
 
 int main() {

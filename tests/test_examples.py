@@ -109,6 +109,32 @@ def test_cpp_multi_gpu_example_picks_the_python_paths_candidate():
 
 
 @pytest.mark.gpu
+def test_cpp_multi_gpu_example_fails_fast_instead_of_hanging():
+    """a rank that fails before a collective must not leave the process hanging in join().  A failure is injected
+    (--fail-rank) into (a) the RCCL world of one rank -- its thread aborts the communicator, (b) rank 1 of three no-collective
+    ranks on device 0; both must exit with status 1 and name the cause, well inside the timeout.  (c) process mode with a
+    STALE id file from "an earlier run" beside a fresh --run-id: the stale file is never read."""
+    import tempfile
+    import time
+
+    exe = _build_multi()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for cmd in ([exe, "32", "--fail-rank", "0"], [exe, "48", "--no-collective", "--devices", "0,0,0", "--fail-rank", "1"]):
+        t0 = time.time()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 1 and "injected failure" in r.stderr, " ".join(cmd) + "\n" + r.stdout + r.stderr
+        assert time.time() - t0 < 120
+    with tempfile.TemporaryDirectory() as tmp:
+        stale = os.path.join(tmp, "rccl_id")
+        with open(stale, "wb") as f:
+            f.write(b"\0" * 128)            # an earlier run's id under the bare name
+        r = subprocess.run([exe, "32", "--rank", "0", "--world", "1", "--id-file", stale, "--run-id", "run%d" % os.getpid()],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "best candidate" in r.stdout, r.stdout + r.stderr
+        assert os.path.exists(stale) and not os.path.exists(stale + ".run%d" % os.getpid())   # ours was removed after init, theirs untouched
+
+
+@pytest.mark.gpu
 def test_cpp_example_sweep_agrees_with_ctypes_path():
     import torch
 

@@ -86,6 +86,7 @@ struct twr_batch {
   int n_dyn = 0, n_rom = 0, n_node = 0, n_cu = 0;
   int node_families = 4;                     // 2 when no problem has more than terrain-* / force-* work for the node kernel
   int rom_max_vals = 0;                      // Jacobian values of the largest rom slice (picks the copy-out length)
+  int64_t cache_bytes = 0;                   // memory-side cache of the batch's device (structure.h MemorySideCacheBytes)
   bool stream_nt = false;                    // non-temporal copy-out stores in dyn_kernel / rom_kernel / the fused kernel (set by twr_batch_create)
   int dyn_map_chunks = 2;                    // 2: every dyn slice of the batch stages <= 128 doubles of x (256-byte staging maps), else 4
   std::vector<int64_t> x_off, g_off, j_off;  // n_problems+1
@@ -527,6 +528,8 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     hipDeviceProp_t prop;
     TWR_HIP(hipGetDeviceProperties(&prop, device));
     b->n_cu = prop.multiProcessorCount;
+    // (a compute partition -- CPX -- shows up as a device with a fraction of the chip's CUs: its share of the cache follows)
+    b->cache_bytes = twr::MemorySideCacheBytes(prop.gcnArchName, prop.l2CacheSize, 1);
     std::vector<twr::DynWork> dyn;
     std::vector<twr::RomWork> rom;
     std::vector<twr::NodeWork> node;
@@ -710,7 +713,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     b->n_rom = (int)rom.size();
     // Store policy of the copy-out (kernels.hip copy_out_fixed): non-temporal when the batch is SWEEP-LIKE -- fewer than four
     // problems per structure on average, so every evaluation re-reads tables (and x) that only that problem uses -- AND one
-    // evaluation writes more than the Infinity Cache holds (256 MB on an MI355X), so that plain stores would flush those
+    // evaluation writes more than the device's memory-side cache holds (256 MB on an MI355X; by architecture name, structure.h), so that plain stores would flush those
     // tables out of it between two evaluations.  Measured (one box, no per-kernel events): the C5 sweep at 512 /
     // 1024 candidates 116-118 / 223-224 -> 99 / 209-211 us per step; at 256 candidates (220 MB of output, absorbed by the
     // Infinity Cache as it is) 52 -> 55 us, and 8192 problems of ONE structure lose 15 % in rom_kernel -- hence the two conditions.
@@ -723,7 +726,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
           ++n_used;
         }
       const int64_t out_bytes = 8 * (b->g_off[n_problems] + b->j_off[n_problems]);
-      b->stream_nt = twr::StreamNonTemporal(n_used, n_problems, out_bytes);
+      b->stream_nt = twr::StreamNonTemporal(n_used, n_problems, out_bytes, b->cache_bytes);
 #ifdef TWR_TUNING_KNOBS   // (include/towr_amd.h, "Tuning knobs")
       if (const char* e = getenv("TWR_STREAM_NT")) b->stream_nt = atoi(e) != 0;
 #endif
@@ -952,6 +955,8 @@ int twr_batch_profile_begin(twr_batch* b, int max_evals) {
 int twr_batch_profile_end(twr_batch* b, double avg_ms[3], int* n_evals) {
   if (!b || !avg_ms) return fail(TWR_ERR_INVALID, "null argument");
   try {
+    DeviceScope on(b->device);   // (events belong to the batch's device, like in _begin)
+    TWR_HIP(on.status);
     const int n = b->prof_count;
     avg_ms[0] = avg_ms[1] = avg_ms[2] = 0.0;
     if (n > 0) {
@@ -978,11 +983,15 @@ int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_
     DeviceScope on(b->device);
     TWR_HIP(on.status);
     const size_t nx = b->x_off.back(), ng = b->g_off.back(), nj = b->j_off.back();
-    if (!b->d_x) {
-      TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_x), nx * sizeof(double)));
-      TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_g), ng * sizeof(double)));
-      TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_j), nj * sizeof(double)));
-    }
+    // device staging buffers, each on first need (the zero-copy branch below needs none of them: a single-problem adapter
+    // batch that only ever hands over its own page-locked buffers allocates nothing in HBM here)
+    auto need_x = [&]() {
+      if (!b->d_x) TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_x), nx * sizeof(double)));
+    };
+    auto need_out = [&]() {
+      if (!b->d_g) TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_g), ng * sizeof(double)));
+      if (!b->d_j) TWR_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_j), nj * sizeof(double)));
+    };
     if (!b->host_stream) TWR_HIP(hipStreamCreateWithFlags(&b->host_stream, hipStreamNonBlocking));
     hipStream_t hs = b->host_stream;
     // one stream-ordered chain on the batch's own stream and a single synchronisation (with page-locked buffers the copies are DMA)
@@ -993,10 +1002,12 @@ int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_
     const bool zero_copy = true, zero_copy_x = true;
 #endif
     const bool zc = zero_copy && b->p_g && h_g == b->p_g && h_jac == b->p_j && nj * sizeof(double) <= (size_t)(32u << 20);
-    const double* dx = b->d_x;
+    const double* dx = nullptr;
     if (zc && zero_copy_x && h_x == b->p_x) {   // x too: the kernels gather it straight from the page-locked buffer
       TWR_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(const_cast<double**>(&dx)), b->p_x, 0));
     } else {
+      need_x();
+      dx = b->d_x;
       TWR_HIP(hipMemcpyAsync(b->d_x, h_x, nx * sizeof(double), hipMemcpyHostToDevice, hs));
     }
     if (zc) {
@@ -1011,7 +1022,8 @@ int twr_batch_eval_host(twr_batch* b, const double* h_x, double* h_g, double* h_
       TWR_HIP(hipStreamSynchronize(hs));
       return TWR_OK;
     }
-    int rc = twr_batch_eval(b, b->d_x, b->d_g, b->d_j, flags, hs);
+    need_out();
+    int rc = twr_batch_eval(b, dx, b->d_g, b->d_j, flags, hs);
     if (rc != TWR_OK) return rc;
     if ((flags & TWR_EVAL_VALUES) && h_g)
       TWR_HIP(hipMemcpyAsync(h_g, b->d_g, ng * sizeof(double), hipMemcpyDeviceToHost, hs));

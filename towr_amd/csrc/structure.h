@@ -132,9 +132,21 @@ LayoutShare ShareLayoutTables(const std::vector<const Structure*>& structs);
 // Store policy of a batch (kernels.hip copy_out_fixed): non-temporal stores for SWEEP-LIKE batches -- fewer than
 // four problems per structure on average, so that every evaluation re-reads tables and x that only one problem uses -- whose
 // evaluation writes more than the Infinity Cache holds, so that plain stores would flush those tables out of it.
-constexpr int64_t kInfinityCacheBytes = (int64_t)256 << 20;   // MI355X
-inline bool StreamNonTemporal(int structures_used, int n_problems, int64_t output_bytes_per_evaluation) {
-  return (int64_t)structures_used * 4 > n_problems && output_bytes_per_evaluation > kInfinityCacheBytes;
+// The memory-side cache is a property of the DEVICE the batch lives on (HIP reports no field for it -- hipDeviceProp_t has
+// l2CacheSize, the per-XCD L2 --, so it is a table by architecture name; a partitioned device, CPX / NPS4, sees its share):
+//   gfx950 (MI350X / MI355X), gfx942 (MI300X / MI300A / MI325X): 256 MB;  anything else: eight times the L2 it reports
+//   (a conservative stand-in: plain stores are the safe policy, they are never more than a few percent behind on a sweep,
+//   while non-temporal stores cost rom_kernel 10-15 % where nothing needs protecting).
+inline int64_t MemorySideCacheBytes(const char* gcn_arch_name, int64_t l2_bytes, int compute_partitions = 1) {
+  const std::string arch = gcn_arch_name ? gcn_arch_name : "";
+  int64_t bytes = 8 * l2_bytes;
+  if (arch.rfind("gfx950", 0) == 0 || arch.rfind("gfx942", 0) == 0) bytes = (int64_t)256 << 20;
+  return bytes / (compute_partitions > 0 ? compute_partitions : 1);
+}
+constexpr int64_t kInfinityCacheBytes = (int64_t)256 << 20;   // MI355X (what the measurements of DESIGN 6.R4 were taken on)
+inline bool StreamNonTemporal(int structures_used, int n_problems, int64_t output_bytes_per_evaluation,
+                              int64_t memory_side_cache_bytes = kInfinityCacheBytes) {
+  return (int64_t)structures_used * 4 > n_problems && output_bytes_per_evaluation > memory_side_cache_bytes;
 }
 void GaitCombo(int n_ee, int combo, double t_total, double swing_scale, twr_schedule* out);
 void ModelPreset(int robot, int terrain, twr_model* out);
