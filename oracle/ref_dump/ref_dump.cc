@@ -11,6 +11,11 @@
 //                        "<in contact at start 0|1> <d0> <d1> ..." (what the fixtures and the sweep candidates carry)
 //     --dt DYN ROM       dt_constraint_dynamic_ / dt_constraint_range_of_motion_ (BASELINE sizes: T / (K - 1.5))
 //     --csv FILE         terrain = HeightMapFromCSV(FILE) instead of <terrain id>
+//     --grid-map FILE RES PX PY   terrain = the `Grid` height map fpowr runs on (towr/include/towr/terrain/grid_height_map.h,
+//                        fpowr/src/footstep_plan_server.cc:155) over the float "elevation" layer in FILE (first line
+//                        "<size_x> <size_y>", then size_x * size_y values, x index fastest = grid_map's column-major
+//                        storage), resolution RES, map position (PX, PY).  Needs grid_map_ros and
+//                        convex_plane_decomposition_msgs (ROS) on the box: exit code 4 where they are missing
 //     --binding          ALSO build the device sets through towr_amd/csrc/towr_binding.h on the same NlpFormulation and
 //                        compare them with the reference's own sets on this x: names, rows, bounds, values, Jacobian
 //                        (needs -DTOWR_AMD_ROOT=<repository> at configure time, libtowr_amd.so and a GPU); exit code 3
@@ -20,6 +25,10 @@
 #include <towr/nlp_formulation.h>
 #include <towr/terrain/examples/height_map_examples.h>
 #include <towr/terrain/height_map_from_csv.h>
+#if __has_include(<grid_map_ros/grid_map_ros.hpp>) && __has_include(<convex_plane_decomposition_msgs/PlanarTerrain.h>)
+#include <towr/terrain/grid_height_map.h>
+#define TWR_REF_HAVE_GRID_MAP 1
+#endif
 
 #include <cmath>
 #include <cstdio>
@@ -42,13 +51,19 @@ int main(int argc, char** argv) {
   const int mask = std::atoi(argv[5]);
   const std::string xfile = argv[6], prefix = argv[8];
   const double goal_x = std::atof(argv[7]);
-  std::string phases_file, csv_file;
-  double dt_dyn = 0.0, dt_rom = 0.0;
+  std::string phases_file, csv_file, grid_file;
+  double dt_dyn = 0.0, dt_rom = 0.0, grid_res = 0.0, grid_px = 0.0, grid_py = 0.0;
   bool binding = false;
   for (int i = 9; i < argc; ++i) {
     const std::string a = argv[i];
     if (a == "--phases" && i + 1 < argc) phases_file = argv[++i];
     else if (a == "--csv" && i + 1 < argc) csv_file = argv[++i];
+    else if (a == "--grid-map" && i + 4 < argc) {
+      grid_file = argv[++i];
+      grid_res = std::atof(argv[++i]);
+      grid_px = std::atof(argv[++i]);
+      grid_py = std::atof(argv[++i]);
+    }
     else if (a == "--dt" && i + 2 < argc) {
       dt_dyn = std::atof(argv[++i]);
       dt_rom = std::atof(argv[++i]);
@@ -60,7 +75,33 @@ int main(int argc, char** argv) {
   }
 
   towr::NlpFormulation f;
-  if (csv_file.empty()) f.terrain_ = towr::HeightMap::MakeTerrain(static_cast<towr::HeightMap::TerrainID>(terrain));
+#ifdef TWR_REF_HAVE_GRID_MAP
+  std::shared_ptr<grid_map::GridMap> ref_grid_map;   // (kept for --binding: the device side is built from the same map)
+#endif
+  if (!grid_file.empty()) {
+#ifdef TWR_REF_HAVE_GRID_MAP
+    // the message fpowr's action goal carries (args->terrain): a grid_map with an "elevation" layer
+    std::ifstream in(grid_file);
+    int sx = 0, sy = 0;
+    in >> sx >> sy;
+    grid_map::GridMap map({"elevation"});
+    map.setGeometry(grid_map::Length(sx * grid_res, sy * grid_res), grid_res, grid_map::Position(grid_px, grid_py));
+    if (map.getSize()(0) != sx || map.getSize()(1) != sy) {
+      std::fprintf(stderr, "grid_map made a %d x %d map of the %d x %d layer\n", map.getSize()(0), map.getSize()(1), sx, sy);
+      return 2;
+    }
+    grid_map::Matrix& e = map["elevation"];
+    for (int j = 0; j < sy; ++j)
+      for (int i = 0; i < sx; ++i) in >> e(i, j);
+    convex_plane_decomposition_msgs::PlanarTerrain msg;
+    grid_map::GridMapRosConverter::toMessage(map, msg.gridmap);
+    f.terrain_ = std::make_shared<Grid>(msg);
+    ref_grid_map = std::make_shared<grid_map::GridMap>(map);
+#else
+    std::fprintf(stderr, "--grid-map: grid_map_ros / convex_plane_decomposition_msgs are not on this box\n");
+    return 4;
+#endif
+  } else if (csv_file.empty()) f.terrain_ = towr::HeightMap::MakeTerrain(static_cast<towr::HeightMap::TerrainID>(terrain));
   else f.terrain_ = std::make_shared<HeightMapFromCSV>(csv_file);
   f.model_ = towr::RobotModel(static_cast<towr::RobotModel::Robot>(robot));
   const auto nominal = f.model_.kinematic_model_->GetNominalStanceInBase();
@@ -137,8 +178,15 @@ int main(int argc, char** argv) {
     towr::SplineHolder solution2;
     for (auto c : f.GetVariableSets(solution2)) dev.AddVariableSet(c);
     towr_amd::DeviceTerrain csv_terrain;
+    bool own_terrain = !csv_file.empty();
     if (!csv_file.empty()) csv_terrain = towr_amd::CsvTerrain(csv_file);
-    const auto sets = towr_amd::MakeDeviceConstraints(f, 0, csv_file.empty() ? nullptr : &csv_terrain);
+#if defined(TWR_REF_HAVE_GRID_MAP) && defined(TOWR_AMD_HAVE_GRID_MAP)
+    if (ref_grid_map) {
+      csv_terrain = towr_amd::GridTerrain(*ref_grid_map);
+      own_terrain = true;
+    }
+#endif
+    const auto sets = towr_amd::MakeDeviceConstraints(f, 0, own_terrain ? &csv_terrain : nullptr);
     const auto ref_sets = f.GetConstraints(solution2);
     int bad = sets.size() != ref_sets.size();
     for (size_t i = 0; !bad && i < sets.size(); ++i)

@@ -57,8 +57,20 @@ def test_reference_build_recipe_reports_its_availability(tmp_path):
                 f.write("%d %s\n" % (int(con), " ".join("%.17g" % v for v in d["phase_durations"][o:o + k])))
                 o += k
         dt = [float(d["dt_dynamic"]), float(d["dt_rom"])] if "dt_dynamic" in d.files else [0.1, 0.08]
-        subprocess.check_call([os.path.join(REF, "ref_dump"), str(robots[str(d["robot"])]), str(terrains[str(d["terrain"])]), "0", "0",
-                               str(sets), prefix + "_xin.txt", "1.0", prefix, "--phases", prefix + "_phases.txt", "--dt", str(dt[0]), str(dt[1])])
+        cmd = [os.path.join(REF, "ref_dump"), str(robots[str(d["robot"])]), str(terrains.get(str(d["terrain"]), 0)), "0", "0",
+               str(sets), prefix + "_xin.txt", "1.0", prefix, "--phases", prefix + "_phases.txt", "--dt", str(dt[0]), str(dt[1])]
+        if str(d["terrain"]) == "grid_map":   # the fpowr fixture: the real `Grid` over the fixture's elevation layer (needs ROS packages)
+            el = d["grid_elevation"]
+            with open(prefix + "_grid.txt", "w") as f:
+                f.write("%d %d\n" % el.shape)
+                f.write("\n".join("%.9g" % v for v in el.reshape(-1, order="F")) + "\n")
+            cmd += ["--grid-map", prefix + "_grid.txt", "%.17g" % float(d["grid_resolution"]), "%.17g" % d["grid_position"][0],
+                    "%.17g" % d["grid_position"][1]]
+        rc = subprocess.call(cmd)
+        if rc == 4 and str(d["terrain"]) == "grid_map":
+            print("skipped %s: grid_map_ros / convex_plane_decomposition_msgs are not on this box" % os.path.basename(path))
+            continue
+        assert rc == 0, cmd
         g = np.loadtxt(prefix + "_g.txt")
         trip = np.loadtxt(prefix + "_jac.txt")
         og, rp, ci, ov = P.eval(d["x"])
