@@ -311,27 +311,27 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
     best_d = torch.zeros(2, dtype=torch.float64, device=dev)
     best_h = torch.zeros(2, dtype=torch.float64).pin_memory()
 
-    def planner_enqueue():
+    def planner_enqueue():   # values -> scores -> this shard's decision (twr_batch_score_best: two launches behind one call)
         batch.eval_device(x.data_ptr(), g.data_ptr(), 0, ta.EVAL_VALUES, stream)
-        batch.score_device(g.data_ptr(), scores.data_ptr(), stream)
-        table = scores
-        if dist_on(world):
-            table = gather_scores(scores if backend == "nccl" else scores.cpu(), sizes)
-            if backend != "nccl":
-                table = table.to(dev)
-        batch.best_device(table.data_ptr(), table.shape[0], best_d.data_ptr(), stream=stream)
-        return table
+        batch.score_best_device(g.data_ptr(), scores.data_ptr(), best_d.data_ptr(), index_offset=lo, stream=stream)
 
     def planner_step():   # one decision per step ON THE HOST: the 16-byte copy and its synchronisation are part of the step
-        table = planner_enqueue()
+        planner_enqueue()
+        if dist_on(world):   # every rank's 16-byte decision, all-gathered; the winner on every rank
+            from towr_amd.dist import gather_best
+            return gather_best(best_d if backend == "nccl" else best_d.cpu()) + (None,)
         best_h.copy_(best_d, non_blocking=True)
         torch.cuda.current_stream().synchronize()
-        return int(best_h[0]), float(best_h[1]), table
+        return int(best_h[0]), float(best_h[1]), None
 
     for _ in range(3):
         best = planner_step()
-    # the device's decision is the host rule's (towr_amd.dist.best_candidate) on the same table
-    assert (best[0], best[1]) == best_candidate(best[2]), (best[:2], best_candidate(best[2]))
+    # the device's decision is the host rule's (towr_amd.dist.best_candidate) on the all-gathered score table
+    torch.cuda.synchronize()
+    table = scores
+    if dist_on(world):
+        table = gather_scores(scores if backend == "nccl" else scores.cpu(), sizes)
+    assert (best[0], best[1]) == best_candidate(table), (best[:2], best_candidate(table))
     torch.cuda.synchronize()
     if dist_on(world):
         dist.barrier()
@@ -376,8 +376,8 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
             # rocprofv3 FETCH_SIZE / WRITE_SIZE passes): every candidate reads its own ~150 KB of tables
             "traffic_ratio": sweep_traffic_ratio(bytes_total) if world == 1 else None,
             "traffic_source": traffic_source() if world == 1 else None,
-            "planner": {"what": "values only -> twr_batch_score -> all-gather of 16 scores per candidate -> twr_batch_best "
-                                "(device arg-min) -> one 16-byte copy to the host + synchronisation per step",
+            "planner": {"what": "values only -> twr_batch_score_best (scores, then this shard's arg-min on the device) -> [all-gather of the "
+                                "ranks' 16-byte decisions] -> one 16-byte copy to the host + synchronisation per step",
                         "steps": p_steps, "value": n_total * p_steps / p_elapsed, "unit": "candidates scored/s",
                         "ms_per_step": p_elapsed / p_steps * 1e3,
                         "ms_per_step_decision_left_on_device": q_elapsed / p_steps * 1e3, "best_candidate": int(best[0])},

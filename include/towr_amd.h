@@ -309,6 +309,13 @@ int twr_batch_score(twr_batch* b, const double* d_g, double* d_scores /* 16 * n_
  * choice). */
 int twr_batch_best(twr_batch* b, const double* d_scores, int32_t n_candidates, uint32_t families, double* d_best /* 2 */,
                    void* hip_stream);
+/* twr_batch_score and twr_batch_best over THIS batch's candidates behind one call (two stream-ordered launches):
+ * d_scores as twr_batch_score, d_best[0] = index_offset + the winning problem's index in the batch
+ * (index_offset = the shard's first candidate: the result is then a global candidate index), d_best[1] = its total.  A
+ * multi-rank sweep all-gathers the ranks' 16-byte results (the smallest total, then the smallest index, wins) instead of
+ * 128 bytes per candidate.  Asynchronous on hip_stream, capturable; shares the scratch of twr_batch_best. */
+int twr_batch_score_best(twr_batch* b, const double* d_g, double* d_scores /* 16 * n_problems */, uint32_t families,
+                         int64_t index_offset, double* d_best /* 2 */, void* hip_stream);
 /* fpowr::ExtractFootstepPlan (fpowr/include/fpowr/footstep_plan_extractor.h:69-133) for every problem of the batch,
  * up to the nearest-plane lookup (twr_batch_contact_planes below): the solution x sampled every dt
  * (GetTrajectory, :19-53), a footstep state at the first sample and wherever HasEndEffectorContactChanged (:55-67)

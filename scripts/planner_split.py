@@ -41,7 +41,12 @@ for B in sizes:
     def all3():
         ev(); sc(); be()
 
+    def fused2():
+        ev()
+        batch.score_best_device(g.data_ptr(), scores.data_ptr(), best.data_ptr(), stream=st)
+
     t_ev, t_sc, t_be, t_all = timed(ev), timed(sc), timed(be), timed(all3)
+    t_f2 = timed(fused2)
     t_both = timed(lambda: batch.eval_device(x.data_ptr(), g.data_ptr(), j.data_ptr(), ta.EVAL_BOTH, st))
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
@@ -63,5 +68,5 @@ for B in sizes:
             graph.replay()
         torch.cuda.synchronize()
         t_graph = (time.perf_counter() - t0) / 300 * 1e6
-    print("B=%4d  values-only eval %.1f us, score %.1f us, best %.1f us, the three %.1f us, from a graph %.1f us;  values + Jacobian %.1f us"
-          % (B, t_ev, t_sc, t_be, t_all, t_graph, t_both), flush=True)
+    print("B=%4d  values-only eval %.1f us, score %.1f us, best %.1f us, the three %.1f us, from a graph %.1f us, values + score_best %.1f us;  values + Jacobian %.1f us"
+          % (B, t_ev, t_sc, t_be, t_all, t_graph, t_f2, t_both), flush=True)

@@ -13,7 +13,7 @@ sys.path.insert(0, os.environ["TWR_ROOT"])
 import numpy as np, torch, torch.distributed as dist
 import towr_amd as ta
 from towr_amd import sweep
-from towr_amd.dist import broadcast_model, broadcast_grid, my_shard, gather_scores, best_candidate
+from towr_amd.dist import broadcast_model, broadcast_grid, my_shard, gather_scores, best_candidate, gather_best
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 model = broadcast_model(ta.model_preset("anymal", "stairs") if rank == 0 else None)
@@ -72,6 +72,14 @@ assert table.shape == (len(cands), 16)
 assert torch.equal(table[:, 0], torch.arange(len(cands), dtype=torch.float64))
 best, score = best_candidate(table, families=(1,))
 assert best == 29 and score == 0.25
+# the lighter exchange: every rank's own 16-byte decision (what twr_batch_score_best leaves on the device: global index,
+# total), all-gathered -- the same winner on every rank; an all-NaN shard loses
+mine_best = best_candidate(local, families=(1,))
+winner = gather_best(torch.tensor([a + mine_best[0], mine_best[1]], dtype=torch.float64))
+assert winner == (29, 0.25), winner
+nan_row = torch.tensor([float(a), float("nan")], dtype=torch.float64) if rank == 0 else torch.tensor([a + 1.0, 7.5], dtype=torch.float64)
+w2 = gather_best(nan_row)
+assert w2[1] == 7.5 and w2[0] >= 1, w2
 oks = [None] * world
 dist.all_gather_object(oks, (rank, int(a), int(b)))
 dist.barrier()
@@ -126,6 +134,10 @@ scores = torch.empty((len(structs), 16), dtype=torch.float64, device=dev)
 batch.score_device(g.data_ptr(), scores.data_ptr(), st)
 table = gather_scores(scores, [len(structs)])           # device tensors through RCCL's all-gather
 assert table.is_cuda and torch.equal(table, scores)
+from towr_amd.dist import gather_best
+best_d = torch.zeros(2, dtype=torch.float64, device=dev)
+batch.score_best_device(g.data_ptr(), scores.data_ptr(), best_d.data_ptr(), stream=st)
+assert gather_best(best_d) == best_candidate(table)     # the 16-byte decision through RCCL
 t = torch.tensor([1.5], dtype=torch.float64, device=dev)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 dist.barrier()

@@ -924,6 +924,16 @@ def test_candidate_scores_and_contact_plans():
     batch.score_device(g.data_ptr(), scores.data_ptr(), st)
     torch.cuda.synchronize()
     sc = scores.cpu().numpy()
+    # ... and the one-launch form: the same scores bit for bit, plus the shard's decision (twr_batch_score_best)
+    from towr_amd.dist import best_candidate
+    scores2 = torch.full((len(order), 16), -1.0, dtype=torch.float64, device=dev)
+    best = torch.zeros(2, dtype=torch.float64, device=dev)
+    for fam in ((0, 1, 3, 4), (1, 4)):
+        batch.score_best_device(g.data_ptr(), scores2.data_ptr(), best.data_ptr(), families=fam, index_offset=1000, stream=st)
+        torch.cuda.synchronize()
+        assert np.array_equal(scores2.cpu().numpy(), sc, equal_nan=True)
+        idx, total = best_candidate(scores, families=fam)
+        assert (int(best[0]), float(best[1])) == (1000 + idx, total)
     for p, s in enumerate(order):
         S = cases[s].S
         rg = cases[s].P.values(xs[p])

@@ -143,6 +143,7 @@ def lib():
         L.twr_batch_initial_guess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
         L.twr_batch_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.twr_batch_best.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.twr_batch_score_best.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p]
         L.twr_structure_contact_steps_max.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.twr_planes_create.argtypes = [_dp, _dp, C.POINTER(C.c_int32), C.c_int32, C.c_int, C.POINTER(C.c_void_p)]
         L.twr_planes_destroy.argtypes = [C.c_void_p]
@@ -463,6 +464,15 @@ class Batch:
     def score_device(self, d_g, d_scores, stream=0):
         """twr_batch_score: d_scores[16 p + 2 f + {0: inf-norm, 1: 1-norm}] of the bound violation per family f."""
         _check(lib().twr_batch_score(self._h, C.c_void_p(d_g), C.c_void_p(d_scores), C.c_void_p(stream)))
+
+    def score_best_device(self, d_g, d_scores, d_best, families=(0, 1, 3, 4), index_offset=0, stream=0):
+        """twr_batch_score_best: score_device + best_device over this batch's candidates behind one call; d_best[0] is
+        index_offset + the winner's index in the batch."""
+        mask = 0
+        for f in families:
+            mask |= 1 << int(f)
+        _check(lib().twr_batch_score_best(self._h, C.c_void_p(d_g), C.c_void_p(d_scores), mask, int(index_offset), C.c_void_p(d_best),
+                                          C.c_void_p(stream)))
 
     def best_device(self, d_scores, n_candidates, d_best, families=(0, 1, 3, 4), stream=0):
         """twr_batch_best: device arg-min of the summed inf-norm violations of `families` (indices into FAMILIES) over a

@@ -30,7 +30,8 @@ hipError_t launch_check(int n_problems, const int64_t* g_off, const int64_t* j_o
                         int32_t* status, int flags, hipStream_t stream);
 hipError_t launch_score(const NodeWork* work, int n_problems, const double* g, double* scores, hipStream_t stream);
 int best_max_blocks();
-hipError_t launch_best(const double* scores, int n, unsigned families, double* partial, unsigned* counter, double* best, hipStream_t stream);
+hipError_t launch_best(const double* scores, int n, unsigned families, double* partial, unsigned* counter, double* best, double index_offset,
+                       hipStream_t stream);
 hipError_t launch_contact_plan(const NodeWork* work, int n_problems, const double* x, double* out, int32_t* counts, double dt,
                                double time_horizon, int n_samples_max, int max_steps, hipStream_t stream);
 hipError_t launch_planes(const double* plan, const int32_t* counts, const double* poly_xy, const int32_t* poly_start, int n_polys,
@@ -1203,6 +1204,23 @@ int twr_batch_score(twr_batch* b, const double* d_g, double* d_scores, void* hip
   return TWR_OK;
 }
 
+int twr_batch_score_best(twr_batch* b, const double* d_g, double* d_scores, uint32_t families, int64_t index_offset, double* d_best,
+                         void* hip_stream) {
+  if (!b || !d_g || !d_scores || !d_best) return fail(TWR_ERR_INVALID, "null argument");
+  if (!(families & 0xffu) || (families & ~0xffu)) return fail(TWR_ERR_INVALID, "families must be a non-empty mask of the eight TWR_SET_* bits");
+  DeviceScope on(b->device);
+  if (on.status != hipSuccess) return fail(TWR_ERR_HIP, "hipSetDevice failed");
+  // two launches behind one call: the scores, then the arg-min over this batch's rows.  (One launch -- the scoring kernel's
+  // last workgroup taking the decision behind a block counter -- was built and measured: 1024 atomics on one address cost
+  // more than the launch they save, 73 vs 63 us per planner step of 1024 candidates)
+  unsigned* counter = reinterpret_cast<unsigned*>(b->d_best + 2 * (size_t)twr::best_max_blocks());
+  hipError_t e = twr::launch_score(b->d_node, b->n_problems, d_g, d_scores, static_cast<hipStream_t>(hip_stream));
+  if (e == hipSuccess)
+    e = twr::launch_best(d_scores, b->n_problems, families, b->d_best, counter, d_best, (double)index_offset, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  return TWR_OK;
+}
+
 int twr_batch_best(twr_batch* b, const double* d_scores, int32_t n_candidates, uint32_t families, double* d_best, void* hip_stream) {
   if (!b || !d_scores || !d_best) return fail(TWR_ERR_INVALID, "null argument");
   if (n_candidates < 1) return fail(TWR_ERR_INVALID, "twr_batch_best needs at least one candidate");
@@ -1210,7 +1228,7 @@ int twr_batch_best(twr_batch* b, const double* d_scores, int32_t n_candidates, u
   DeviceScope on(b->device);
   if (on.status != hipSuccess) return fail(TWR_ERR_HIP, "hipSetDevice failed");
   unsigned* counter = reinterpret_cast<unsigned*>(b->d_best + 2 * (size_t)twr::best_max_blocks());
-  hipError_t e = twr::launch_best(d_scores, n_candidates, families, b->d_best, counter, d_best, static_cast<hipStream_t>(hip_stream));
+  hipError_t e = twr::launch_best(d_scores, n_candidates, families, b->d_best, counter, d_best, 0.0, static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   return TWR_OK;
 }

@@ -1439,7 +1439,13 @@ __global__ __launch_bounds__(256, 4) void node_kernel(const NodeWork* __restrict
                                                    double* __restrict__ g, double* __restrict__ jac, int flags) {
   __shared__ __attribute__((aligned(16))) double stage_all[kStageTerrain + kStageForce + kStageAcc + kStageSwing];
   const int family = threadIdx.x >> 6;  // wave-uniform
-  node_body(work[blockIdx.x], x, g, jac, flags, stage_all + kNodeStageOff[family], family, threadIdx.x & 63);
+  // (one call site per CONSTANT family: each wave's code holds its own family's body only)
+  const NodeWork w = work[blockIdx.x];
+  const int lane = threadIdx.x & 63;
+  if (family == 0) node_body(w, x, g, jac, flags, stage_all + kNodeStageOff[0], 0, lane);
+  else if (family == 1) node_body(w, x, g, jac, flags, stage_all + kNodeStageOff[1], 1, lane);
+  else if (family == 2) node_body(w, x, g, jac, flags, stage_all + kNodeStageOff[2], 2, lane);
+  else node_body(w, x, g, jac, flags, stage_all + kNodeStageOff[3], 3, lane);
 }
 
 // Batches whose problems carry terrain-* and force-* sets only (the hot-path sets): workgroups of those two families.
@@ -1450,7 +1456,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4))) void n
                                                     double* __restrict__ g, double* __restrict__ jac, int flags) {
   __shared__ __attribute__((aligned(16))) double stage_all[kStageTerrain + kStageForce];
   const int family = threadIdx.x >> 6;  // wave-uniform
-  node_body(work[blockIdx.x], x, g, jac, flags, stage_all + kNodeStageOff[family], family, threadIdx.x & 63);
+  // (two call sites with a CONSTANT family: the bodies of the other families are not compiled into this kernel, and the
+  // register allocation is that of terrain / force alone)
+  if (family == 0) node_body(work[blockIdx.x], x, g, jac, flags, stage_all + kNodeStageOff[0], 0, threadIdx.x & 63);
+  else node_body(work[blockIdx.x], x, g, jac, flags, stage_all + kNodeStageOff[1], 1, threadIdx.x & 63);
 }
 
 // ---------------------------------------------------------------- node-based sets of large batches: persistent chunks
@@ -2754,6 +2763,12 @@ hipError_t launch_sample(const SampleWork* work, int n_work, const double* x, do
 // running (max, sum) pair and hands it to its LDS cell when the slot moves on.  Round 4's kernel fetched a cold candidate's
 // fields one s_load at a time and 16 bytes of bounds per row: 25 us for 128 candidates, 43 us for 1024.
 TWR_DEV double nan_max(double a, double b) { return (a != a || b != b) ? (a != a ? a : b) : fmax(a, b); }
+__device__ __forceinline__ void best_of(double& v, int& i, double ov, int oi) {
+  if (ov < v || (ov == v && oi < i)) {
+    v = ov;
+    i = oi;
+  }
+}
 __global__ __launch_bounds__(256) void score_kernel(const NodeWork* __restrict__ work, const double* __restrict__ g,
                                                     double* __restrict__ scores) {
   constexpr int kHeadDwords = kScoreHeadBytes / 4, kTabDwords = (int)(sizeof(ScoreTables) / 4);
@@ -2852,14 +2867,8 @@ hipError_t launch_score(const NodeWork* work, int n_problems, const double* g, d
 // every rank).  Same rule as towr_amd.dist.best_candidate: families summed in ascending order, NaN loses, first index wins
 // a tie.  One launch: every block reduces its stride of candidates, the last block to finish reduces the blocks' results
 // (threadfence + counter, reset for the next call) and writes best[0] = index, best[1] = its total.
-__device__ __forceinline__ void best_of(double& v, int& i, double ov, int oi) {
-  if (ov < v || (ov == v && oi < i)) {
-    v = ov;
-    i = oi;
-  }
-}
 __global__ __launch_bounds__(256) void best_kernel(const double* __restrict__ scores, int n, unsigned families, double* __restrict__ partial,
-                                                   unsigned* __restrict__ counter, double* __restrict__ best) {
+                                                   unsigned* __restrict__ counter, double* __restrict__ best, double index_offset) {
   __shared__ double s_v[4];
   __shared__ int s_i[4];
   __shared__ bool s_last;
@@ -2907,16 +2916,17 @@ __global__ __launch_bounds__(256) void best_kernel(const double* __restrict__ sc
   __syncthreads();
   block_reduce();
   if (tid == 0) {
-    best[0] = (double)(bi == 0x7fffffff ? 0 : bi);
+    best[0] = index_offset + (double)(bi == 0x7fffffff ? 0 : bi);
     best[1] = bv;
     *counter = 0u;
   }
 }
 int best_max_blocks() { return 256; }
-hipError_t launch_best(const double* scores, int n, unsigned families, double* partial, unsigned* counter, double* best, hipStream_t stream) {
+hipError_t launch_best(const double* scores, int n, unsigned families, double* partial, unsigned* counter, double* best, double index_offset,
+                       hipStream_t stream) {
   int blocks = (n + 1023) / 1024;   // >= four candidates per thread before another block pays
   blocks = blocks < 1 ? 1 : (blocks > best_max_blocks() ? best_max_blocks() : blocks);
-  return twr_launch(best_kernel, dim3(blocks), dim3(256), 0, stream, scores, n, families, partial, counter, best);
+  return twr_launch(best_kernel, dim3(blocks), dim3(256), 0, stream, scores, n, families, partial, counter, best, index_offset);
 }
 
 // ---------------------------------------------------------------- contact plan

@@ -91,3 +91,18 @@ def best_candidate(table, families=(0, 1, 3, 4)):
     total = torch.where(torch.isnan(total), torch.full_like(total, float("inf")), total)
     idx = int(torch.argmin(total))
     return idx, float(total[idx])
+
+
+def gather_best(local_best):
+    """All-gather of every rank's 16-byte decision (twr_batch_score_best with index_offset = the shard's first candidate:
+    [global candidate index, total]); returns the winner (index, total) on every rank -- the smallest total, on a tie the
+    smallest index (ranks hold ascending candidate ranges, so the first minimum is it); a NaN total loses."""
+    import torch
+    import torch.distributed as dist
+
+    rows = [torch.empty_like(local_best) for _ in range(dist.get_world_size())]
+    dist.all_gather(rows, local_best)
+    table = torch.stack(rows)
+    total = torch.where(torch.isnan(table[:, 1]), torch.full_like(table[:, 1], float("inf")), table[:, 1])
+    r = int(torch.argmin(total))
+    return int(table[r, 0]), float(total[r])
