@@ -228,7 +228,7 @@ def traffic_from_profile(workload, kernel, problems_per_gpu):
 def traffic_source():
     """Where roofline.traffic comes from: it is NOT measured by this run (PMC counters need rocprofv3 around the process);
     it is the committed profile of the same kernels -- the hash ties it to the kernel sources of this tree."""
-    return "profiles/traffic.json@%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, scripts/profile_r04.sh)" % kernel_source_hash()
+    return "profiles/traffic.json@%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, scripts/profile_r05.sh)" % kernel_source_hash()
 
 
 def sweep_traffic_ratio(algorithmic_bytes):
@@ -427,7 +427,7 @@ def shard_curve(ta, torch, sweep, m5, cands, structs, x_host, dev, dev_index, st
 def values_c3(ta, torch, model, dev, dev_index, stream, steps=50, B=8192):
     """What Ipopt calls most (every line-search trial point is an eval_g): the C3 callback with TWR_EVAL_VALUES at batch
     size, per-kernel events.  Algorithmic bytes = 8 (n + m) per problem: x read once, g written once -- 36 KB against the
-    859 KB of the full callback, so neither HBM nor the FP64 pipe is the bound; the leg says how far from both it runs."""
+    859 KB of the full callback, so HBM is not the bound; the leg reports the fraction of both roofs."""
     m = ta.Model.from_buffer_copy(bytes(model))
     m.terrain_id = ta.TERRAINS["flat"]
     sched, params, S = build_case(ta, m)
@@ -453,7 +453,7 @@ def values_c3(ta, torch, model, dev, dev_index, stream, steps=50, B=8192):
         batch.eval_device(x.data_ptr(), g.data_ptr(), 0, ta.EVAL_VALUES, stream)
     torch.cuda.synchronize()
     free_ms = (time.perf_counter() - t0) / steps * 1e3
-    names = {"dynamic": "twr::dyn_kernel<values>", "rangeofmotion": "twr::rom_kernel<values>", "nodes": "twr::node_kernel2<values>"}
+    names = {"dynamic": "twr::dyn_values_kernel", "rangeofmotion": "twr::rom_values_kernel", "nodes": "twr::node_kernel2 (values)"}
     bytes_values = 8 * (S.n + S.m) * B
     path_ms = sum(kern_ms.values())
     # FP64 vector peak: 256 CUs x 4 SIMDs x 16 FP64 lanes/clk x 2 (FMA) x 2.4 GHz = 78.6 TFLOP/s = half the guide's FP32
@@ -471,9 +471,12 @@ def values_c3(ta, torch, model, dev, dev_index, stream, steps=50, B=8192):
             "fp64_valu": {"peak_TFLOPs": 78.6, "issue_frac_upper_bound": valu_frac,
                           "source": "SQ_INSTS_VALU of profiles/traffic.json values_8192 (rocprofv3 --pmc), 4 cycles per wave64 instruction"
                                     if valu_frac else None},
-            "bound": "latency: neither HBM (frac above) nor the FP64 VALU pipe (issue fraction) is near its roof -- a values-only "
-                     "slice is one dependent chain (records -> x -> spline points -> sin/cos -> SRBD) per wave with "
-                     "two to four waves per SIMD to hide it"}
+            "bound": ("VALU issue: the SIMDs issue a vector instruction in %.0f %% (dyn) / %.0f %% (rom) of their slots at 2.4 GHz -- every "
+                      "wave64 FP64 instruction holds its SIMD for four cycles -- while HBM sees %.0f %% of its roof; fewer instructions per "
+                      "time node (or all 64 lanes busy: a 13-node slice uses 52) is what would make it faster"
+                      % (100 * valu_frac.get(names["dynamic"], 0), 100 * valu_frac.get(names["rangeofmotion"], 0),
+                         100 * bytes_values / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)) if valu_frac else
+                     "HBM fraction above; no VALU instruction counts for these kernel sources (profiles/traffic.json is of another tree)"}
 
 
 def valu_from_profile(problems_per_gpu):
@@ -484,7 +487,7 @@ def valu_from_profile(problems_per_gpu):
         if t.get("kernel_source_sha256") == kernel_source_hash() and v.get("problems_per_gpu") == problems_per_gpu:
             per = v.get("valu_insts_per_launch", {})
             out = {}
-            for role, key in (("dynamic", "twr::dyn_kernel"), ("rangeofmotion", "twr::rom_kernel"), ("nodes", "twr::node_kernel")):
+            for role, key in (("dynamic", "twr::dyn_values_kernel"), ("rangeofmotion", "twr::rom_values_kernel")):
                 vals = [c for k, c in per.items() if k.startswith(key)]
                 if vals:
                     out[role] = sum(vals)

@@ -33,7 +33,7 @@ def keep_twr(src, dst):
                 w.writerow(row)
 
 
-for d, name in (("ktrace", ""), ("ktrace_t", "_timings"), ("ktrace_s", "_sweep"), ("ktrace_a", "_all_sets")):
+for d, name in (("ktrace", ""), ("ktrace_t", "_timings"), ("ktrace_s", "_sweep"), ("ktrace_a", "_all_sets"), ("ktrace_v", "_values")):
     src = find(d, "*kernel_stats.csv")
     if not src:
         continue
@@ -89,8 +89,15 @@ for d in ("tcc1_a", "tcc2_a"):
     alls.update(c)
     for k, v in sorted(c.items()):
         lines.append("%-22s %-26s %.6g" % (k[0], k[1], v))
+lines.append("# default bench incl. the values-only leg (dyn_values_kernel / rom_values_kernel, 8192 problems)")
+vals = {}
+for d in ("sq_v",):
+    c = {k: v for k, v in counters(d).items() if "values_kernel" in k[0]}
+    vals.update(c)
+    for k, v in sorted(c.items()):
+        lines.append("%-22s %-26s %.6g" % (k[0], k[1], v))
 lines.append("# derived")
-for k, src in [(k_, allc) for k_ in sorted({k[0] for k in allc})] + [(k_, tim) for k_ in sorted({k[0] for k in tim})]:
+for k, src in [(k_, allc) for k_ in sorted({k[0] for k in allc})] + [(k_, tim) for k_ in sorted({k[0] for k in tim})] + [(k_, vals) for k_ in sorted({k[0] for k in vals})]:
     g = lambda n: src.get((k, n))
     if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"):
         lines.append("%-22s LDS bank conflict / idx active = %.3f" % (k, g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")))
@@ -117,6 +124,8 @@ json.dump({"workload": "C3", "problems_per_gpu": 8192, "kernel_source_sha256": k
            "hbm_bytes_per_launch": traffic(allc),
            "timings_2048": {"hbm_bytes_per_launch": traffic(tim)},
            "sweep_1024": {"hbm_bytes_per_launch": traffic(swp)},
-           "all_sets_8192": {"hbm_bytes_per_launch": traffic(alls)}},
+           "all_sets_8192": {"hbm_bytes_per_launch": traffic(alls)},
+           "values_8192": {"problems_per_gpu": 8192,
+                           "valu_insts_per_launch": {"twr::" + k[0]: v for k, v in vals.items() if k[1] == "SQ_INSTS_VALU"}}},
           open(os.path.join(prof, "traffic.json"), "w"), indent=1)
 print("\n".join(lines[-12:]))

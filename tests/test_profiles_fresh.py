@@ -13,7 +13,7 @@ def test_traffic_profile_matches_kernel_sources():
     with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
         t = json.load(f)
     assert t["kernel_source_sha256"] == bench.kernel_source_hash(), \
-        "kernel sources changed after profiles/ was taken: re-run scripts/profile_r03.sh (GPU box) and scripts/profile_summary.py gpurun_out/prof_r03 r03"
+        "kernel sources changed after profiles/ was taken: re-run scripts/profile_r05.sh (GPU box) and scripts/profile_summary.py gpurun_out/prof_r05 r05"
     assert bench.traffic_from_profile("C3", "twr::rom_kernel", t["problems_per_gpu"]) > 0
     assert bench.traffic_from_profile("C3+timings", "twr::dyn_phase_kernel", 2048) > 0
     assert sum(t["sweep_1024"]["hbm_bytes_per_launch"].values()) > 0
