@@ -910,8 +910,11 @@ def test_candidate_scores_and_contact_plans():
     cases = [Case("anymal", "stairs", ta.gait_combo(4, 1, 2.0), constraint_sets=63),
              Case("anymal", "gap", ta.gait_combo(4, 0, 2.4, 0.9), constraint_sets=255, base_z_init=0.42),
              Case("go1", "flat", ta.gait_combo(4, 4, 1.8), constraint_sets=127),
-             Case("anymal", "block", ta.gait_combo(4, 3, 2.2), constraint_sets=27)]
-    order = [0, 1, 2, 3, 2, 0]
+             Case("anymal", "block", ta.gait_combo(4, 3, 2.2), constraint_sets=27),
+             # more than 4096 rows (K = 460: 8.7 k): the scoring kernel takes sixteen rows per thread and trip
+             Case("hyq", "slope", ta.gait_combo(4, 2, 2.0), constraint_sets=63, **k_params(2.0, 460))]
+    assert cases[4].S.m > 2 * 4096
+    order = [0, 1, 2, 3, 2, 0, 4]
     batch = ta.Batch([c.S for c in cases], order, device=0)
     xs = [cases[s].x_perturbed(i, 1.5) if i % 2 else cases[s].x_wild(i) for i, s in enumerate(order)]
     xs[4][cases[2].S.var_sets[0]["offset"] + 2] = float("nan")     # one problem with a poisoned base height

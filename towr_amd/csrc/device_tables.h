@@ -314,8 +314,9 @@ static_assert(sizeof(SampleWork) == 32, "SampleWork layout");
 // bytes follow o_score, so that the head can be requested without knowing n_pairs.
 constexpr int kMaxConSets = 24;   // 4 terrain + dynamic + 2 splineacc + 4 rangeofmotion + 4 force + 4 swing + baseMotion + 4 totalduration
 constexpr int kScoreHeadBytes = 2048;
-constexpr int kScoreMaxPairs = 256;     // distinct pairs per structure (12-bit index; score_kernel keeps them all in LDS).  A real
-                                        // structure has a few dozen: twr_structure_create rejects one with more
+constexpr int kScoreMaxPairs = 127;     // distinct pairs per structure: what the 2-KB head of the record holds behind the 16-byte
+                                        // ScoreTables (score_kernel keeps them all in LDS).  A real structure has one or two
+                                        // dozen; twr_structure_create rejects one with more
 struct ScoreTables {
   int32_t n_rows, n_pairs;
   int8_t slot_of_family[8];        // -1: the structure has no set of that family

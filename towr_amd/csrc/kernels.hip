@@ -2772,8 +2772,8 @@ __device__ __forceinline__ void best_of(double& v, int& i, double ov, int oi) {
 __global__ __launch_bounds__(256) void score_kernel(const NodeWork* __restrict__ work, const double* __restrict__ g,
                                                     double* __restrict__ scores) {
   constexpr int kHeadDwords = kScoreHeadBytes / 4, kTabDwords = (int)(sizeof(ScoreTables) / 4);
-  static_assert(kHeadDwords == 512 && kTabDwords + 4 * kScoreMaxPairs <= 2 * kHeadDwords + 4 * 256, "record head: two loads per thread (+ four for a full table)");
-  __shared__ __attribute__((aligned(16))) int32_t s_tab[kTabDwords + 4 * kScoreMaxPairs];   // the record as in the blob
+  static_assert(kHeadDwords == 512 && kTabDwords + 4 * kScoreMaxPairs <= kHeadDwords, "the whole record within its head: two loads per thread");
+  __shared__ __attribute__((aligned(16))) int32_t s_tab[kHeadDwords];   // the record as in the blob
   __shared__ double red[256 * 16 + 16 * 16];   // cell (2 slot + {max, sum}, thread), then the partial results of the fold
   const int tid = threadIdx.x;
   const NodeWork w = work[blockIdx.x];
@@ -2799,11 +2799,6 @@ __global__ __launch_bounds__(256) void score_kernel(const NodeWork* __restrict__
       s_tab[tid] = a;
       s_tab[tid + 256] = c;
       __syncthreads();
-      const int n_pairs = min(__builtin_amdgcn_readfirstlane(s_tab[1]), kScoreMaxPairs);   // (never more: twr_structure_create)
-      if (kTabDwords + 4 * n_pairs > kHeadDwords) {   // uniform; more pairs than the head held
-        for (int d = kHeadDwords + tid; d < kTabDwords + 4 * n_pairs; d += 256) s_tab[d] = Tw[d];
-        __syncthreads();
-      }
     }
     const double* s_pairs = reinterpret_cast<const double*>(s_tab + kTabDwords);
 #pragma unroll

@@ -1216,7 +1216,7 @@ void Structure::PackBlob() {
           pairs.push_back(lower[r]);
           pairs.push_back(upper[r]);
         }
-        if (it->second >= kScoreMaxPairs) throw std::runtime_error("more than 256 distinct constraint bounds in one structure");
+        if (it->second >= kScoreMaxPairs) throw std::runtime_error("more than 127 distinct constraint bounds in one structure");
         meta[r] = (uint16_t)(slot_of[fam] << 12 | it->second);
       }
     }
