@@ -901,6 +901,26 @@ def test_device_arg_min_matches_the_host_decision():
                 assert int(got[0]) == idx and (got[1] == total or (np.isinf(got[1]) and np.isinf(total))), (n, variant, fam, got, idx, total)
 
 
+def test_scores_of_a_structure_without_rows():
+    """A constraint list that yields no rows at all (swing-* only, a gait without interior swing nodes): the evaluation writes
+    nothing, the scoring kernel reads nothing (it must not touch g[-1]) and reports zero violation."""
+    import torch
+
+    case = random_case(5111)
+    assert case.S.m == 0 and case.S.nnz == 0
+    batch = ta.Batch([case.S], [0, 0, 0], device=0)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.from_numpy(np.concatenate([case.x_wild(i) for i in range(3)])).to(dev)
+    g = torch.zeros(1, dtype=torch.float64, device=dev)
+    scores = torch.full((3, 16), -1.0, dtype=torch.float64, device=dev)
+    best = torch.full((2,), -1.0, dtype=torch.float64, device=dev)
+    batch.eval_device(x.data_ptr(), g.data_ptr(), 0, ta.EVAL_VALUES, st)
+    batch.score_best_device(g.data_ptr(), scores.data_ptr(), best.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    assert bool((scores == 0).all()) and best.cpu().tolist() == [0.0, 0.0]
+
+
 def test_candidate_scores_and_contact_plans():
     """Sweep post-processing on the device: per-family bound violations (twr_batch_score) against numpy on the oracle's
     g and bounds, and fpowr::ExtractFootstepPlan (footstep_plan_extractor.h:69-133, minus the plane lookup) against

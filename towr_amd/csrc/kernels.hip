@@ -2778,6 +2778,10 @@ __global__ __launch_bounds__(256) void score_kernel(const NodeWork* __restrict__
   const int tid = threadIdx.x;
   const NodeWork w = work[blockIdx.x];
   const int n_rows = (int)(work[blockIdx.x + 1].g_off - w.g_off);
+  if (n_rows <= 0) {   // (uniform) a structure whose constraint sets have no rows: nothing is violated, nothing is read
+    if (tid < 16) scores[16 * (size_t)blockIdx.x + tid] = 0.0;
+    return;
+  }
   const double* gp = g + w.g_off;
   const char* blob = reinterpret_cast<const char*>(w.blob);
   const DevStruct* S = reinterpret_cast<const DevStruct*>(blob);
