@@ -359,6 +359,14 @@ struct DevStruct {
   uint32_t pad3_;
 };
 
+// Right behind the header, at FIXED offsets: the first 64 TerrainRow and the first 64 ForceNode records (zero padded) -- what
+// the first (for most structures: the only) pass of node_kernel's terrain and force waves reads.  Their address does not
+// depend on any header field, so those loads go out together with the header's instead of behind them (one dependent
+// round trip less in a kernel that is nothing but a chain of them).  The full tables follow as before.
+constexpr uint32_t kNodeHeadTerrainOff = (uint32_t)((sizeof(DevStruct) + 15) / 16 * 16);
+constexpr uint32_t kNodeHeadForceOff = kNodeHeadTerrainOff + 64 * (uint32_t)sizeof(TerrainRow);
+constexpr uint32_t kNodeHeadBytes = 64 * (uint32_t)(sizeof(TerrainRow) + sizeof(ForceNode));
+
 // Work items: one contiguous run of time nodes of one constraint set of one problem.  All
 // pointers / offsets are absolute so that a workgroup needs no header lookup.
 struct DynWork {          // cnt <= 16 time nodes of "dynamic"

@@ -1297,14 +1297,13 @@ TWR_DEV void node_body(const NodeWork& w, const double* __restrict__ x, double* 
   double* jp = jac + w.j_off;
   const bool want_g = flags & 1, want_j = flags & 2;
   if (family == 0) {
-    const TerrainRow* rows = tbl<TerrainRow>(blob, S->o_terrain_rows);
-    const int nr = S->n_terrain_rows;
-    for (int r0 = 0; r0 < nr; r0 += 64) {
+    // The first 64 rows sit at a fixed offset behind the header (device_tables.h, node head): their load does not wait for a
+    // header field.  One chunk body, called for the head records and -- structures with more than 64 rows -- for the rest.
+    auto chunk = [&](const TerrainRow tr, int r0, int nr) {
       const int cnt = min(64, nr - r0);
       double* dst = jp + S->nnz_terrain + 3 * r0;
       const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
       if (lane < cnt) {
-        const TerrainRow tr = rows[r0 + lane];
         const double px = xp[tr.idx], py = xp[tr.idx + tr.stride], pz = xp[tr.idx + 2 * tr.stride];
         const Terr t = terrain_eval(S, S->terrain_id, S->flat_height, px, py);
         if (want_g) gp[S->row_terrain + r0 + lane] = pz - t.h;
@@ -1315,17 +1314,28 @@ TWR_DEV void node_body(const NodeWork& w, const double* __restrict__ x, double* 
         }
       }
       if (want_j) copy_out(dst, stage, 3 * cnt, par, lane);  // single wave: LDS accesses are ordered
+    };
+    const TerrainRow tr0 = tbl<TerrainRow>(blob, kNodeHeadTerrainOff)[lane];
+    const int nr = S->n_terrain_rows;
+    if (nr > 0) chunk(tr0, 0, nr);
+    if (nr > 64) {
+      const TerrainRow* rows = tbl<TerrainRow>(blob, S->o_terrain_rows);
+      for (int r0 = 64; r0 < nr; r0 += 64) chunk(rows[min(r0 + lane, nr - 1)], r0, nr);
     }
   } else if (family == 1) {
-    const ForceNode* nodes = tbl<ForceNode>(blob, S->o_force_nodes);
-    const int nn = S->n_force_nodes;
-    for (int i0 = 0; i0 < nn; i0 += 64) {
+    auto chunk = [&](const ForceNode fn, int i0, int nn) {
       const int cnt = min(64, nn - i0);
       double* dst = jp + S->nnz_force + 25 * i0;
       const int par = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-      if (lane < cnt)
-        force_item(S, nodes[i0 + lane], xp, gp + S->row_force + 5 * (i0 + lane), stage + par + 25 * lane, want_g, want_j);
+      if (lane < cnt) force_item(S, fn, xp, gp + S->row_force + 5 * (i0 + lane), stage + par + 25 * lane, want_g, want_j);
       if (want_j) copy_out(dst, stage, 25 * cnt, par, lane);
+    };
+    const ForceNode fn0 = tbl<ForceNode>(blob, kNodeHeadForceOff)[lane];   // (fixed offset, see the terrain family)
+    const int nn = S->n_force_nodes;
+    if (nn > 0) chunk(fn0, 0, nn);
+    if (nn > 64) {
+      const ForceNode* nodes = tbl<ForceNode>(blob, S->o_force_nodes);
+      for (int i0 = 64; i0 < nn; i0 += 64) chunk(nodes[min(i0 + lane, nn - 1)], i0, nn);
     }
   } else if (family == 2) {
     // splineacc-base-lin | splineacc-base-ang (spline_acc_constraint.cc:49-81): lane = row (set, junction j,

@@ -571,6 +571,13 @@ void Structure::PackBlob() {
     row_rom[e] = si->offset;
     nnz_rom[e] = si->nnz_offset;
   }
+  {  // the node head (device_tables.h): first 64 terrain rows, first 64 force nodes, at fixed offsets behind the header
+    std::vector<char> head(kNodeHeadBytes, 0);
+    if (!all_rows.empty()) std::memcpy(head.data(), all_rows.data(), std::min<size_t>(64, all_rows.size()) * sizeof(TerrainRow));
+    if (!all_nodes.empty())
+      std::memcpy(head.data() + 64 * sizeof(TerrainRow), all_nodes.data(), std::min<size_t>(64, all_nodes.size()) * sizeof(ForceNode));
+    if (put(head.data(), head.size()) != kNodeHeadTerrainOff) throw std::runtime_error("node head is not the first table of the blob");
+  }
   h.o_force_nodes = put(all_nodes.data(), all_nodes.size() * sizeof(ForceNode));
   h.o_terrain_rows = put(all_rows.data(), all_rows.size() * sizeof(TerrainRow));
   h.o_acc = put(acc_junctions.data(), acc_junctions.size() * sizeof(AccJunction));
