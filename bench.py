@@ -536,7 +536,7 @@ def timings_c3(ta, torch, dist, model, world, rank, dev, dev_index, backend, str
     # (batches of >= 2048 problems with splineacc / swing rows and fixed timings: the persistent node_chunk_kernel)
     names = {"dynamic": "twr::phase_locate_kernel + twr::dyn_phase_kernel" if timings else "twr::dyn_kernel",
              "rangeofmotion": "twr::rom_phase_kernel" if timings else "twr::rom_kernel",
-             "nodes": "twr::node_kernel" if (timings or B < 2048) else "twr::node_chunk_kernel"}
+             "nodes": "twr::node_kernel" if (timings or B < 2048) else "twr::node_chunk_kernel"}   # (8 problems per CU)
     kbytes = batch.kernel_bytes()
     dom = max(kern_ms, key=kern_ms.get)
     path_ms = sum(kern_ms.values())

@@ -757,7 +757,9 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     // one-workgroup-per-problem kernel is as good -- stay with node_kernel).
     {
       // (hot-path batches -- terrain and force rows only -- are faster on node_kernel2: 0.041 vs 0.047 ms per 8192 C3 problems)
-      bool eligible = n_problems >= 2048 && b->node_families == 4;
+      // (from eight problems per CU on -- 2048 on the 256 CUs of an MI355X, where the cut-over was measured: below that the
+      // one-workgroup-per-problem kernel has enough waves in flight and no persistent loop to fill)
+      bool eligible = n_problems >= 8 * b->n_cu && b->node_families == 4;
       for (int i = 0; i < n_structs && eligible; ++i)
         if (structs[i]->s.params.constraint_sets & (TWR_SET_BASE_ROM | TWR_SET_TOTAL_TIME)) eligible = false;
       if (eligible) {
