@@ -372,11 +372,13 @@ int twr_batch_host_buffers(twr_batch* b, double** h_x, double** h_g, double** h_
  *   TWR_DYN_BPC, TWR_ROM_BPC        persistent workgroups per CU of dyn_kernel / rom_kernel (8 / 4: their LDS images fill a CU)
  *   TWR_PDYN_BPC, TWR_PROM_BPC      the same for dyn_phase_kernel / rom_phase_kernel (default: what their LDS images allow,
  *                                   at most 4 / 8)
- *   TWR_FUSED_MAX_ROM               rom slices up to which one fused launch replaces the three kernels (default: 10 rounds
- *                                   of the rom residency = 10 x TWR_ROM_BPC x number of CUs; 20 rounds for batches that
- *                                   stream their output with non-temporal stores, twr_batch_streaming_stores)
+ *   TWR_FUSED_MAX_ROM               rom slices up to which one fused launch replaces the three kernels (default: 20 rounds
+ *                                   of the rom residency = 20 x TWR_ROM_BPC x number of CUs)
  *   TWR_FUSED_SPLIT                 eighths of the residency the fused launch gives the rom role when both roles do not fit
- *                                   (default: 5 up to 25/8 rounds of rom slices, else no split)
+ *                                   (default: 5 up to 34/8 rounds of rom slices, 4 above; 8 = one role after the other)
+ *   TWR_FUSED_GROM, TWR_FUSED_GDYN  explicit block counts of the two roles of the fused launch (experiments)
+ *   TWR_VALUES_WPC                  workgroups (= waves) per CU of the values-only kernels (default 12 = three per SIMD)
+ *   TWR_VALUES_MIN_ROM              rom slices from which TWR_EVAL_VALUES takes the dedicated values-only kernels (default 1)
  *   TWR_STREAM_NT=0|1               overrides the store policy twr_batch_create picks (twr_batch_streaming_stores)
  *   TWR_HOST_ZERO_COPY[_X]=0        twr_batch_eval_host: copy through device buffers instead of letting the kernels store
  *                                   into (gather x from) the page-locked host buffers */
