@@ -453,45 +453,40 @@ def values_c3(ta, torch, model, dev, dev_index, stream, steps=50, B=8192):
         batch.eval_device(x.data_ptr(), g.data_ptr(), 0, ta.EVAL_VALUES, stream)
     torch.cuda.synchronize()
     free_ms = (time.perf_counter() - t0) / steps * 1e3
-    names = {"dynamic": "twr::dyn_values_kernel", "rangeofmotion": "twr::rom_values_kernel", "nodes": "twr::node_kernel2 (values)"}
+    names = {"dynamic": "twr::dyn_values_kernel", "rangeofmotion": "twr::rom_values_flat_kernel", "nodes": "twr::node_kernel2 (values)"}
     bytes_values = 8 * (S.n + S.m) * B
     path_ms = sum(kern_ms.values())
     # FP64 vector peak: 256 CUs x 4 SIMDs x 16 FP64 lanes/clk x 2 (FMA) x 2.4 GHz = 78.6 TFLOP/s = half the guide's FP32
-    # vector rate (157.3 TF); VALU instructions per launch from the committed PMC pass (profiles/traffic.json,
-    # SQ_INSTS_VALU), each charged as a 4-cycle wave64 FP64 issue -- an UPPER bound of the pipe's occupancy
+    # vector rate (157.3 TF); VALU instructions per step from the committed PMC pass (profiles/traffic.json,
+    # SQ_INSTS_VALU of the event-free launch, eval_values_kernel: dynamic + range of motion + node sets), each charged as a
+    # 4-cycle wave64 FP64 issue -- an UPPER bound of the pipe's occupancy
     valu = valu_from_profile(B)
     issue_peak = 256 * 4 * 2.4e9 / 4.0   # wave64 FP64 instructions per second, chip-wide
-    valu_frac = {names[k]: valu[k] / (kern_ms[k] * 1e-3) / issue_peak for k in kern_ms if valu and k in valu} or None
+    valu_frac = valu / (free_ms * 1e-3) / issue_peak if valu else None
     return {"workload": "C3 values only (TWR_EVAL_VALUES): n=%d m=%d, %d problems/GPU" % (S.n, S.m, B), "problems_per_gpu": B,
             "steps": steps, "value": B * steps / elapsed, "unit": "callbacks/s", "ms_per_step": elapsed / steps * 1e3,
             "ms_per_step_without_events": free_ms, "bytes_per_callback": 8 * (S.n + S.m),
             "kernel_ms": {names[k]: v for k, v in kern_ms.items()},
             "hbm": {"achieved": bytes_values / (path_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": bytes_values / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "fp64_valu": {"peak_TFLOPs": 78.6, "issue_frac_upper_bound": valu_frac,
-                          "source": "SQ_INSTS_VALU of profiles/traffic.json values_8192 (rocprofv3 --pmc), 4 cycles per wave64 instruction"
-                                    if valu_frac else None},
-            "bound": ("VALU issue: the SIMDs issue a vector instruction in %.0f %% (dyn) / %.0f %% (rom) of their slots at 2.4 GHz -- every "
-                      "wave64 FP64 instruction holds its SIMD for four cycles -- while HBM sees %.0f %% of its roof; fewer instructions per "
-                      "time node (or all 64 lanes busy: a 13-node slice uses 52) is what would make it faster"
-                      % (100 * valu_frac.get(names["dynamic"], 0), 100 * valu_frac.get(names["rangeofmotion"], 0),
-                         100 * bytes_values / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)) if valu_frac else
-                     "HBM fraction above; no VALU instruction counts for these kernel sources (profiles/traffic.json is of another tree)"}
+                    "frac": bytes_values / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "frac_without_events": bytes_values / (free_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "fp64_valu": {"peak_TFLOPs": 78.6, "issue_frac_upper_bound": valu_frac, "valu_insts_per_step": valu,
+                          "source": "SQ_INSTS_VALU of profiles/traffic.json values_8192 (rocprofv3 --pmc; the one-launch step), 4 cycles per "
+                                    "wave64 instruction, over ms_per_step_without_events" if valu_frac else None},
+            "bound": ("vector-instruction issue: %.0f %% of the issue slots at 2.4 GHz (every wave64 FP64 instruction holds its SIMD for "
+                      "four cycles) against %.0f %% of HBM" % (100 * valu_frac, 100 * bytes_values / (free_ms * 1e-3) / 1e9 / HBM_PEAK_GBS))
+                     if valu_frac else "HBM fraction above; no VALU instruction counts for these kernel sources (profiles/traffic.json is of another tree)"}
 
 
 def valu_from_profile(problems_per_gpu):
+    """VALU wave-instructions of one event-free values-only step (the single eval_values_kernel launch)
+    from the committed PMC pass, or None when the profile is of other kernel sources / another batch size."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
         v = t.get("values_8192", {})
         if t.get("kernel_source_sha256") == kernel_source_hash() and v.get("problems_per_gpu") == problems_per_gpu:
-            per = v.get("valu_insts_per_launch", {})
-            out = {}
-            for role, key in (("dynamic", "twr::dyn_values_kernel"), ("rangeofmotion", "twr::rom_values_kernel")):
-                vals = [c for k, c in per.items() if k.startswith(key)]
-                if vals:
-                    out[role] = sum(vals)
-            return out or None
+            return v.get("valu_insts_per_step") or None
     except (OSError, ValueError):
         pass
     return None

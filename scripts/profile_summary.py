@@ -57,6 +57,13 @@ def counters(d):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
+def values_step_valu(d):
+    """SQ_INSTS_VALU of the ONE-launch values-only step (eval_values_kernel), mean per dispatch."""
+    c = counters(d)
+    v = [val for (k, name), val in c.items() if k.startswith("eval_values_kernel") and name == "SQ_INSTS_VALU"]
+    return v[0] if v else None
+
+
 lines = ["# rocprofv3 --pmc passes at kernel sources %s (mean per launch; default bench = C3, 8192 problems)" % kernel_source_hash()]
 allc = {}
 for d in ("sq1", "sq2", "tcc1", "tcc2"):
@@ -92,7 +99,7 @@ for d in ("tcc1_a", "tcc2_a"):
 lines.append("# default bench incl. the values-only leg (dyn_values_kernel / rom_values_kernel, 8192 problems)")
 vals = {}
 for d in ("sq_v",):
-    c = {k: v for k, v in counters(d).items() if "values_kernel" in k[0]}
+    c = {k: v for k, v in counters(d).items() if "values" in k[0]}
     vals.update(c)
     for k, v in sorted(c.items()):
         lines.append("%-22s %-26s %.6g" % (k[0], k[1], v))
@@ -125,7 +132,6 @@ json.dump({"workload": "C3", "problems_per_gpu": 8192, "kernel_source_sha256": k
            "timings_2048": {"hbm_bytes_per_launch": traffic(tim)},
            "sweep_1024": {"hbm_bytes_per_launch": traffic(swp)},
            "all_sets_8192": {"hbm_bytes_per_launch": traffic(alls)},
-           "values_8192": {"problems_per_gpu": 8192,
-                           "valu_insts_per_launch": {"twr::" + k[0]: v for k, v in vals.items() if k[1] == "SQ_INSTS_VALU"}}},
+           "values_8192": {"problems_per_gpu": 8192, "valu_insts_per_step": values_step_valu("sq_v")}},
           open(os.path.join(prof, "traffic.json"), "w"), indent=1)
 print("\n".join(lines[-12:]))

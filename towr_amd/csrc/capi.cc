@@ -22,7 +22,8 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
                        const NodeWork* node, int n_node, int node_families, const FamWork* const fam[4], const int n_fam[4],
                        const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap,
                        const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
-                       double* g, double* jac, double* dump, int flags, bool stream_nt, hipStream_t stream, hipEvent_t* ev);
+                       double* g, double* jac, double* dump, int flags, bool stream_nt, const FlatWork* flat, int n_flat_rom,
+                       hipStream_t stream, hipEvent_t* ev);
 int dyn_dump_doubles();
 int node_force_chunk();
 hipError_t prepare_phase_kernels(int pdyn_img_cap, int prom_img_cap);
@@ -112,6 +113,8 @@ struct twr_batch {
   twr::DynWork* d_dyn = nullptr;
   twr::RomWork* d_rom = nullptr;
   twr::NodeWork* d_node = nullptr;
+  twr::FlatWork* d_flat = nullptr;           // values-only evaluation of rangeofmotion-*, one lane per time node
+  int n_flat_rom = 0;                        // (0 when a problem of the batch has optimised timings)
   twr::FamWork* d_fam[4] = {nullptr, nullptr, nullptr, nullptr};   // chunk lists of node_chunk_kernel (large batches only)
   int n_fam[4] = {0, 0, 0, 0};
   // optimised-timings problems have their own work lists
@@ -534,6 +537,8 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     std::vector<twr::DynWork> dyn;
     std::vector<twr::RomWork> rom;
     std::vector<twr::NodeWork> node;
+    std::vector<twr::FlatWork> flat_rom;
+    bool flat_ok = true;
     std::vector<twr::PDynWork> pdyn;
     std::vector<int> pdyn_first;   // first dynamic run of every optimised-timings problem (+ end)
     // dyn_phase_kernel: a pass = the time nodes whose expanded rows fit the LDS image (four at sixteen lanes each,
@@ -679,6 +684,25 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
         }
         (void)any_rom;
       }
+      {  // values-only work items (device_tables.h FlatWork): 64 time nodes of the range-of-motion grid each
+        if (S.timings) flat_ok = false;
+        if (S.off_flat_tables) {
+          for (int k0 = 0; k0 < S.flat_n_rom; k0 += 64) {
+            twr::FlatWork fw;
+            std::memset(&fw, 0, sizeof(fw));
+            fw.nodes = blob + S.off_flat_rom + sizeof(twr::FlatNode) * (size_t)k0;
+            fw.tables = blob + S.off_flat_tables;
+            fw.hdr = blob;
+            fw.x_off = b->x_off[p];
+            fw.g_off = b->g_off[p];
+            fw.k0 = k0;
+            fw.cnt = std::min(64, S.flat_n_rom - k0);
+            flat_rom.push_back(fw);
+          }
+        } else if (S.FindSet("rangeofmotion-0")) {
+          flat_ok = false;
+        }
+      }
       twr::NodeWork nw;
       nw.blob = blob;
       nw.x_off = b->x_off[p];
@@ -752,6 +776,10 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
       node.push_back(end);
     }
     upload(node.data(), node.size() * sizeof(twr::NodeWork), reinterpret_cast<void**>(&b->d_node));
+    if (flat_ok && !flat_rom.empty()) {
+      b->n_flat_rom = (int)flat_rom.size();
+      upload(flat_rom.data(), flat_rom.size() * sizeof(twr::FlatWork), reinterpret_cast<void**>(&b->d_flat));
+    }
     // Large batches whose node-based sets are terrain / force / splineacc / swing only: per-family chunk lists for the
     // persistent node_chunk_kernel (baseMotion and totalduration rows, and small batches -- where the fused launch or the
     // one-workgroup-per-problem kernel is as good -- stay with node_kernel).
@@ -867,6 +895,7 @@ void twr_batch_destroy(twr_batch* b) {
   if (b->d_joff) (void)hipFree(b->d_joff);
   if (b->d_status) (void)hipFree(b->d_status);
   if (b->d_dump) (void)hipFree(b->d_dump);
+  if (b->d_flat) (void)hipFree(b->d_flat);
   if (b->d_best) (void)hipFree(b->d_best);
   if (b->d_swork) (void)hipFree(b->d_swork);
   if (b->d_gwork) (void)hipFree(b->d_gwork);
@@ -916,7 +945,7 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->dyn_map_chunks, b->d_rom, b->n_rom, b->rom_max_vals, b->d_node, b->n_node, b->node_families, b->d_fam, b->n_fam,
                                   b->d_pdyn, b->n_pdyn, b->pdyn_img_cap, b->d_ploc, b->n_ploc, b->d_prom, b->n_prom,
-                                  b->prom_img_cap, d_x, d_g, d_jac, b->d_dump, flags & TWR_EVAL_BOTH, b->stream_nt, stream, ev);
+                                  b->prom_img_cap, d_x, d_g, d_jac, b->d_dump, flags & TWR_EVAL_BOTH, b->stream_nt, b->d_flat, b->n_flat_rom, stream, ev);
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   if (flags & TWR_EVAL_CHECK) {
     e = twr::launch_check(b->n_problems, b->d_goff, b->d_joff, d_g, d_jac, b->d_status, flags & TWR_EVAL_BOTH, stream);

@@ -323,6 +323,35 @@ struct ScoreTables {
 };
 static_assert(sizeof(ScoreTables) == 16, "ScoreTables layout");
 
+// Values-only evaluation (TWR_EVAL_VALUES, fixed timings) of "rangeofmotion-*": ONE LANE PER TIME NODE, all end-effectors
+// (kernels.hip flat_rom_item) -- the base splines and the rotation of a time node are evaluated once instead of once per
+// end-effector slice.  Tables: per time node of the range-of-motion grid a FlatNode (which polynomials are active: decided on
+// the host by the reference's rule, spline.cc:48-78), per end-effector the PolyDesc table the trajectory sampling uses and the
+// start time of every polynomial (local time = t - t0, as in the Jacobian kernels).
+struct FlatNode {
+  double t;                // grid time (TimeDiscretizationConstraint::dts_)
+  double tb, iTb;          // base spline: local time in the active polynomial, 1 / duration
+  int32_t q6;              // 6 * (active base polynomial): offset of its first node in base-lin / base-ang
+  uint8_t qm[4];           // active polynomial of ee-motion_e
+  int32_t pad[2];
+};
+static_assert(sizeof(FlatNode) == 40, "FlatNode layout");
+struct FlatTables {
+  int32_t n_ee, off_lin, off_ang;
+  int32_t row_rom[kMaxEE];                     // first row of "rangeofmotion-e"
+  uint32_t o_mt0[kMaxEE];                      // double[n_poly]: start time of every polynomial of ee-motion_e
+  uint32_t o_mdesc[kMaxEE];                    // PolyDesc[n_poly] (SampleTables' table)
+  int32_t pad;
+};
+struct FlatWork {          // cnt <= 64 consecutive time nodes of the range-of-motion grid of one problem
+  uint64_t nodes;          // FlatNode[k0..]
+  uint64_t tables;         // FlatTables
+  uint64_t hdr;            // DevStruct
+  int64_t x_off, g_off;    // the problem's x / g
+  int32_t k0, cnt;
+};
+static_assert(sizeof(FlatWork) == 48, "FlatWork layout");
+
 // Blob header: model constants + what the node kernel needs.  The terrain-ee-motion_e sets are
 // adjacent in g / jac, and so are the force-ee-force_e sets, so each family is one flat node list.
 struct DevStruct {
@@ -356,7 +385,7 @@ struct DevStruct {
   uint32_t pad2_;
   double grid_px, grid_py;  // Grid: map centre
   uint32_t o_score;         // ScoreTables
-  uint32_t pad3_;
+  uint32_t o_flat;          // FlatTables (values-only evaluation, fixed timings); 0: none
 };
 
 // Right behind the header, at FIXED offsets: the first 64 TerrainRow and the first 64 ForceNode records (zero padded) -- what

@@ -52,9 +52,6 @@ TWR_DEV void diag_put(double v) {
 #else
 #define TWR_ROM_PUT(idx, ...) stage[idx] = (__VA_ARGS__)
 #endif
-#ifndef TWR_VALUES_WAVES
-#define TWR_VALUES_WAVES 3   // waves per SIMD the values-only kernels (dyn_values_kernel, rom_values_kernel) are compiled for
-#endif
 constexpr int TWR_MAX_PHASES_DEV = 32;  // = TWR_MAX_PHASES of include/towr_amd.h
 
 template <typename T>
@@ -1178,13 +1175,13 @@ __global__ __launch_bounds__(64, TWR_DYN_WAVES) void dyn_kernel(const DynWork* _
   dyn_body<WANT_G, WANT_J, XC, NT>(work, n_work, x, g, jac, dump, stage, threadIdx.x, blockIdx.x, gridDim.x);
 }
 
-// Values only (TWR_EVAL_VALUES: what Ipopt's eval_g and a planner's scoring step ask for): the same body, but a wave then
-// owns 2.6 KB of LDS instead of 20 KB (no image) and the kernel is compiled for more waves per SIMD -- a values-only slice is
-// one chain of dependent loads and FP64 latencies per wave, so waves in flight are what it runs on.
+// Values only (TWR_EVAL_VALUES: Ipopt's eval_g, a planner's scoring step), "dynamic": the same body, but a wave then owns 2.6 KB
+// of LDS instead of 20 KB (no image) and the kernel is compiled for three waves per SIMD.  (The range-of-motion sets take
+// values_flat_kernel's form, one lane per time node, below.)
 constexpr int kDynValuesLds = 96 + 2 + kDynXsCap;
 template <int XC>
-__global__ __launch_bounds__(64, TWR_VALUES_WAVES) void dyn_values_kernel(const DynWork* __restrict__ work, int n_work, const double* __restrict__ x,
-                                                                          double* __restrict__ g, double* __restrict__ dump) {
+__global__ __launch_bounds__(64, 3) void dyn_values_kernel(const DynWork* __restrict__ work, int n_work, const double* __restrict__ x,
+                                                           double* __restrict__ g, double* __restrict__ dump) {
   __shared__ __attribute__((aligned(16))) double stage[kDynValuesLds];
   dyn_body<true, false, XC, false>(work, n_work, x, g, nullptr, dump, stage, threadIdx.x, blockIdx.x, gridDim.x);
 }
@@ -1248,16 +1245,6 @@ __global__ __launch_bounds__(64, 1) void rom_kernel(const RomWork* __restrict__ 
   rom_body<NIT, WANT_G, WANT_J, NT>(work, n_work, x, g, jac, stage, threadIdx.x, blockIdx.x, gridDim.x);
 }
 
-// values only: 1.5 KB of LDS per wave instead of 40 KB, compiled for more waves per SIMD (see dyn_values_kernel)
-__global__ __launch_bounds__(64, TWR_VALUES_WAVES) void rom_values_kernel(const RomWork* __restrict__ work, int n_work, const double* __restrict__ x,
-                                                                          double* __restrict__ g) {
-  __shared__ __attribute__((aligned(16))) double stage[192];
-  rom_body<26, true, false, false>(work, n_work, x, g, nullptr, stage, threadIdx.x, blockIdx.x, gridDim.x);
-}
-hipError_t launch_rom_values_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, const double* x, double* g) {
-  return twr_launch(rom_values_kernel, dim3(grid), dim3(64), 0, stream, rom, n_rom, x, g);
-}
-
 // max_vals: Jacobian values of the largest slice of the batch
 hipError_t launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, int max_vals, const double* x, double* g,
                              double* jac, int flags, bool nt) {
@@ -1280,7 +1267,6 @@ hipError_t launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, i
 #else   // !TWR_TU_ROM
 hipError_t launch_rom_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, int max_vals, const double* x, double* g,
                              double* jac, int flags, bool nt);
-hipError_t launch_rom_values_kernel(int grid, hipStream_t stream, const RomWork* rom, int n_rom, const double* x, double* g);
 
 // all terrain-ee-motion_e (terrain_constraint.cc:57-108), force-ee-force_e, splineacc-base-* and
 // swing-ee-motion_e sets of one problem.  One workgroup of four waves per problem, one wave per family
@@ -1696,25 +1682,84 @@ __global__ __launch_bounds__(128, 2) void eval_fused_kernel(const RomWork* __res
   node_body(node[b >> 1], x, g, jac, (WANT_G ? 1 : 0) | (WANT_J ? 2 : 0), stage + wave * kDynLds, family, lane);
 }
 
-// Values only, one launch: blocks [0, g_rom) take the rom role, the next g_dyn the dyn role, the rest one node family of
-// one problem each -- single-wave blocks with the small LDS of the values-only bodies (no image), compiled for
-// TWR_VALUES_WAVES waves per SIMD.  The three roles are latency chains of different shape; in one launch their heads and
-// tails overlap (a planner step at 128 ... 1024 candidates is 10 ... 50 us of it).
-constexpr int kValuesLds = kDynValuesLds > 192 ? kDynValuesLds : 192;
+// ---------------------------------------------------------------- values only: range of motion, one lane per time node
+// TWR_EVAL_VALUES -- Ipopt's eval_g (every line-search trial point), a planner's scoring step -- for problems with fixed
+// timings.  The values-only instantiations of the Jacobian bodies were bound by vector-instruction issue, not by memory
+// (72 % / 55 % of the issue slots at 0.12 of the HBM roof).  For "rangeofmotion-*" the Jacobian kernel's cut --
+// one slice per end-effector, lane = time node -- evaluates the base splines and the rotation (three sin / cos pairs) of a
+// time node once per END-EFFECTOR; without an image to assemble one lane can take a time node for ALL end-effectors
+// (device_tables.h FlatNode / FlatTables / FlatWork): 0.150 -> 0.101 ms per 8192 C3 problems.  The same recipe for "dynamic"
+// -- one lane per time node instead of a quad -- was built and is SLOWER (0.205 vs 0.142 ms): a lane then gathers ~120
+// doubles of x through eight polynomial records, and the vector-memory pipe, not the VALU, sets the pace; "dynamic" keeps the
+// quad body (dyn_values_kernel).
+// Same formula as rom_item (RangeOfMotionConstraint::UpdateConstraintAtInstance, range_of_motion_constraint.cc:58-69).
+TWR_DEV void flat_point(const double* __restrict__ xp, const PolyDesc* __restrict__ desc, const double* __restrict__ t0, int q, double t,
+                        double p[3]) {
+  const PolyDesc pd = desc[q];
+  double X[12], nv[4][3], w[4];
+  gather12c(xp, pd.xbase, pd.cand, X);
+  node_values(slots_of(pd.cand), meta_shared(pd.meta), X, nv);
+  hermite_pos(t - t0[q], pd.iT, w);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) p[d] = w[0] * nv[0][d] + w[1] * nv[1][d] + w[2] * nv[2][d] + w[3] * nv[3][d];
+}
+TWR_DEV void flat_rom_item(const FlatWork& w, const double* __restrict__ x, double* __restrict__ g, int lane) {
+  const FlatTables* T = gptr<FlatTables>(w.tables);
+  const double* xp = x + w.x_off;
+  double* gp = g + w.g_off;
+  const FlatNode n = gptr<FlatNode>(w.nodes)[min(lane, w.cnt - 1)];   // (clamped: every lane loads, the tail lanes store nothing)
+  const bool live = lane < w.cnt;
+  const int n_ee = T->n_ee;
+  const char* blob = reinterpret_cast<const char*>(w.hdr);
+  // base splines: the twelve node values of the active polynomial are contiguous in x (nodes q, q + 1: p then v)
+  double wP[4], c[3], e[3];
+  hermite_pos(n.tb, n.iTb, wP);
+  {
+    const double* xl = xp + T->off_lin + n.q6;
+    const double* xa = xp + T->off_ang + n.q6;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      c[d] = wP[0] * xl[d] + wP[1] * xl[3 + d] + wP[2] * xl[6 + d] + wP[3] * xl[9 + d];
+      e[d] = wP[0] * xa[d] + wP[1] * xa[3 + d] + wP[2] * xa[6 + d] + wP[3] * xa[9 + d];
+    }
+  }
+  Rot ro;
+  rotation(e, ro);
+#pragma unroll
+  for (int ee = 0; ee < kMaxEE; ++ee)
+    if (ee < n_ee) {   // g = b_R_w (p_ee - c)
+      double p[3], v[3], gv[3];
+      flat_point(xp, tbl<PolyDesc>(blob, T->o_mdesc[ee]), tbl<double>(blob, T->o_mt0[ee]), n.qm[ee], n.t, p);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) v[d] = p[d] - c[d];
+      matTvec(ro.R, v, gv);
+      if (live) {
+        double* go = gp + T->row_rom[ee] + 3 * (w.k0 + lane);
+        go[0] = gv[0];
+        go[1] = gv[1];
+        go[2] = gv[2];
+      }
+    }
+}
+// One launch per values-only evaluation: blocks [0, g_dyn) are persistent "dynamic" waves (the quad body), the next n_flat take
+// one range-of-motion item each, the rest one node family of one problem each.  Single-wave blocks, 2.6 KB of LDS.
 template <int XC>
-__global__ __launch_bounds__(64, TWR_VALUES_WAVES) void eval_values_kernel(const RomWork* __restrict__ rom, int n_rom, int g_rom,
-                                                                           const DynWork* __restrict__ dyn, int n_dyn, int g_dyn,
-                                                                           const NodeWork* __restrict__ node, int node_families,
-                                                                           const double* __restrict__ x, double* __restrict__ g,
-                                                                           double* __restrict__ dump) {
-  __shared__ __attribute__((aligned(16))) double stage[kValuesLds];
+__global__ __launch_bounds__(64, 3) void eval_values_kernel(const DynWork* __restrict__ dyn, int n_dyn, int g_dyn, const FlatWork* __restrict__ flat,
+                                                            int n_flat, const NodeWork* __restrict__ node, int node_families,
+                                                            const double* __restrict__ x, double* __restrict__ g, double* __restrict__ dump) {
+  __shared__ __attribute__((aligned(16))) double stage[kDynValuesLds];
   const int lane = threadIdx.x;
   int b = blockIdx.x;
-  if (b < g_rom) return rom_body<26, true, false, false>(rom, n_rom, x, g, nullptr, stage, lane, b, g_rom);
-  b -= g_rom;
   if (b < g_dyn) return dyn_body<true, false, XC, false>(dyn, n_dyn, x, g, nullptr, dump, stage, lane, b, g_dyn);
   b -= g_dyn;
+  if (b < n_flat) return flat_rom_item(flat[b], x, g, lane);
+  b -= n_flat;
   node_body(node[b / node_families], x, g, nullptr, 1, stage, b % node_families, lane);   // (values only: the node image is not touched)
+}
+// (with per-kernel events: the range-of-motion items alone)
+__global__ __launch_bounds__(64, 3) void rom_values_flat_kernel(const FlatWork* __restrict__ flat, const double* __restrict__ x,
+                                                                double* __restrict__ g) {
+  flat_rom_item(flat[blockIdx.x], x, g, threadIdx.x);
 }
 
 // ---------------------------------------------------------------- optimised timings (PhaseSpline) kernels
@@ -3166,7 +3211,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
                        const FamWork* const fam[4], const int n_fam[4] /* chunk lists of node_chunk_kernel; all 0: none */,
                        const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap, const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
                        double* g, double* jac, double* dump /* kDynDump doubles */, int flags, bool stream_nt /* non-temporal copy-out of
-                       dyn / rom (copy_out_fixed) */, hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */) {
+                       dyn / rom (copy_out_fixed) */, const FlatWork* flat /* values-only range-of-motion work items; nullptr: none */, int n_flat_rom, hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */) {
   static const int dyn_bpc = env_int("TWR_DYN_BPC", 8), rom_bpc = env_int("TWR_ROM_BPC", 4);
   dim3 block(64);
   hipError_t st = hipSuccess;
@@ -3203,45 +3248,36 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
       st = twr_first(st, twr_launch(node_kernel, dim3(n_node), dim3(256), 0, stream, node, x, g, jac, flags));
   };
   const int cap = rom_bpc * n_cu;
-  // Values only (no Jacobian): the dedicated high-occupancy kernels, except for batches so small that one launch matters
-  // more than waves in flight (the fused launch below).
-  static const int values_min_rom = env_int("TWR_VALUES_MIN_ROM", 1);
-  if (!(flags & 2) && (flags & 1) && n_pdyn == 0 && n_prom == 0 && n_ploc == 0 && n_rom >= values_min_rom && n_dyn > 0) {
-    static const int vw = env_int("TWR_VALUES_WPC", 4 * TWR_VALUES_WAVES);   // workgroups (= waves) per CU
-    static const int values_fused = env_int("TWR_VALUES_FUSED", 1);
-    if (!ev && values_fused && n_node > 0 && n_chunks_of(n_fam) == 0) {
-      // one launch; the residency is shared out by the roles' slice counts (a rom slice and a dyn slice cost about the same
-      // here), whole multiples of 8 so that a role's block r still takes the list positions r modulo 8 (one problem, one XCD)
-      const int res = vw * n_cu;
-      int g_rom = n_rom, g_dyn = n_dyn;
-      if (g_rom + g_dyn > res) {
-        g_rom = (int)((long long)res * n_rom / (n_rom + n_dyn));
-        g_dyn = res - g_rom;
-        if (g_rom > n_rom) g_rom = n_rom;
-        if (g_dyn > n_dyn) g_dyn = n_dyn;
-      }
-      if (g_rom >= 8) g_rom &= ~7;
-      if (g_dyn >= 8) g_dyn &= ~7;
-      const dim3 vgrid(g_rom + g_dyn + node_families * n_node);
+  // Values only (no Jacobian), every problem with fixed timings: "dynamic" on the quad body with its small LDS, "rangeofmotion-*"
+  // one lane per time node (flat items), the node-based sets -- one launch (eval_values_kernel); with per-kernel events three.
+  if (!(flags & 2) && (flags & 1) && flat && n_flat_rom > 0 && n_dyn > 0 && n_pdyn == 0 && n_prom == 0 && n_ploc == 0) {
+    const int nf = n_chunks_of(n_fam) == 0 ? node_families : 0;   // (large batches: the chunk kernel takes the node sets)
+    // persistent dyn waves per CU of the 12 the kernel's registers allow (one box, 128 / 1024 candidates, us per evaluation:
+    // 4: 8.9 / 45.2, 6: 8.7 / 37.1, 8: 10.3 / 37.9, 10: 9.6 / 37.9, 12: 9.7 / 38.4) -- the rest streams the range-of-motion items
+    static const int dyn_wpc = env_int("TWR_VALUES_DYN_WPC", 6);
+    int g_dyn = n_dyn < dyn_wpc * n_cu ? n_dyn : dyn_wpc * n_cu;
+    if (g_dyn >= 8) g_dyn &= ~7;   // (block r takes the list positions r modulo 8: one problem, one XCD)
+    if (!ev) {
+      const dim3 vgrid(g_dyn + n_flat_rom + nf * n_node);
       if (dyn_map_chunks == 2)
-        return twr_launch(eval_values_kernel<2>, vgrid, block, 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, node_families, x, g, dump);
-      return twr_launch(eval_values_kernel<4>, vgrid, block, 0, stream, rom, n_rom, g_rom, dyn, n_dyn, g_dyn, node, node_families, x, g, dump);
+        st = twr_first(st, twr_launch(eval_values_kernel<2>, vgrid, block, 0, stream, dyn, n_dyn, g_dyn, flat, n_flat_rom, node, nf > 0 ? nf : 1, x, g, dump));
+      else
+        st = twr_first(st, twr_launch(eval_values_kernel<4>, vgrid, block, 0, stream, dyn, n_dyn, g_dyn, flat, n_flat_rom, node, nf > 0 ? nf : 1, x, g, dump));
+      if (nf == 0) launch_nodes();
+      return st;
     }
-    if (ev) (void)hipEventRecord(ev[0], stream);
+    (void)hipEventRecord(ev[0], stream);
     {
-      const int res = vw * n_cu;
+      const int res = 12 * n_cu;
       dim3 grid(n_dyn < res ? n_dyn : res);
       if (dyn_map_chunks == 2) st = twr_first(st, twr_launch(dyn_values_kernel<2>, grid, block, 0, stream, dyn, n_dyn, x, g, dump));
       else st = twr_first(st, twr_launch(dyn_values_kernel<4>, grid, block, 0, stream, dyn, n_dyn, x, g, dump));
     }
-    if (ev) (void)hipEventRecord(ev[1], stream);
-    {
-      const int res = vw * n_cu;
-      st = twr_first(st, launch_rom_values_kernel(n_rom < res ? n_rom : res, stream, rom, n_rom, x, g));
-    }
-    if (ev) (void)hipEventRecord(ev[2], stream);
+    (void)hipEventRecord(ev[1], stream);
+    st = twr_first(st, twr_launch(rom_values_flat_kernel, dim3(n_flat_rom), block, 0, stream, flat, x, g));
+    (void)hipEventRecord(ev[2], stream);
     launch_nodes();
-    if (ev) (void)hipEventRecord(ev[3], stream);
+    (void)hipEventRecord(ev[3], stream);
     return st;
   }
   // With non-temporal stores (sweep-like batches) the fused launch stays ahead for longer -- 768 / 896 / 1024 candidates of the

@@ -1262,6 +1262,38 @@ void Structure::PackBlob() {
     }
     if (st.n_base > 2 * kMaxPhasePolys) st.n_base = -1;
     h.o_sample = put(&st, sizeof(st));
+    // values-only evaluation of rangeofmotion-* with one lane per time node (device_tables.h FlatNode): fixed timings only --
+    // with optimised timings the active polynomials depend on x and the phase kernels keep that path
+    const bool rom_set = FindSet("rangeofmotion-0") != nullptr;
+    bool fits = true;   // polynomial ids are bytes
+    for (int e = 0; e < n_ee; ++e) fits = fits && mpoly[e].size() <= 256;
+    if (!timings && fits && rom_set) {
+      FlatTables ft;
+      std::memset(&ft, 0, sizeof(ft));
+      ft.n_ee = n_ee;
+      ft.off_lin = off_base_lin;
+      ft.off_ang = off_base_ang;
+      for (int e = 0; e < n_ee; ++e) {
+        ft.row_rom[e] = FindSet("rangeofmotion-" + std::to_string(e))->offset;
+        // start time of every polynomial: the running sum Spline::GetSegmentID compares t against (spline.cc:52-57)
+        std::vector<double> t0m(motion[e].durations.size(), 0.0);
+        for (size_t q = 1; q < t0m.size(); ++q) t0m[q] = t0m[q - 1] + motion[e].durations[q - 1];
+        ft.o_mt0[e] = put(t0m.data(), t0m.size() * sizeof(double));
+        ft.o_mdesc[e] = st.o_mdesc[e];
+      }
+      std::vector<FlatNode> fn(grid_rom.size());
+      for (size_t k = 0; k < grid_rom.size(); ++k) {
+        std::memset(&fn[k], 0, sizeof(FlatNode));
+        fn[k].t = grid_rom[k];
+        fn[k].tb = rom_base[k].t_local;
+        fn[k].iTb = 1.0 / base.durations[rom_base[k].poly];
+        fn[k].q6 = 6 * rom_base[k].poly;
+        for (int e = 0; e < n_ee; ++e) fn[k].qm[e] = (uint8_t)rom_motion[e][k].poly;
+      }
+      off_flat_rom = put(fn.data(), fn.size() * sizeof(FlatNode));
+      flat_n_rom = (int)fn.size();
+      off_flat_tables = h.o_flat = put(&ft, sizeof(ft));
+    }
   }
   h.mass = model.mass; h.gravity = model.gravity; h.mu = model.friction; h.flat_height = model.flat_height;
   // BuildInertiaTensor (single_rigid_body_dynamics.cc:36-44): off-diagonals are the negated products of inertia

@@ -99,6 +99,9 @@ struct Structure {
   };
   std::vector<std::vector<RomSlice>> rom_slices;   // [ee]
   uint32_t off_rom_nodes = 0;
+  // values-only evaluation of rangeofmotion-*, one lane per time node (device_tables.h FlatNode / FlatTables): blob offsets, 0 = none
+  uint32_t off_flat_tables = 0, off_flat_rom = 0;
+  int flat_n_rom = 0;
 
   const SetInfo* FindSet(const std::string& name) const;  // nullptr if the family is switched off
   void Build();            // throws std::runtime_error
