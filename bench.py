@@ -56,6 +56,49 @@ def device_power_warmup(torch, dev, seconds):
     return time.perf_counter() - t0
 
 
+PLACEMENT_BALLAST_GB = (0.0, 2.0, 5.0, 10.0)   # what is held while the buffers of placement try i are allocated
+
+
+def place_outputs(torch, dev, alloc, run_steps, tries):
+    """The FIRST large output buffers a fresh process allocates are 5-10 % slower to evaluate into than any later allocation
+    (profiles/r05_output_placement_probe.txt): the same binary, batch and addresses, `rom_kernel` 0.94 ms on them
+    and 0.85 ms on buffers allocated after them -- whatever is held in between (ballast of 0 ... 112 GB), while a plain
+    torch.fill_ of the same buffer runs at 6.75 TB/s either way.  Keeping the first buffers and running for seconds does not
+    help, re-allocating them with nothing else in between does not either; allocating, freeing and allocating again behind
+    another allocation does.  What it is underneath (the mapping of the first large range of a process, most likely: the
+    kernels' thousands of concurrent 18-39-KB store streams need far more address translations in flight than one dense
+    stream) is not established; it is what earlier rounds had filed as "the box" (5.3 vs 5.7 M callbacks/s).
+    A caller that evaluates into the same buffers millions of times allocates them once and can afford to look: this
+    allocates the buffers `tries` times -- each time behind a ballast allocation of another size, which is freed again --,
+    runs a few untimed steps on each and keeps the fastest.  Nothing of it is inside the timed region; the line reports
+    every try.  tries = 1: the buffers as the allocator hands them out."""
+    best, report = None, []
+    for i in range(max(1, tries)):
+        gb = PLACEMENT_BALLAST_GB[i % len(PLACEMENT_BALLAST_GB)] + 20.0 * (i // len(PLACEMENT_BALLAST_GB))
+        ballast = torch.empty(int(gb * (1 << 27)), dtype=torch.float64, device=dev) if gb > 0 else None
+        bufs = alloc()
+        del ballast
+        if tries > 1:
+            for _ in range(3):
+                run_steps(bufs, 1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_steps(bufs, 10)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 10 * 1e3
+        else:
+            ms = None
+        report.append({"ballast_GB": gb, "ms_per_step": ms})
+        if best is None or (ms is not None and ms < best[0]):
+            best = (ms, bufs, i)
+        del bufs
+        torch.cuda.empty_cache()
+    return best[1], {"tries": report, "kept": best[2],
+                     "what": "x / g / Jacobian buffers allocated `tries` times (each behind a ballast allocation that is freed again), ten "
+                             "untimed steps on each, the fastest kept (bench.place_outputs: the first large allocation of a process "
+                             "evaluates 5-10 % slower than later ones); --placement-tries 1 switches it off"}
+
+
 def build_case(ta, model, K=200, T=2.0, combo=1, constraint_sets=27):
     sched = ta.gait_combo(model.n_ee, combo, T)
     dt = T / (K - 1.5)  # reference rule floor(T/dt)+2 then yields K nodes
@@ -571,6 +614,9 @@ def main():
                          "optimised phase durations (ee-schedule variables, all-variables rows); c3 only")
     ap.add_argument("--device-warmup-s", type=float, default=0.5,
                     help="seconds of plain HBM writes before the W warm-up steps, to leave the idle power state (0: none)")
+    ap.add_argument("--placement-tries", type=int, default=4,
+                    help="allocate the output buffers this many times at different places of device memory and keep the fastest "
+                         "(untimed probe steps, before the W warm-up steps; 1: as the allocator hands them out)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scale-c5", action="store_true", help="skip the strong-scaling C5 leg of the default run")
     ap.add_argument("--no-values-c3", action="store_true", help="skip the values-only leg of the default run")
@@ -644,17 +690,24 @@ def main():
         B = len(mine)
         workload = "C5 sweep: %d enumerated ANYmal candidates (combo x T x swing scale) on Stairs, K=200, ragged" % n_all
         bytes_per_callback = batch.algorithmic_bytes // B
-    x = torch.from_numpy(x_host).to(dev)
-    g = torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device=dev)
-    jac = torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
+    global LEG_WARMUP_S
+    LEG_WARMUP_S = min(LEG_WARMUP_S, args.device_warmup_s)   # (--device-warmup-s 0 switches every such warm-up off)
+    warm_s = device_power_warmup(torch, dev, args.device_warmup_s)
+
+    def alloc():
+        return (torch.from_numpy(x_host).to(dev), torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device=dev),
+                torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev))
+
+    def run_steps(bufs, n):
+        for _ in range(n):
+            batch.eval_device(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), ta.EVAL_BOTH, stream)
+
+    (x, g, jac), placement = place_outputs(torch, dev, alloc, run_steps, args.placement_tries)
 
     def step():
         batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)
 
-    global LEG_WARMUP_S
-    LEG_WARMUP_S = min(LEG_WARMUP_S, args.device_warmup_s)   # (--device-warmup-s 0 switches every such warm-up off)
-    warm_s = device_power_warmup(torch, dev, args.device_warmup_s)
     for _ in range(args.warmup):
         step()
     # HIP events on the launch stream bracket each of the three kernels of every timed step
@@ -739,7 +792,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": workload, "problems_per_gpu": B, "bytes_per_callback": bytes_per_callback,
-                       "setup_s": setup_s},
+                       "setup_s": setup_s, "output_placement": placement},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": main_traffic,
                          "kernel": names[dom], "kernel_ms": kern_ms[dom],
