@@ -56,7 +56,7 @@ def device_power_warmup(torch, dev, seconds):
     return time.perf_counter() - t0
 
 
-PLACEMENT_BALLAST_GB = (0.0, 2.0, 5.0, 10.0)   # what is held while the buffers of placement try i are allocated
+PLACEMENT_BALLAST_GB = (0.0, 2.0, 5.0, 10.0, 1.0, 3.0, 7.0, 14.0)   # what is held while the buffers of placement try i are allocated
 
 
 def place_outputs(torch, dev, alloc, run_steps, tries):
@@ -65,9 +65,9 @@ def place_outputs(torch, dev, alloc, run_steps, tries):
     and 0.85 ms on buffers allocated after them -- whatever is held in between (ballast of 0 ... 112 GB), while a plain
     torch.fill_ of the same buffer runs at 6.75 TB/s either way.  Keeping the first buffers and running for seconds does not
     help, re-allocating them with nothing else in between does not either; allocating, freeing and allocating again behind
-    another allocation does.  What it is underneath (the mapping of the first large range of a process, most likely: the
-    kernels' thousands of concurrent 18-39-KB store streams need far more address translations in flight than one dense
-    stream) is not established; it is what earlier rounds had filed as "the box" (5.3 vs 5.7 M callbacks/s).
+    another allocation often does.  The state belongs to the allocation (every offset inside a slow one is slow; backing it with
+    2-MiB or 1-GiB physical chunks through the HIP virtual-memory API changes nothing); why is not established.  It is what
+    earlier rounds had filed as "the box" (5.3 vs 5.7 M callbacks/s).
     A caller that evaluates into the same buffers millions of times allocates them once and can afford to look: this
     allocates the buffers `tries` times -- each time behind a ballast allocation of another size, which is freed again --,
     runs a few untimed steps on each and keeps the fastest.  Nothing of it is inside the timed region; the line reports
@@ -621,7 +621,7 @@ def main():
                          "optimised phase durations (ee-schedule variables, all-variables rows); c3 only")
     ap.add_argument("--device-warmup-s", type=float, default=0.5,
                     help="seconds of plain HBM writes before the W warm-up steps, to leave the idle power state (0: none)")
-    ap.add_argument("--placement-tries", type=int, default=4,
+    ap.add_argument("--placement-tries", type=int, default=8,
                     help="allocate the output buffers this many times at different places of device memory and keep the fastest "
                          "(untimed probe steps, before the W warm-up steps; 1: as the allocator hands them out)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
