@@ -56,47 +56,7 @@ def device_power_warmup(torch, dev, seconds):
     return time.perf_counter() - t0
 
 
-PLACEMENT_BALLAST_GB = (0.0, 2.0, 5.0, 10.0, 1.0, 3.0, 7.0, 14.0)   # what is held while the buffers of placement try i are allocated
-
-
-def place_outputs(torch, dev, alloc, run_steps, tries):
-    """The FIRST large output buffers a fresh process allocates are 5-10 % slower to evaluate into than any later allocation
-    (profiles/r05_output_placement_probe.txt): the same binary, batch and addresses, `rom_kernel` 0.94 ms on them
-    and 0.85 ms on buffers allocated after them -- whatever is held in between (ballast of 0 ... 112 GB), while a plain
-    torch.fill_ of the same buffer runs at 6.75 TB/s either way.  Keeping the first buffers and running for seconds does not
-    help, re-allocating them with nothing else in between does not either; allocating, freeing and allocating again behind
-    another allocation often does.  The state belongs to the allocation (every offset inside a slow one is slow; backing it with
-    2-MiB or 1-GiB physical chunks through the HIP virtual-memory API changes nothing); why is not established.  It is what
-    earlier rounds had filed as "the box" (5.3 vs 5.7 M callbacks/s).
-    A caller that evaluates into the same buffers millions of times allocates them once and can afford to look: this
-    allocates the buffers `tries` times -- each time behind a ballast allocation of another size, which is freed again --,
-    runs a few untimed steps on each and keeps the fastest.  Nothing of it is inside the timed region; the line reports
-    every try.  tries = 1: the buffers as the allocator hands them out."""
-    best, report = None, []
-    for i in range(max(1, tries)):
-        gb = PLACEMENT_BALLAST_GB[i % len(PLACEMENT_BALLAST_GB)] + 20.0 * (i // len(PLACEMENT_BALLAST_GB))
-        ballast = torch.empty(int(gb * (1 << 27)), dtype=torch.float64, device=dev) if gb > 0 else None
-        bufs = alloc()
-        del ballast
-        if tries > 1:
-            for _ in range(3):
-                run_steps(bufs, 1)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            run_steps(bufs, 10)
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / 10 * 1e3
-        else:
-            ms = None
-        report.append({"ballast_GB": gb, "ms_per_step": ms})
-        if best is None or (ms is not None and ms < best[0]):
-            best = (ms, bufs, i)
-        del bufs
-        torch.cuda.empty_cache()
-    return best[1], {"tries": report, "kept": best[2],
-                     "what": "x / g / Jacobian buffers allocated `tries` times (each behind a ballast allocation that is freed again), ten "
-                             "untimed steps on each, the fastest kept (bench.place_outputs: the first large allocation of a process "
-                             "evaluates 5-10 % slower than later ones); --placement-tries 1 switches it off"}
+from towr_amd.placement import PLACEMENT_BALLAST_GB, place_outputs  # noqa: E402,F401  (a user-side utility: it lives in the package)
 
 
 def build_case(ta, model, K=200, T=2.0, combo=1, constraint_sets=27):

@@ -324,3 +324,34 @@ def test_base_motion_needs_the_initial_base_height():
     lo, up = S.bounds()
     bm = [s for s in S.con_sets if s["name"] == "baseMotion"][0]
     assert lo[bm["offset"] + 5] == pytest.approx(0.40) and up[bm["offset"] + 5] == pytest.approx(0.52)
+
+
+def test_place_outputs_keeps_the_fastest_allocation():
+    """towr_amd.placement.place_outputs (what bench.py places its x / g / Jacobian buffers with): allocates `tries` times, each
+    time behind a ballast allocation that is freed again, times a few steps on each and keeps the fastest; tries = 1 takes the
+    first allocation untimed.  Driven here with stand-ins for torch and for the buffers (no device)."""
+    import time
+    import types
+
+    from towr_amd.placement import PLACEMENT_BALLAST_GB, place_outputs
+
+    log = []
+    fake = types.SimpleNamespace(float64="f64", cuda=types.SimpleNamespace(synchronize=lambda: None, empty_cache=lambda: log.append("empty_cache")),
+                                 empty=lambda n, dtype=None, device=None: log.append(("ballast", n)) or object())
+    cost = {0: 0.004, 1: 0.001, 2: 0.003}   # seconds per step of allocation i
+    made = []
+
+    def alloc():
+        made.append(len(made))
+        return ("buffers", made[-1])
+
+    def run_steps(bufs, n):
+        time.sleep(cost[bufs[1]] * n)
+
+    kept, report = place_outputs(fake, "dev", alloc, run_steps, 3)
+    assert kept == ("buffers", 1) and report["kept"] == 1 and len(report["tries"]) == 3
+    assert [t["ballast_GB"] for t in report["tries"]] == list(PLACEMENT_BALLAST_GB[:3])
+    assert report["tries"][1]["ms_per_step"] < report["tries"][2]["ms_per_step"] < report["tries"][0]["ms_per_step"]
+    assert [e for e in log if isinstance(e, tuple)] == [("ballast", int(g * (1 << 27))) for g in PLACEMENT_BALLAST_GB[1:3]]
+    kept, report = place_outputs(fake, "dev", alloc, run_steps, 1)
+    assert kept == ("buffers", 3) and report["tries"] == [{"ballast_GB": 0.0, "ms_per_step": None}]
