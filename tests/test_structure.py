@@ -336,7 +336,8 @@ def test_place_outputs_keeps_the_fastest_allocation():
     from towr_amd.placement import PLACEMENT_BALLAST_GB, place_outputs
 
     log = []
-    fake = types.SimpleNamespace(float64="f64", cuda=types.SimpleNamespace(synchronize=lambda: None, empty_cache=lambda: log.append("empty_cache")),
+    fake = types.SimpleNamespace(float64="f64", cuda=types.SimpleNamespace(synchronize=lambda: None, empty_cache=lambda: log.append("empty_cache"),
+                                                                      mem_get_info=lambda dev: (200 << 30, 288 << 30)),
                                  empty=lambda n, dtype=None, device=None: log.append(("ballast", n)) or object())
     cost = {0: 0.004, 1: 0.001, 2: 0.003}   # seconds per step of allocation i
     made = []
@@ -355,3 +356,13 @@ def test_place_outputs_keeps_the_fastest_allocation():
     assert [e for e in log if isinstance(e, tuple)] == [("ballast", int(g * (1 << 27))) for g in PLACEMENT_BALLAST_GB[1:3]]
     kept, report = place_outputs(fake, "dev", alloc, run_steps, 1)
     assert kept == ("buffers", 3) and report["tries"] == [{"ballast_GB": 0.0, "ms_per_step": None}]
+    # a device that is nearly full: the second placement would not fit beside the first -- the first is kept, and the line says why
+    state = {"free": 100 << 30}
+
+    def alloc_big():
+        state["free"] -= 60 << 30
+        return ("buffers", 0)
+
+    fake.cuda.mem_get_info = lambda dev: (state["free"], 288 << 30)
+    kept, report = place_outputs(fake, "dev", alloc_big, run_steps, 4)
+    assert kept == ("buffers", 0) and len(report["tries"]) == 2 and "skipped" in report["tries"][1]

@@ -27,9 +27,17 @@ def place_outputs(torch, dev, alloc, run_steps, tries):
     every try.  tries = 1: the buffers as the allocator hands them out."""
     best, report = None, []
     for i in range(max(1, tries)):
+        if i > 0:   # a second placement must fit beside the one that is kept, plus its ballast: otherwise stop trying
+            free, _total = torch.cuda.mem_get_info(dev)
+            next_gb = PLACEMENT_BALLAST_GB[i % len(PLACEMENT_BALLAST_GB)] + 20.0 * (i // len(PLACEMENT_BALLAST_GB))
+            if free < 1.25 * kept_bytes + next_gb * 2 ** 30:
+                report.append({"ballast_GB": next_gb, "ms_per_step": None, "skipped": "not enough free device memory for another placement"})
+                break
         gb = PLACEMENT_BALLAST_GB[i % len(PLACEMENT_BALLAST_GB)] + 20.0 * (i // len(PLACEMENT_BALLAST_GB))
         ballast = torch.empty(int(gb * (1 << 27)), dtype=torch.float64, device=dev) if gb > 0 else None
+        before = torch.cuda.mem_get_info(dev)[0] if hasattr(torch.cuda, "mem_get_info") else 0
         bufs = alloc()
+        kept_bytes = max(0, before - (torch.cuda.mem_get_info(dev)[0] if hasattr(torch.cuda, "mem_get_info") else 0))
         del ballast
         if tries > 1:
             for _ in range(3):
