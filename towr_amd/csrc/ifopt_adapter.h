@@ -128,7 +128,8 @@ class DeviceProblem {
       found.push_back(c);
     }
     linked_ = vars.get();
-    keep_.clear();
+    // (observers of an EARLIER link stay alive in keep_: their subjects hold raw pointers to them and may still call them --
+    // all such a call does is flag a set, i.e. cost one extra read)
     have_ = 0;
     have_x_ = false;
     if (link_hook_) link_hook_(*this, found);
