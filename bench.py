@@ -463,7 +463,7 @@ def values_c3(ta, torch, model, dev, dev_index, stream, steps=50, B=8192):
         batch.eval_device(x.data_ptr(), g.data_ptr(), 0, ta.EVAL_VALUES, stream)
     torch.cuda.synchronize()
     free_ms = (time.perf_counter() - t0) / steps * 1e3
-    names = {"dynamic": "twr::dyn_values_kernel", "rangeofmotion": "twr::rom_values_flat_kernel", "nodes": "twr::node_kernel2 (values)"}
+    names = {"dynamic": "twr::values_flat_kernel<dynamic>", "rangeofmotion": "twr::values_flat_kernel<rangeofmotion>", "nodes": "twr::node_kernel2 (values)"}
     bytes_values = 8 * (S.n + S.m) * B
     path_ms = sum(kern_ms.values())
     # FP64 vector peak: 256 CUs x 4 SIMDs x 16 FP64 lanes/clk x 2 (FMA) x 2.4 GHz = 78.6 TFLOP/s = half the guide's FP32

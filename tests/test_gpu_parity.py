@@ -273,6 +273,13 @@ def test_edge_sizes(name, make):
     for p, x in enumerate(xs):
         rg, _, _, rj = case.P.eval(x)
         assert_parity(case.S, *_split(batch, g, j, p), rg, rj, "%s x[%d]" % (name, p), x=x)
+    # the values-only path (one lane per time node for "dynamic" / "rangeofmotion-*": items are cut at 64 time nodes or eight
+    # polynomials of one spline; structures with more than 2046 variables or optimised timings keep the Jacobian kernels' cut)
+    px, pg, pj = batch.host_buffers()
+    px[:] = np.concatenate(xs)
+    pg[:] = np.nan
+    batch.eval_host_pinned(ta.EVAL_VALUES)
+    assert np.abs(pg - g).max() <= 1e-12 * max(1.0, np.abs(g).max()), name
 
 
 def test_optimised_timings_at_scale():

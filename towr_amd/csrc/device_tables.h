@@ -323,34 +323,55 @@ struct ScoreTables {
 };
 static_assert(sizeof(ScoreTables) == 16, "ScoreTables layout");
 
-// Values-only evaluation (TWR_EVAL_VALUES, fixed timings) of "rangeofmotion-*": ONE LANE PER TIME NODE, all end-effectors
-// (kernels.hip flat_rom_item) -- the base splines and the rotation of a time node are evaluated once instead of once per
-// end-effector slice.  Tables: per time node of the range-of-motion grid a FlatNode (which polynomials are active: decided on
-// the host by the reference's rule, spline.cc:48-78), per end-effector the PolyDesc table the trajectory sampling uses and the
-// start time of every polynomial (local time = t - t0, as in the Jacobian kernels).
+// Values-only evaluation (TWR_EVAL_VALUES, fixed timings) of "dynamic" and "rangeofmotion-*": ONE LANE PER TIME NODE, all
+// end-effectors (kernels.hip flat_dyn_item / flat_rom_item) -- the base splines and the rotation of a time node are evaluated
+// once instead of once per end-effector (the Jacobian kernels' cuts: a quad of lanes per time node resp. one slice per
+// end-effector).  Nothing a lane needs is gathered from global memory: the wave copies the problem's x into LDS (coalesced)
+// and, beside it, the WINDOW of polynomial records its time nodes use -- per spline (ee-motion_e: 2 e, ee-force_e: 2 e + 1)
+// at most kFlatWindow consecutive polynomials, lane 8 s + j fetching record j of spline s --, all in ONE round trip behind
+// the work item.  Tables: per time node of an item a FlatNode (which polynomials are active -- decided on the host by the
+// reference's rule, spline.cc:48-78 -- as indices INTO THE ITEM'S WINDOWS), per structure one array of FlatPoly over all
+// splines: start time (local time = t - t0, as in the Jacobian kernels), 1 / duration and, for each of the twelve candidates
+// (node value j = p0, v0, p1, v1 x dimension), the BYTE offset of its variable in the wave's copy of x (a zero pair, then
+// x) -- a candidate that is not a variable points at the zero pair, p1 of a stance ee-motion polynomial at the same variable
+// as p0 (nodes_variables_phase_based.cc:210-298): no selects in the evaluation.  An item is cut where it would exceed 64 time
+// nodes or kFlatWindow polynomials of one spline (structure.cc).
+constexpr int kFlatXCap = 2046;    // doubles of x a problem may have for this path (16 KB of LDS per wave; C3: 640)
+constexpr int kFlatWindow = 8;     // polynomials per spline and item
+struct FlatPoly {
+  double t0, iT;
+  uint16_t off[12];        // 8 * (2 + x index), or 0 (the zero pair)
+  int32_t pad[2];
+};
+static_assert(sizeof(FlatPoly) == 48, "FlatPoly layout");
+constexpr int kFlatPolyLds = 2 * kMaxEE * kFlatWindow * (int)sizeof(FlatPoly);   // bytes: the windows of one item (3072)
 struct FlatNode {
   double t;                // grid time (TimeDiscretizationConstraint::dts_)
   double tb, iTb;          // base spline: local time in the active polynomial, 1 / duration
   int32_t q6;              // 6 * (active base polynomial): offset of its first node in base-lin / base-ang
-  uint8_t qm[4];           // active polynomial of ee-motion_e
-  int32_t pad[2];
-};
-static_assert(sizeof(FlatNode) == 40, "FlatNode layout");
-struct FlatTables {
-  int32_t n_ee, off_lin, off_ang;
-  int32_t row_rom[kMaxEE];                     // first row of "rangeofmotion-e"
-  uint32_t o_mt0[kMaxEE];                      // double[n_poly]: start time of every polynomial of ee-motion_e
-  uint32_t o_mdesc[kMaxEE];                    // PolyDesc[n_poly] (SampleTables' table)
+  uint8_t qm[4];           // active polynomial of ee-motion_e, relative to the item's window
+  uint8_t qf[4];           // active polynomial of ee-force_e ("dynamic" items only)
   int32_t pad;
 };
-struct FlatWork {          // cnt <= 64 consecutive time nodes of the range-of-motion grid of one problem
-  uint64_t nodes;          // FlatNode[k0..]
-  uint64_t tables;         // FlatTables
-  uint64_t hdr;            // DevStruct
-  int64_t x_off, g_off;    // the problem's x / g
-  int32_t k0, cnt;
+static_assert(sizeof(FlatNode) == 40, "FlatNode layout");
+// Everything an item needs that is the same for all its lanes is in its work record -- addresses, window starts, the
+// structure's offsets and rows and (for "dynamic") the model constants: the wave reads the record with ONE coalesced vector
+// load (lane k = dword k) an iteration ahead and takes the fields with v_readlane.  (Scalar loads cannot be prefetched in this
+// loop: they share their counter with the LDS reads and return out of order, so every LDS wait drains them.)
+struct FlatWork {          // cnt <= 64 consecutive time nodes of the dynamic (or range-of-motion) grid of one problem
+  uint64_t nodes;          // dwords 0-1    FlatNode[cnt]
+  uint64_t polys;          //        2-3    FlatPoly[] of the structure
+  int64_t x_off, g_off;    //        4-7    the problem's x / g
+  int32_t k0, cnt;         //        8-9
+  uint64_t start[2];       //        10-13  16 bits per spline: first polynomial of its window in the FlatPoly array (splines 0-3 | 4-7)
+  uint64_t count;          //        14-15  8 bits per spline: polynomials in its window (0: spline not used by the item)
+  int32_t n_x, n_ee;       //        16-17  variables of the problem (<= kFlatXCap), end-effectors
+  int32_t off_lin, off_ang;   //     18-19  x offsets of base-lin / base-ang
+  int32_t row[kMaxEE];     //        20-23  first row of "rangeofmotion-e"; "dynamic" items: row[0] = first row of "dynamic"
+  double mass, gravity;    //        24-27  ("dynamic" items)
+  double Ib[6];            //        28-39
 };
-static_assert(sizeof(FlatWork) == 48, "FlatWork layout");
+static_assert(sizeof(FlatWork) == 160 && offsetof(FlatWork, n_x) == 64 && offsetof(FlatWork, mass) == 96, "FlatWork layout");
 
 // Blob header: model constants + what the node kernel needs.  The terrain-ee-motion_e sets are
 // adjacent in g / jac, and so are the force-ee-force_e sets, so each family is one flat node list.
@@ -385,7 +406,7 @@ struct DevStruct {
   uint32_t pad2_;
   double grid_px, grid_py;  // Grid: map centre
   uint32_t o_score;         // ScoreTables
-  uint32_t o_flat;          // FlatTables (values-only evaluation, fixed timings); 0: none
+  uint32_t o_flat;          // FlatPoly[] (values-only evaluation, fixed timings); 0: none
 };
 
 // Right behind the header, at FIXED offsets: the first 64 TerrainRow and the first 64 ForceNode records (zero padded) -- what

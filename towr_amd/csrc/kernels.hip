@@ -1076,7 +1076,7 @@ template <bool WANT_G, bool WANT_J, int XC, bool NT>
 TWR_DEV void dyn_body(const DynWork* __restrict__ work, int n_work, const double* __restrict__ x, double* __restrict__ g,
                       double* __restrict__ jac, double* __restrict__ dump, double* stage, int lane, int i, int stride) {
   static_assert(XC == 2 || XC == 4, "staging map chunks");
-  // (values only: no image -- the wave's LDS is g + xs, kDynValuesLds doubles, see dyn_values_kernel)
+  // (WANT_J false: no image -- the wave's LDS would be g + xs alone)
   constexpr int kG0 = WANT_J ? kDynG0 : 0, kX0 = kG0 + 96;
   double* gst = stage + kG0;
   char* xs = reinterpret_cast<char*>(stage + kX0);
@@ -1175,16 +1175,9 @@ __global__ __launch_bounds__(64, TWR_DYN_WAVES) void dyn_kernel(const DynWork* _
   dyn_body<WANT_G, WANT_J, XC, NT>(work, n_work, x, g, jac, dump, stage, threadIdx.x, blockIdx.x, gridDim.x);
 }
 
-// Values only (TWR_EVAL_VALUES: Ipopt's eval_g, a planner's scoring step), "dynamic": the same body, but a wave then owns 2.6 KB
-// of LDS instead of 20 KB (no image) and the kernel is compiled for three waves per SIMD.  (The range-of-motion sets take
-// values_flat_kernel's form, one lane per time node, below.)
+// Values only (TWR_EVAL_VALUES: Ipopt's eval_g, a planner's scoring step): problems with fixed timings take the one-lane-per-
+// time-node kernels below (eval_values_kernel); kDynValuesLds is what node_body needs of a wave's LDS there.
 constexpr int kDynValuesLds = 96 + 2 + kDynXsCap;
-template <int XC>
-__global__ __launch_bounds__(64, 3) void dyn_values_kernel(const DynWork* __restrict__ work, int n_work, const double* __restrict__ x,
-                                                           double* __restrict__ g, double* __restrict__ dump) {
-  __shared__ __attribute__((aligned(16))) double stage[kDynValuesLds];
-  dyn_body<true, false, XC, false>(work, n_work, x, g, nullptr, dump, stage, threadIdx.x, blockIdx.x, gridDim.x);
-}
 
 #endif  // !TWR_TU_ROM
 
@@ -1682,41 +1675,120 @@ __global__ __launch_bounds__(128, 2) void eval_fused_kernel(const RomWork* __res
   node_body(node[b >> 1], x, g, jac, (WANT_G ? 1 : 0) | (WANT_J ? 2 : 0), stage + wave * kDynLds, family, lane);
 }
 
-// ---------------------------------------------------------------- values only: range of motion, one lane per time node
+// ---------------------------------------------------------------- values only: one lane per time node
 // TWR_EVAL_VALUES -- Ipopt's eval_g (every line-search trial point), a planner's scoring step -- for problems with fixed
 // timings.  The values-only instantiations of the Jacobian bodies were bound by vector-instruction issue, not by memory
-// (72 % / 55 % of the issue slots at 0.12 of the HBM roof).  For "rangeofmotion-*" the Jacobian kernel's cut --
-// one slice per end-effector, lane = time node -- evaluates the base splines and the rotation (three sin / cos pairs) of a
-// time node once per END-EFFECTOR; without an image to assemble one lane can take a time node for ALL end-effectors
-// (device_tables.h FlatNode / FlatTables / FlatWork): 0.150 -> 0.101 ms per 8192 C3 problems.  The same recipe for "dynamic"
-// -- one lane per time node instead of a quad -- was built and is SLOWER (0.205 vs 0.142 ms): a lane then gathers ~120
-// doubles of x through eight polynomial records, and the vector-memory pipe, not the VALU, sets the pace; "dynamic" keeps the
-// quad body (dyn_values_kernel).
-// Same formula as rom_item (RangeOfMotionConstraint::UpdateConstraintAtInstance, range_of_motion_constraint.cc:58-69).
-TWR_DEV void flat_point(const double* __restrict__ xp, const PolyDesc* __restrict__ desc, const double* __restrict__ t0, int q, double t,
-                        double p[3]) {
-  const PolyDesc pd = desc[q];
-  double X[12], nv[4][3], w[4];
-  gather12c(xp, pd.xbase, pd.cand, X);
-  node_values(slots_of(pd.cand), meta_shared(pd.meta), X, nv);
-  hermite_pos(t - t0[q], pd.iT, w);
-#pragma unroll
-  for (int d = 0; d < 3; ++d) p[d] = w[0] * nv[0][d] + w[1] * nv[1][d] + w[2] * nv[2][d] + w[3] * nv[3][d];
+// (72 % / 55 % of the issue slots at 0.12 of the HBM roof).  The Jacobian kernels' cuts -- "rangeofmotion-e":
+// one slice per end-effector, lane = time node; "dynamic": a quad of lanes per time node -- evaluate the base splines and the
+// rotation (three sin / cos pairs) of a time node once per END-EFFECTOR resp. per LANE OF THE QUAD; without an image to
+// assemble one lane can take a time node for ALL end-effectors (device_tables.h FlatNode / FlatPoly / FlatTables / FlatWork).
+// What made the first form of this slower for "dynamic" (0.205 vs 0.142 ms per 8192 C3 problems) was the ~120 per-lane global
+// gathers of x behind eight 40-byte polynomial records; here the wave copies the problem's x and the item's windows of
+// polynomial records into LDS (coalesced, one round trip behind the work item) and a candidate is ONE LDS read at a byte
+// offset the host prepared (zero pair for candidates that are not variables, p0's variable for p1 of a stance polynomial):
+// no selects, no global gathers.
+// LDS of a wave (dynamic size, the launcher knows the largest problem of the batch): [ polynomial windows: 2 kMaxEE x
+// kFlatWindow records | zero pair | x ]
+typedef uint32_t twr_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t twr_u2 __attribute__((ext_vector_type(2)));
+struct FlatIn {            // what a lane fetches for an item: its time node and one polynomial record of the windows, as whole
+  twr_u4 na, nb;           // dwords (no sub-dword struct fields across the loop back-edge): FlatNode = na | nb | nc
+  twr_u2 nc;
+  twr_u4 pa, pb, pc;       // FlatPoly
+};
+struct FlatNodeR {         // FlatNode unpacked (registers)
+  double t, tb, iTb;
+  int q6;
+  uint32_t qm, qf;         // four bytes each
+};
+TWR_DEV FlatNodeR flat_node(const FlatIn& in) {
+  static_assert(offsetof(FlatNode, q6) == 24 && offsetof(FlatNode, qm) == 28 && offsetof(FlatNode, qf) == 32, "FlatNode dwords");
+  FlatNodeR n;
+  n.t = __hiloint2double((int)in.na.y, (int)in.na.x);
+  n.tb = __hiloint2double((int)in.na.w, (int)in.na.z);
+  n.iTb = __hiloint2double((int)in.nb.y, (int)in.nb.x);
+  n.q6 = (int)in.nb.z;
+  n.qm = in.nb.w;
+  n.qf = in.nc.x;
+  return n;
 }
-TWR_DEV void flat_rom_item(const FlatWork& w, const double* __restrict__ x, double* __restrict__ g, int lane) {
-  const FlatTables* T = gptr<FlatTables>(w.tables);
-  const double* xp = x + w.x_off;
-  double* gp = g + w.g_off;
-  const FlatNode n = gptr<FlatNode>(w.nodes)[min(lane, w.cnt - 1)];   // (clamped: every lane loads, the tail lanes store nothing)
-  const bool live = lane < w.cnt;
-  const int n_ee = T->n_ee;
-  const char* blob = reinterpret_cast<const char*>(w.hdr);
+// The work record of an item: wave-uniform, read with scalar loads (one round trip: everything an item needs that is the
+// same for all its lanes is IN the record, nothing behind a pointer of it); a field is addressed by its dword.
+struct FlatRec {
+  const TWR_CONST uint32_t* p;
+  TWR_DEV uint32_t u32(int k) const { return p[k]; }
+  TWR_DEV int i32(int k) const { return (int)p[k]; }
+  TWR_DEV uint64_t u64(int k) const { return ((uint64_t)p[k + 1] << 32) | p[k]; }
+  TWR_DEV double f64(int k) const { return __hiloint2double((int)p[k + 1], (int)p[k]); }
+};
+TWR_DEV void flat_load(const FlatRec& w, int lane, FlatIn& in) {
+  static_assert(offsetof(FlatWork, nodes) == 0 && offsetof(FlatWork, polys) == 8 && offsetof(FlatWork, cnt) == 36 && offsetof(FlatWork, start) == 40 &&
+                    offsetof(FlatWork, count) == 56, "FlatWork dwords");
+  {
+    const TWR_GLOBAL twr_u2* nd = reinterpret_cast<const TWR_GLOBAL twr_u2*>(gptr<FlatNode>(w.u64(0)) + min(lane, w.i32(9) - 1));   // (clamped:
+    const twr_u2 a = nd[0], b = nd[1], c = nd[2], d = nd[3];   // every lane loads, the tail lanes store nothing; 8-byte aligned records)
+    in.na = twr_u4{a.x, a.y, b.x, b.y};
+    in.nb = twr_u4{c.x, c.y, d.x, d.y};
+    in.nc = nd[4];
+  }
+  // lane 8 s + j: record j of spline s's window (clamped to the window: no predicates)
+  const int s = lane >> 3, j = lane & 7;
+  const uint64_t st = lane < 32 ? w.u64(10) : w.u64(12);
+  const int first = (int)((st >> (16 * (s & 3))) & 0xFFFFu), cnt = (int)((w.u64(14) >> (8 * s)) & 0xFFu);
+  const TWR_GLOBAL twr_u4* rec = reinterpret_cast<const TWR_GLOBAL twr_u4*>(gptr<FlatPoly>(w.u64(2)) + first + min(j, max(cnt, 1) - 1));
+  in.pa = rec[0];
+  in.pb = rec[1];
+  in.pc = rec[2];
+}
+TWR_DEV void flat_stage_polys(const FlatIn& in, char* lds, int lane) {
+  twr_u4* dst = reinterpret_cast<twr_u4*>(lds + lane * (int)sizeof(FlatPoly));
+  dst[0] = in.pa;
+  dst[1] = in.pb;
+  dst[2] = in.pc;
+}
+// x of a problem, NX doubles per lane (the launcher picks the smallest instantiation that covers the largest problem)
+template <int NX>
+TWR_DEV void flat_load_x(const double* __restrict__ xp, int n_x, int lane, double xr[NX]) {
+#pragma unroll
+  for (int j = 0; j < NX; ++j) xr[j] = xp[min(64 * j + lane, n_x - 1)];
+}
+template <int NX>
+TWR_DEV void flat_stage_x(const double xr[NX], int n_x, double* xs, int lane) {
+  if (lane < 2) xs[lane] = 0.0;
+#pragma unroll
+  for (int j = 0; j < NX; ++j) xs[2 + min(64 * j + lane, n_x - 1)] = xr[j];   // (clamped like the loads: the lanes past the end
+}                                                                            // write the last variable once more)
+// Spline::GetPoint (spline.cc:80-93) of an ee spline in Hermite basis form, position only; `rec`: the polynomial's record in LDS
+TWR_DEV void flat_point(const char* __restrict__ xs, const char* __restrict__ rec, double t, double p[3]) {
+  const double2 ti = *reinterpret_cast<const double2*>(rec);   // t0, iT
+  const uint4 oa = reinterpret_cast<const uint4*>(rec)[1];
+  const uint2 ob = reinterpret_cast<const uint2*>(rec)[4];
+  const uint32_t o[6] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y};
+  double w[4], X[12];
+#pragma unroll
+  for (int c = 0; c < 12; ++c) X[c] = lds_f64(xs, (c & 1) ? o[c >> 1] >> 16 : o[c >> 1] & 0xFFFFu);
+  hermite_pos(t - ti.x, ti.y, w);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) p[d] = w[0] * X[d] + w[1] * X[3 + d] + w[2] * X[6 + d] + w[3] * X[9 + d];
+}
+TWR_DEV const char* flat_rec(const char* lds, int spline, int local) {
+  return lds + (spline * kFlatWindow + local) * (int)sizeof(FlatPoly);
+}
+// Same formula as rom_item (RangeOfMotionConstraint::UpdateConstraintAtInstance, range_of_motion_constraint.cc:58-69).
+TWR_DEV void flat_rom_math(const FlatRec& w, const FlatNodeR& n, double* __restrict__ g, const char* lds, int lane) {
+  static_assert(offsetof(FlatWork, g_off) == 24 && offsetof(FlatWork, k0) == 32 && offsetof(FlatWork, n_ee) == 68 && offsetof(FlatWork, off_lin) == 72 &&
+                    offsetof(FlatWork, row) == 80 && offsetof(FlatWork, Ib) == 112, "FlatWork dwords");
+  const char* xs = lds + kFlatPolyLds;
+  const double* xv = reinterpret_cast<const double*>(xs) + 2;
+  double* gp = g + (int64_t)w.u64(6);
+  double* gs = const_cast<double*>(xv) + ((w.i32(16) + 1) & ~1);   // 192 doubles behind the staged x
+  const int n_ee = w.i32(17);
   // base splines: the twelve node values of the active polynomial are contiguous in x (nodes q, q + 1: p then v)
   double wP[4], c[3], e[3];
   hermite_pos(n.tb, n.iTb, wP);
   {
-    const double* xl = xp + T->off_lin + n.q6;
-    const double* xa = xp + T->off_ang + n.q6;
+    const double* xl = xv + w.i32(18) + n.q6;
+    const double* xa = xv + w.i32(19) + n.q6;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       c[d] = wP[0] * xl[d] + wP[1] * xl[3 + d] + wP[2] * xl[6 + d] + wP[3] * xl[9 + d];
@@ -1729,37 +1801,165 @@ TWR_DEV void flat_rom_item(const FlatWork& w, const double* __restrict__ x, doub
   for (int ee = 0; ee < kMaxEE; ++ee)
     if (ee < n_ee) {   // g = b_R_w (p_ee - c)
       double p[3], v[3], gv[3];
-      flat_point(xp, tbl<PolyDesc>(blob, T->o_mdesc[ee]), tbl<double>(blob, T->o_mt0[ee]), n.qm[ee], n.t, p);
+      flat_point(xs, flat_rec(lds, 2 * ee, (n.qm >> (8 * ee)) & 0xFFu), n.t, p);
 #pragma unroll
       for (int d = 0; d < 3; ++d) v[d] = p[d] - c[d];
       matTvec(ro.R, v, gv);
-      if (live) {
-        double* go = gp + T->row_rom[ee] + 3 * (w.k0 + lane);
-        go[0] = gv[0];
-        go[1] = gv[1];
-        go[2] = gv[2];
-      }
+      // the 3 cnt values of this end-effector's rows are contiguous in g: through LDS, then whole lines (a lane storing its own
+      // three values writes 16 + 8 of every 24 bytes per instruction)
+      gs[3 * lane] = gv[0];
+      gs[3 * lane + 1] = gv[1];
+      gs[3 * lane + 2] = gv[2];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      double* go = gp + w.i32(20 + ee) + 3 * w.i32(8);
+      const int last_g = 3 * w.i32(9) - 1;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) go[min(lane + 64 * t, last_g)] = gs[min(lane + 64 * t, last_g)];
     }
 }
-// One launch per values-only evaluation: blocks [0, g_dyn) are persistent "dynamic" waves (the quad body), the next n_flat take
-// one range-of-motion item each, the rest one node family of one problem each.  Single-wave blocks, 2.6 KB of LDS.
-template <int XC>
-__global__ __launch_bounds__(64, 3) void eval_values_kernel(const DynWork* __restrict__ dyn, int n_dyn, int g_dyn, const FlatWork* __restrict__ flat,
-                                                            int n_flat, const NodeWork* __restrict__ node, int node_families,
-                                                            const double* __restrict__ x, double* __restrict__ g, double* __restrict__ dump) {
-  __shared__ __attribute__((aligned(16))) double stage[kDynValuesLds];
+// DynamicConstraint::UpdateConstraintAtInstance (dynamic_constraint.cc:59-77) with SingleRigidBodyDynamics::GetDynamicViolation
+// (single_rigid_body_dynamics.cc:76-101) and the EulerConverter quantities (euler_converter.cc:58-83,133-166,207-221) of one time
+// node on ONE lane -- the statements of dyn2_front / dyn2_back without the quad.
+TWR_DEV void flat_dyn_math(const FlatRec& w, const FlatNodeR& n, double* __restrict__ g, const char* lds, int lane) {
+  const char* xs = lds + kFlatPolyLds;
+  const double* xv = reinterpret_cast<const double*>(xs) + 2;
+  const int n_ee = w.i32(17);
+  const double* bl = xv + w.i32(18) + n.q6;   // base splines: the twelve node values of the active polynomial
+  const double* ba = xv + w.i32(19) + n.q6;
+  // force and torque sums over the end-effectors (single_rigid_body_dynamics.cc:81-88)
+  double F[3] = {0.0, 0.0, 0.0}, tau[3] = {0.0, 0.0, 0.0};
+  {
+    double wP[4], c[3];
+    hermite_pos(n.tb, n.iTb, wP);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) c[d] = wP[0] * bl[d] + wP[1] * bl[3 + d] + wP[2] * bl[6 + d] + wP[3] * bl[9 + d];
+#pragma unroll
+    for (int ee = 0; ee < kMaxEE; ++ee)
+      if (ee < n_ee) {
+        double p[3], f[3], rv[3], t3[3];
+        flat_point(xs, flat_rec(lds, 2 * ee, (n.qm >> (8 * ee)) & 0xFFu), n.t, p);
+        flat_point(xs, flat_rec(lds, 2 * ee + 1, (n.qf >> (8 * ee)) & 0xFFu), n.t, f);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) rv[d] = c[d] - p[d];
+        cross3(f, rv, t3);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          F[d] += f[d];
+          tau[d] += t3[d];
+        }
+      }
+  }
+  double cdd[3], e[3], ed[3], edd[3];
+  {
+    double wP[4], wV[4], wA[4];
+    hermite_all(n.tb, n.iTb, wP, wV, wA);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      cdd[d] = wA[0] * bl[d] + wA[1] * bl[3 + d] + wA[2] * bl[6 + d] + wA[3] * bl[9 + d];
+      e[d] = wP[0] * ba[d] + wP[1] * ba[3 + d] + wP[2] * ba[6 + d] + wP[3] * ba[9 + d];
+      ed[d] = wV[0] * ba[d] + wV[1] * ba[3 + d] + wV[2] * ba[6 + d] + wV[3] * ba[9 + d];
+      edd[d] = wA[0] * ba[d] + wA[1] * ba[3 + d] + wA[2] * ba[6 + d] + wA[3] * ba[9 + d];
+    }
+  }
+  Rot ro;
+  rotation(e, ro);
+  const double sy = ro.sy, cy = ro.cy, sz = ro.sz, cz = ro.cz;
+  const double xd = ed[0], yd = ed[1], zd = ed[2];
+  const double Mx[3] = {cy * cz, cy * sz, -sy}, My[3] = {-sz, cz, 0.0};
+  const double Mdx[3] = {-cz * sy * yd - cy * sz * zd, cy * cz * zd - sy * sz * yd, -cy * yd};
+  const double Mdy[3] = {-cz * zd, -sz * zd, 0.0};
+  double om[3], omd[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    om[i] = Mx[i] * xd + My[i] * yd;
+    omd[i] = Mdx[i] * xd + Mdy[i] * yd + Mx[i] * edd[0] + My[i] * edd[1];
+  }
+  om[2] += zd;
+  omd[2] += edd[2];
+  double Iw6[6];  // I_w = R I_b R^T (single_rigid_body_dynamics.cc:91), symmetric: (00,01,02,11,12,22)
+  {
+    const double (&R)[3][3] = ro.R;
+    double Ib[6], Tm[3][3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Ib[i] = w.f64(28 + 2 * i);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      Tm[i][0] = R[i][0] * Ib[0] + R[i][1] * Ib[1] + R[i][2] * Ib[2];
+      Tm[i][1] = R[i][0] * Ib[1] + R[i][1] * Ib[3] + R[i][2] * Ib[4];
+      Tm[i][2] = R[i][0] * Ib[2] + R[i][1] * Ib[4] + R[i][2] * Ib[5];
+    }
+    Iw6[0] = Tm[0][0] * R[0][0] + Tm[0][1] * R[0][1] + Tm[0][2] * R[0][2];
+    Iw6[1] = Tm[0][0] * R[1][0] + Tm[0][1] * R[1][1] + Tm[0][2] * R[1][2];
+    Iw6[2] = Tm[0][0] * R[2][0] + Tm[0][1] * R[2][1] + Tm[0][2] * R[2][2];
+    Iw6[3] = Tm[1][0] * R[1][0] + Tm[1][1] * R[1][1] + Tm[1][2] * R[1][2];
+    Iw6[4] = Tm[1][0] * R[2][0] + Tm[1][1] * R[2][1] + Tm[1][2] * R[2][2];
+    Iw6[5] = Tm[2][0] * R[2][0] + Tm[2][1] * R[2][1] + Tm[2][2] * R[2][2];
+  }
+  double Iw_wd[3], Iw_w[3], wxIw[3];
+  symmul(Iw6, omd, Iw_wd);
+  symmul(Iw6, om, Iw_w);
+  cross3(om, Iw_w, wxIw);
+  const double m = w.f64(24);
+  // the 6 cnt values of the item are contiguous in g: through LDS (the polynomial windows are no longer needed), then whole lines
+  double* gs = reinterpret_cast<double*>(const_cast<char*>(lds)) + 6 * lane;
+  static_assert(kFlatPolyLds >= 64 * 6 * 8, "constraint values of a dynamic item in the window region");
+#pragma unroll
+  for (int i = 0; i < 3; ++i) gs[i] = Iw_wd[i] + wxIw[i] - tau[i];
+  gs[3] = m * cdd[0] - F[0];
+  gs[4] = m * cdd[1] - F[1];
+  gs[5] = m * cdd[2] - F[2] + m * w.f64(26);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  {
+    const double* gl = reinterpret_cast<const double*>(lds);
+    double* go = g + (int64_t)w.u64(6) + w.i32(20) + 6 * w.i32(8);
+    const int last_g = 6 * w.i32(9) - 1;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) go[min(lane + 64 * t, last_g)] = gl[min(lane + 64 * t, last_g)];
+  }
+}
+// One item: fetch (the lane's time node, its share of x, one polynomial record of the windows -- one round trip behind the
+// work record), stage in LDS, evaluate.  NX = doubles of x per lane (the launcher picks the smallest instantiation that covers
+// the largest problem of the batch).
+template <bool DYN, int NX>
+TWR_DEV void flat_item(const FlatWork* __restrict__ work, int idx, const double* __restrict__ x, double* __restrict__ g, double* stage, int lane) {
+  char* lds = reinterpret_cast<char*>(stage);
+  FlatRec w;
+  w.p = cptr<uint32_t>(reinterpret_cast<uint64_t>(work + idx));
+  FlatIn in;
+  double xr[NX];
+  flat_load(w, lane, in);
+  flat_load_x<NX>(x + (int64_t)w.u64(4), w.i32(16), lane, xr);
+  flat_stage_x<NX>(xr, w.i32(16), stage + kFlatPolyLds / 8, lane);
+  flat_stage_polys(in, lds, lane);
+  __syncthreads();   // (one wave: orders the LDS writes before the per-lane reads)
+  if (DYN) flat_dyn_math(w, flat_node(in), g, lds, lane);
+  else flat_rom_math(w, flat_node(in), g, lds, lane);
+}
+// One launch per values-only evaluation: blocks [0, n_fdyn) take one "dynamic" item each, the next n_from one range-of-motion
+// item, the rest one node family of one problem each.  Single-wave blocks; LDS: flat_lds_bytes(largest x of the batch).
+// (A persistent form of this -- waves looping over strided items, the fetches of item i + 1 in flight during the math of item
+// i, the work record read by one vector load and v_readlane so that no scalar load sat in the loop -- was built, is parity-
+// green and is NOT faster: 0.084-0.092 / 0.067-0.072 ms against 0.073-0.080 / 0.066-0.070 ms per 8192 C3 problems, at three
+// waves per SIMD instead of four because of the prefetch registers)
+inline size_t flat_lds_bytes(int max_n_x) {   // windows | zero pair | x (rounded up to a pair) | 192 constraint values of one end-effector
+  return std::max((size_t)kFlatPolyLds + sizeof(double) * (size_t)(2 + ((max_n_x + 1) & ~1) + 192), sizeof(double) * (size_t)kDynValuesLds);
+}
+template <int NX>
+__global__ __launch_bounds__(64, NX <= 12 ? 4 : 3) void eval_values_kernel(const FlatWork* __restrict__ flat, int n_fdyn, int n_from, const NodeWork* __restrict__ node,
+                                                                           int node_families, const double* __restrict__ x, double* __restrict__ g) {
+  extern __shared__ __attribute__((aligned(16))) double flat_stage[];   // (>= kDynValuesLds: node_body stages its constraint values here)
   const int lane = threadIdx.x;
   int b = blockIdx.x;
-  if (b < g_dyn) return dyn_body<true, false, XC, false>(dyn, n_dyn, x, g, nullptr, dump, stage, lane, b, g_dyn);
-  b -= g_dyn;
-  if (b < n_flat) return flat_rom_item(flat[b], x, g, lane);
-  b -= n_flat;
-  node_body(node[b / node_families], x, g, nullptr, 1, stage, b % node_families, lane);   // (values only: the node image is not touched)
+  if (b < n_fdyn) return flat_item<true, NX>(flat, b, x, g, flat_stage, lane);
+  if (b < n_fdyn + n_from) return flat_item<false, NX>(flat, b, x, g, flat_stage, lane);
+  b -= n_fdyn + n_from;
+  node_body(node[b / node_families], x, g, nullptr, 1, flat_stage, b % node_families, lane);   // (values only: the node image is not touched)
 }
-// (with per-kernel events: the range-of-motion items alone)
-__global__ __launch_bounds__(64, 3) void rom_values_flat_kernel(const FlatWork* __restrict__ flat, const double* __restrict__ x,
-                                                                double* __restrict__ g) {
-  flat_rom_item(flat[blockIdx.x], x, g, threadIdx.x);
+// (with per-kernel events: the two flat families in launches of their own)
+template <bool DYN, int NX>
+__global__ __launch_bounds__(64, NX <= 12 ? 4 : 3) void values_flat_kernel(const FlatWork* __restrict__ flat, const double* __restrict__ x, double* __restrict__ g) {
+  extern __shared__ __attribute__((aligned(16))) double flat_stage[];
+  flat_item<DYN, NX>(flat, blockIdx.x, x, g, flat_stage, threadIdx.x);
 }
 
 // ---------------------------------------------------------------- optimised timings (PhaseSpline) kernels
@@ -3211,7 +3411,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
                        const FamWork* const fam[4], const int n_fam[4] /* chunk lists of node_chunk_kernel; all 0: none */,
                        const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap, const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
                        double* g, double* jac, double* dump /* kDynDump doubles */, int flags, bool stream_nt /* non-temporal copy-out of
-                       dyn / rom (copy_out_fixed) */, const FlatWork* flat /* values-only range-of-motion work items; nullptr: none */, int n_flat_rom, hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */) {
+                       dyn / rom (copy_out_fixed) */, const FlatWork* flat /* values-only work items, "dynamic" first; nullptr: none */, int n_flat_dyn, int n_flat_rom, int flat_max_x /* variables of the largest problem */, hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */) {
   static const int dyn_bpc = env_int("TWR_DYN_BPC", 8), rom_bpc = env_int("TWR_ROM_BPC", 4);
   dim3 block(64);
   hipError_t st = hipSuccess;
@@ -3248,34 +3448,35 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
       st = twr_first(st, twr_launch(node_kernel, dim3(n_node), dim3(256), 0, stream, node, x, g, jac, flags));
   };
   const int cap = rom_bpc * n_cu;
-  // Values only (no Jacobian), every problem with fixed timings: "dynamic" on the quad body with its small LDS, "rangeofmotion-*"
-  // one lane per time node (flat items), the node-based sets -- one launch (eval_values_kernel); with per-kernel events three.
-  if (!(flags & 2) && (flags & 1) && flat && n_flat_rom > 0 && n_dyn > 0 && n_pdyn == 0 && n_prom == 0 && n_ploc == 0) {
+  // Values only (no Jacobian), every problem with fixed timings and at most kFlatXCap variables: "dynamic" and "rangeofmotion-*"
+  // with one lane per time node (flat items), the node-based sets -- one launch (eval_values_kernel); with per-kernel events three.
+  if (!(flags & 2) && (flags & 1) && flat && n_flat_dyn + n_flat_rom > 0 && n_pdyn == 0 && n_prom == 0 && n_ploc == 0) {
     const int nf = n_chunks_of(n_fam) == 0 ? node_families : 0;   // (large batches: the chunk kernel takes the node sets)
-    // persistent dyn waves per CU of the 12 the kernel's registers allow (one box, 128 / 1024 candidates, us per evaluation:
-    // 4: 8.9 / 45.2, 6: 8.7 / 37.1, 8: 10.3 / 37.9, 10: 9.6 / 37.9, 12: 9.7 / 38.4) -- the rest streams the range-of-motion items
-    static const int dyn_wpc = env_int("TWR_VALUES_DYN_WPC", 6);
-    int g_dyn = n_dyn < dyn_wpc * n_cu ? n_dyn : dyn_wpc * n_cu;
-    if (g_dyn >= 8) g_dyn &= ~7;   // (block r takes the list positions r modulo 8: one problem, one XCD)
+    const size_t lds = flat_lds_bytes(flat_max_x);
+    const int nx = (flat_max_x + 63) / 64;
+#define TWR_VALUES_LAUNCH(NX)                                                                                                                   \
+  {                                                                                                                                             \
+    if (!ev) {                                                                                                                                  \
+      st = twr_first(st, twr_launch(eval_values_kernel<NX>, dim3(n_flat_dyn + n_flat_rom + nf * n_node), block, lds, stream, flat, n_flat_dyn,  \
+                                    n_flat_rom, node, nf > 0 ? nf : 1, x, g));                                                                  \
+    } else {                                                                                                                                    \
+      (void)hipEventRecord(ev[0], stream);                                                                                                      \
+      if (n_flat_dyn > 0) st = twr_first(st, twr_launch(values_flat_kernel<true, NX>, dim3(n_flat_dyn), block, lds, stream, flat, x, g));       \
+      (void)hipEventRecord(ev[1], stream);                                                                                                      \
+      if (n_flat_rom > 0)                                                                                                                       \
+        st = twr_first(st, twr_launch(values_flat_kernel<false, NX>, dim3(n_flat_rom), block, lds, stream, flat + n_flat_dyn, x, g));           \
+      (void)hipEventRecord(ev[2], stream);                                                                                                      \
+    }                                                                                                                                           \
+  }
+    if (nx <= 12) TWR_VALUES_LAUNCH(12)
+    else if (nx <= 20) TWR_VALUES_LAUNCH(20)
+    else TWR_VALUES_LAUNCH(32)
+#undef TWR_VALUES_LAUNCH
+    static_assert(kFlatXCap <= 32 * 64, "largest instantiation of the values-only kernels");
     if (!ev) {
-      const dim3 vgrid(g_dyn + n_flat_rom + nf * n_node);
-      if (dyn_map_chunks == 2)
-        st = twr_first(st, twr_launch(eval_values_kernel<2>, vgrid, block, 0, stream, dyn, n_dyn, g_dyn, flat, n_flat_rom, node, nf > 0 ? nf : 1, x, g, dump));
-      else
-        st = twr_first(st, twr_launch(eval_values_kernel<4>, vgrid, block, 0, stream, dyn, n_dyn, g_dyn, flat, n_flat_rom, node, nf > 0 ? nf : 1, x, g, dump));
       if (nf == 0) launch_nodes();
       return st;
     }
-    (void)hipEventRecord(ev[0], stream);
-    {
-      const int res = 12 * n_cu;
-      dim3 grid(n_dyn < res ? n_dyn : res);
-      if (dyn_map_chunks == 2) st = twr_first(st, twr_launch(dyn_values_kernel<2>, grid, block, 0, stream, dyn, n_dyn, x, g, dump));
-      else st = twr_first(st, twr_launch(dyn_values_kernel<4>, grid, block, 0, stream, dyn, n_dyn, x, g, dump));
-    }
-    (void)hipEventRecord(ev[1], stream);
-    st = twr_first(st, twr_launch(rom_values_flat_kernel, dim3(n_flat_rom), block, 0, stream, flat, x, g));
-    (void)hipEventRecord(ev[2], stream);
     launch_nodes();
     (void)hipEventRecord(ev[3], stream);
     return st;

@@ -1262,37 +1262,85 @@ void Structure::PackBlob() {
     }
     if (st.n_base > 2 * kMaxPhasePolys) st.n_base = -1;
     h.o_sample = put(&st, sizeof(st));
-    // values-only evaluation of rangeofmotion-* with one lane per time node (device_tables.h FlatNode): fixed timings only --
-    // with optimised timings the active polynomials depend on x and the phase kernels keep that path
+    // values-only evaluation of dynamic / rangeofmotion-* with one lane per time node (device_tables.h FlatNode): fixed
+    // timings only -- with optimised timings the active polynomials depend on x and the phase kernels keep that path
     const bool rom_set = FindSet("rangeofmotion-0") != nullptr;
-    bool fits = true;   // polynomial ids are bytes
-    for (int e = 0; e < n_ee; ++e) fits = fits && mpoly[e].size() <= 256;
-    if (!timings && fits && rom_set) {
-      FlatTables ft;
-      std::memset(&ft, 0, sizeof(ft));
-      ft.n_ee = n_ee;
-      ft.off_lin = off_base_lin;
-      ft.off_ang = off_base_ang;
+    const SetInfo* dyn_set = FindSet("dynamic");
+    flat_items_rom.clear();
+    flat_items_dyn.clear();
+    size_t n_flat_polys = 0;
+    for (int e = 0; e < n_ee; ++e) n_flat_polys += mpoly[e].size() + fpoly[e].size();
+    // x is staged in LDS (16-bit byte offsets); window starts are 16-bit indices
+    if (!timings && n_vars <= kFlatXCap && n_flat_polys < 65536 && (rom_set || dyn_set)) {
+      flat_row_dyn = dyn_set ? dyn_set->offset : 0;
+      std::vector<FlatPoly> fp;
+      int first[2 * kMaxEE] = {0};   // spline s = 2 e (ee-motion_e), 2 e + 1 (ee-force_e): its first record in fp
+      auto flat_polys = [&](const std::vector<PolyDesc>& polys, const std::vector<double>& durations) {
+        double t0 = 0.0;   // the running sum Spline::GetSegmentID compares t against (spline.cc:52-57)
+        for (size_t q = 0; q < polys.size(); ++q) {
+          FlatPoly r;
+          std::memset(&r, 0, sizeof(r));
+          r.t0 = t0;
+          r.iT = polys[q].iT;
+          t0 += durations[q];
+          const bool shared = (polys[q].meta >> 16) & 1;
+          for (int c = 0; c < 12; ++c) {
+            const int src = shared && c >= 6 && c < 9 ? c - 6 : c;   // stance: p1 is the same variable as p0
+            const int sl = polys[q].cand[src] & 0xF;
+            r.off[c] = (uint16_t)(sl != 0xF ? 8 * (2 + polys[q].xbase + sl) : 0);
+          }
+          fp.push_back(r);
+        }
+      };
       for (int e = 0; e < n_ee; ++e) {
-        ft.row_rom[e] = FindSet("rangeofmotion-" + std::to_string(e))->offset;
-        // start time of every polynomial: the running sum Spline::GetSegmentID compares t against (spline.cc:52-57)
-        std::vector<double> t0m(motion[e].durations.size(), 0.0);
-        for (size_t q = 1; q < t0m.size(); ++q) t0m[q] = t0m[q - 1] + motion[e].durations[q - 1];
-        ft.o_mt0[e] = put(t0m.data(), t0m.size() * sizeof(double));
-        ft.o_mdesc[e] = st.o_mdesc[e];
+        if (rom_set) flat_row_rom[e] = FindSet("rangeofmotion-" + std::to_string(e))->offset;
+        first[2 * e] = (int)fp.size();
+        flat_polys(mpoly[e], motion[e].durations);
+        first[2 * e + 1] = (int)fp.size();
+        flat_polys(fpoly[e], force[e].durations);
       }
-      std::vector<FlatNode> fn(grid_rom.size());
-      for (size_t k = 0; k < grid_rom.size(); ++k) {
-        std::memset(&fn[k], 0, sizeof(FlatNode));
-        fn[k].t = grid_rom[k];
-        fn[k].tb = rom_base[k].t_local;
-        fn[k].iTb = 1.0 / base.durations[rom_base[k].poly];
-        fn[k].q6 = 6 * rom_base[k].poly;
-        for (int e = 0; e < n_ee; ++e) fn[k].qm[e] = (uint8_t)rom_motion[e][k].poly;
-      }
-      off_flat_rom = put(fn.data(), fn.size() * sizeof(FlatNode));
-      flat_n_rom = (int)fn.size();
-      off_flat_tables = h.o_flat = put(&ft, sizeof(ft));
+      off_flat_polys = h.o_flat = put(fp.data(), fp.size() * sizeof(FlatPoly));
+      // items: <= 64 consecutive time nodes whose active polynomials span <= kFlatWindow per spline
+      auto flat_items = [&](const std::vector<double>& grid, const std::vector<TimeNode>& at_base, const std::vector<std::vector<TimeNode>>& at_motion,
+                            const std::vector<std::vector<TimeNode>>* at_force, std::vector<FlatItem>& items) {
+        std::vector<FlatNode> fn(grid.size());
+        auto poly_at = [&](int s, size_t k) { return (s & 1) ? (*at_force)[s >> 1][k].poly : at_motion[s >> 1][k].poly; };
+        const int step = at_force ? 1 : 2;   // range of motion: the ee-motion splines only
+        size_t k0 = 0;
+        while (k0 < grid.size()) {
+          size_t k1 = k0 + 1;
+          auto fits = [&](size_t k) {
+            for (int s = 0; s < 2 * n_ee; s += step)
+              if (poly_at(s, k) - poly_at(s, k0) >= kFlatWindow) return false;
+            return true;
+          };
+          while (k1 < grid.size() && k1 - k0 < 64 && fits(k1)) ++k1;
+          FlatItem it;
+          it.k0 = (int)k0;
+          it.cnt = (int)(k1 - k0);
+          for (int s = 0; s < 2 * n_ee; s += step) {
+            const int lo = poly_at(s, k0), hi = poly_at(s, k1 - 1);
+            it.start[s >> 2] |= (uint64_t)(first[s] + lo) << (16 * (s & 3));
+            it.count |= (uint64_t)(hi - lo + 1) << (8 * s);
+          }
+          items.push_back(it);
+          for (size_t k = k0; k < k1; ++k) {
+            std::memset(&fn[k], 0, sizeof(FlatNode));
+            fn[k].t = grid[k];
+            fn[k].tb = at_base[k].t_local;
+            fn[k].iTb = 1.0 / base.durations[at_base[k].poly];
+            fn[k].q6 = 6 * at_base[k].poly;
+            for (int e = 0; e < n_ee; ++e) {
+              fn[k].qm[e] = (uint8_t)(at_motion[e][k].poly - at_motion[e][k0].poly);
+              if (at_force) fn[k].qf[e] = (uint8_t)((*at_force)[e][k].poly - (*at_force)[e][k0].poly);
+            }
+          }
+          k0 = k1;
+        }
+        return put(fn.data(), fn.size() * sizeof(FlatNode));
+      };
+      if (rom_set) off_flat_rom = flat_items(grid_rom, rom_base, rom_motion, nullptr, flat_items_rom);
+      if (dyn_set) off_flat_dyn = flat_items(grid_dyn, dyn_base, dyn_motion, &dyn_force, flat_items_dyn);
     }
   }
   h.mass = model.mass; h.gravity = model.gravity; h.mu = model.friction; h.flat_height = model.flat_height;

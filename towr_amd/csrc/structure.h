@@ -99,9 +99,16 @@ struct Structure {
   };
   std::vector<std::vector<RomSlice>> rom_slices;   // [ee]
   uint32_t off_rom_nodes = 0;
-  // values-only evaluation of rangeofmotion-*, one lane per time node (device_tables.h FlatNode / FlatTables): blob offsets, 0 = none
-  uint32_t off_flat_tables = 0, off_flat_rom = 0;
-  int flat_n_rom = 0;
+  // values-only evaluation of dynamic / rangeofmotion-*, one lane per time node (device_tables.h FlatNode / FlatTables /
+  // FlatWork): blob offsets (0 = none) and the items of a problem of this structure (twr_batch_create adds the problem's
+  // addresses)
+  struct FlatItem {
+    int k0 = 0, cnt = 0;                 // time nodes [k0, k0 + cnt) of the grid
+    uint64_t start[2] = {0, 0}, count = 0;   // FlatWork::start / count
+  };
+  uint32_t off_flat_polys = 0, off_flat_rom = 0, off_flat_dyn = 0;   // FlatPoly[] | FlatNode[] of the two grids
+  int flat_row_dyn = 0, flat_row_rom[kMaxEE] = {0, 0, 0, 0};
+  std::vector<FlatItem> flat_items_rom, flat_items_dyn;
 
   const SetInfo* FindSet(const std::string& name) const;  // nullptr if the family is switched off
   void Build();            // throws std::runtime_error
