@@ -35,7 +35,7 @@ pmc tcc2_s "--workload sweep --batch 1024" WRITE_SIZE || exit 1
 pmc tcc1_a "--sets all" FETCH_SIZE || exit 1
 pmc tcc2_a "--sets all" WRITE_SIZE || exit 1
 pmc sq1_s "--workload sweep --batch 1024" SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS || exit 1
-# round 5: the values-only leg (dyn_values_kernel / rom_values_kernel): kernel trace + VALU instruction counts
+# round 5: the values-only leg (eval_values_kernel; with per-kernel events values_flat_kernel): kernel trace + VALU instruction counts
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace_v -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scale-c5 --no-timings-c3 > $OUT/bench_ktrace_v.json 2> $OUT/ktrace_v.err || exit 1
 echo "ktrace ktrace_v done"
 timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq_v -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scale-c5 --no-timings-c3 > $OUT/sq_v.log 2>&1 || exit 1

@@ -96,7 +96,7 @@ for d in ("tcc1_a", "tcc2_a"):
     alls.update(c)
     for k, v in sorted(c.items()):
         lines.append("%-22s %-26s %.6g" % (k[0], k[1], v))
-lines.append("# default bench incl. the values-only leg (dyn_values_kernel / rom_values_kernel, 8192 problems)")
+lines.append("# default bench incl. the values-only leg (eval_values_kernel resp. values_flat_kernel, 8192 problems)")
 vals = {}
 for d in ("sq_v",):
     c = {k: v for k, v in counters(d).items() if "values" in k[0]}

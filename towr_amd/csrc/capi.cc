@@ -707,9 +707,10 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
               fw.n_ee = S.n_ee;
               fw.off_lin = S.off_base_lin;
               fw.off_ang = S.off_base_ang;
-              for (int e = 0; e < twr::kMaxEE; ++e) fw.row[e] = S.flat_row_rom[e];
+              for (int e = 0; e < twr::kMaxEE; ++e) fw.row_rom[e] = S.flat_row_rom[e];
               if (dynamic) {
-                fw.row[0] = S.flat_row_dyn;
+                fw.row_dyn = S.flat_row_dyn;
+                fw.with_rom = S.flat_with_rom ? 1 : 0;
                 fw.mass = H->mass;
                 fw.gravity = H->gravity;
                 for (int i = 0; i < 6; ++i) fw.Ib[i] = H->Ib[i];

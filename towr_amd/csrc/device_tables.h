@@ -355,23 +355,36 @@ struct FlatNode {
 };
 static_assert(sizeof(FlatNode) == 40, "FlatNode layout");
 // Everything an item needs that is the same for all its lanes is in its work record -- addresses, window starts, the
-// structure's offsets and rows and (for "dynamic") the model constants: the wave reads the record with ONE coalesced vector
-// load (lane k = dword k) an iteration ahead and takes the fields with v_readlane.  (Scalar loads cannot be prefetched in this
-// loop: they share their counter with the LDS reads and return out of order, so every LDS wait drains them.)
+// structure's offsets and rows and (for "dynamic") the model constants: one scalar round trip, nothing behind a pointer of it.
 struct FlatWork {          // cnt <= 64 consecutive time nodes of the dynamic (or range-of-motion) grid of one problem
-  uint64_t nodes;          // dwords 0-1    FlatNode[cnt]
-  uint64_t polys;          //        2-3    FlatPoly[] of the structure
-  int64_t x_off, g_off;    //        4-7    the problem's x / g
-  int32_t k0, cnt;         //        8-9
-  uint64_t start[2];       //        10-13  16 bits per spline: first polynomial of its window in the FlatPoly array (splines 0-3 | 4-7)
-  uint64_t count;          //        14-15  8 bits per spline: polynomials in its window (0: spline not used by the item)
-  int32_t n_x, n_ee;       //        16-17  variables of the problem (<= kFlatXCap), end-effectors
-  int32_t off_lin, off_ang;   //     18-19  x offsets of base-lin / base-ang
-  int32_t row[kMaxEE];     //        20-23  first row of "rangeofmotion-e"; "dynamic" items: row[0] = first row of "dynamic"
-  double mass, gravity;    //        24-27  ("dynamic" items)
-  double Ib[6];            //        28-39
+  uint64_t nodes;          // FlatNode[cnt]
+  uint64_t polys;          // FlatPoly[] of the structure
+  int64_t x_off, g_off;    // the problem's x / g
+  int32_t k0, cnt;
+  uint64_t start[2];       // 16 bits per spline: first polynomial of its window in the FlatPoly array (splines 0-3 | 4-7)
+  uint64_t count;          // 8 bits per spline: polynomials in its window (0: spline not used by the item)
+  int32_t n_x, n_ee;       // variables of the problem (<= kFlatXCap), end-effectors
+  int32_t off_lin, off_ang;   // x offsets of base-lin / base-ang
+  int32_t row_rom[kMaxEE]; // first row of "rangeofmotion-e"
+  int32_t row_dyn;         // first row of "dynamic"
+  int32_t with_rom;        // "dynamic" items: the two grids coincide and the lane evaluates "rangeofmotion-*" of its time node as well
+  double mass, gravity;    // ("dynamic" items)
+  double Ib[6];
 };
-static_assert(sizeof(FlatWork) == 160 && offsetof(FlatWork, n_x) == 64 && offsetof(FlatWork, mass) == 96, "FlatWork layout");
+static_assert(sizeof(FlatWork) == 168, "FlatWork layout");
+// (the kernel addresses the fields by dword)
+enum FlatWorkDword {
+  kFwNodes = 0, kFwPolys = 2, kFwX = 4, kFwG = 6, kFwK0 = 8, kFwCnt = 9, kFwStart = 10, kFwCount = 14, kFwNx = 16, kFwNee = 17, kFwOffLin = 18,
+  kFwOffAng = 19, kFwRowRom = 20, kFwRowDyn = 24, kFwWithRom = 25, kFwMass = 26, kFwGravity = 28, kFwIb = 30
+};
+static_assert(offsetof(FlatWork, nodes) == 4 * kFwNodes && offsetof(FlatWork, polys) == 4 * kFwPolys && offsetof(FlatWork, x_off) == 4 * kFwX &&
+                  offsetof(FlatWork, g_off) == 4 * kFwG && offsetof(FlatWork, k0) == 4 * kFwK0 && offsetof(FlatWork, cnt) == 4 * kFwCnt &&
+                  offsetof(FlatWork, start) == 4 * kFwStart && offsetof(FlatWork, count) == 4 * kFwCount && offsetof(FlatWork, n_x) == 4 * kFwNx &&
+                  offsetof(FlatWork, n_ee) == 4 * kFwNee && offsetof(FlatWork, off_lin) == 4 * kFwOffLin && offsetof(FlatWork, off_ang) == 4 * kFwOffAng &&
+                  offsetof(FlatWork, row_rom) == 4 * kFwRowRom && offsetof(FlatWork, row_dyn) == 4 * kFwRowDyn &&
+                  offsetof(FlatWork, with_rom) == 4 * kFwWithRom && offsetof(FlatWork, mass) == 4 * kFwMass &&
+                  offsetof(FlatWork, gravity) == 4 * kFwGravity && offsetof(FlatWork, Ib) == 4 * kFwIb,
+              "FlatWork dwords");
 
 // Blob header: model constants + what the node kernel needs.  The terrain-ee-motion_e sets are
 // adjacent in g / jac, and so are the force-ee-force_e sets, so each family is one flat node list.

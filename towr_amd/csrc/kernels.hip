@@ -1722,10 +1722,8 @@ struct FlatRec {
   TWR_DEV double f64(int k) const { return __hiloint2double((int)p[k + 1], (int)p[k]); }
 };
 TWR_DEV void flat_load(const FlatRec& w, int lane, FlatIn& in) {
-  static_assert(offsetof(FlatWork, nodes) == 0 && offsetof(FlatWork, polys) == 8 && offsetof(FlatWork, cnt) == 36 && offsetof(FlatWork, start) == 40 &&
-                    offsetof(FlatWork, count) == 56, "FlatWork dwords");
   {
-    const TWR_GLOBAL twr_u2* nd = reinterpret_cast<const TWR_GLOBAL twr_u2*>(gptr<FlatNode>(w.u64(0)) + min(lane, w.i32(9) - 1));   // (clamped:
+    const TWR_GLOBAL twr_u2* nd = reinterpret_cast<const TWR_GLOBAL twr_u2*>(gptr<FlatNode>(w.u64(kFwNodes)) + min(lane, w.i32(kFwCnt) - 1));   // (clamped:
     const twr_u2 a = nd[0], b = nd[1], c = nd[2], d = nd[3];   // every lane loads, the tail lanes store nothing; 8-byte aligned records)
     in.na = twr_u4{a.x, a.y, b.x, b.y};
     in.nb = twr_u4{c.x, c.y, d.x, d.y};
@@ -1733,9 +1731,9 @@ TWR_DEV void flat_load(const FlatRec& w, int lane, FlatIn& in) {
   }
   // lane 8 s + j: record j of spline s's window (clamped to the window: no predicates)
   const int s = lane >> 3, j = lane & 7;
-  const uint64_t st = lane < 32 ? w.u64(10) : w.u64(12);
-  const int first = (int)((st >> (16 * (s & 3))) & 0xFFFFu), cnt = (int)((w.u64(14) >> (8 * s)) & 0xFFu);
-  const TWR_GLOBAL twr_u4* rec = reinterpret_cast<const TWR_GLOBAL twr_u4*>(gptr<FlatPoly>(w.u64(2)) + first + min(j, max(cnt, 1) - 1));
+  const uint64_t st = lane < 32 ? w.u64(kFwStart) : w.u64(kFwStart + 2);
+  const int first = (int)((st >> (16 * (s & 3))) & 0xFFFFu), cnt = (int)((w.u64(kFwCount) >> (8 * s)) & 0xFFu);
+  const TWR_GLOBAL twr_u4* rec = reinterpret_cast<const TWR_GLOBAL twr_u4*>(gptr<FlatPoly>(w.u64(kFwPolys)) + first + min(j, max(cnt, 1) - 1));
   in.pa = rec[0];
   in.pb = rec[1];
   in.pc = rec[2];
@@ -1776,19 +1774,17 @@ TWR_DEV const char* flat_rec(const char* lds, int spline, int local) {
 }
 // Same formula as rom_item (RangeOfMotionConstraint::UpdateConstraintAtInstance, range_of_motion_constraint.cc:58-69).
 TWR_DEV void flat_rom_math(const FlatRec& w, const FlatNodeR& n, double* __restrict__ g, const char* lds, int lane) {
-  static_assert(offsetof(FlatWork, g_off) == 24 && offsetof(FlatWork, k0) == 32 && offsetof(FlatWork, n_ee) == 68 && offsetof(FlatWork, off_lin) == 72 &&
-                    offsetof(FlatWork, row) == 80 && offsetof(FlatWork, Ib) == 112, "FlatWork dwords");
   const char* xs = lds + kFlatPolyLds;
   const double* xv = reinterpret_cast<const double*>(xs) + 2;
-  double* gp = g + (int64_t)w.u64(6);
-  double* gs = const_cast<double*>(xv) + ((w.i32(16) + 1) & ~1);   // 192 doubles behind the staged x
-  const int n_ee = w.i32(17);
+  double* gp = g + (int64_t)w.u64(kFwG);
+  double* gs = const_cast<double*>(xv) + ((w.i32(kFwNx) + 1) & ~1);   // 192 doubles behind the staged x
+  const int n_ee = w.i32(kFwNee);
   // base splines: the twelve node values of the active polynomial are contiguous in x (nodes q, q + 1: p then v)
   double wP[4], c[3], e[3];
   hermite_pos(n.tb, n.iTb, wP);
   {
-    const double* xl = xv + w.i32(18) + n.q6;
-    const double* xa = xv + w.i32(19) + n.q6;
+    const double* xl = xv + w.i32(kFwOffLin) + n.q6;
+    const double* xa = xv + w.i32(kFwOffAng) + n.q6;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       c[d] = wP[0] * xl[d] + wP[1] * xl[3 + d] + wP[2] * xl[6 + d] + wP[3] * xl[9 + d];
@@ -1811,8 +1807,8 @@ TWR_DEV void flat_rom_math(const FlatRec& w, const FlatNodeR& n, double* __restr
       gs[3 * lane + 1] = gv[1];
       gs[3 * lane + 2] = gv[2];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      double* go = gp + w.i32(20 + ee) + 3 * w.i32(8);
-      const int last_g = 3 * w.i32(9) - 1;
+      double* go = gp + w.i32(kFwRowRom + ee) + 3 * w.i32(kFwK0);
+      const int last_g = 3 * w.i32(kFwCnt) - 1;
 #pragma unroll
       for (int t = 0; t < 3; ++t) go[min(lane + 64 * t, last_g)] = gs[min(lane + 64 * t, last_g)];
     }
@@ -1823,16 +1819,28 @@ TWR_DEV void flat_rom_math(const FlatRec& w, const FlatNodeR& n, double* __restr
 TWR_DEV void flat_dyn_math(const FlatRec& w, const FlatNodeR& n, double* __restrict__ g, const char* lds, int lane) {
   const char* xs = lds + kFlatPolyLds;
   const double* xv = reinterpret_cast<const double*>(xs) + 2;
-  const int n_ee = w.i32(17);
-  const double* bl = xv + w.i32(18) + n.q6;   // base splines: the twelve node values of the active polynomial
-  const double* ba = xv + w.i32(19) + n.q6;
+  const int n_ee = w.i32(kFwNee);
+  const double* bl = xv + w.i32(kFwOffLin) + n.q6;   // base splines: the twelve node values of the active polynomial
+  const double* ba = xv + w.i32(kFwOffAng) + n.q6;
+  // base position and rotation first: with coinciding grids (FlatWork::with_rom) the lane evaluates "rangeofmotion-e" of its
+  // time node along the way -- g = b_R_w (p_e - c), range_of_motion_constraint.cc:58-69 -- from the same base point, rotation and
+  // end-effector positions
+  const bool with_rom = w.i32(kFwWithRom) != 0;
+  double* gs_rom = const_cast<double*>(xv) + ((w.i32(kFwNx) + 1) & ~1);   // 192 doubles behind the staged x
+  double* gp = g + (int64_t)w.u64(kFwG);
+  const int last_rom = 3 * w.i32(kFwCnt) - 1;
+  Rot ro;
   // force and torque sums over the end-effectors (single_rigid_body_dynamics.cc:81-88)
   double F[3] = {0.0, 0.0, 0.0}, tau[3] = {0.0, 0.0, 0.0};
   {
-    double wP[4], c[3];
+    double wP[4], c[3], e[3];
     hermite_pos(n.tb, n.iTb, wP);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) c[d] = wP[0] * bl[d] + wP[1] * bl[3 + d] + wP[2] * bl[6 + d] + wP[3] * bl[9 + d];
+    for (int d = 0; d < 3; ++d) {
+      c[d] = wP[0] * bl[d] + wP[1] * bl[3 + d] + wP[2] * bl[6 + d] + wP[3] * bl[9 + d];
+      e[d] = wP[0] * ba[d] + wP[1] * ba[3 + d] + wP[2] * ba[6 + d] + wP[3] * ba[9 + d];
+    }
+    rotation(e, ro);
 #pragma unroll
     for (int ee = 0; ee < kMaxEE; ++ee)
       if (ee < n_ee) {
@@ -1847,22 +1855,32 @@ TWR_DEV void flat_dyn_math(const FlatRec& w, const FlatNodeR& n, double* __restr
           F[d] += f[d];
           tau[d] += t3[d];
         }
+        if (with_rom) {
+          double v[3], gv[3];
+#pragma unroll
+          for (int d = 0; d < 3; ++d) v[d] = p[d] - c[d];
+          matTvec(ro.R, v, gv);
+          gs_rom[3 * lane] = gv[0];
+          gs_rom[3 * lane + 1] = gv[1];
+          gs_rom[3 * lane + 2] = gv[2];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          double* go = gp + w.i32(kFwRowRom + ee) + 3 * w.i32(kFwK0);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) go[min(lane + 64 * t, last_rom)] = gs_rom[min(lane + 64 * t, last_rom)];
+        }
       }
   }
-  double cdd[3], e[3], ed[3], edd[3];
+  double cdd[3], ed[3], edd[3];
   {
     double wP[4], wV[4], wA[4];
     hermite_all(n.tb, n.iTb, wP, wV, wA);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       cdd[d] = wA[0] * bl[d] + wA[1] * bl[3 + d] + wA[2] * bl[6 + d] + wA[3] * bl[9 + d];
-      e[d] = wP[0] * ba[d] + wP[1] * ba[3 + d] + wP[2] * ba[6 + d] + wP[3] * ba[9 + d];
       ed[d] = wV[0] * ba[d] + wV[1] * ba[3 + d] + wV[2] * ba[6 + d] + wV[3] * ba[9 + d];
       edd[d] = wA[0] * ba[d] + wA[1] * ba[3 + d] + wA[2] * ba[6 + d] + wA[3] * ba[9 + d];
     }
   }
-  Rot ro;
-  rotation(e, ro);
   const double sy = ro.sy, cy = ro.cy, sz = ro.sz, cz = ro.cz;
   const double xd = ed[0], yd = ed[1], zd = ed[2];
   const double Mx[3] = {cy * cz, cy * sz, -sy}, My[3] = {-sz, cz, 0.0};
@@ -1881,7 +1899,7 @@ TWR_DEV void flat_dyn_math(const FlatRec& w, const FlatNodeR& n, double* __restr
     const double (&R)[3][3] = ro.R;
     double Ib[6], Tm[3][3];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) Ib[i] = w.f64(28 + 2 * i);
+    for (int i = 0; i < 6; ++i) Ib[i] = w.f64(kFwIb + 2 * i);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       Tm[i][0] = R[i][0] * Ib[0] + R[i][1] * Ib[1] + R[i][2] * Ib[2];
@@ -1899,7 +1917,7 @@ TWR_DEV void flat_dyn_math(const FlatRec& w, const FlatNodeR& n, double* __restr
   symmul(Iw6, omd, Iw_wd);
   symmul(Iw6, om, Iw_w);
   cross3(om, Iw_w, wxIw);
-  const double m = w.f64(24);
+  const double m = w.f64(kFwMass);
   // the 6 cnt values of the item are contiguous in g: through LDS (the polynomial windows are no longer needed), then whole lines
   double* gs = reinterpret_cast<double*>(const_cast<char*>(lds)) + 6 * lane;
   static_assert(kFlatPolyLds >= 64 * 6 * 8, "constraint values of a dynamic item in the window region");
@@ -1907,12 +1925,12 @@ TWR_DEV void flat_dyn_math(const FlatRec& w, const FlatNodeR& n, double* __restr
   for (int i = 0; i < 3; ++i) gs[i] = Iw_wd[i] + wxIw[i] - tau[i];
   gs[3] = m * cdd[0] - F[0];
   gs[4] = m * cdd[1] - F[1];
-  gs[5] = m * cdd[2] - F[2] + m * w.f64(26);
+  gs[5] = m * cdd[2] - F[2] + m * w.f64(kFwGravity);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   {
     const double* gl = reinterpret_cast<const double*>(lds);
-    double* go = g + (int64_t)w.u64(6) + w.i32(20) + 6 * w.i32(8);
-    const int last_g = 6 * w.i32(9) - 1;
+    double* go = gp + w.i32(kFwRowDyn) + 6 * w.i32(kFwK0);
+    const int last_g = 6 * w.i32(kFwCnt) - 1;
 #pragma unroll
     for (int t = 0; t < 6; ++t) go[min(lane + 64 * t, last_g)] = gl[min(lane + 64 * t, last_g)];
   }
@@ -1928,8 +1946,8 @@ TWR_DEV void flat_item(const FlatWork* __restrict__ work, int idx, const double*
   FlatIn in;
   double xr[NX];
   flat_load(w, lane, in);
-  flat_load_x<NX>(x + (int64_t)w.u64(4), w.i32(16), lane, xr);
-  flat_stage_x<NX>(xr, w.i32(16), stage + kFlatPolyLds / 8, lane);
+  flat_load_x<NX>(x + (int64_t)w.u64(kFwX), w.i32(kFwNx), lane, xr);
+  flat_stage_x<NX>(xr, w.i32(kFwNx), stage + kFlatPolyLds / 8, lane);
   flat_stage_polys(in, lds, lane);
   __syncthreads();   // (one wave: orders the LDS writes before the per-lane reads)
   if (DYN) flat_dyn_math(w, flat_node(in), g, lds, lane);

@@ -1268,6 +1268,7 @@ void Structure::PackBlob() {
     const SetInfo* dyn_set = FindSet("dynamic");
     flat_items_rom.clear();
     flat_items_dyn.clear();
+    flat_with_rom = false;
     size_t n_flat_polys = 0;
     for (int e = 0; e < n_ee; ++e) n_flat_polys += mpoly[e].size() + fpoly[e].size();
     // x is staged in LDS (16-bit byte offsets); window starts are 16-bit indices
@@ -1339,7 +1340,10 @@ void Structure::PackBlob() {
         }
         return put(fn.data(), fn.size() * sizeof(FlatNode));
       };
-      if (rom_set) off_flat_rom = flat_items(grid_rom, rom_base, rom_motion, nullptr, flat_items_rom);
+      // coinciding grids (the BASELINE configurations choose one dt for both; towr's defaults are 0.1 / 0.08 s): the "dynamic"
+      // items evaluate the range-of-motion rows of their time nodes as well -- same base point, rotation and ee positions
+      flat_with_rom = rom_set && dyn_set && grid_rom == grid_dyn;
+      if (rom_set && !flat_with_rom) off_flat_rom = flat_items(grid_rom, rom_base, rom_motion, nullptr, flat_items_rom);
       if (dyn_set) off_flat_dyn = flat_items(grid_dyn, dyn_base, dyn_motion, &dyn_force, flat_items_dyn);
     }
   }

@@ -108,6 +108,7 @@ struct Structure {
   };
   uint32_t off_flat_polys = 0, off_flat_rom = 0, off_flat_dyn = 0;   // FlatPoly[] | FlatNode[] of the two grids
   int flat_row_dyn = 0, flat_row_rom[kMaxEE] = {0, 0, 0, 0};
+  bool flat_with_rom = false;   // the two grids coincide: the "dynamic" items take the range-of-motion rows along
   std::vector<FlatItem> flat_items_rom, flat_items_dyn;
 
   const SetInfo* FindSet(const std::string& name) const;  // nullptr if the family is switched off
