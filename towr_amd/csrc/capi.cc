@@ -22,7 +22,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
                        const NodeWork* node, int n_node, int node_families, const FamWork* const fam[4], const int n_fam[4],
                        const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap,
                        const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
-                       double* g, double* jac, double* dump, int flags, bool stream_nt, const FlatWork* flat, int n_flat_dyn, int n_flat_rom, int flat_max_x,
+                       double* g, double* jac, double* dump, int flags, bool stream_nt, const FlatWork* flat, int n_flat, int flat_max_x,
                        hipStream_t stream, hipEvent_t* ev);
 int dyn_dump_doubles();
 int node_force_chunk();
@@ -115,7 +115,7 @@ struct twr_batch {
   twr::NodeWork* d_node = nullptr;
   twr::FlatWork* d_flat = nullptr;           // values-only evaluation of dynamic / rangeofmotion-*, one lane per time node:
   int flat_max_x = 0;                        // variables of the largest problem (the LDS a wave of that path stages x in)
-  int n_flat_dyn = 0, n_flat_rom = 0;        // "dynamic" items first (nullptr when a problem of the batch cannot take that path)
+  int n_flat = 0;                            // records, in groups of four per problem (nullptr when a problem of the batch cannot take that path)
   twr::FamWork* d_fam[4] = {nullptr, nullptr, nullptr, nullptr};   // chunk lists of node_chunk_kernel (large batches only)
   int n_fam[4] = {0, 0, 0, 0};
   // optimised-timings problems have their own work lists
@@ -538,8 +538,8 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
     std::vector<twr::DynWork> dyn;
     std::vector<twr::RomWork> rom;
     std::vector<twr::NodeWork> node;
-    std::vector<twr::FlatWork> flat_dyn, flat_rom;
-    std::vector<int> flat_dyn_p, flat_rom_p;   // the problem of every item
+    std::vector<twr::FlatWork> flat_items;     // groups of four records, every group of one problem (device_tables.h FlatWork)
+    std::vector<int> flat_group_p;             // the problem of every group
     bool flat_ok = true;
     std::vector<twr::PDynWork> pdyn;
     std::vector<int> pdyn_first;   // first dynamic run of every optimised-timings problem (+ end)
@@ -690,7 +690,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
         if (S.timings) flat_ok = false;
         if (S.off_flat_polys) {
           const twr::DevStruct* H = reinterpret_cast<const twr::DevStruct*>(S.blob.data());
-          auto items = [&](uint32_t off_nodes, const std::vector<twr::Structure::FlatItem>& list, bool dynamic, std::vector<twr::FlatWork>& out) {
+          auto items = [&](uint32_t off_nodes, const std::vector<twr::Structure::FlatItem>& list, bool dynamic) {
             for (const auto& it : list) {
               twr::FlatWork fw;
               std::memset(&fw, 0, sizeof(fw));
@@ -708,6 +708,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
               fw.off_lin = S.off_base_lin;
               fw.off_ang = S.off_base_ang;
               for (int e = 0; e < twr::kMaxEE; ++e) fw.row_rom[e] = S.flat_row_rom[e];
+              fw.dynamic = dynamic ? 1 : 0;
               if (dynamic) {
                 fw.row_dyn = S.flat_row_dyn;
                 fw.with_rom = S.flat_with_rom ? 1 : 0;
@@ -715,14 +716,20 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
                 fw.gravity = H->gravity;
                 for (int i = 0; i < 6; ++i) fw.Ib[i] = H->Ib[i];
               }
-              out.push_back(fw);
+              flat_items.push_back(fw);
             }
           };
           b->flat_max_x = std::max(b->flat_max_x, S.n_vars);
-          items(S.off_flat_dyn, S.flat_items_dyn, true, flat_dyn);
-          items(S.off_flat_rom, S.flat_items_rom, false, flat_rom);
-          flat_dyn_p.resize(flat_dyn.size(), p);
-          flat_rom_p.resize(flat_rom.size(), p);
+          items(S.off_flat_dyn, S.flat_items_dyn, true);
+          items(S.off_flat_rom, S.flat_items_rom, false);
+          while (flat_items.size() % 4 != 0) {   // whole groups: empty items that still carry the problem's x (the group copies it
+            twr::FlatWork fw;                    // to LDS with all its threads)
+            std::memset(&fw, 0, sizeof(fw));
+            fw.x_off = b->x_off[p];
+            fw.n_x = S.n_vars;
+            flat_items.push_back(fw);
+          }
+          flat_group_p.resize(flat_items.size() / 4, p);
         } else if (S.FindSet("rangeofmotion-0") || S.FindSet("dynamic")) {
           flat_ok = false;
         }
@@ -800,33 +807,26 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
       node.push_back(end);
     }
     upload(node.data(), node.size() * sizeof(twr::NodeWork), reinterpret_cast<void**>(&b->d_node));
-    if (flat_ok && !(flat_dyn.empty() && flat_rom.empty())) {
-      // One problem, one XCD: workgroup r of the launch runs on XCD r modulo 8 and takes item r.  The items of problem p go to
-      // workgroups = p modulo 8: its x comes from HBM once and from that XCD's L2 for its other items (four "dynamic" and four
-      // range-of-motion items per C3 problem; in list order every one of them ran on another XCD and fetched x again).
-      auto by_xcd = [](std::vector<twr::FlatWork>& list, const std::vector<int>& problem, size_t first_block) {
-        std::vector<twr::FlatWork> queue[8], out;   // queue c: the items that go to the list positions = c modulo 8
-        for (size_t i = 0; i < list.size(); ++i) queue[(problem[i] + 8 - first_block % 8) % 8].push_back(list[i]);
-        size_t depth = 0;
-        for (const auto& q : queue) depth = std::max(depth, q.size());
-        out.reserve(list.size());
-        size_t k = 0;
-        for (; k < depth; ++k) {   // whole rounds of eight; a round in which a queue has run dry ends the interleaving
-          bool whole = true;
-          for (const auto& q : queue) whole = whole && k < q.size();
-          if (!whole) break;
-          for (const auto& q : queue) out.push_back(q[k]);
-        }
-        for (const auto& q : queue)
-          for (size_t i = k; i < q.size(); ++i) out.push_back(q[i]);
-        list.swap(out);
-      };
-      by_xcd(flat_dyn, flat_dyn_p, 0);
-      by_xcd(flat_rom, flat_rom_p, flat_dyn.size());   // (one launch: the range-of-motion items follow the "dynamic" ones)
-      b->n_flat_dyn = (int)flat_dyn.size();
-      b->n_flat_rom = (int)flat_rom.size();
-      flat_dyn.insert(flat_dyn.end(), flat_rom.begin(), flat_rom.end());
-      upload(flat_dyn.data(), flat_dyn.size() * sizeof(twr::FlatWork), reinterpret_cast<void**>(&b->d_flat));
+    if (flat_ok && !flat_items.empty()) {
+      // One problem, one XCD: workgroup r of the launch runs on XCD r modulo 8 and takes group r.  The groups of problem p go to
+      // workgroups = p modulo 8: its x comes from HBM once and from that XCD's L2 for its other groups.
+      std::vector<size_t> queue[8];   // queue c: the groups that go to the list positions = c modulo 8
+      for (size_t i = 0; i < flat_group_p.size(); ++i) queue[flat_group_p[i] % 8].push_back(i);
+      std::vector<twr::FlatWork> out;
+      out.reserve(flat_items.size());
+      auto emit = [&](size_t group) { out.insert(out.end(), flat_items.begin() + 4 * group, flat_items.begin() + 4 * group + 4); };
+      size_t depth = 0, k = 0;
+      for (const auto& q : queue) depth = std::max(depth, q.size());
+      for (; k < depth; ++k) {   // whole rounds of eight; a round in which a queue has run dry ends the interleaving
+        bool whole = true;
+        for (const auto& q : queue) whole = whole && k < q.size();
+        if (!whole) break;
+        for (const auto& q : queue) emit(q[k]);
+      }
+      for (const auto& q : queue)
+        for (size_t i = k; i < q.size(); ++i) emit(q[i]);
+      b->n_flat = (int)out.size();
+      upload(out.data(), out.size() * sizeof(twr::FlatWork), reinterpret_cast<void**>(&b->d_flat));
     }
     // Large batches whose node-based sets are terrain / force / splineacc / swing only: per-family chunk lists for the
     // persistent node_chunk_kernel (baseMotion and totalduration rows, and small batches -- where the fused launch or the
@@ -993,7 +993,7 @@ int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, 
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   hipError_t e = twr::launch_eval(b->n_ee, b->n_cu, b->d_dyn, b->n_dyn, b->dyn_map_chunks, b->d_rom, b->n_rom, b->rom_max_vals, b->d_node, b->n_node, b->node_families, b->d_fam, b->n_fam,
                                   b->d_pdyn, b->n_pdyn, b->pdyn_img_cap, b->d_ploc, b->n_ploc, b->d_prom, b->n_prom,
-                                  b->prom_img_cap, d_x, d_g, d_jac, b->d_dump, flags & TWR_EVAL_BOTH, b->stream_nt, b->d_flat, b->n_flat_dyn, b->n_flat_rom, b->flat_max_x, stream, ev);
+                                  b->prom_img_cap, d_x, d_g, d_jac, b->d_dump, flags & TWR_EVAL_BOTH, b->stream_nt, b->d_flat, b->n_flat, b->flat_max_x, stream, ev);
   if (e != hipSuccess) return fail(TWR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   if (flags & TWR_EVAL_CHECK) {
     e = twr::launch_check(b->n_problems, b->d_goff, b->d_joff, d_g, d_jac, b->d_status, flags & TWR_EVAL_BOTH, stream);

@@ -356,7 +356,8 @@ struct FlatNode {
 static_assert(sizeof(FlatNode) == 40, "FlatNode layout");
 // Everything an item needs that is the same for all its lanes is in its work record -- addresses, window starts, the
 // structure's offsets and rows and (for "dynamic") the model constants: one scalar round trip, nothing behind a pointer of it.
-struct FlatWork {          // cnt <= 64 consecutive time nodes of the dynamic (or range-of-motion) grid of one problem
+struct FlatWork {          // cnt <= 64 consecutive time nodes of the dynamic (or range-of-motion) grid of one problem; cnt = 0: an
+                           // empty item (pads a problem's list to whole groups of four; x_off and n_x are the problem's all the same)
   uint64_t nodes;          // FlatNode[cnt]
   uint64_t polys;          // FlatPoly[] of the structure
   int64_t x_off, g_off;    // the problem's x / g
@@ -370,12 +371,14 @@ struct FlatWork {          // cnt <= 64 consecutive time nodes of the dynamic (o
   int32_t with_rom;        // "dynamic" items: the two grids coincide and the lane evaluates "rangeofmotion-*" of its time node as well
   double mass, gravity;    // ("dynamic" items)
   double Ib[6];
+  int32_t dynamic;         // 1: item of the "dynamic" grid, 0: of the range-of-motion grid
+  int32_t pad;
 };
-static_assert(sizeof(FlatWork) == 168, "FlatWork layout");
+static_assert(sizeof(FlatWork) == 176, "FlatWork layout");
 // (the kernel addresses the fields by dword)
 enum FlatWorkDword {
   kFwNodes = 0, kFwPolys = 2, kFwX = 4, kFwG = 6, kFwK0 = 8, kFwCnt = 9, kFwStart = 10, kFwCount = 14, kFwNx = 16, kFwNee = 17, kFwOffLin = 18,
-  kFwOffAng = 19, kFwRowRom = 20, kFwRowDyn = 24, kFwWithRom = 25, kFwMass = 26, kFwGravity = 28, kFwIb = 30
+  kFwOffAng = 19, kFwRowRom = 20, kFwRowDyn = 24, kFwWithRom = 25, kFwMass = 26, kFwGravity = 28, kFwIb = 30, kFwDynamic = 42
 };
 static_assert(offsetof(FlatWork, nodes) == 4 * kFwNodes && offsetof(FlatWork, polys) == 4 * kFwPolys && offsetof(FlatWork, x_off) == 4 * kFwX &&
                   offsetof(FlatWork, g_off) == 4 * kFwG && offsetof(FlatWork, k0) == 4 * kFwK0 && offsetof(FlatWork, cnt) == 4 * kFwCnt &&
@@ -383,7 +386,7 @@ static_assert(offsetof(FlatWork, nodes) == 4 * kFwNodes && offsetof(FlatWork, po
                   offsetof(FlatWork, n_ee) == 4 * kFwNee && offsetof(FlatWork, off_lin) == 4 * kFwOffLin && offsetof(FlatWork, off_ang) == 4 * kFwOffAng &&
                   offsetof(FlatWork, row_rom) == 4 * kFwRowRom && offsetof(FlatWork, row_dyn) == 4 * kFwRowDyn &&
                   offsetof(FlatWork, with_rom) == 4 * kFwWithRom && offsetof(FlatWork, mass) == 4 * kFwMass &&
-                  offsetof(FlatWork, gravity) == 4 * kFwGravity && offsetof(FlatWork, Ib) == 4 * kFwIb,
+                  offsetof(FlatWork, gravity) == 4 * kFwGravity && offsetof(FlatWork, Ib) == 4 * kFwIb && offsetof(FlatWork, dynamic) == 4 * kFwDynamic,
               "FlatWork dwords");
 
 // Blob header: model constants + what the node kernel needs.  The terrain-ee-motion_e sets are

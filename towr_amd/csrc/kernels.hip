@@ -1744,18 +1744,20 @@ TWR_DEV void flat_stage_polys(const FlatIn& in, char* lds, int lane) {
   dst[1] = in.pb;
   dst[2] = in.pc;
 }
-// x of a problem, NX doubles per lane (the launcher picks the smallest instantiation that covers the largest problem)
+// x of a problem by the 256 threads of a group, NX doubles per thread (the launcher picks the smallest instantiation that
+// covers the largest problem)
+constexpr int kFlatGroup = 4;   // items (= waves) per workgroup
 template <int NX>
-TWR_DEV void flat_load_x(const double* __restrict__ xp, int n_x, int lane, double xr[NX]) {
+TWR_DEV void flat_load_x(const double* __restrict__ xp, int n_x, int tid, double xr[NX]) {
 #pragma unroll
-  for (int j = 0; j < NX; ++j) xr[j] = xp[min(64 * j + lane, n_x - 1)];
+  for (int j = 0; j < NX; ++j) xr[j] = xp[min(64 * kFlatGroup * j + tid, n_x - 1)];
 }
 template <int NX>
-TWR_DEV void flat_stage_x(const double xr[NX], int n_x, double* xs, int lane) {
-  if (lane < 2) xs[lane] = 0.0;
+TWR_DEV void flat_stage_x(const double xr[NX], int n_x, double* xs, int tid) {
+  if (tid < 2) xs[tid] = 0.0;
 #pragma unroll
-  for (int j = 0; j < NX; ++j) xs[2 + min(64 * j + lane, n_x - 1)] = xr[j];   // (clamped like the loads: the lanes past the end
-}                                                                            // write the last variable once more)
+  for (int j = 0; j < NX; ++j) xs[2 + min(64 * kFlatGroup * j + tid, n_x - 1)] = xr[j];   // (clamped like the loads: the threads past
+}                                                                                        // the end write the last variable once more)
 // Spline::GetPoint (spline.cc:80-93) of an ee spline in Hermite basis form, position only; `rec`: the polynomial's record in LDS
 TWR_DEV void flat_point(const char* __restrict__ xs, const char* __restrict__ rec, double t, double p[3]) {
   const double2 ti = *reinterpret_cast<const double2*>(rec);   // t0, iT
@@ -1773,11 +1775,10 @@ TWR_DEV const char* flat_rec(const char* lds, int spline, int local) {
   return lds + (spline * kFlatWindow + local) * (int)sizeof(FlatPoly);
 }
 // Same formula as rom_item (RangeOfMotionConstraint::UpdateConstraintAtInstance, range_of_motion_constraint.cc:58-69).
-TWR_DEV void flat_rom_math(const FlatRec& w, const FlatNodeR& n, double* __restrict__ g, const char* lds, int lane) {
-  const char* xs = lds + kFlatPolyLds;
+// `lds`: the wave's polynomial windows; `xs`: the group's copy of x (zero pair first); `gs`: 192 doubles of the wave's own
+TWR_DEV void flat_rom_math(const FlatRec& w, const FlatNodeR& n, double* __restrict__ g, const char* lds, const char* xs, double* gs, int lane) {
   const double* xv = reinterpret_cast<const double*>(xs) + 2;
   double* gp = g + (int64_t)w.u64(kFwG);
-  double* gs = const_cast<double*>(xv) + ((w.i32(kFwNx) + 1) & ~1);   // 192 doubles behind the staged x
   const int n_ee = w.i32(kFwNee);
   // base splines: the twelve node values of the active polynomial are contiguous in x (nodes q, q + 1: p then v)
   double wP[4], c[3], e[3];
@@ -1816,8 +1817,7 @@ TWR_DEV void flat_rom_math(const FlatRec& w, const FlatNodeR& n, double* __restr
 // DynamicConstraint::UpdateConstraintAtInstance (dynamic_constraint.cc:59-77) with SingleRigidBodyDynamics::GetDynamicViolation
 // (single_rigid_body_dynamics.cc:76-101) and the EulerConverter quantities (euler_converter.cc:58-83,133-166,207-221) of one time
 // node on ONE lane -- the statements of dyn2_front / dyn2_back without the quad.
-TWR_DEV void flat_dyn_math(const FlatRec& w, const FlatNodeR& n, double* __restrict__ g, const char* lds, int lane) {
-  const char* xs = lds + kFlatPolyLds;
+TWR_DEV void flat_dyn_math(const FlatRec& w, const FlatNodeR& n, double* __restrict__ g, const char* lds, const char* xs, double* gs_rom, int lane) {
   const double* xv = reinterpret_cast<const double*>(xs) + 2;
   const int n_ee = w.i32(kFwNee);
   const double* bl = xv + w.i32(kFwOffLin) + n.q6;   // base splines: the twelve node values of the active polynomial
@@ -1826,7 +1826,6 @@ TWR_DEV void flat_dyn_math(const FlatRec& w, const FlatNodeR& n, double* __restr
   // time node along the way -- g = b_R_w (p_e - c), range_of_motion_constraint.cc:58-69 -- from the same base point, rotation and
   // end-effector positions
   const bool with_rom = w.i32(kFwWithRom) != 0;
-  double* gs_rom = const_cast<double*>(xv) + ((w.i32(kFwNx) + 1) & ~1);   // 192 doubles behind the staged x
   double* gp = g + (int64_t)w.u64(kFwG);
   const int last_rom = 3 * w.i32(kFwCnt) - 1;
   Rot ro;
@@ -1935,49 +1934,49 @@ TWR_DEV void flat_dyn_math(const FlatRec& w, const FlatNodeR& n, double* __restr
     for (int t = 0; t < 6; ++t) go[min(lane + 64 * t, last_g)] = gl[min(lane + 64 * t, last_g)];
   }
 }
-// One item: fetch (the lane's time node, its share of x, one polynomial record of the windows -- one round trip behind the
-// work record), stage in LDS, evaluate.  NX = doubles of x per lane (the launcher picks the smallest instantiation that covers
-// the largest problem of the batch).
-template <bool DYN, int NX>
-TWR_DEV void flat_item(const FlatWork* __restrict__ work, int idx, const double* __restrict__ x, double* __restrict__ g, double* stage, int lane) {
-  char* lds = reinterpret_cast<char*>(stage);
-  FlatRec w;
-  w.p = cptr<uint32_t>(reinterpret_cast<uint64_t>(work + idx));
-  FlatIn in;
-  double xr[NX];
-  flat_load(w, lane, in);
-  flat_load_x<NX>(x + (int64_t)w.u64(kFwX), w.i32(kFwNx), lane, xr);
-  flat_stage_x<NX>(xr, w.i32(kFwNx), stage + kFlatPolyLds / 8, lane);
-  flat_stage_polys(in, lds, lane);
-  __syncthreads();   // (one wave: orders the LDS writes before the per-lane reads)
-  if (DYN) flat_dyn_math(w, flat_node(in), g, lds, lane);
-  else flat_rom_math(w, flat_node(in), g, lds, lane);
-}
-// One launch per values-only evaluation: blocks [0, n_fdyn) take one "dynamic" item each, the next n_from one range-of-motion
-// item, the rest one node family of one problem each.  Single-wave blocks; LDS: flat_lds_bytes(largest x of the batch).
+// One launch per values-only evaluation.  Workgroups of four waves: the first n_groups take a GROUP each -- four consecutive work
+// records, items of ONE problem (twr_batch_create pads a problem's list to whole groups with empty items, cnt = 0) --, so that
+// the problem's x is fetched and copied to LDS once per group by all 256 threads and every wave evaluates its own item on it
+// (K = 200 with coinciding grids: one group per problem); the remaining workgroups take the node families of one problem each,
+// one family per wave.  Per item: fetch (the lane's time node, the thread's share of x, one polynomial record of the windows
+// -- one round trip behind the work record), copy to LDS, evaluate.
+// LDS (dynamic, the launcher knows the largest problem of the batch): [ zero pair | x ] [ per wave: polynomial windows | 192
+// constraint values ].
 // (A persistent form of this -- waves looping over strided items, the fetches of item i + 1 in flight during the math of item
 // i, the work record read by one vector load and v_readlane so that no scalar load sat in the loop -- was built, is parity-
-// green and is NOT faster: 0.084-0.092 / 0.067-0.072 ms against 0.073-0.080 / 0.066-0.070 ms per 8192 C3 problems, at three
-// waves per SIMD instead of four because of the prefetch registers)
-inline size_t flat_lds_bytes(int max_n_x) {   // windows | zero pair | x (rounded up to a pair) | 192 constraint values of one end-effector
-  return std::max((size_t)kFlatPolyLds + sizeof(double) * (size_t)(2 + ((max_n_x + 1) & ~1) + 192), sizeof(double) * (size_t)kDynValuesLds);
-}
+// green and is NOT faster: 0.084-0.092 / 0.067-0.072 ms against 0.068-0.073 / 0.066 ms per 8192 C3 problems as single-wave
+// workgroups, at three waves per SIMD instead of four because of the prefetch registers)
+constexpr int kFlatWaveLds = kFlatPolyLds + 192 * 8;   // bytes of a wave's own region
+static_assert(kFlatWaveLds >= kDynValuesLds * 8, "node_body stages its constraint values in a wave's region");
+inline size_t flat_x_bytes(int max_n_x) { return sizeof(double) * (size_t)(2 + ((max_n_x + 1) & ~1)); }
+inline size_t flat_lds_bytes(int max_n_x) { return flat_x_bytes(max_n_x) + (size_t)kFlatGroup * kFlatWaveLds; }
 template <int NX>
-__global__ __launch_bounds__(64, NX <= 12 ? 4 : 3) void eval_values_kernel(const FlatWork* __restrict__ flat, int n_fdyn, int n_from, const NodeWork* __restrict__ node,
-                                                                           int node_families, const double* __restrict__ x, double* __restrict__ g) {
-  extern __shared__ __attribute__((aligned(16))) double flat_stage[];   // (>= kDynValuesLds: node_body stages its constraint values here)
-  const int lane = threadIdx.x;
-  int b = blockIdx.x;
-  if (b < n_fdyn) return flat_item<true, NX>(flat, b, x, g, flat_stage, lane);
-  if (b < n_fdyn + n_from) return flat_item<false, NX>(flat, b, x, g, flat_stage, lane);
-  b -= n_fdyn + n_from;
-  node_body(node[b / node_families], x, g, nullptr, 1, flat_stage, b % node_families, lane);   // (values only: the node image is not touched)
-}
-// (with per-kernel events: the two flat families in launches of their own)
-template <bool DYN, int NX>
-__global__ __launch_bounds__(64, NX <= 12 ? 4 : 3) void values_flat_kernel(const FlatWork* __restrict__ flat, const double* __restrict__ x, double* __restrict__ g) {
+__global__ __launch_bounds__(64 * kFlatGroup, 4) void eval_values_kernel(const FlatWork* __restrict__ flat, int n_groups, int x_bytes, const NodeWork* __restrict__ node,
+                                                                         int node_families, const double* __restrict__ x, double* __restrict__ g) {
   extern __shared__ __attribute__((aligned(16))) double flat_stage[];
-  flat_item<DYN, NX>(flat, blockIdx.x, x, g, flat_stage, threadIdx.x);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* xs = reinterpret_cast<char*>(flat_stage);
+  char* mine = xs + x_bytes + wave * kFlatWaveLds;
+  int b = blockIdx.x;
+  if (b >= n_groups) {
+    if (wave < node_families)   // (values only: the node image is not touched)
+      node_body(node[b - n_groups], x, g, nullptr, 1, reinterpret_cast<double*>(mine), wave, lane);
+    return;
+  }
+  FlatRec w;
+  w.p = cptr<uint32_t>(reinterpret_cast<uint64_t>(flat + (kFlatGroup * b + wave)));
+  const int cnt = w.i32(kFwCnt);
+  FlatIn in;
+  double xr[NX];
+  if (cnt > 0) flat_load(w, lane, in);
+  flat_load_x<NX>(x + (int64_t)w.u64(kFwX), w.i32(kFwNx), tid, xr);   // (the empty items of a group carry the problem's x as well)
+  flat_stage_x<NX>(xr, w.i32(kFwNx), reinterpret_cast<double*>(xs), tid);
+  if (cnt > 0) flat_stage_polys(in, mine, lane);
+  __syncthreads();
+  if (cnt <= 0) return;
+  double* gs = reinterpret_cast<double*>(mine + kFlatPolyLds);
+  if (w.i32(kFwDynamic) != 0) flat_dyn_math(w, flat_node(in), g, mine, xs, gs, lane);
+  else flat_rom_math(w, flat_node(in), g, mine, xs, gs, lane);
 }
 
 // ---------------------------------------------------------------- optimised timings (PhaseSpline) kernels
@@ -3429,7 +3428,7 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
                        const FamWork* const fam[4], const int n_fam[4] /* chunk lists of node_chunk_kernel; all 0: none */,
                        const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap, const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
                        double* g, double* jac, double* dump /* kDynDump doubles */, int flags, bool stream_nt /* non-temporal copy-out of
-                       dyn / rom (copy_out_fixed) */, const FlatWork* flat /* values-only work items, "dynamic" first; nullptr: none */, int n_flat_dyn, int n_flat_rom, int flat_max_x /* variables of the largest problem */, hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */) {
+                       dyn / rom (copy_out_fixed) */, const FlatWork* flat /* values-only work items in groups of four; nullptr: none */, int n_flat, int flat_max_x /* variables of the largest problem */, hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */) {
   static const int dyn_bpc = env_int("TWR_DYN_BPC", 8), rom_bpc = env_int("TWR_ROM_BPC", 4);
   dim3 block(64);
   hipError_t st = hipSuccess;
@@ -3468,35 +3467,25 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
   const int cap = rom_bpc * n_cu;
   // Values only (no Jacobian), every problem with fixed timings and at most kFlatXCap variables: "dynamic" and "rangeofmotion-*"
   // with one lane per time node (flat items), the node-based sets -- one launch (eval_values_kernel); with per-kernel events three.
-  if (!(flags & 2) && (flags & 1) && flat && n_flat_dyn + n_flat_rom > 0 && n_pdyn == 0 && n_prom == 0 && n_ploc == 0) {
-    const int nf = n_chunks_of(n_fam) == 0 ? node_families : 0;   // (large batches: the chunk kernel takes the node sets)
+  if (!(flags & 2) && (flags & 1) && flat && n_flat > 0 && n_pdyn == 0 && n_prom == 0 && n_ploc == 0) {
+    const int nf = !ev && n_chunks_of(n_fam) == 0 ? node_families : 0;   // (large batches: the chunk kernel takes the node sets; with
+                                                                          // per-kernel events they are a launch of their own)
     const size_t lds = flat_lds_bytes(flat_max_x);
-    const int nx = (flat_max_x + 63) / 64;
-#define TWR_VALUES_LAUNCH(NX)                                                                                                                   \
-  {                                                                                                                                             \
-    if (!ev) {                                                                                                                                  \
-      st = twr_first(st, twr_launch(eval_values_kernel<NX>, dim3(n_flat_dyn + n_flat_rom + nf * n_node), block, lds, stream, flat, n_flat_dyn,  \
-                                    n_flat_rom, node, nf > 0 ? nf : 1, x, g));                                                                  \
-    } else {                                                                                                                                    \
-      (void)hipEventRecord(ev[0], stream);                                                                                                      \
-      if (n_flat_dyn > 0) st = twr_first(st, twr_launch(values_flat_kernel<true, NX>, dim3(n_flat_dyn), block, lds, stream, flat, x, g));       \
-      (void)hipEventRecord(ev[1], stream);                                                                                                      \
-      if (n_flat_rom > 0)                                                                                                                       \
-        st = twr_first(st, twr_launch(values_flat_kernel<false, NX>, dim3(n_flat_rom), block, lds, stream, flat + n_flat_dyn, x, g));           \
-      (void)hipEventRecord(ev[2], stream);                                                                                                      \
-    }                                                                                                                                           \
-  }
-    if (nx <= 12) TWR_VALUES_LAUNCH(12)
-    else if (nx <= 20) TWR_VALUES_LAUNCH(20)
-    else TWR_VALUES_LAUNCH(32)
-#undef TWR_VALUES_LAUNCH
-    static_assert(kFlatXCap <= 32 * 64, "largest instantiation of the values-only kernels");
-    if (!ev) {
-      if (nf == 0) launch_nodes();
-      return st;
+    const int x_bytes = (int)flat_x_bytes(flat_max_x);
+    const int nx = (flat_max_x + 64 * kFlatGroup - 1) / (64 * kFlatGroup);
+    const int n_groups = n_flat / kFlatGroup;
+    const dim3 vgrid(n_groups + (nf > 0 ? n_node : 0)), vblock(64 * kFlatGroup);
+    if (ev) (void)hipEventRecord(ev[0], stream);
+    if (nx <= 3) st = twr_first(st, twr_launch(eval_values_kernel<3>, vgrid, vblock, lds, stream, flat, n_groups, x_bytes, node, nf, x, g));
+    else if (nx <= 5) st = twr_first(st, twr_launch(eval_values_kernel<5>, vgrid, vblock, lds, stream, flat, n_groups, x_bytes, node, nf, x, g));
+    else st = twr_first(st, twr_launch(eval_values_kernel<8>, vgrid, vblock, lds, stream, flat, n_groups, x_bytes, node, nf, x, g));
+    static_assert(kFlatXCap <= 8 * 64 * kFlatGroup, "largest instantiation of the values-only kernel");
+    if (ev) {   // (the two flat families are one launch: the second interval is empty)
+      (void)hipEventRecord(ev[1], stream);
+      (void)hipEventRecord(ev[2], stream);
     }
-    launch_nodes();
-    (void)hipEventRecord(ev[3], stream);
+    if (nf == 0) launch_nodes();
+    if (ev) (void)hipEventRecord(ev[3], stream);
     return st;
   }
   // With non-temporal stores (sweep-like batches) the fused launch stays ahead for longer -- 768 / 896 / 1024 candidates of the
