@@ -376,6 +376,19 @@ def test_random_structures_in_one_ragged_batch():
         for p, c in enumerate(group):
             rg, _, _, rj = c.P.eval(xs[p])
             assert_parity(c.S, *_split(batch, g, j, p), rg, rj, "n_ee %d problem %d" % (n_ee, p), x=xs[p])
+        # values only on the same ragged batch (fixed and optimised timings mixed: one problem that cannot take the
+        # lane-per-node kernels keeps the whole batch on the Jacobian kernels' cut) and on its fixed-timings problems alone
+        fixed = [i for i, c in enumerate(group) if not (c.params.constraint_sets & 64)]
+        for sel in (list(range(len(group))), fixed):
+            if not sel:
+                continue
+            sub = ta.Batch([group[i].S for i in sel], list(range(len(sel))), device=0)
+            px, pg, pj = sub.host_buffers()
+            px[:] = np.concatenate([xs[i] for i in sel])
+            pg[:] = np.nan
+            sub.eval_host_pinned(ta.EVAL_VALUES)
+            want = np.concatenate([g[batch.g_off[i]:batch.g_off[i + 1]] for i in sel])
+            assert np.abs(pg - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (n_ee, sel)
 
 
 def test_gridded_terrain():
