@@ -463,10 +463,11 @@ def values_c3(ta, torch, model, dev, dev_index, stream, steps=50, B=8192):
         batch.eval_device(x.data_ptr(), g.data_ptr(), 0, ta.EVAL_VALUES, stream)
     torch.cuda.synchronize()
     free_ms = (time.perf_counter() - t0) / steps * 1e3
-    names = {"dynamic": "twr::values_flat_kernel<dynamic>", "rangeofmotion": "twr::values_flat_kernel<rangeofmotion>", "nodes": "twr::node_kernel2 (values)"}
-    if kern_ms.get("rangeofmotion", 1.0) < 0.02:   # (an empty event interval is ~5 us) coinciding grids (C3): the "dynamic" items take the range-of-motion rows along
+    # (with per-kernel events the lane-per-node items of both sets are still ONE launch: the second interval is empty, ~5 us of
+    # event overhead; the node sets follow in a launch of their own)
+    names = {"dynamic": "twr::eval_values_kernel (dynamic + rangeofmotion items)", "rangeofmotion": "(empty interval)", "nodes": "twr::node_kernel2 (values)"}
+    if kern_ms.get("rangeofmotion", 1.0) < 0.02:
         kern_ms.pop("rangeofmotion")
-        names["dynamic"] = "twr::values_flat_kernel<dynamic + rangeofmotion>"
     bytes_values = 8 * (S.n + S.m) * B
     path_ms = sum(kern_ms.values())
     # FP64 vector peak: 256 CUs x 4 SIMDs x 16 FP64 lanes/clk x 2 (FMA) x 2.4 GHz = 78.6 TFLOP/s = half the guide's FP32
