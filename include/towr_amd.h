@@ -377,8 +377,6 @@ int twr_batch_host_buffers(twr_batch* b, double** h_x, double** h_g, double** h_
  *   TWR_FUSED_SPLIT                 eighths of the residency the fused launch gives the rom role when both roles do not fit
  *                                   (default: 5 up to 34/8 rounds of rom slices, 4 above; 8 = one role after the other)
  *   TWR_FUSED_GROM, TWR_FUSED_GDYN  explicit block counts of the two roles of the fused launch (experiments)
- *   TWR_VALUES_DYN_WPC              persistent "dynamic" waves per CU of the values-only launch (default 6 of the 12 its
- *                                   registers allow; the rest streams the range-of-motion items and the node sets)
  *   TWR_STREAM_NT=0|1               overrides the store policy twr_batch_create picks (twr_batch_streaming_stores)
  *   TWR_HOST_ZERO_COPY[_X]=0        twr_batch_eval_host: copy through device buffers instead of letting the kernels store
  *                                   into (gather x from) the page-locked host buffers */

@@ -1,3 +1,4 @@
+# (historical: the TWR_FLAT_DIAG hooks lived in the persistent form of the values-only kernels, which was not kept)
 # values-only kernels, what the time is made of: diagnostic builds (WRONG RESULTS on purpose) 1: no math, 2: no sin / cos, 3: x loaded once per wave
 mkdir -p gpurun_out/r05e
 for d in 0 1 2 3; do

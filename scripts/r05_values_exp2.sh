@@ -1,3 +1,4 @@
+# (historical: the persistent form of the values-only kernels, not kept -- its knobs TWR_VALUES_WPC / TWR_VALUES_DYN_WEIGHT are no longer read)
 # values-only evaluation, persistent flat kernels: resident waves per CU and the dyn : rom share of the one-launch form; make TUNING=1
 mkdir -p gpurun_out/r05e
 make -C towr_amd/csrc clean > /dev/null; make -C towr_amd/csrc TUNING=1 > /dev/null 2>&1

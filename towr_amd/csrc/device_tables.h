@@ -324,10 +324,10 @@ struct ScoreTables {
 static_assert(sizeof(ScoreTables) == 16, "ScoreTables layout");
 
 // Values-only evaluation (TWR_EVAL_VALUES, fixed timings) of "dynamic" and "rangeofmotion-*": ONE LANE PER TIME NODE, all
-// end-effectors (kernels.hip flat_dyn_item / flat_rom_item) -- the base splines and the rotation of a time node are evaluated
+// end-effectors (kernels.hip flat_dyn_math / flat_rom_math) -- the base splines and the rotation of a time node are evaluated
 // once instead of once per end-effector (the Jacobian kernels' cuts: a quad of lanes per time node resp. one slice per
-// end-effector).  Nothing a lane needs is gathered from global memory: the wave copies the problem's x into LDS (coalesced)
-// and, beside it, the WINDOW of polynomial records its time nodes use -- per spline (ee-motion_e: 2 e, ee-force_e: 2 e + 1)
+// end-effector).  Nothing a lane needs is gathered from global memory: the workgroup (four waves, the items of one problem)
+// copies the problem's x into LDS (coalesced) and every wave, beside it, the WINDOW of polynomial records its time nodes use -- per spline (ee-motion_e: 2 e, ee-force_e: 2 e + 1)
 // at most kFlatWindow consecutive polynomials, lane 8 s + j fetching record j of spline s --, all in ONE round trip behind
 // the work item.  Tables: per time node of an item a FlatNode (which polynomials are active -- decided on the host by the
 // reference's rule, spline.cc:48-78 -- as indices INTO THE ITEM'S WINDOWS), per structure one array of FlatPoly over all

@@ -1681,7 +1681,7 @@ __global__ __launch_bounds__(128, 2) void eval_fused_kernel(const RomWork* __res
 // (72 % / 55 % of the issue slots at 0.12 of the HBM roof).  The Jacobian kernels' cuts -- "rangeofmotion-e":
 // one slice per end-effector, lane = time node; "dynamic": a quad of lanes per time node -- evaluate the base splines and the
 // rotation (three sin / cos pairs) of a time node once per END-EFFECTOR resp. per LANE OF THE QUAD; without an image to
-// assemble one lane can take a time node for ALL end-effectors (device_tables.h FlatNode / FlatPoly / FlatTables / FlatWork).
+// assemble one lane can take a time node for ALL end-effectors (device_tables.h FlatNode / FlatPoly / FlatWork).
 // What made the first form of this slower for "dynamic" (0.205 vs 0.142 ms per 8192 C3 problems) was the ~120 per-lane global
 // gathers of x behind eight 40-byte polynomial records; here the wave copies the problem's x and the item's windows of
 // polynomial records into LDS (coalesced, one round trip behind the work item) and a candidate is ONE LDS read at a byte

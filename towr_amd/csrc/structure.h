@@ -99,7 +99,7 @@ struct Structure {
   };
   std::vector<std::vector<RomSlice>> rom_slices;   // [ee]
   uint32_t off_rom_nodes = 0;
-  // values-only evaluation of dynamic / rangeofmotion-*, one lane per time node (device_tables.h FlatNode / FlatTables /
+  // values-only evaluation of dynamic / rangeofmotion-*, one lane per time node (device_tables.h FlatNode / FlatPoly /
   // FlatWork): blob offsets (0 = none) and the items of a problem of this structure (twr_batch_create adds the problem's
   // addresses)
   struct FlatItem {
