@@ -487,8 +487,10 @@ def values_c3(ta, torch, model, dev, dev_index, stream, steps=50, B=8192):
             "fp64_valu": {"peak_TFLOPs": 78.6, "issue_frac_upper_bound": valu_frac, "valu_insts_per_step": valu,
                           "source": "SQ_INSTS_VALU of profiles/traffic.json values_8192 (rocprofv3 --pmc; the one-launch step), 4 cycles per "
                                     "wave64 instruction, over ms_per_step_without_events" if valu_frac else None},
-            "bound": ("vector-instruction issue: %.0f %% of the issue slots at 2.4 GHz (every wave64 FP64 instruction holds its SIMD for "
-                      "four cycles) against %.0f %% of HBM" % (100 * valu_frac, 100 * bytes_values / (free_ms * 1e-3) / 1e9 / HBM_PEAK_GBS))
+            "bound": (("vector-instruction issue" if valu_frac >= 0.6 else "neither roof alone (per-wave latency: a wave is parked at a wait or the group "
+                       "barrier for more than half of its life, profiles/r05_pmc_summary.txt)")
+                      + ": %.0f %% of the issue slots at 2.4 GHz (every wave64 FP64 instruction holds its SIMD for four cycles) against %.0f %% of HBM"
+                      % (100 * valu_frac, 100 * bytes_values / (free_ms * 1e-3) / 1e9 / HBM_PEAK_GBS))
                      if valu_frac else "HBM fraction above; no VALU instruction counts for these kernel sources (profiles/traffic.json is of another tree)"}
 
 
