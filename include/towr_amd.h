@@ -200,6 +200,15 @@ int twr_shard_bounds(const double* weights /* n */, int n, int world, int32_t* b
 int twr_terrain_grid_info(const twr_terrain_grid* g, int32_t* kind, int32_t* rows_or_size_x, int32_t* cols_or_size_y,
                           double* resolution, double* pos_x, double* pos_y, const void** data);
 int twr_structure_sizes(const twr_structure* s, twr_sizes* out);
+/* Introspection of the values-only path (TWR_EVAL_VALUES; fixed timings, at most 2046 variables): the work items a problem
+ * of this structure is cut into -- at most 64 consecutive time nodes of the "dynamic" resp. range-of-motion grid whose active
+ * polynomials span at most eight polynomials per ee spline (time_discretization_constraint.cc:36-58 gives the grids,
+ * spline.cc:48-78 the active polynomials).  *dynamic_takes_rom is 1 when the two grids coincide and the "dynamic" items
+ * evaluate the "rangeofmotion-*" rows of their time nodes as well (then *n_rom_items is 0).  `items` may be NULL; otherwise
+ * it receives (first time node, time nodes, polynomials of the widest window) per item, "dynamic" items first.  All counts
+ * are 0 for a structure that keeps the Jacobian kernels' cut. */
+int twr_structure_values_items(const twr_structure* s, int32_t* n_dynamic_items, int32_t* n_rom_items, int32_t* dynamic_takes_rom,
+                               int32_t* items /* [n_dynamic_items + n_rom_items][3] or NULL */);
 int twr_structure_var_set(const twr_structure* s, int i, twr_set_info* out);
 int twr_structure_con_set(const twr_structure* s, int i, twr_set_info* out);
 /* Library-owned, valid until twr_structure_destroy: CSR row_ptr[n_rows+1], col_idx[nnz]. */

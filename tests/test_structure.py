@@ -366,3 +366,35 @@ def test_place_outputs_keeps_the_fastest_allocation():
     fake.cuda.mem_get_info = lambda dev: (state["free"], 288 << 30)
     kept, report = place_outputs(fake, "dev", alloc_big, run_steps, 4)
     assert kept == ("buffers", 0) and len(report["tries"]) == 2 and "skipped" in report["tries"][1]
+
+
+def test_values_only_items_are_cut_at_64_nodes_and_eight_polynomials():
+    """Host side of the values-only path (twr_structure_values_items): every time node of the two grids is in exactly one
+    item, an item has at most 64 time nodes and at most eight polynomials of one ee spline in its window, coinciding grids
+    fold the range-of-motion rows into the "dynamic" items, and structures with optimised timings or more than 2046
+    variables keep the Jacobian kernels' cut."""
+    model = ta.model_preset("anymal", "flat")
+
+    def check(S, grids_coincide):
+        it = S.values_items()
+        assert it["dynamic_takes_rom"] == grids_coincide
+        for name, k in (("dynamic", S.k_dynamic), ("rom", 0 if grids_coincide else S.k_rom)):
+            nxt = 0
+            for k0, cnt, widest in it[name]:
+                assert k0 == nxt and 1 <= cnt <= 64 and 1 <= widest <= 8
+                nxt = k0 + cnt
+            assert nxt == k
+        return it
+
+    # BASELINE C3: one dt for both grids, 200 time nodes, 2 s -- four items, none cut by its windows
+    dt = 2.0 / (200 - 1.5)
+    it = check(ta.Structure(model, ta.gait_combo(4, 1, 2.0), ta.params_default(dt_dynamic=dt, dt_rom=dt)), True)
+    assert [c for _, c, _ in it["dynamic"]] == [64, 64, 64, 8] and it["rom"] == []
+    # towr's default grids (0.1 / 0.08 s) on a long horizon with many polynomials per phase: the windows cut first
+    it = check(ta.Structure(model, ta.gait_combo(4, 2, 8.0), ta.params_default(polys_per_swing=4, polys_per_stance_force=5)), False)
+    assert any(c < 64 and w == 8 for _, c, w in it["dynamic"][:-1]) and len(it["rom"]) >= 2
+    # no such items: optimised timings; more than 2046 variables
+    for S in (ta.Structure(model, ta.gait_combo(4, 1, 2.0), ta.params_default(constraint_sets=127)),
+              ta.Structure(model, ta.gait_combo(4, 1, 24.0), ta.params_default())):
+        it = S.values_items()
+        assert it["dynamic"] == [] and it["rom"] == [] and not it["dynamic_takes_rom"], S.n

@@ -145,6 +145,7 @@ def lib():
         L.twr_batch_best.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.twr_batch_score_best.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p]
         L.twr_structure_contact_steps_max.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        L.twr_structure_values_items.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]
         L.twr_planes_create.argtypes = [_dp, _dp, C.POINTER(C.c_int32), C.c_int32, C.c_int, C.POINTER(C.c_void_p)]
         L.twr_planes_destroy.argtypes = [C.c_void_p]
         L.twr_planes_destroy.restype = None
@@ -358,6 +359,16 @@ class Structure:
         n = C.c_int32()
         _check(lib().twr_structure_contact_steps_max(self._h, C.byref(n)))
         return n.value
+
+    def values_items(self):
+        """The work items of the values-only path (twr_structure_values_items): {"dynamic": [(k0, cnt, widest window)],
+        "rom": [...], "dynamic_takes_rom": bool}; empty lists for a structure that keeps the Jacobian kernels' cut."""
+        nd, nr, both = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(lib().twr_structure_values_items(self._h, C.byref(nd), C.byref(nr), C.byref(both), None))
+        items = np.zeros((nd.value + nr.value, 3), dtype=np.int32)
+        _check(lib().twr_structure_values_items(self._h, C.byref(nd), C.byref(nr), C.byref(both), items.ctypes.data))
+        rows = [tuple(int(v) for v in r) for r in items]
+        return {"dynamic": rows[:nd.value], "rom": rows[nd.value:], "dynamic_takes_rom": bool(both.value)}
 
     def sample_count(self, dt=0.01):
         """Records fpowr::GetTrajectory produces for this structure at step dt."""

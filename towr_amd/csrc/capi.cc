@@ -404,6 +404,27 @@ int twr_structure_sizes(const twr_structure* s, twr_sizes* out) {
   return TWR_OK;
 }
 
+int twr_structure_values_items(const twr_structure* s, int32_t* n_dynamic_items, int32_t* n_rom_items, int32_t* dynamic_takes_rom,
+                               int32_t* items) {
+  if (!s || !n_dynamic_items || !n_rom_items || !dynamic_takes_rom) return fail(TWR_ERR_INVALID, "null argument");
+  const bool on = s->s.off_flat_polys != 0;
+  *n_dynamic_items = on ? (int32_t)s->s.flat_items_dyn.size() : 0;
+  *n_rom_items = on ? (int32_t)s->s.flat_items_rom.size() : 0;
+  *dynamic_takes_rom = on && s->s.flat_with_rom ? 1 : 0;
+  if (items && on) {
+    int32_t* o = items;
+    for (const auto* list : {&s->s.flat_items_dyn, &s->s.flat_items_rom})
+      for (const auto& it : *list) {
+        int widest = 0;
+        for (int sp = 0; sp < 8; ++sp) widest = std::max(widest, (int)((it.count >> (8 * sp)) & 0xFFu));
+        *o++ = it.k0;
+        *o++ = it.cnt;
+        *o++ = widest;
+      }
+  }
+  return TWR_OK;
+}
+
 int twr_structure_var_set(const twr_structure* s, int i, twr_set_info* out) {
   if (!s || !out || i < 0 || i >= (int)s->s.var_sets.size()) return fail(TWR_ERR_INVALID, "bad variable set index");
   copy_set(s->s.var_sets[i], out);
