@@ -270,7 +270,11 @@ int twr_batch_layout(const twr_batch* b, int64_t* x_off, int64_t* g_off, int64_t
  * in a batch, on every device and rank.  The kernels are instantiated per output selection, and the selections (values
  * only / Jacobian only / both) agree with each other to rounding (<= 1e-13 of the set scale), NOT bit for bit.  A sweep
  * that compares candidates across ranks or calls must therefore score all of them with the SAME flags (near-tied
- * candidates could otherwise be ranked differently); twr_batch_score / twr_batch_best are deterministic given g. */
+ * candidates could otherwise be ranked differently); twr_batch_score / twr_batch_best are deterministic given g.
+ * (Values only: a batch in which EVERY problem has fixed timings and at most 2046 variables takes the lane-per-time-node
+ * kernel, see twr_structure_values_items; one problem that cannot keeps the whole batch on the values-only instantiation of
+ * the Jacobian kernels.  The two agree to rounding, so the shards of one sweep -- which all take the same path -- compare
+ * bit for bit, a batch of another composition to rounding.) */
 int twr_batch_eval(twr_batch* b, const double* d_x, double* d_g, double* d_jac, int flags, void* hip_stream);
 /* Failure detection (the reference only has Release-mode-silent asserts, spline.cc:52,65): after an evaluation with
  * TWR_EVAL_CHECK, h_status[p] has bit 0 set if a constraint value of problem p is NaN/Inf and bit 1 if a Jacobian
