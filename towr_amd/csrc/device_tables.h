@@ -307,11 +307,11 @@ static_assert(sizeof(SampleWork) == 32, "SampleWork layout");
 // quadruped candidate).  "family" in a meta word is a SLOT: the families of a structure numbered in the order of their
 // first row, so that the slot never falls along the rows (a thread of score_kernel walks ascending rows and keeps ONE
 // running pair of accumulators, handing it over when the slot moves on); slot_of_family maps back.  Layout in the blob,
-// one record:
-//     [ meta: uint16[n_rows], padded to 16 bytes ][ ScoreTables ][ pairs: (lower, upper) x n_pairs ][ zero padding ]
-// DevStruct::o_score points at the ScoreTables; the meta words END there (the kernel knows n_rows from its work list, so it
-// requests them together with the head of the record, before any field of it has arrived), and at least kScoreHeadBytes
-// bytes follow o_score, so that the head can be requested without knowing n_pairs.
+// one record at a FIXED offset (kScoreOff, right behind the node head):
+//     [ ScoreTables ][ pairs: (lower, upper) x n_pairs ][ zero padding to kScoreHeadBytes ][ meta: uint16[n_rows] ]
+// The kernel knows n_rows from its work list and the addresses from the blob's alone, so it asks for the head, the meta
+// words and the rows of g in ONE round trip behind the work item, without a field of the header (DevStruct::o_score ==
+// kScoreOff; round 5's first form had the record behind a header field: one dependent round trip more).
 constexpr int kMaxConSets = 24;   // 4 terrain + dynamic + 2 splineacc + 4 rangeofmotion + 4 force + 4 swing + baseMotion + 4 totalduration
 constexpr int kScoreHeadBytes = 2048;
 constexpr int kScoreMaxPairs = 127;     // distinct pairs per structure: what the 2-KB head of the record holds behind the 16-byte
@@ -432,6 +432,8 @@ struct DevStruct {
 constexpr uint32_t kNodeHeadTerrainOff = (uint32_t)((sizeof(DevStruct) + 15) / 16 * 16);
 constexpr uint32_t kNodeHeadForceOff = kNodeHeadTerrainOff + 64 * (uint32_t)sizeof(TerrainRow);
 constexpr uint32_t kNodeHeadBytes = 64 * (uint32_t)(sizeof(TerrainRow) + sizeof(ForceNode));
+constexpr uint32_t kScoreOff = kNodeHeadTerrainOff + kNodeHeadBytes;   // the score record (ScoreTables), see above
+static_assert(kScoreOff % 16 == 0, "score record alignment");
 
 // Work items: one contiguous run of time nodes of one constraint set of one problem.  All
 // pointers / offsets are absolute so that a workgroup needs no header lookup.

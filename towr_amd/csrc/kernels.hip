@@ -3029,9 +3029,9 @@ hipError_t launch_sample(const SampleWork* work, int n_work, const double* x, do
 // A sweep then returns 16 doubles per candidate instead of its Jacobian.
 // (round 5: 256 threads per problem, row r = 256 k + thread, sixteen rows per thread; family slot and bounds of a row come
 // from its 16-bit meta word and the structure's short table of distinct (lower, upper) pairs, device_tables.h ScoreTables.)
-// Three dependent round trips: (1) the work item and its successor (row count = difference of their g offsets; the list
-// carries an end entry), (2) the rows of g AND the structure's header, (3) the meta words of the rows AND the head of the
-// score record (2 KB requested on spec: the pair table) -> LDS.  The slot of a thread's rows never falls, so it keeps one
+// Two dependent round trips: (1) the work item and its successor (row count = difference of their g offsets; the list
+// carries an end entry), (2) the rows of g, the meta words of the rows AND the head of the score record (2 KB requested on spec:
+// the pair table) -> LDS -- the record sits at a fixed offset of the blob (kScoreOff), no field of the header is needed.  The slot of a thread's rows never falls, so it keeps one
 // running (max, sum) pair and hands it to its LDS cell when the slot moves on.  Round 4's kernel fetched a cold candidate's
 // fields one s_load at a time and 16 bytes of bounds per row: 25 us for 128 candidates, 43 us for 1024.
 TWR_DEV double nan_max(double a, double b) { return (a != a || b != b) ? (a != a ? a : b) : fmax(a, b); }
@@ -3056,7 +3056,6 @@ __global__ __launch_bounds__(256) void score_kernel(const NodeWork* __restrict__
   }
   const double* gp = g + w.g_off;
   const char* blob = reinterpret_cast<const char*>(w.blob);
-  const DevStruct* S = reinterpret_cast<const DevStruct*>(blob);
 #pragma unroll
   for (int c = 0; c < 16; ++c) red[c * 256 + tid] = 0.0;   // (a cell is written at most once more; own cells only: no barrier)
   int cur = 0;
@@ -3065,8 +3064,8 @@ __global__ __launch_bounds__(256) void score_kernel(const NodeWork* __restrict__
     double v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = gp[min(base + 256 * k + tid, n_rows - 1)];
-    const int32_t* Tw = reinterpret_cast<const int32_t*>(tbl<ScoreTables>(blob, S->o_score));
-    const uint16_t* meta = reinterpret_cast<const uint16_t*>(Tw) - n_rows;   // the meta words end where the record starts
+    const int32_t* Tw = reinterpret_cast<const int32_t*>(tbl<ScoreTables>(blob, kScoreOff));   // (fixed offset: no header field)
+    const uint16_t* meta = reinterpret_cast<const uint16_t*>(blob + kScoreOff + kScoreHeadBytes);
     uint32_t m[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) m[k] = meta[min(base + 256 * k + tid, n_rows - 1)];

@@ -578,6 +578,53 @@ void Structure::PackBlob() {
       std::memcpy(head.data() + 64 * sizeof(TerrainRow), all_nodes.data(), std::min<size_t>(64, all_nodes.size()) * sizeof(ForceNode));
     if (put(head.data(), head.size()) != kNodeHeadTerrainOff) throw std::runtime_error("node head is not the first table of the blob");
   }
+  {  // candidate scoring: family and bounds of every row (device_tables.h, ScoreTables)
+    if (con_sets.size() > (size_t)kMaxConSets) throw std::runtime_error("too many constraint sets");
+    std::vector<double> pairs;
+    std::map<std::pair<uint64_t, uint64_t>, int> pair_index;   // distinct (lower, upper), by bit pattern
+    std::vector<uint16_t> meta((size_t)n_rows, 0);
+    int slot_of[8] = {-1, -1, -1, -1, -1, -1, -1, -1}, n_slots = 0;
+    // (sets in row order: the slots are handed out in the order the families first appear along the rows)
+    std::vector<size_t> by_row(con_sets.size());
+    std::iota(by_row.begin(), by_row.end(), (size_t)0);
+    std::sort(by_row.begin(), by_row.end(), [&](size_t a, size_t b) { return con_sets[a].offset < con_sets[b].offset; });
+    for (size_t i : by_row) {
+      const std::string& nm = con_sets[i].name;
+      auto starts = [&](const char* p) { return nm.rfind(p, 0) == 0; };
+      const int fam = starts("terrain-") ? 0 : starts("dynamic") ? 1 : starts("splineacc-") ? 2 : starts("rangeofmotion-") ? 3
+                    : starts("force-") ? 4 : starts("swing-") ? 5 : starts("totalduration-") ? 6 : starts("baseMotion") ? 7 : -1;
+      if (fam < 0) throw std::runtime_error("constraint set of an unknown family");
+      if (con_sets[i].size > 0 && slot_of[fam] < 0) slot_of[fam] = n_slots++;
+      if (con_sets[i].size > 0 && slot_of[fam] != n_slots - 1) throw std::runtime_error("the sets of a constraint family are not adjacent in g");
+      for (int r = con_sets[i].offset; r < con_sets[i].offset + con_sets[i].size; ++r) {
+        uint64_t kl, ku;
+        std::memcpy(&kl, &lower[r], 8);
+        std::memcpy(&ku, &upper[r], 8);
+        auto it = pair_index.find({kl, ku});
+        if (it == pair_index.end()) {
+          it = pair_index.emplace(std::make_pair(kl, ku), (int)(pairs.size() / 2)).first;
+          pairs.push_back(lower[r]);
+          pairs.push_back(upper[r]);
+        }
+        if (it->second >= kScoreMaxPairs) throw std::runtime_error("more than 127 distinct constraint bounds in one structure");
+        meta[r] = (uint16_t)(slot_of[fam] << 12 | it->second);
+      }
+    }
+    ScoreTables sc;
+    std::memset(&sc, 0, sizeof(sc));
+    sc.n_rows = n_rows;
+    sc.n_pairs = (int)(pairs.size() / 2);
+    for (int f = 0; f < 8; ++f) sc.slot_of_family[f] = (int8_t)slot_of[f];
+    // [ ScoreTables | pairs | zero padding to kScoreHeadBytes ][ meta words ] at a FIXED offset behind the node head: score_kernel
+    // asks for all of it without having seen a single field of the header
+    if (sizeof(sc) + pairs.size() * sizeof(double) > (size_t)kScoreHeadBytes) throw std::runtime_error("score record head overflows");
+    std::vector<char> rec(kScoreHeadBytes + (meta.size() * sizeof(uint16_t) + 15) / 16 * 16, 0);
+    std::memcpy(rec.data(), &sc, sizeof(sc));
+    std::memcpy(rec.data() + sizeof(sc), pairs.data(), pairs.size() * sizeof(double));
+    if (!meta.empty()) std::memcpy(rec.data() + kScoreHeadBytes, meta.data(), meta.size() * sizeof(uint16_t));
+    h.o_score = put(rec.data(), rec.size());
+    if (h.o_score != kScoreOff) throw std::runtime_error("score record is not at its fixed offset");
+  }
   h.o_force_nodes = put(all_nodes.data(), all_nodes.size() * sizeof(ForceNode));
   h.o_terrain_rows = put(all_rows.data(), all_rows.size() * sizeof(TerrainRow));
   h.o_acc = put(acc_junctions.data(), acc_junctions.size() * sizeof(AccJunction));
@@ -1194,51 +1241,6 @@ void Structure::PackBlob() {
     h.grid_eps = grid->eps;
     h.grid_px = grid->pos_x;
     h.grid_py = grid->pos_y;
-  }
-  {  // candidate scoring: family and bounds of every row (device_tables.h, ScoreTables)
-    if (con_sets.size() > (size_t)kMaxConSets) throw std::runtime_error("too many constraint sets");
-    std::vector<double> pairs;
-    std::map<std::pair<uint64_t, uint64_t>, int> pair_index;   // distinct (lower, upper), by bit pattern
-    std::vector<uint16_t> meta((size_t)n_rows, 0);
-    int slot_of[8] = {-1, -1, -1, -1, -1, -1, -1, -1}, n_slots = 0;
-    // (sets in row order: the slots are handed out in the order the families first appear along the rows)
-    std::vector<size_t> by_row(con_sets.size());
-    std::iota(by_row.begin(), by_row.end(), (size_t)0);
-    std::sort(by_row.begin(), by_row.end(), [&](size_t a, size_t b) { return con_sets[a].offset < con_sets[b].offset; });
-    for (size_t i : by_row) {
-      const std::string& nm = con_sets[i].name;
-      auto starts = [&](const char* p) { return nm.rfind(p, 0) == 0; };
-      const int fam = starts("terrain-") ? 0 : starts("dynamic") ? 1 : starts("splineacc-") ? 2 : starts("rangeofmotion-") ? 3
-                    : starts("force-") ? 4 : starts("swing-") ? 5 : starts("totalduration-") ? 6 : starts("baseMotion") ? 7 : -1;
-      if (fam < 0) throw std::runtime_error("constraint set of an unknown family");
-      if (con_sets[i].size > 0 && slot_of[fam] < 0) slot_of[fam] = n_slots++;
-      if (con_sets[i].size > 0 && slot_of[fam] != n_slots - 1) throw std::runtime_error("the sets of a constraint family are not adjacent in g");
-      for (int r = con_sets[i].offset; r < con_sets[i].offset + con_sets[i].size; ++r) {
-        uint64_t kl, ku;
-        std::memcpy(&kl, &lower[r], 8);
-        std::memcpy(&ku, &upper[r], 8);
-        auto it = pair_index.find({kl, ku});
-        if (it == pair_index.end()) {
-          it = pair_index.emplace(std::make_pair(kl, ku), (int)(pairs.size() / 2)).first;
-          pairs.push_back(lower[r]);
-          pairs.push_back(upper[r]);
-        }
-        if (it->second >= kScoreMaxPairs) throw std::runtime_error("more than 127 distinct constraint bounds in one structure");
-        meta[r] = (uint16_t)(slot_of[fam] << 12 | it->second);
-      }
-    }
-    ScoreTables sc;
-    std::memset(&sc, 0, sizeof(sc));
-    sc.n_rows = n_rows;
-    sc.n_pairs = (int)(pairs.size() / 2);
-    for (int f = 0; f < 8; ++f) sc.slot_of_family[f] = (int8_t)slot_of[f];
-    const size_t meta_bytes = (meta.size() * sizeof(uint16_t) + 15) / 16 * 16;
-    const size_t tail = std::max(sizeof(sc) + pairs.size() * sizeof(double), (size_t)kScoreHeadBytes);
-    std::vector<char> rec(meta_bytes + tail, 0);
-    std::memcpy(rec.data() + meta_bytes - meta.size() * sizeof(uint16_t), meta.data(), meta.size() * sizeof(uint16_t));   // the meta words END at the record
-    std::memcpy(rec.data() + meta_bytes, &sc, sizeof(sc));
-    std::memcpy(rec.data() + meta_bytes + sizeof(sc), pairs.data(), pairs.size() * sizeof(double));
-    h.o_score = put(rec.data(), rec.size()) + (uint32_t)meta_bytes;
   }
   {  // trajectory sampling tables
     SampleTables st;
