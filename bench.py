@@ -799,7 +799,7 @@ def main():
         t3 = timings_c3(ta, torch, dist, model, world, rank, dev, dev_index, backend, stream, placement_tries=tries)
         a3 = timings_c3(ta, torch, dist, model, world, rank, dev, dev_index, backend, stream, B=8192, constraint_sets=63, placement_tries=tries)
     if default_run and not args.no_scale_c5:
-        c5 = scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, stream, placement_tries=min(3, args.placement_tries))
+        c5 = scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, stream, placement_tries=min(8, args.placement_tries))
     if rank == 0:
         if t3 is not None:
             out["timings_c3"] = t3
