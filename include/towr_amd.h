@@ -205,8 +205,10 @@ int twr_structure_sizes(const twr_structure* s, twr_sizes* out);
  * polynomials span at most eight polynomials per ee spline (time_discretization_constraint.cc:36-58 gives the grids,
  * spline.cc:48-78 the active polynomials).  *dynamic_takes_rom is 1 when the two grids coincide and the "dynamic" items
  * evaluate the "rangeofmotion-*" rows of their time nodes as well (then *n_rom_items is 0).  `items` may be NULL; otherwise
- * it receives (first time node, time nodes, polynomials of the widest window) per item, "dynamic" items first.  All counts
- * are 0 for a structure that keeps the Jacobian kernels' cut. */
+ * it receives (first time node, time nodes, polynomials of the widest window) per item, "dynamic" items first; a grid so coarse
+ * that the windows would cut over a quarter more items than 64 time nodes each give (towr's default grids) is cut at 64 time
+ * nodes alone, its lanes fetch their own polynomial records, and the third number is 0.  All counts are 0 for a structure that keeps
+ * the Jacobian kernels' cut. */
 int twr_structure_values_items(const twr_structure* s, int32_t* n_dynamic_items, int32_t* n_rom_items, int32_t* dynamic_takes_rom,
                                int32_t* items /* [n_dynamic_items + n_rom_items][3] or NULL */);
 int twr_structure_var_set(const twr_structure* s, int i, twr_set_info* out);

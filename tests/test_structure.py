@@ -371,8 +371,8 @@ def test_place_outputs_keeps_the_fastest_allocation():
 def test_values_only_items_are_cut_at_64_nodes_and_eight_polynomials():
     """Host side of the values-only path (twr_structure_values_items): every time node of the two grids is in exactly one
     item, an item has at most 64 time nodes and at most eight polynomials of one ee spline in its window, coinciding grids
-    fold the range-of-motion rows into the "dynamic" items, and structures with optimised timings or more than 2046
-    variables keep the Jacobian kernels' cut."""
+    fold the range-of-motion rows into the "dynamic" items, a coarse grid is cut at 64 time nodes alone, and structures with
+    optimised timings or more than 2046 variables keep the Jacobian kernels' cut."""
     model = ta.model_preset("anymal", "flat")
 
     def check(S, grids_coincide):
@@ -380,8 +380,11 @@ def test_values_only_items_are_cut_at_64_nodes_and_eight_polynomials():
         assert it["dynamic_takes_rom"] == grids_coincide
         for name, k in (("dynamic", S.k_dynamic), ("rom", 0 if grids_coincide else S.k_rom)):
             nxt = 0
-            for k0, cnt, widest in it[name]:
-                assert k0 == nxt and 1 <= cnt <= 64 and 1 <= widest <= 8
+            gather = any(w == 0 for _, _, w in it[name])
+            for i, (k0, cnt, widest) in enumerate(it[name]):
+                assert k0 == nxt and 1 <= cnt <= 64
+                # a coarse grid is cut at 64 time nodes alone (widest 0: its lanes fetch their own records), else by the windows too
+                assert (widest == 0 and (cnt == 64 or i == len(it[name]) - 1)) if gather else 1 <= widest <= 8
                 nxt = k0 + cnt
             assert nxt == k
         return it
@@ -390,9 +393,15 @@ def test_values_only_items_are_cut_at_64_nodes_and_eight_polynomials():
     dt = 2.0 / (200 - 1.5)
     it = check(ta.Structure(model, ta.gait_combo(4, 1, 2.0), ta.params_default(dt_dynamic=dt, dt_rom=dt)), True)
     assert [c for _, c, _ in it["dynamic"]] == [64, 64, 64, 8] and it["rom"] == []
-    # towr's default grids (0.1 / 0.08 s) on a long horizon with many polynomials per phase: the windows cut first
+    # 200 time nodes over 4 s with five polynomials per stance force: the windows cut first (still four items)
+    dt = 4.0 / (200 - 1.5)
+    it = check(ta.Structure(model, ta.gait_combo(4, 2, 4.0), ta.params_default(dt_dynamic=dt, dt_rom=dt, polys_per_stance_force=5)), True)
+    assert any(c < 64 and w == 8 for _, c, w in it["dynamic"][:-1]) and len(it["dynamic"]) == 4
+    # towr's default grids (0.1 / 0.08 s): the windows would cut items of a few time nodes -- 64 time nodes each, records per lane
+    it = check(ta.Structure(model, ta.gait_combo(4, 1, 2.0), ta.params_default()), False)
+    assert it["dynamic"] == [(0, 22, 0)] and it["rom"] == [(0, 27, 0)]
     it = check(ta.Structure(model, ta.gait_combo(4, 2, 8.0), ta.params_default(polys_per_swing=4, polys_per_stance_force=5)), False)
-    assert any(c < 64 and w == 8 for _, c, w in it["dynamic"][:-1]) and len(it["rom"]) >= 2
+    assert [c for _, c, _ in it["dynamic"]] == [64, 17] and [c for _, c, _ in it["rom"]] == [64, 37]
     # no such items: optimised timings; more than 2046 variables
     for S in (ta.Structure(model, ta.gait_combo(4, 1, 2.0), ta.params_default(constraint_sets=127)),
               ta.Structure(model, ta.gait_combo(4, 1, 24.0), ta.params_default())):

@@ -419,7 +419,7 @@ int twr_structure_values_items(const twr_structure* s, int32_t* n_dynamic_items,
         for (int sp = 0; sp < 8; ++sp) widest = std::max(widest, (int)((it.count >> (8 * sp)) & 0xFFu));
         *o++ = it.k0;
         *o++ = it.cnt;
-        *o++ = widest;
+        *o++ = it.gather ? 0 : widest;
       }
   }
   return TWR_OK;
@@ -730,6 +730,7 @@ int twr_batch_create(const twr_structure* const* structs, int n_structs, const i
               fw.off_ang = S.off_base_ang;
               for (int e = 0; e < twr::kMaxEE; ++e) fw.row_rom[e] = S.flat_row_rom[e];
               fw.dynamic = dynamic ? 1 : 0;
+              fw.gather = it.gather ? 1 : 0;
               if (dynamic) {
                 fw.row_dyn = S.flat_row_dyn;
                 fw.with_rom = S.flat_with_rom ? 1 : 0;

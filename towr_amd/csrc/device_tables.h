@@ -372,13 +372,13 @@ struct FlatWork {          // cnt <= 64 consecutive time nodes of the dynamic (o
   double mass, gravity;    // ("dynamic" items)
   double Ib[6];
   int32_t dynamic;         // 1: item of the "dynamic" grid, 0: of the range-of-motion grid
-  int32_t pad;
+  int32_t gather;          // 1: a coarse grid -- no windows, every lane fetches the records of its own active polynomials
 };
 static_assert(sizeof(FlatWork) == 176, "FlatWork layout");
 // (the kernel addresses the fields by dword)
 enum FlatWorkDword {
   kFwNodes = 0, kFwPolys = 2, kFwX = 4, kFwG = 6, kFwK0 = 8, kFwCnt = 9, kFwStart = 10, kFwCount = 14, kFwNx = 16, kFwNee = 17, kFwOffLin = 18,
-  kFwOffAng = 19, kFwRowRom = 20, kFwRowDyn = 24, kFwWithRom = 25, kFwMass = 26, kFwGravity = 28, kFwIb = 30, kFwDynamic = 42
+  kFwOffAng = 19, kFwRowRom = 20, kFwRowDyn = 24, kFwWithRom = 25, kFwMass = 26, kFwGravity = 28, kFwIb = 30, kFwDynamic = 42, kFwGather = 43
 };
 static_assert(offsetof(FlatWork, nodes) == 4 * kFwNodes && offsetof(FlatWork, polys) == 4 * kFwPolys && offsetof(FlatWork, x_off) == 4 * kFwX &&
                   offsetof(FlatWork, g_off) == 4 * kFwG && offsetof(FlatWork, k0) == 4 * kFwK0 && offsetof(FlatWork, cnt) == 4 * kFwCnt &&
@@ -386,7 +386,8 @@ static_assert(offsetof(FlatWork, nodes) == 4 * kFwNodes && offsetof(FlatWork, po
                   offsetof(FlatWork, n_ee) == 4 * kFwNee && offsetof(FlatWork, off_lin) == 4 * kFwOffLin && offsetof(FlatWork, off_ang) == 4 * kFwOffAng &&
                   offsetof(FlatWork, row_rom) == 4 * kFwRowRom && offsetof(FlatWork, row_dyn) == 4 * kFwRowDyn &&
                   offsetof(FlatWork, with_rom) == 4 * kFwWithRom && offsetof(FlatWork, mass) == 4 * kFwMass &&
-                  offsetof(FlatWork, gravity) == 4 * kFwGravity && offsetof(FlatWork, Ib) == 4 * kFwIb && offsetof(FlatWork, dynamic) == 4 * kFwDynamic,
+                  offsetof(FlatWork, gravity) == 4 * kFwGravity && offsetof(FlatWork, Ib) == 4 * kFwIb && offsetof(FlatWork, dynamic) == 4 * kFwDynamic &&
+                  offsetof(FlatWork, gather) == 4 * kFwGather,
               "FlatWork dwords");
 
 // Blob header: model constants + what the node kernel needs.  The terrain-ee-motion_e sets are

@@ -1729,6 +1729,8 @@ TWR_DEV void flat_load(const FlatRec& w, int lane, FlatIn& in) {
     in.nb = twr_u4{c.x, c.y, d.x, d.y};
     in.nc = nd[4];
   }
+}
+TWR_DEV void flat_load_polys(const FlatRec& w, int lane, FlatIn& in) {
   // lane 8 s + j: record j of spline s's window (clamped to the window: no predicates)
   const int s = lane >> 3, j = lane & 7;
   const uint64_t st = lane < 32 ? w.u64(kFwStart) : w.u64(kFwStart + 2);
@@ -1758,24 +1760,45 @@ TWR_DEV void flat_stage_x(const double xr[NX], int n_x, double* xs, int tid) {
 #pragma unroll
   for (int j = 0; j < NX; ++j) xs[2 + min(64 * kFlatGroup * j + tid, n_x - 1)] = xr[j];   // (clamped like the loads: the threads past
 }                                                                                        // the end write the last variable once more)
-// Spline::GetPoint (spline.cc:80-93) of an ee spline in Hermite basis form, position only; `rec`: the polynomial's record in LDS
-TWR_DEV void flat_point(const char* __restrict__ xs, const char* __restrict__ rec, double t, double p[3]) {
-  const double2 ti = *reinterpret_cast<const double2*>(rec);   // t0, iT
-  const uint4 oa = reinterpret_cast<const uint4*>(rec)[1];
-  const uint2 ob = reinterpret_cast<const uint2*>(rec)[4];
-  const uint32_t o[6] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y};
+// A polynomial's record in registers: from the wave's window in LDS, or -- items of a coarse grid, whose time nodes hardly
+// share polynomials (FlatWork::gather) -- fetched by the lane itself from the structure's table.
+struct FlatPolyR {
+  double t0, iT;
+  uint32_t o[6];
+};
+template <bool GATHER>
+TWR_DEV FlatPolyR flat_poly(const FlatRec& w, const char* __restrict__ lds, int spline, int local) {
+  FlatPolyR r;
+  if (GATHER) {
+    const int first = (int)((w.u64(kFwStart + 2 * (spline >> 2)) >> (16 * (spline & 3))) & 0xFFFFu);   // (uniform)
+    const TWR_GLOBAL twr_u4* rec = reinterpret_cast<const TWR_GLOBAL twr_u4*>(gptr<FlatPoly>(w.u64(kFwPolys)) + first + local);
+    const twr_u4 a = rec[0], b = rec[1];
+    const twr_u2 c = reinterpret_cast<const TWR_GLOBAL twr_u2*>(rec)[4];
+    r.t0 = __hiloint2double((int)a.y, (int)a.x);
+    r.iT = __hiloint2double((int)a.w, (int)a.z);
+    r.o[0] = b.x; r.o[1] = b.y; r.o[2] = b.z; r.o[3] = b.w; r.o[4] = c.x; r.o[5] = c.y;
+  } else {
+    const char* rec = lds + (spline * kFlatWindow + local) * (int)sizeof(FlatPoly);
+    const double2 ti = *reinterpret_cast<const double2*>(rec);
+    const uint4 oa = reinterpret_cast<const uint4*>(rec)[1];
+    const uint2 ob = reinterpret_cast<const uint2*>(rec)[4];
+    r.t0 = ti.x; r.iT = ti.y;
+    r.o[0] = oa.x; r.o[1] = oa.y; r.o[2] = oa.z; r.o[3] = oa.w; r.o[4] = ob.x; r.o[5] = ob.y;
+  }
+  return r;
+}
+// Spline::GetPoint (spline.cc:80-93) of an ee spline in Hermite basis form, position only
+TWR_DEV void flat_point(const char* __restrict__ xs, const FlatPolyR& r, double t, double p[3]) {
   double w[4], X[12];
 #pragma unroll
-  for (int c = 0; c < 12; ++c) X[c] = lds_f64(xs, (c & 1) ? o[c >> 1] >> 16 : o[c >> 1] & 0xFFFFu);
-  hermite_pos(t - ti.x, ti.y, w);
+  for (int c = 0; c < 12; ++c) X[c] = lds_f64(xs, (c & 1) ? r.o[c >> 1] >> 16 : r.o[c >> 1] & 0xFFFFu);
+  hermite_pos(t - r.t0, r.iT, w);
 #pragma unroll
   for (int d = 0; d < 3; ++d) p[d] = w[0] * X[d] + w[1] * X[3 + d] + w[2] * X[6 + d] + w[3] * X[9 + d];
 }
-TWR_DEV const char* flat_rec(const char* lds, int spline, int local) {
-  return lds + (spline * kFlatWindow + local) * (int)sizeof(FlatPoly);
-}
 // Same formula as rom_item (RangeOfMotionConstraint::UpdateConstraintAtInstance, range_of_motion_constraint.cc:58-69).
 // `lds`: the wave's polynomial windows; `xs`: the group's copy of x (zero pair first); `gs`: 192 doubles of the wave's own
+template <bool GATHER>
 TWR_DEV void flat_rom_math(const FlatRec& w, const FlatNodeR& n, double* __restrict__ g, const char* lds, const char* xs, double* gs, int lane) {
   const double* xv = reinterpret_cast<const double*>(xs) + 2;
   double* gp = g + (int64_t)w.u64(kFwG);
@@ -1798,7 +1821,7 @@ TWR_DEV void flat_rom_math(const FlatRec& w, const FlatNodeR& n, double* __restr
   for (int ee = 0; ee < kMaxEE; ++ee)
     if (ee < n_ee) {   // g = b_R_w (p_ee - c)
       double p[3], v[3], gv[3];
-      flat_point(xs, flat_rec(lds, 2 * ee, (n.qm >> (8 * ee)) & 0xFFu), n.t, p);
+      flat_point(xs, flat_poly<GATHER>(w, lds, 2 * ee, (n.qm >> (8 * ee)) & 0xFFu), n.t, p);
 #pragma unroll
       for (int d = 0; d < 3; ++d) v[d] = p[d] - c[d];
       matTvec(ro.R, v, gv);
@@ -1817,6 +1840,7 @@ TWR_DEV void flat_rom_math(const FlatRec& w, const FlatNodeR& n, double* __restr
 // DynamicConstraint::UpdateConstraintAtInstance (dynamic_constraint.cc:59-77) with SingleRigidBodyDynamics::GetDynamicViolation
 // (single_rigid_body_dynamics.cc:76-101) and the EulerConverter quantities (euler_converter.cc:58-83,133-166,207-221) of one time
 // node on ONE lane -- the statements of dyn2_front / dyn2_back without the quad.
+template <bool GATHER>
 TWR_DEV void flat_dyn_math(const FlatRec& w, const FlatNodeR& n, double* __restrict__ g, const char* lds, const char* xs, double* gs_rom, int lane) {
   const double* xv = reinterpret_cast<const double*>(xs) + 2;
   const int n_ee = w.i32(kFwNee);
@@ -1844,8 +1868,8 @@ TWR_DEV void flat_dyn_math(const FlatRec& w, const FlatNodeR& n, double* __restr
     for (int ee = 0; ee < kMaxEE; ++ee)
       if (ee < n_ee) {
         double p[3], f[3], rv[3], t3[3];
-        flat_point(xs, flat_rec(lds, 2 * ee, (n.qm >> (8 * ee)) & 0xFFu), n.t, p);
-        flat_point(xs, flat_rec(lds, 2 * ee + 1, (n.qf >> (8 * ee)) & 0xFFu), n.t, f);
+        flat_point(xs, flat_poly<GATHER>(w, lds, 2 * ee, (n.qm >> (8 * ee)) & 0xFFu), n.t, p);
+        flat_point(xs, flat_poly<GATHER>(w, lds, 2 * ee + 1, (n.qf >> (8 * ee)) & 0xFFu), n.t, f);
 #pragma unroll
         for (int d = 0; d < 3; ++d) rv[d] = c[d] - p[d];
         cross3(f, rv, t3);
@@ -1968,15 +1992,23 @@ __global__ __launch_bounds__(64 * kFlatGroup, 4) void eval_values_kernel(const F
   const int cnt = w.i32(kFwCnt);
   FlatIn in;
   double xr[NX];
+  const bool gather = w.i32(kFwGather) != 0;   // (uniform) a coarse grid: every lane fetches its own polynomial records
   if (cnt > 0) flat_load(w, lane, in);
+  if (cnt > 0 && !gather) flat_load_polys(w, lane, in);
   flat_load_x<NX>(x + (int64_t)w.u64(kFwX), w.i32(kFwNx), tid, xr);   // (the empty items of a group carry the problem's x as well)
   flat_stage_x<NX>(xr, w.i32(kFwNx), reinterpret_cast<double*>(xs), tid);
-  if (cnt > 0) flat_stage_polys(in, mine, lane);
+  if (cnt > 0 && !gather) flat_stage_polys(in, mine, lane);
   __syncthreads();
   if (cnt <= 0) return;
   double* gs = reinterpret_cast<double*>(mine + kFlatPolyLds);
-  if (w.i32(kFwDynamic) != 0) flat_dyn_math(w, flat_node(in), g, mine, xs, gs, lane);
-  else flat_rom_math(w, flat_node(in), g, mine, xs, gs, lane);
+  const bool dynamic = w.i32(kFwDynamic) != 0;
+  if (gather) {
+    if (dynamic) flat_dyn_math<true>(w, flat_node(in), g, mine, xs, gs, lane);
+    else flat_rom_math<true>(w, flat_node(in), g, mine, xs, gs, lane);
+  } else {
+    if (dynamic) flat_dyn_math<false>(w, flat_node(in), g, mine, xs, gs, lane);
+    else flat_rom_math<false>(w, flat_node(in), g, mine, xs, gs, lane);
+  }
 }
 
 // ---------------------------------------------------------------- optimised timings (PhaseSpline) kernels

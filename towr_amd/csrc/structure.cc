@@ -1303,43 +1303,54 @@ void Structure::PackBlob() {
         flat_polys(fpoly[e], force[e].durations);
       }
       off_flat_polys = h.o_flat = put(fp.data(), fp.size() * sizeof(FlatPoly));
-      // items: <= 64 consecutive time nodes whose active polynomials span <= kFlatWindow per spline
+      // items: <= 64 consecutive time nodes whose active polynomials span <= kFlatWindow per spline.  On a COARSE grid (towr's
+      // defaults: 0.1 / 0.08 s against polynomials of that length) the time nodes hardly share polynomials and the windows would
+      // cut items of a few time nodes: such a grid is cut at 64 time nodes alone and its lanes fetch their own records
+      // (FlatWork::gather; the indices stay relative to the item's first polynomials, 8 bits)
       auto flat_items = [&](const std::vector<double>& grid, const std::vector<TimeNode>& at_base, const std::vector<std::vector<TimeNode>>& at_motion,
                             const std::vector<std::vector<TimeNode>>* at_force, std::vector<FlatItem>& items) {
         std::vector<FlatNode> fn(grid.size());
         auto poly_at = [&](int s, size_t k) { return (s & 1) ? (*at_force)[s >> 1][k].poly : at_motion[s >> 1][k].poly; };
         const int step = at_force ? 1 : 2;   // range of motion: the ee-motion splines only
-        size_t k0 = 0;
-        while (k0 < grid.size()) {
-          size_t k1 = k0 + 1;
-          auto fits = [&](size_t k) {
-            for (int s = 0; s < 2 * n_ee; s += step)
-              if (poly_at(s, k) - poly_at(s, k0) >= kFlatWindow) return false;
-            return true;
-          };
-          while (k1 < grid.size() && k1 - k0 < 64 && fits(k1)) ++k1;
-          FlatItem it;
-          it.k0 = (int)k0;
-          it.cnt = (int)(k1 - k0);
-          for (int s = 0; s < 2 * n_ee; s += step) {
-            const int lo = poly_at(s, k0), hi = poly_at(s, k1 - 1);
-            it.start[s >> 2] |= (uint64_t)(first[s] + lo) << (16 * (s & 3));
-            it.count |= (uint64_t)(hi - lo + 1) << (8 * s);
-          }
-          items.push_back(it);
-          for (size_t k = k0; k < k1; ++k) {
-            std::memset(&fn[k], 0, sizeof(FlatNode));
-            fn[k].t = grid[k];
-            fn[k].tb = at_base[k].t_local;
-            fn[k].iTb = 1.0 / base.durations[at_base[k].poly];
-            fn[k].q6 = 6 * at_base[k].poly;
-            for (int e = 0; e < n_ee; ++e) {
-              fn[k].qm[e] = (uint8_t)(at_motion[e][k].poly - at_motion[e][k0].poly);
-              if (at_force) fn[k].qf[e] = (uint8_t)((*at_force)[e][k].poly - (*at_force)[e][k0].poly);
+        auto cut = [&](int window, bool gather) {
+          items.clear();
+          size_t k0 = 0;
+          while (k0 < grid.size()) {
+            size_t k1 = k0 + 1;
+            auto fits = [&](size_t k) {
+              for (int s = 0; s < 2 * n_ee; s += step)
+                if (poly_at(s, k) - poly_at(s, k0) >= window) return false;
+              return true;
+            };
+            while (k1 < grid.size() && k1 - k0 < 64 && fits(k1)) ++k1;
+            FlatItem it;
+            it.k0 = (int)k0;
+            it.cnt = (int)(k1 - k0);
+            it.gather = gather;
+            for (int s = 0; s < 2 * n_ee; s += step) {
+              const int lo = poly_at(s, k0), hi = poly_at(s, k1 - 1);
+              it.start[s >> 2] |= (uint64_t)(first[s] + lo) << (16 * (s & 3));
+              it.count |= (uint64_t)(hi - lo + 1) << (8 * s);
             }
+            items.push_back(it);
+            for (size_t k = k0; k < k1; ++k) {
+              std::memset(&fn[k], 0, sizeof(FlatNode));
+              fn[k].t = grid[k];
+              fn[k].tb = at_base[k].t_local;
+              fn[k].iTb = 1.0 / base.durations[at_base[k].poly];
+              fn[k].q6 = 6 * at_base[k].poly;
+              for (int e = 0; e < n_ee; ++e) {
+                fn[k].qm[e] = (uint8_t)(at_motion[e][k].poly - at_motion[e][k0].poly);
+                if (at_force) fn[k].qf[e] = (uint8_t)((*at_force)[e][k].poly - (*at_force)[e][k0].poly);
+              }
+            }
+            k0 = k1;
           }
-          k0 = k1;
-        }
+        };
+        cut(kFlatWindow, false);
+        // (an item costs about the same whatever it holds, fetching the records per lane a quarter more: the windows stay while
+        // they cut at most a quarter more items than 64 time nodes each would)
+        if (4 * items.size() > 5 * ((grid.size() + 63) / 64)) cut(256, true);
         return put(fn.data(), fn.size() * sizeof(FlatNode));
       };
       // coinciding grids (the BASELINE configurations choose one dt for both; towr's defaults are 0.1 / 0.08 s): the "dynamic"

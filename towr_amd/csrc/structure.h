@@ -105,6 +105,7 @@ struct Structure {
   struct FlatItem {
     int k0 = 0, cnt = 0;                 // time nodes [k0, k0 + cnt) of the grid
     uint64_t start[2] = {0, 0}, count = 0;   // FlatWork::start / count
+    bool gather = false;                 // FlatWork::gather
   };
   uint32_t off_flat_polys = 0, off_flat_rom = 0, off_flat_dyn = 0;   // FlatPoly[] | FlatNode[] of the two grids
   int flat_row_dyn = 0, flat_row_rom[kMaxEE] = {0, 0, 0, 0};
