@@ -366,7 +366,8 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
         dist.all_reduce(p_elapsed, op=dist.ReduceOp.MAX)
         dist.all_reduce(q_elapsed, op=dist.ReduceOp.MAX)
     p_elapsed, q_elapsed = float(p_elapsed[0]), float(q_elapsed[0])
-    curve = shard_curve(ta, torch, sweep, m5, cands, mine, x_host, dev, dev_index, stream, elapsed / steps, threads) if world == 1 else None
+    curve = shard_curve(ta, torch, sweep, m5, cands, mine, x_host, dev, dev_index, stream, elapsed / steps, threads,
+                        placement_tries=min(4, placement_tries)) if world == 1 else None
     return {"workload": "C5 sweep: %d enumerated ANYmal candidates (combo x T x swing scale) on Stairs, K=200, ragged"
                         % n_total,
             "candidates": n_total, "scaling": "strong", "steps": steps,
@@ -395,7 +396,7 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
             "shard_curve": curve}
 
 
-def shard_curve(ta, torch, sweep, m5, cands, structs, x_host, dev, dev_index, stream, step_s_1024, threads, steps=400):
+def shard_curve(ta, torch, sweep, m5, cands, structs, x_host, dev, dev_index, stream, step_s_1024, threads, steps=400, placement_tries=1):
     """The shards an N-rank run of the 1024-candidate sweep cuts (byte-balanced, twr_shard_bounds), each evaluated ON THIS
     GPU, event-free: rank 0's shard and the largest one for N = 2, 4, 8 -- microseconds per step, TB/s, fraction of 8 TB/s
     -- and what the sweep's speed-up would be if nothing but the slowest shard's step mattered.  A PROJECTION from one
@@ -413,9 +414,17 @@ def shard_curve(ta, torch, sweep, m5, cands, structs, x_host, dev, dev_index, st
         for r in picks:
             lo, hi = bounds[r], bounds[r + 1]
             batch = ta.Batch(structs[lo:hi], list(range(hi - lo)), device=dev_index)
-            x = torch.from_numpy(x_host[x_off[lo]:x_off[hi]].copy()).to(dev)
-            g = torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device=dev)
-            jac = torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev)
+            xh = x_host[x_off[lo]:x_off[hi]].copy()
+
+            def alloc():
+                return (torch.from_numpy(xh).to(dev), torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device=dev),
+                        torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev))
+
+            def run_steps(bufs, n):
+                for _ in range(n):
+                    batch.eval_device(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), ta.EVAL_BOTH, stream)
+
+            (x, g, jac), placed = place_outputs(torch, dev, alloc, run_steps, placement_tries)   # (as for the 1024-candidate step)
             for _ in range(20):
                 batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)
             torch.cuda.synchronize()
@@ -427,7 +436,8 @@ def shard_curve(ta, torch, sweep, m5, cands, structs, x_host, dev, dev_index, st
             assert bool(torch.isfinite(g).all()) and bool(torch.isfinite(jac).all())
             rows.append({"rank": r, "candidates": hi - lo, "bytes": int(batch.algorithmic_bytes), "us_per_step": dt * 1e6,
                          "TBps": batch.algorithmic_bytes / dt / 1e12, "frac": batch.algorithmic_bytes / dt / 1e9 / HBM_PEAK_GBS,
-                         "largest": r == int(np.argmax(sizes))})
+                         "largest": r == int(np.argmax(sizes)),
+                         "placement_tries_us": [round(t_["ms_per_step"] * 1e3, 1) for t_ in placed["tries"] if t_.get("ms_per_step") is not None]})
             del batch, x, g, jac
         slowest = max(r_["us_per_step"] for r_ in rows)
         out["world"][str(world)] = {"shards": rows, "projected_speedup_no_overhead": step_s_1024 * 1e6 / slowest}
