@@ -605,7 +605,7 @@ def main():
                          "optimised phase durations (ee-schedule variables, all-variables rows); c3 only")
     ap.add_argument("--device-warmup-s", type=float, default=0.5,
                     help="seconds of plain HBM writes before the W warm-up steps, to leave the idle power state (0: none)")
-    ap.add_argument("--placement-tries", type=int, default=8,
+    ap.add_argument("--placement-tries", type=int, default=12,
                     help="allocate the output buffers this many times at different places of device memory and keep the fastest "
                          "(untimed probe steps, before the W warm-up steps; 1: as the allocator hands them out)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
