@@ -3460,7 +3460,11 @@ hipError_t launch_eval(int n_ee, int n_cu, const DynWork* dyn, int n_dyn, int dy
                        const PDynWork* pdyn, int n_pdyn, int pdyn_img_cap, const LocWork* ploc, int n_ploc, const RomPhaseWork* prom, int n_prom, int prom_img_cap, const double* x,
                        double* g, double* jac, double* dump /* kDynDump doubles */, int flags, bool stream_nt /* non-temporal copy-out of
                        dyn / rom (copy_out_fixed) */, const FlatWork* flat /* values-only work items in groups of four; nullptr: none */, int n_flat, int flat_max_x /* variables of the largest problem */, hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */) {
+#ifdef TWR_TUNING_KNOBS   // (read on every launch: an experiment can change them between evaluations of one process)
+  const int dyn_bpc = env_int("TWR_DYN_BPC", 8), rom_bpc = env_int("TWR_ROM_BPC", 4);
+#else
   static const int dyn_bpc = env_int("TWR_DYN_BPC", 8), rom_bpc = env_int("TWR_ROM_BPC", 4);
+#endif
   dim3 block(64);
   hipError_t st = hipSuccess;
   if (n_ee < 1 || n_ee > 4) return hipErrorInvalidValue;
