@@ -273,15 +273,15 @@ def scale_c5(ta, torch, dist, model, world, rank, dev, dev_index, backend, strea
     x_host = np.concatenate([perturbed_inputs(s_, m5, 1, first_seed=lo + i_)[0] for i_, s_ in enumerate(mine)])
     device_power_warmup(torch, dev, LEG_WARMUP_S)   # (the CPU-baseline leg and the structure builds left the device idle)
 
-    def alloc():
+    def alloc(jac=None):
         return (torch.from_numpy(x_host).to(dev), torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device=dev),
-                torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev))
+                jac if jac is not None else torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev))
 
     def run_steps(bufs, n):
         for _ in range(n):
             batch.eval_device(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), ta.EVAL_BOTH, stream)
 
-    (x, g, jac), placement = place_outputs(torch, dev, alloc, run_steps, placement_tries)   # (as for the headline's buffers)
+    (x, g, jac), placement = place_outputs(torch, dev, alloc, run_steps, placement_tries, jac_numel=int(batch.jac_off[-1]))   # (as for the headline's buffers)
     for _ in range(10):
         batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)
     torch.cuda.synchronize()
@@ -416,15 +416,15 @@ def shard_curve(ta, torch, sweep, m5, cands, structs, x_host, dev, dev_index, st
             batch = ta.Batch(structs[lo:hi], list(range(hi - lo)), device=dev_index)
             xh = x_host[x_off[lo]:x_off[hi]].copy()
 
-            def alloc():
+            def alloc(jac=None):
                 return (torch.from_numpy(xh).to(dev), torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device=dev),
-                        torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev))
+                        jac if jac is not None else torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev))
 
             def run_steps(bufs, n):
                 for _ in range(n):
                     batch.eval_device(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), ta.EVAL_BOTH, stream)
 
-            (x, g, jac), placed = place_outputs(torch, dev, alloc, run_steps, placement_tries)   # (as for the 1024-candidate step)
+            (x, g, jac), placed = place_outputs(torch, dev, alloc, run_steps, placement_tries, jac_numel=int(batch.jac_off[-1]))   # (as for the 1024-candidate step)
             for _ in range(20):
                 batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)
             torch.cuda.synchronize()
@@ -532,15 +532,15 @@ def timings_c3(ta, torch, dist, model, world, rank, dev, dev_index, backend, str
     x_host = np.tile(base, ((B + base.shape[0] - 1) // base.shape[0], 1))[:B].reshape(-1)
     device_power_warmup(torch, dev, LEG_WARMUP_S)
 
-    def alloc():
+    def alloc(jac=None):
         return (torch.from_numpy(x_host).to(dev), torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device=dev),
-                torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev))
+                jac if jac is not None else torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev))
 
     def run_steps(bufs, n):
         for _ in range(n):
             batch.eval_device(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), ta.EVAL_BOTH, stream)
 
-    (x, g, jac), placement = place_outputs(torch, dev, alloc, run_steps, placement_tries)   # (as for the headline's buffers)
+    (x, g, jac), placement = place_outputs(torch, dev, alloc, run_steps, placement_tries, jac_numel=int(batch.jac_off[-1]))   # (as for the headline's buffers)
     for _ in range(3):
         batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)
     batch.profile_begin(steps)
@@ -686,15 +686,15 @@ def main():
     LEG_WARMUP_S = min(LEG_WARMUP_S, args.device_warmup_s)   # (--device-warmup-s 0 switches every such warm-up off)
     warm_s = device_power_warmup(torch, dev, args.device_warmup_s)
 
-    def alloc():
+    def alloc(jac=None):
         return (torch.from_numpy(x_host).to(dev), torch.empty(int(batch.g_off[-1]), dtype=torch.float64, device=dev),
-                torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev))
+                jac if jac is not None else torch.empty(int(batch.jac_off[-1]), dtype=torch.float64, device=dev))
 
     def run_steps(bufs, n):
         for _ in range(n):
             batch.eval_device(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), ta.EVAL_BOTH, stream)
 
-    (x, g, jac), placement = place_outputs(torch, dev, alloc, run_steps, args.placement_tries)
+    (x, g, jac), placement = place_outputs(torch, dev, alloc, run_steps, args.placement_tries, jac_numel=int(batch.jac_off[-1]))
 
     def step():
         batch.eval_device(x.data_ptr(), g.data_ptr(), jac.data_ptr(), ta.EVAL_BOTH, stream)

@@ -368,6 +368,50 @@ def test_place_outputs_keeps_the_fastest_allocation():
     assert kept == ("buffers", 0) and len(report["tries"]) == 2 and "skipped" in report["tries"][1]
 
 
+def test_place_in_arena_keeps_the_fastest_window():
+    """towr_amd.placement.place_outputs with jac_numel: the Jacobian buffer is a window of ONE arena allocation (0.7 of the free
+    device memory), 2 x tries windows spread evenly over it, the fastest kept; without an arena (no mem_get_info) it falls back
+    to placement by allocation.  Stand-ins for torch and the buffers (no device)."""
+    import time
+    import types
+
+    from towr_amd import placement
+
+    class Arena:
+        def __init__(self, numel):
+            self.n = numel
+
+        def numel(self):
+            return self.n
+
+        def __getitem__(self, sl):
+            return ("window", sl.start, sl.stop - sl.start)
+
+    made = []
+    fake = types.SimpleNamespace(float64="f64", empty=lambda n, dtype=None, device=None: made.append(n) or Arena(n),
+                                 cuda=types.SimpleNamespace(synchronize=lambda: None, empty_cache=lambda: None,
+                                                            mem_get_info=lambda dev: (100 << 30, 288 << 30)))
+    placement._ARENAS.pop("fake-dev", None)
+    n_jac = 1 << 27   # 1 GiB of doubles
+
+    def alloc(jac=None):
+        assert jac is not None
+        return ("x", "g", jac)
+
+    def run_steps(bufs, n):   # windows in the third quarter of the arena are the fast ones
+        frac = bufs[2][1] / made[0]
+        time.sleep((0.001 if 0.5 < frac < 0.75 else 0.003) * n)
+
+    (x, g, jac), report = placement.place_outputs(fake, "fake-dev", alloc, run_steps, 4, jac_numel=n_jac)
+    assert made == [int(0.7 * (100 << 30)) // (1 << 21) * (1 << 18)] and report["arena_GB"] == 70.0
+    assert len(report["tries"]) == 8 and jac[2] == n_jac and jac[1] % 32 == 0 and 0.5 < jac[1] / made[0] < 0.75
+    assert report["tries"][report["kept"]]["ms_per_step"] == min(t["ms_per_step"] for t in report["tries"])
+    # a second call reuses the arena of the process
+    placement.place_outputs(fake, "fake-dev", alloc, run_steps, 2, jac_numel=n_jac)
+    assert len(made) == 1
+    placement._ARENAS.pop("fake-dev", None)
+
+
 def test_values_only_items_are_cut_at_64_nodes_and_eight_polynomials():
     """Host side of the values-only path (twr_structure_values_items): every time node of the two grids is in exactly one
     item, an item has at most 64 time nodes and at most eight polynomials of one ee spline in its window, coinciding grids
